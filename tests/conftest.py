@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are selected with `-m gpu`; on a box without a GPU they are skipped, never faked.
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason='no GPU visible')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def golden_dir():
+    return GOLDEN
