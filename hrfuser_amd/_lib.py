@@ -1,0 +1,119 @@
+"""ctypes binding of libhrfuser_hip.so — the C-ABI boundary (include/hrfuser_hip.h).
+
+Prototypes are derived from the public header itself, so the header is the single source of
+truth for the ABI.  There is NO CPU fallback: if the HIP library is missing or a tensor is not
+on a ROCm device the call raises.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'hrfuser_hip.h')
+LIB_PATH = os.path.join(_HERE, 'libhrfuser_hip.so')
+
+_ERR = {1: 'HRF_ERR_ARG (bad argument)', 2: 'HRF_ERR_LAUNCH (kernel launch failed)'}
+
+
+class HRFuserHipError(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER):
+    """-> {name: [(ctype, argname), ...]} for every `int hrf_*(...)` declared in the header."""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'\bint\s+(hrf_\w+)\s*\(([^)]*)\)\s*;', src):
+        args = []
+        for a in m.group(2).split(','):
+            a = ' '.join(a.split())
+            if not a or a == 'void':
+                continue
+            name = re.findall(r'(\w+)$', a)[0]
+            if '*' in a:
+                ct = ctypes.c_void_p
+            elif a.startswith('float'):
+                ct = ctypes.c_float
+            elif a.startswith('double'):
+                ct = ctypes.c_double
+            elif a.startswith('long'):
+                ct = ctypes.c_long
+            else:
+                ct = ctypes.c_int
+            args.append((ct, name))
+        protos[m.group(1)] = args
+    return protos
+
+
+class Lib:
+    """Loaded C-ABI library; attribute access returns checked callables taking tensors/ints."""
+
+    def __init__(self, path, require_cuda=True):
+        if not os.path.exists(path):
+            raise HRFuserHipError(
+                f'{path} not found: the HRFuser HIP extension is not built. Run '
+                '`python -m hrfuser_amd.build_ext` (needs hipcc). There is no CPU fallback.')
+        self.path = path
+        self.require_cuda = require_cuda
+        self._dll = ctypes.CDLL(path)
+        self.protos = parse_header()
+        self._fns = {}
+        for name, args in self.protos.items():
+            fn = getattr(self._dll, name)          # AttributeError if a declared symbol is missing
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ct for ct, _ in args]
+            self._fns[name] = self._wrap(name, fn, args)
+
+    def _wrap(self, name, fn, args):
+        kinds = [ct for ct, _ in args]
+        nargs = len(kinds)
+        require_cuda = self.require_cuda
+
+        def call(*a):
+            if len(a) != nargs:
+                raise TypeError(f'{name} expects {nargs} args, got {len(a)}')
+            conv = []
+            for v, ct in zip(a, kinds):
+                if ct is ctypes.c_void_p:
+                    if v is None:
+                        conv.append(None)
+                    elif isinstance(v, torch.Tensor):
+                        if require_cuda and not v.is_cuda:
+                            raise HRFuserHipError(f'{name}: tensor on {v.device}; the HIP path has no CPU fallback')
+                        conv.append(v.data_ptr())
+                    else:
+                        conv.append(int(v))
+                else:
+                    conv.append(v)
+            rc = fn(*conv)
+            if rc != 0:
+                raise HRFuserHipError(f'{name} failed: {_ERR.get(rc, rc)}')
+        call.__name__ = name
+        return call
+
+    def __getattr__(self, name):
+        try:
+            return self.__dict__['_fns'][name]
+        except KeyError:
+            raise AttributeError(name)
+
+
+_LIB = None
+
+
+def lib():
+    """The process-wide HIP library handle (loaded lazily, after torch so its HIP runtime is shared)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = Lib(LIB_PATH, require_cuda=True)
+    return _LIB
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream (0 when no GPU context: emulation tests only)."""
+    if torch.cuda.is_available():
+        return torch.cuda.current_stream().cuda_stream
+    return 0

@@ -1,0 +1,41 @@
+// Runtime shim for the HRFuser gfx950 kernels.
+//
+// Product build (hipcc --offload-arch=gfx950): plain HIP, nothing else.
+// Test build (-DHRF_EMUL, g++): the SAME kernel sources run on a CPU fiber emulator
+// (tests/emul/emul_rt.h) so kernel index math / barriers / shuffles / MFMA fragment layouts can
+// be debugged and sanitised (ASan/UBSan) without a GPU.  The emulator is test infrastructure:
+// the product package never loads the emulation library.
+#pragma once
+
+#ifdef HRF_EMUL
+#include "emul_rt.h"
+#else
+#include <hip/hip_runtime.h>
+#define HRF_DYN_SMEM(T, name)                                                   \
+  extern __shared__ __attribute__((aligned(16))) unsigned char hrf_dyn_smem_[]; \
+  T* name = reinterpret_cast<T*>(hrf_dyn_smem_)
+#define HRF_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+typedef float hrf_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ hrf_f4 hrf_mfma16(float a, float b, hrf_f4 c) {
+  // v_mfma_f32_16x16x4_f32: exact fp32 (fmaf chain), A[l&15][l>>4], B[l>>4][l&15],
+  // C/D: col = lane&15, row = (lane>>4)*4 + reg.
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void hrf_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void hrf_atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+#endif
+
+#define HRF_OK 0
+#define HRF_ERR_ARG 1
+#define HRF_ERR_LAUNCH 2
+
+static inline int hrf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#ifndef HRF_EMUL
+static inline int hrf_check_launch() {
+  return hipGetLastError() == hipSuccess ? HRF_OK : HRF_ERR_LAUNCH;
+}
+#else
+static inline int hrf_check_launch() { return HRF_OK; }
+#endif
