@@ -1,0 +1,310 @@
+// Depthwise 3x3 convolution (pad 1, stride 1|2) for NHWC fp32 on gfx950 - HBM/LDS-bound stencil.
+//
+// The CrossFFN depthwise conv (hrformer.py:271-277: 4C channels, bias, stride 1) and the HRModule
+// fuse-down depthwise convs (hrformer.py:532-541: stride 2, no bias) are ~95 launches per forward
+// of the reference.  Channels are innermost, so a wave reads 32 consecutive channels of one pixel
+// (128 B) and each LDS bank holds exactly one channel: the 3x3 window walks the LDS tile with zero
+// bank conflicts.  The producer BatchNorm+GELU/ReLU is applied ONCE per element while staging the
+// halo tile ("transform on load"), never per tap.
+#include "hrf_common.h"
+#include "../../include/hrfuser_hip.h"
+
+namespace {
+
+constexpr int CB = 32;    // channels per block (one LDS bank each)
+constexpr int TW = 16;
+
+template <int S> struct DwTile {
+  static constexpr int TH = S == 1 ? 8 : 4;              // output tile rows
+  static constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+};
+
+struct DwFwdArgs {
+  const float* x; const float* w; const float* bias; float* y; double* stats;
+  int tf_mode; const float* tf_scale; const float* tf_shift;
+  int B, H, W, C, Ho, Wo, tilesX, tilesY;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(DwFwdArgs a) {
+  constexpr int TH = DwTile<S>::TH, IH = DwTile<S>::IH, IW = DwTile<S>::IW;
+  __shared__ float sIn[IH * IW * CB];
+  __shared__ float sStat[2 * CB];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % a.tilesX; t /= a.tilesX;
+  const int ty = t % a.tilesY; const int b = t / a.tilesY;
+  const int c0 = blockIdx.y * CB;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  if (tid < 2 * CB) sStat[tid] = 0.f;
+  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  {
+    const int c = tid & 31, cg = c0 + c;
+    const bool cv = cg < a.C;
+    float sc = 1.f, sh = 0.f;
+    if (a.tf_mode != HRF_TF_NONE && cv) { sc = a.tf_scale[cg]; sh = a.tf_shift[cg]; }
+    for (int pix = tid >> 5; pix < IH * IW; pix += 8) {
+      const int iy = pix / IW, ix = pix - iy * IW;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      float v = 0.f;
+      if (cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+        v = a.x[(((long)b * a.H + gy) * a.W + gx) * a.C + cg];
+        if (a.tf_mode != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
+      }
+      sIn[pix * CB + c] = v;
+    }
+  }
+  __syncthreads();
+  const int c = tid & 31, cg = c0 + c, rg = tid >> 5;
+  const bool cv = cg < a.C;
+  float wr[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wr[k] = cv ? a.w[cg * 9 + k] : 0.f;
+  const float bv = (a.bias && cv) ? a.bias[cg] : 0.f;
+  // S=1: thread = one output row of 16; S=2: 8 row-groups over 4 rows -> half rows of 8
+  const int row = S == 1 ? rg : (rg >> 1);
+  const int xbeg = S == 1 ? 0 : (rg & 1) * 8, xcnt = S == 1 ? 16 : 8;
+  const int oy = oy0 + row;
+  float s1 = 0.f, s2 = 0.f;
+  if (cv && oy < a.Ho) {
+    for (int q = 0; q < xcnt; ++q) {
+      const int oxl = xbeg + q, ox = ox0 + oxl;
+      if (ox >= a.Wo) break;
+      float acc = bv;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          acc = fmaf(sIn[((row * S + dy) * IW + oxl * S + dx) * CB + c], wr[dy * 3 + dx], acc);
+      a.y[(((long)b * a.Ho + oy) * a.Wo + ox) * a.C + cg] = acc;
+      s1 += acc; s2 = fmaf(acc, acc, s2);
+    }
+  }
+  if (a.stats) {
+    hrf_atomic_add(&sStat[c], s1);
+    hrf_atomic_add(&sStat[CB + c], s2);
+    __syncthreads();
+    if (tid < CB && c0 + tid < a.C) {
+      hrf_atomic_add(&a.stats[c0 + tid], (double)sStat[tid]);
+      hrf_atomic_add(&a.stats[a.C + c0 + tid], (double)sStat[CB + tid]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- backward data
+struct DwBwdDataArgs {
+  const float* dy; const float* yraw; const float* cA; const float* cB; const float* cC;
+  const float* w;
+  float* dx; int accumulate;
+  int epi; const float* xraw; const float* tf_scale; const float* tf_shift; int act; double* stats;
+  int B, H, W, C, Ho, Wo, tilesX, tilesY;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
+  // tile over INPUT pixels 8 x 16; staged dY region: S=1 (10 x 18, origin -1), S=2 (5 x 9, origin y0/2)
+  constexpr int TH = 8, RH = S == 1 ? 10 : 5, RW = S == 1 ? 18 : 9;
+  __shared__ float sD[RH * RW * CB];
+  __shared__ float sStat[2 * CB];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % a.tilesX; t /= a.tilesX;
+  const int ty = t % a.tilesY; const int b = t / a.tilesY;
+  const int c0 = blockIdx.y * CB;
+  const int y0 = ty * TH, x0 = tx * TW;
+  if (tid < 2 * CB) sStat[tid] = 0.f;
+  const int ry0 = S == 1 ? y0 - 1 : y0 / 2, rx0 = S == 1 ? x0 - 1 : x0 / 2;
+  const int c = tid & 31, cg = c0 + c;
+  const bool cv = cg < a.C;
+  {
+    const bool bnb = a.cA != nullptr;
+    float ca = 1.f, cb = 0.f, cc = 0.f;
+    if (bnb && cv) { ca = a.cA[cg]; cb = a.cB[cg]; cc = a.cC[cg]; }
+    for (int pix = tid >> 5; pix < RH * RW; pix += 8) {
+      const int ly = pix / RW, lx = pix - ly * RW;
+      const int oy = ry0 + ly, ox = rx0 + lx;
+      float v = 0.f;
+      if (cv && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo) {
+        const long idx = (((long)b * a.Ho + oy) * a.Wo + ox) * a.C + cg;
+        v = a.dy[idx];
+        if (bnb) v = fmaf(ca, v, fmaf(cb, a.yraw[idx], cc));
+      }
+      sD[pix * CB + c] = v;
+    }
+  }
+  __syncthreads();
+  const int r = tid >> 5;                                 // input row within tile (0..7)
+  float wr[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wr[k] = cv ? a.w[cg * 9 + k] : 0.f;
+  float sc = 1.f, sh = 0.f;
+  if (a.epi == 1 && cv) { sc = a.tf_scale[cg]; sh = a.tf_shift[cg]; }
+  const int yi = y0 + r;
+  float s1 = 0.f, s2 = 0.f;
+  if (cv && yi < a.H) {
+    for (int q = 0; q < TW; ++q) {
+      const int xi = x0 + q;
+      if (xi >= a.W) break;
+      float acc = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          if (S == 1) {
+            acc = fmaf(sD[((r + 2 - dy) * RW + (q + 2 - dx)) * CB + c], wr[dy * 3 + dx], acc);
+          } else {
+            const int ty2 = r + 1 - dy, tx2 = q + 1 - dx;   // relative to (y0, x0), both even
+            if (ty2 >= 0 && tx2 >= 0 && ((ty2 | tx2) & 1) == 0)
+              acc = fmaf(sD[((ty2 >> 1) * RW + (tx2 >> 1)) * CB + c], wr[dy * 3 + dx], acc);
+          }
+        }
+      const long o = (((long)b * a.H + yi) * a.W + xi) * a.C + cg;
+      if (a.epi == 1) {
+        const float xr = a.xraw[o];
+        acc *= hrf_act_grad(a.act, fmaf(xr, sc, sh));
+        s1 += acc; s2 = fmaf(acc, xr, s2);
+        a.dx[o] = acc;
+      } else {
+        a.dx[o] = a.accumulate ? a.dx[o] + acc : acc;
+      }
+    }
+  }
+  if (a.epi == 1 && a.stats) {
+    hrf_atomic_add(&sStat[c], s1);
+    hrf_atomic_add(&sStat[CB + c], s2);
+    __syncthreads();
+    if (tid < CB && c0 + tid < a.C) {
+      hrf_atomic_add(&a.stats[c0 + tid], (double)sStat[tid]);
+      hrf_atomic_add(&a.stats[a.C + c0 + tid], (double)sStat[CB + tid]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- backward weight
+struct DwBwdWgtArgs {
+  const float* dy; const float* yraw; const float* cA; const float* cB; const float* cC;
+  const float* x; int tf_mode; const float* tf_scale; const float* tf_shift;
+  float* dw; float* dbias;
+  int B, H, W, C, Ho, Wo, tilesX, tilesY;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) {
+  constexpr int TH = DwTile<S>::TH, IH = DwTile<S>::IH, IW = DwTile<S>::IW;
+  __shared__ float sIn[IH * IW * CB];
+  __shared__ float sAcc[10 * CB];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % a.tilesX; t /= a.tilesX;
+  const int ty = t % a.tilesY; const int b = t / a.tilesY;
+  const int c0 = blockIdx.y * CB;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  for (int i = tid; i < 10 * CB; i += 256) sAcc[i] = 0.f;
+  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  const int c = tid & 31, cg = c0 + c;
+  const bool cv = cg < a.C;
+  {
+    float sc = 1.f, sh = 0.f;
+    if (a.tf_mode != HRF_TF_NONE && cv) { sc = a.tf_scale[cg]; sh = a.tf_shift[cg]; }
+    for (int pix = tid >> 5; pix < IH * IW; pix += 8) {
+      const int iy = pix / IW, ix = pix - iy * IW;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      float v = 0.f;
+      if (cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+        v = a.x[(((long)b * a.H + gy) * a.W + gx) * a.C + cg];
+        if (a.tf_mode != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
+      }
+      sIn[pix * CB + c] = v;
+    }
+  }
+  __syncthreads();
+  const int rg = tid >> 5;
+  const int row = S == 1 ? rg : (rg >> 1);
+  const int xbeg = S == 1 ? 0 : (rg & 1) * 8, xcnt = S == 1 ? 16 : 8;
+  const int oy = oy0 + row;
+  const bool bnb = a.cA != nullptr;
+  float ca = 1.f, cb = 0.f, cc = 0.f;
+  if (bnb && cv) { ca = a.cA[cg]; cb = a.cB[cg]; cc = a.cC[cg]; }
+  float acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+  if (cv && oy < a.Ho) {
+    for (int q = 0; q < xcnt; ++q) {
+      const int oxl = xbeg + q, ox = ox0 + oxl;
+      if (ox >= a.Wo) break;
+      const long idx = (((long)b * a.Ho + oy) * a.Wo + ox) * a.C + cg;
+      float g = a.dy[idx];
+      if (bnb) g = fmaf(ca, g, fmaf(cb, a.yraw[idx], cc));
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          acc[dy * 3 + dx] = fmaf(g, sIn[((row * S + dy) * IW + oxl * S + dx) * CB + c], acc[dy * 3 + dx]);
+      acc[9] += g;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) hrf_atomic_add(&sAcc[k * CB + c], acc[k]);
+  __syncthreads();
+  for (int i = tid; i < 10 * CB; i += 256) {
+    const int k = i / CB, cc2 = c0 + (i % CB);
+    if (cc2 < a.C) {
+      if (k < 9) hrf_atomic_add(&a.dw[cc2 * 9 + k], sAcc[i]);
+      else if (a.dbias) hrf_atomic_add(&a.dbias[cc2], sAcc[i]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias,
+                              int stride, int tf_mode, const float* tf_scale, const float* tf_shift, float* y,
+                              double* stats, void* stream) {
+  if (stride != 1 && stride != 2) return HRF_ERR_ARG;
+  DwFwdArgs a;
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.tf_mode = tf_mode; a.tf_scale = tf_scale;
+  a.tf_shift = tf_shift; a.B = B; a.H = H; a.W = W; a.C = C;
+  a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+  const int th = stride == 1 ? 8 : 4;
+  a.tilesX = hrf_cdiv(a.Wo, TW); a.tilesY = hrf_cdiv(a.Ho, th);
+  if ((long)B * a.Ho * a.Wo <= 0) return HRF_OK;
+  dim3 grid(a.tilesX * a.tilesY * B, hrf_cdiv(C, CB));
+  if (stride == 1) { HRF_LAUNCH(dw_fwd_kernel<1>, grid, dim3(256), 0, stream, a); }
+  else { HRF_LAUNCH(dw_fwd_kernel<2>, grid, dim3(256), 0, stream, a); }
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const float* cA, const float* cB,
+                                   const float* cC, const float* w, int stride, int B, int H, int W, int C,
+                                   float* dx, int accumulate, int epi, const float* xraw, const float* tf_scale,
+                                   const float* tf_shift, int act, double* stats, void* stream) {
+  if (stride != 1 && stride != 2) return HRF_ERR_ARG;
+  DwBwdDataArgs a;
+  a.dy = dy; a.yraw = yraw; a.cA = cA; a.cB = cB; a.cC = cC; a.w = w; a.dx = dx; a.accumulate = accumulate;
+  a.epi = epi; a.xraw = xraw; a.tf_scale = tf_scale; a.tf_shift = tf_shift; a.act = act; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+  a.tilesX = hrf_cdiv(W, TW); a.tilesY = hrf_cdiv(H, 8);
+  if ((long)B * H * W <= 0) return HRF_OK;
+  dim3 grid(a.tilesX * a.tilesY * B, hrf_cdiv(C, CB));
+  if (stride == 1) { HRF_LAUNCH(dw_bwd_data_kernel<1>, grid, dim3(256), 0, stream, a); }
+  else { HRF_LAUNCH(dw_bwd_data_kernel<2>, grid, dim3(256), 0, stream, a); }
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_dwconv_bwd_weight(const float* dy, const float* yraw, const float* cA, const float* cB,
+                                     const float* cC, const float* x, int B, int H, int W, int C, int stride,
+                                     int tf_mode, const float* tf_scale, const float* tf_shift, float* dw,
+                                     float* dbias, void* stream) {
+  if (stride != 1 && stride != 2) return HRF_ERR_ARG;
+  DwBwdWgtArgs a;
+  a.dy = dy; a.yraw = yraw; a.cA = cA; a.cB = cB; a.cC = cC; a.x = x; a.tf_mode = tf_mode;
+  a.tf_scale = tf_scale; a.tf_shift = tf_shift; a.dw = dw; a.dbias = dbias;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+  const int th = stride == 1 ? 8 : 4;
+  a.tilesX = hrf_cdiv(a.Wo, TW); a.tilesY = hrf_cdiv(a.Ho, th);
+  if ((long)B * a.Ho * a.Wo <= 0) return HRF_OK;
+  dim3 grid(a.tilesX * a.tilesY * B, hrf_cdiv(C, CB));
+  if (stride == 1) { HRF_LAUNCH(dw_bwd_wgt_kernel<1>, grid, dim3(256), 0, stream, a); }
+  else { HRF_LAUNCH(dw_bwd_wgt_kernel<2>, grid, dim3(256), 0, stream, a); }
+  return hrf_check_launch();
+}

@@ -1,0 +1,393 @@
+// HBM-bound elementwise / reduction kernels of the HRFuser backbone (gfx950, wave64, NHWC fp32).
+//
+//   bn_finalize / bn_bwd_finalize   per-channel BatchNorm bookkeeping from atomically-reduced sums
+//   ln_stats / ln_bwd               LayerNorm row statistics and backward (channel-last rows)
+//   affine_act_res / act_bwd        BN-apply + activation + residual materialisation and its adjoint
+//   fuse_sum / bilinear_up_bwd      HRModule cross-resolution exchange (hrnet.py:184-207)
+//   adamw                           fused flat-buffer AdamW step
+//
+// Reference ops replaced: F.batch_norm, F.layer_norm, F.relu/gelu, torch.add, F.interpolate
+// (bilinear, align_corners=False) call sites listed in SURVEY.md 2.1a.
+#include "hrf_common.h"
+#include "../../include/hrfuser_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------- BatchNorm
+__global__ void bn_finalize_kernel(const double* stats, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, double count, float eps,
+                                   float momentum, int update_running, float* scale, float* shift,
+                                   float* mean_out, float* invstd_out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = stats[c] / count;
+  double var = stats[C + c] / count - mean * mean;     // biased variance (train-mode normalisation)
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * invstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  if (update_running) {                                  // torch: running_var uses the UNBIASED var
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* gstats, const float* gamma, const float* mean,
+                                       const float* invstd, double count, int train,
+                                       float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sdu = gstats[c], sdux = gstats[C + c];
+  const double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.f;
+  const double sduy = (sdux - mu * sdu) * is;            // sum du * yhat
+  if (dgamma) dgamma[c] += (float)sduy;
+  if (dbeta) dbeta[c] += (float)sdu;
+  if (train) {
+    const double a = sdu / count, b = sduy / count;
+    cA[c] = (float)(g * is);
+    cB[c] = (float)(-g * is * is * b);
+    cC[c] = (float)(-g * is * a + g * is * is * b * mu);
+  } else {                                               // frozen statistics: dy = gamma*invstd*du
+    cA[c] = (float)(g * is); cB[c] = 0.f; cC[c] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------- LayerNorm
+// 16 lanes cooperate on one row (C = 18..624), 4 rows per wave, 16 rows per 256-thread block.
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* x, int rows, int C, float eps, float* rowstat) {
+  const int sub = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool rv = row < rows;
+  const float* xr = x + (long)(rv ? row : 0) * C;
+  float s = 0.f;
+  for (int c = sub; c < C; c += 16) s += rv ? xr[c] : 0.f;
+  s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+  const float mean = s / (float)C;
+  float v = 0.f;
+  for (int c = sub; c < C; c += 16) { const float d = rv ? xr[c] - mean : 0.f; v = fmaf(d, d, v); }
+  v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+  if (rv && sub == 0) {
+    rowstat[2 * row] = mean;
+    rowstat[2 * row + 1] = 1.0f / sqrtf(v / (float)C + eps);
+  }
+}
+
+// dx (+)= rstd*(g - mean_c(g) - xhat*mean_c(g*xhat)),  g = da*gamma;  dgamma += sum da*xhat; dbeta += sum da
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* da, const float* x, const float* rowstat,
+                                                     const float* gamma, int rows, int C, float* dx,
+                                                     int accumulate, float* dgamma, float* dbeta) {
+  HRF_DYN_SMEM(float, sacc);                              // [2*C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sacc[i] = 0.f;
+  __syncthreads();
+  const int sub = threadIdx.x & 15;
+  const int nrb = (rows + 15) / 16;
+  for (int rbk = blockIdx.x; rbk < nrb; rbk += gridDim.x) {
+    const int row = rbk * 16 + (threadIdx.x >> 4);
+    const bool rv = row < rows;
+    const long base = (long)(rv ? row : 0) * C;
+    const float mean = rv ? rowstat[2 * row] : 0.f, rstd = rv ? rowstat[2 * row + 1] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = sub; c < C; c += 16) {
+      if (rv) {
+        const float g = da[base + c] * gamma[c];
+        const float xh = (x[base + c] - mean) * rstd;
+        s1 += g; s2 = fmaf(g, xh, s2);
+      }
+    }
+    s1 += __shfl_xor(s1, 8); s1 += __shfl_xor(s1, 4); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 1);
+    s2 += __shfl_xor(s2, 8); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 1);
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+    for (int c = sub; c < C; c += 16) {
+      if (rv) {
+        const float d = da[base + c];
+        const float xh = (x[base + c] - mean) * rstd;
+        const float v = rstd * (d * gamma[c] - m1 - xh * m2);
+        dx[base + c] = accumulate ? dx[base + c] + v : v;
+        hrf_atomic_add(&sacc[c], d * xh);
+        hrf_atomic_add(&sacc[C + c], d);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    hrf_atomic_add(&dgamma[i], sacc[i]);
+    hrf_atomic_add(&dbeta[i], sacc[C + i]);
+  }
+}
+
+// ------------------------------------------------------------------------------- BN apply + act + residual
+// act_first=1: out = res + rowscale*act(sc1*y1+sh1)            (CrossFFN tail: x + GELU(BN(h3)))
+// act_first=0: out = act(sc1*y1+sh1 [+ res] [+ sc2*y2+sh2])    (Bottleneck tail / transition ReLU)
+__global__ __launch_bounds__(256) void affine_act_res_kernel(const float* y1, const float* sc1, const float* sh1,
+                                                             const float* y2, const float* sc2, const float* sh2,
+                                                             const float* res, const float* rowscale, int rows_per_sample,
+                                                             int act, int act_first, float* out, long total, int C) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    float v = fmaf(y1[i], sc1[c], sh1[c]);
+    if (act_first) {
+      v = hrf_act(act, v);
+      if (rowscale) v *= rowscale[(i / C) / rows_per_sample];
+      if (res) v += res[i];
+    } else {
+      if (res) v += res[i];
+      if (y2) v += fmaf(y2[i], sc2[c], sh2[c]);
+      v = hrf_act(act, v);
+    }
+    out[i] = v;
+  }
+}
+
+// g = dout * act'(.)  written once; per-channel (sum g, sum g*y_k) for up to three BatchNorms fed by g.
+//   mode 0: mask = out > 0            (ReLU applied last: uses the saved output)
+//   mode 1: g = dout*rowscale*gelu'(sc*y1+sh)   (GELU applied first)
+//   mode 2: g = dout                  (no activation)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* dout, const float* out, const float* y1,
+                                                      const float* sc, const float* sh, const float* rowscale,
+                                                      int rows_per_sample, int mode, float* g, const float* y2,
+                                                      const float* y3, double* st1, double* st2, double* st3,
+                                                      long total, int C) {
+  HRF_DYN_SMEM(float, sacc);                              // [4*C]: sum g, sum g*y1, sum g*y2, sum g*y3
+  for (int i = threadIdx.x; i < 4 * C; i += 256) sacc[i] = 0.f;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    float v = dout[i];
+    if (mode == 0) v = out[i] > 0.f ? v : 0.f;
+    else if (mode == 1) {
+      v *= hrf_gelu_grad(fmaf(y1[i], sc[c], sh[c]));
+      if (rowscale) v *= rowscale[(i / C) / rows_per_sample];
+    }
+    g[i] = v;
+    hrf_atomic_add(&sacc[c], v);
+    if (st1) hrf_atomic_add(&sacc[C + c], v * y1[i]);
+    if (st2) hrf_atomic_add(&sacc[2 * C + c], v * y2[i]);
+    if (st3) hrf_atomic_add(&sacc[3 * C + c], v * y3[i]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double s = (double)sacc[c];
+    if (st1) { hrf_atomic_add(&st1[c], s); hrf_atomic_add(&st1[C + c], (double)sacc[C + c]); }
+    if (st2) { hrf_atomic_add(&st2[c], s); hrf_atomic_add(&st2[C + c], (double)sacc[2 * C + c]); }
+    if (st3) { hrf_atomic_add(&st3[c], s); hrf_atomic_add(&st3[C + c], (double)sacc[3 * C + c]); }
+  }
+}
+
+// ------------------------------------------------------------------------------- cross-resolution exchange
+struct FuseTerm { int type; const float* p; const float* sc; const float* sh; int Hs, Ws; };
+struct FuseArgs { FuseTerm t[4]; float* out; int B, H, W, C; };
+
+__device__ __forceinline__ void bil_src(int dst, int in, int out, int& i0, int& i1, float& w1) {
+  // F.interpolate(mode='bilinear', align_corners=False): src = (dst+0.5)*in/out - 0.5, clamped at 0
+  const float scale = (float)in / (float)out;
+  float s = ((float)dst + 0.5f) * scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  w1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a) {
+  const long total = (long)a.B * a.H * a.W * a.C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % a.C);
+    const long pix = i / a.C;
+    const int x = (int)(pix % a.W), y = (int)((pix / a.W) % a.H), b = (int)(pix / ((long)a.W * a.H));
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const FuseTerm& t = a.t[k];
+      if (t.type == 1) acc += t.p[i];
+      else if (t.type == 2) acc += fmaf(t.p[i], t.sc[c], t.sh[c]);
+      else if (t.type == 3) {
+        int y0, y1, x0, x1; float wy, wx;
+        bil_src(y, t.Hs, a.H, y0, y1, wy);
+        bil_src(x, t.Ws, a.W, x0, x1, wx);
+        const float* base = t.p + (long)b * t.Hs * t.Ws * a.C + c;
+        const float v00 = base[((long)y0 * t.Ws + x0) * a.C], v01 = base[((long)y0 * t.Ws + x1) * a.C];
+        const float v10 = base[((long)y1 * t.Ws + x0) * a.C], v11 = base[((long)y1 * t.Ws + x1) * a.C];
+        // same association as ATen upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+        const float top = (1.f - wx) * v00 + wx * v01, bot = (1.f - wx) * v10 + wx * v11;
+        const float v = (1.f - wy) * top + wy * bot;
+        acc += fmaf(v, t.sc[c], t.sh[c]);
+      }
+    }
+    a.out[i] = fmaxf(acc, 0.f);
+  }
+}
+
+// adjoint of the bilinear up-sampling written as a gather over the low-res grid (no atomics on the
+// tensor), plus the (sum, sum*ylow) moments for the BatchNorm that precedes the up-sampling.
+__global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const float* g, int B, int H, int W, int C,
+                                                              const float* ylow, int Hs, int Ws, float* du,
+                                                              double* stats) {
+  HRF_DYN_SMEM(float, sacc);                              // [2*C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sacc[i] = 0.f;
+  __syncthreads();
+  const long total = (long)B * Hs * Ws * C;
+  const float ry = (float)H / (float)Hs, rx = (float)W / (float)Ws;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long q = i / C;
+    const int qx = (int)(q % Ws), qy = (int)((q / Ws) % Hs), b = (int)(q / ((long)Ws * Hs));
+    // candidate hi-res rows whose i0 or i1 can equal qy: src in (qy-1, qy+1)
+    int ylo = (int)floorf(((float)qy - 1.f + 0.5f) * ry - 0.5f) - 1, yhi = (int)ceilf(((float)qy + 1.f + 0.5f) * ry - 0.5f) + 1;
+    int xlo = (int)floorf(((float)qx - 1.f + 0.5f) * rx - 0.5f) - 1, xhi = (int)ceilf(((float)qx + 1.f + 0.5f) * rx - 0.5f) + 1;
+    ylo = max(ylo, 0); yhi = min(yhi, H - 1); xlo = max(xlo, 0); xhi = min(xhi, W - 1);
+    float acc = 0.f;
+    for (int y = ylo; y <= yhi; ++y) {
+      int y0, y1; float wy;
+      bil_src(y, Hs, H, y0, y1, wy);
+      const float cy = (y0 == qy ? 1.f - wy : 0.f) + (y1 == qy ? wy : 0.f);
+      if (cy == 0.f) continue;
+      for (int x = xlo; x <= xhi; ++x) {
+        int x0, x1; float wx;
+        bil_src(x, Ws, W, x0, x1, wx);
+        const float cx = (x0 == qx ? 1.f - wx : 0.f) + (x1 == qx ? wx : 0.f);
+        if (cx != 0.f) acc = fmaf(cy * cx, g[(((long)b * H + y) * W + x) * C + c], acc);
+      }
+    }
+    du[i] = acc;
+    hrf_atomic_add(&sacc[c], acc);
+    hrf_atomic_add(&sacc[C + c], acc * ylow[i]);
+  }
+  __syncthreads();
+  if (stats)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      hrf_atomic_add(&stats[c], (double)sacc[c]);
+      hrf_atomic_add(&stats[C + c], (double)sacc[C + c]);
+    }
+}
+
+// ------------------------------------------------------------------------------- optimizer
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, const float* wd_mask,
+                                                    long n, float lr, float b1, float b2, float eps, float wd,
+                                                    const float* state, float gscale) {
+  const float bc1 = state[0], bc2 = state[1];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gr = g[i] * gscale;
+    float pi = p[i];
+    pi -= lr * wd * (wd_mask ? wd_mask[i] : 1.f) * pi;           // decoupled weight decay (torch.optim.AdamW)
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+// device-resident step counter so the optimizer stays correct under hipGraph replay
+__global__ void adamw_tick_kernel(float* state, float b1, float b2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float t = state[2] + 1.f;
+    state[2] = t;
+    state[0] = 1.f - powf(b1, t);
+    state[1] = 1.f - powf(b2, t);
+  }
+}
+
+inline int ew_grid(long total) {
+  long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int hrf_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, double count, float eps, float momentum, int update_running,
+                               float* scale, float* shift, float* mean_out, float* invstd_out, int C, void* stream) {
+  HRF_LAUNCH(bn_finalize_kernel, dim3(hrf_cdiv(C, 64)), dim3(64), 0, stream, stats, gamma, beta, running_mean,
+             running_var, count, eps, momentum, update_running, scale, shift, mean_out, invstd_out, C);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_bn_bwd_finalize(const double* gstats, const float* gamma, const float* mean, const float* invstd,
+                                   double count, int train, float* dgamma, float* dbeta, float* cA, float* cB,
+                                   float* cC, int C, void* stream) {
+  HRF_LAUNCH(bn_bwd_finalize_kernel, dim3(hrf_cdiv(C, 64)), dim3(64), 0, stream, gstats, gamma, mean, invstd, count,
+             train, dgamma, dbeta, cA, cB, cC, C);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_ln_stats(const float* x, int rows, int C, float eps, float* rowstat, void* stream) {
+  if (rows <= 0) return HRF_OK;
+  HRF_LAUNCH(ln_stats_kernel, dim3(hrf_cdiv(rows, 16)), dim3(256), 0, stream, x, rows, C, eps, rowstat);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_ln_bwd(const float* da, const float* x, const float* rowstat, const float* gamma, int rows, int C,
+                          float* dx, int accumulate, float* dgamma, float* dbeta, void* stream) {
+  if (rows <= 0) return HRF_OK;
+  int grid = hrf_cdiv(rows, 16 * 8);
+  if (grid > 1024) grid = 1024;
+  HRF_LAUNCH(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), stream, da, x, rowstat, gamma, rows,
+             C, dx, accumulate, dgamma, dbeta);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_affine_act_res(const float* y1, const float* sc1, const float* sh1, const float* y2,
+                                  const float* sc2, const float* sh2, const float* res, const float* rowscale,
+                                  int rows_per_sample, int act, int act_first, float* out, long rows, int C,
+                                  void* stream) {
+  const long total = rows * C;
+  if (total <= 0) return HRF_OK;
+  HRF_LAUNCH(affine_act_res_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, y1, sc1, sh1, y2, sc2, sh2, res,
+             rowscale, rows_per_sample, act, act_first, out, total, C);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_act_bwd(const float* dout, const float* out, const float* y1, const float* sc, const float* sh,
+                           const float* rowscale, int rows_per_sample, int mode, float* g, const float* y2,
+                           const float* y3, double* st1, double* st2, double* st3, long rows, int C, void* stream) {
+  const long total = rows * C;
+  if (total <= 0) return HRF_OK;
+  int grid = ew_grid(total / 4 + 1);
+  HRF_LAUNCH(act_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), stream, dout, out, y1, sc, sh,
+             rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, total, C);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const float* sh0, int Hs0, int Ws0,
+                            int type1, const float* p1, const float* sc1, const float* sh1, int Hs1, int Ws1,
+                            int type2, const float* p2, const float* sc2, const float* sh2, int Hs2, int Ws2,
+                            int type3, const float* p3, const float* sc3, const float* sh3, int Hs3, int Ws3,
+                            float* out, int B, int H, int W, int C, void* stream) {
+  FuseArgs a;
+  a.t[0] = FuseTerm{type0, p0, sc0, sh0, Hs0, Ws0};
+  a.t[1] = FuseTerm{type1, p1, sc1, sh1, Hs1, Ws1};
+  a.t[2] = FuseTerm{type2, p2, sc2, sh2, Hs2, Ws2};
+  a.t[3] = FuseTerm{type3, p3, sc3, sh3, Hs3, Ws3};
+  a.out = out; a.B = B; a.H = H; a.W = W; a.C = C;
+  const long total = (long)B * H * W * C;
+  if (total <= 0) return HRF_OK;
+  HRF_LAUNCH(fuse_sum_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, a);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_bilinear_up_bwd(const float* g, int B, int H, int W, int C, const float* ylow, int Hs, int Ws,
+                                   float* du, double* stats, void* stream) {
+  const long total = (long)B * Hs * Ws * C;
+  if (total <= 0) return HRF_OK;
+  HRF_LAUNCH(bilinear_up_bwd_kernel, dim3(ew_grid(total / 2 + 1)), dim3(256), (size_t)2 * C * sizeof(float), stream, g,
+             B, H, W, C, ylow, Hs, Ws, du, stats);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_adamw_tick(float* state, float beta1, float beta2, void* stream) {
+  HRF_LAUNCH(adamw_tick_kernel, dim3(1), dim3(64), 0, stream, state, beta1, beta2);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_adamw(float* p, const float* g, float* m, float* v, const float* wd_mask, long n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, const float* state,
+                         float grad_scale, void* stream) {
+  if (n <= 0) return HRF_OK;
+  HRF_LAUNCH(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, p, g, m, v, wd_mask, n, lr, beta1, beta2, eps,
+             weight_decay, state, grad_scale);
+  return hrf_check_launch();
+}

@@ -53,6 +53,92 @@ int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const float* yraw,
                         int tf_mode, const float* tf_scale, const float* tf_shift,
                         const float* tf_rowstat, float* dw, float* dbias, void* stream);
 
+/* ---- depthwise 3x3 convolution, pad 1, stride 1|2, NHWC (F.conv2d groups=C) -----------------
+ * CrossFFN hrformer.py:271-277 (bias, stride 1, input = GELU(BN(h1)) applied on load) and the
+ * fuse-down chains hrformer.py:532-541 (stride 2, no bias).  w is (C,1,3,3).                    */
+int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias,
+                   int stride, int tf_mode, const float* tf_scale, const float* tf_shift, float* y,
+                   double* stats, void* stream);
+int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const float* cA, const float* cB,
+                        const float* cC, const float* w, int stride, int B, int H, int W, int C,
+                        float* dx, int accumulate, int epi, const float* xraw, const float* tf_scale,
+                        const float* tf_shift, int act, double* stats, void* stream);
+int hrf_dwconv_bwd_weight(const float* dy, const float* yraw, const float* cA, const float* cB,
+                          const float* cC, const float* x, int B, int H, int W, int C, int stride,
+                          int tf_mode, const float* tf_scale, const float* tf_shift, float* dw,
+                          float* dbias, void* stream);
+
+/* ---- 7x7 windowed attention core (per window x head: q k^T*d^-1/2 + RPB, softmax, @v) --------
+ * WindowMSA hrformer.py:103-128 / WindowMCA hrfuser_hrformer_based.py:115-148 incl. the centre
+ * zero-pad, window partition/merge and de-pad of hrformer.py:196-236 / hrfuser...:202-248 as
+ * index math.  q/k/v/o are (B*H*W, ld) NHWC projections with column offsets (packed qkv = one
+ * buffer, three offsets).  kpad/vpad (C) = key/value of a padded token (the projection biases);
+ * padded keys are attended, not masked (with_pad_mask=False).  head_dim in {8,16,18,32,39}.
+ * bwd: dq/dk/dv written for every real token; dkpad/dvpad/drpb accumulate (+=, atomics).        */
+int hrf_window_attn_fwd(const float* q, int ldq, int qoff, const float* k, int ldk, int koff,
+                        const float* v, int ldv, int voff, const float* kpad, const float* vpad,
+                        const float* rpb, float* o, int ldo, int B, int H, int W, int C, int heads,
+                        void* stream);
+int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const float* k, int ldk, int koff,
+                        const float* v, int ldv, int voff, const float* kpad, const float* vpad,
+                        const float* rpb, const float* dout, int lddo,
+                        float* dq, int lddq, int dqoff, float* dk, int lddk, int dkoff,
+                        float* dv, int lddv, int dvoff, float* dkpad, float* dvpad, float* drpb,
+                        int B, int H, int W, int C, int heads, void* stream);
+
+/* ---- BatchNorm bookkeeping (F.batch_norm, 329 call sites: every build_norm_layer(norm_cfg)) ---
+ * stats = (sum y, sum y^2) from the producing conv -> scale/shift used by consumers' loaders,
+ * saved mean/invstd, running-stat update (momentum, unbiased var).  With SyncBN the host
+ * all-reduces `stats` (RCCL) between the producer and this call.                               */
+int hrf_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, double count, float eps, float momentum, int update_running,
+                    float* scale, float* shift, float* mean_out, float* invstd_out, int C, void* stream);
+/* gstats = (sum du, sum du*yraw): dgamma += , dbeta += , and the on-load backward coefficients
+ * dy = cA*du + cB*yraw + cC.  train=0: frozen statistics (eval / norm_eval).                    */
+int hrf_bn_bwd_finalize(const double* gstats, const float* gamma, const float* mean, const float* invstd,
+                        double count, int train, float* dgamma, float* dbeta, float* cA, float* cB,
+                        float* cC, int C, void* stream);
+
+/* ---- LayerNorm over channels (F.layer_norm: hrformer.py:343,351; hrfuser_hrformer_based.py:279-291) */
+int hrf_ln_stats(const float* x, int rows, int C, float eps, float* rowstat, void* stream);
+int hrf_ln_bwd(const float* da, const float* x, const float* rowstat, const float* gamma, int rows, int C,
+               float* dx, int accumulate, float* dgamma, float* dbeta, void* stream);
+
+/* ---- BN-apply + activation + residual materialisation and its adjoint ---------------------
+ * act: 0 none, 1 ReLU, 2 GELU.  act_first=1: out = res + rowscale[b]*act(sc1*y1+sh1)
+ * (CrossFFN tail hrformer.py:371 / DropPath); act_first=0: out = act(sc1*y1+sh1 + res + sc2*y2+sh2)
+ * (Bottleneck tail resnet.py:282-300, transition ReLU hrnet.py:438-440).                        */
+int hrf_affine_act_res(const float* y1, const float* sc1, const float* sh1, const float* y2,
+                       const float* sc2, const float* sh2, const float* res, const float* rowscale,
+                       int rows_per_sample, int act, int act_first, float* out, long rows, int C,
+                       void* stream);
+/* mode 0: g = dout*(out>0); 1: g = dout*rowscale*gelu'(sc*y1+sh); 2: g = dout.  st_k (nullable)
+ * accumulate (sum g, sum g*y_k) for the BatchNorms whose output fed the activation.            */
+int hrf_act_bwd(const float* dout, const float* out, const float* y1, const float* sc, const float* sh,
+                const float* rowscale, int rows_per_sample, int mode, float* g, const float* y2,
+                const float* y3, double* st1, double* st2, double* st3, long rows, int C, void* stream);
+
+/* ---- HRModule cross-resolution exchange (hrnet.py:184-207; fuse layers hrformer.py:498-561) ---
+ * out = ReLU(sum of up to four terms); term type 0 unused, 1 identity, 2 BN-affine of a same-
+ * resolution raw conv output, 3 BN-affine of a bilinearly up-sampled (align_corners=False)
+ * low-resolution raw conv output (Hs x Ws).                                                     */
+int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const float* sh0, int Hs0, int Ws0,
+                 int type1, const float* p1, const float* sc1, const float* sh1, int Hs1, int Ws1,
+                 int type2, const float* p2, const float* sc2, const float* sh2, int Hs2, int Ws2,
+                 int type3, const float* p3, const float* sc3, const float* sh3, int Hs3, int Ws3,
+                 float* out, int B, int H, int W, int C, void* stream);
+/* adjoint of the bilinear up-sampling (gather form) + (sum du, sum du*ylow) moments              */
+int hrf_bilinear_up_bwd(const float* g, int B, int H, int W, int C, const float* ylow, int Hs, int Ws,
+                        float* du, double* stats, void* stream);
+
+/* ---- fused flat-buffer AdamW (configs/hrfuser: AdamW lr 3e-4, wd 0.01, decay_mult 0 masks) ---
+ * state = float[4] on device: {1-b1^t, 1-b2^t, t, -}; hrf_adamw_tick advances t on device so a
+ * captured hipGraph replays correct bias corrections.                                           */
+int hrf_adamw_tick(float* state, float beta1, float beta2, void* stream);
+int hrf_adamw(float* p, const float* g, float* m, float* v, const float* wd_mask, long n, float lr,
+              float beta1, float beta2, float eps, float weight_decay, const float* state,
+              float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
