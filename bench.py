@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — HRFuser-T backbone training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = forward (train-mode BN) + backward + gradient exchange + fused AdamW of the
+HRFuser-T nuScenes backbone on a synthetic batch of 2 images per GPU (2x3x384x640 camera + lidar +
+radar; BASELINE.json configs[1]; SyncBN + RCCL all-reduce when N > 1; weak scaling).  Everything in
+the timed region runs on the hand-written HIP kernels (no oracle, no CPU fallback).
+
+The JSON line also carries
+  roofline      dominant kernel: algorithmic FLOPs (or bytes) per launch / measured launch time,
+                measured in-process with HIP events on the launch stream (an instrumented eager
+                pass right after the timed region - events cannot bracket kernels inside a
+                captured hipGraph); cross-checked by profiles/*.csv (rocprofv3 --kernel-trace --stats)
+  cpu_baseline  the PyTorch-CPU oracle (kind "port": bit-exact restatement of the reference
+                backbone) timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA = 157.3e12     # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
+PEAK_HBM = 8.0e12            # HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--model', default='t_nus_bn', help='t_nus[_bn] | b_nus[_bn] | t_stf[_bn]')
+    ap.add_argument('--batch', type=int, default=2, help='images per GPU')
+    ap.add_argument('--height', type=int, default=0)
+    ap.add_argument('--width', type=int, default=0)
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--profile-steps', type=int, default=3)
+    ap.add_argument('--dump-kernels', default='', help='write the per-kernel table (JSON) to this path')
+    return ap.parse_args()
+
+
+def load_cfg(tag):
+    with open(os.path.join(ROOT, 'tests', 'golden', 'backbone_cfgs.json')) as fh:
+        return json.load(fh)[tag]
+
+
+def cpu_baseline(tag, B, H, W, mc, iters=2):
+    """Oracle (PyTorch-CPU restatement of the reference backbone, oracle/hrfuser_oracle.py) timed on
+    the host cores: train-mode forward+backward of the same workload.  Bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import hrfuser_oracle as O
+    cfg = copy.deepcopy(load_cfg(tag))
+    cfg.pop('type')
+    orc = O.HRFuserOracle(**cfg)
+    O.seeded_fill_(orc, 0)
+    orc.train()
+    cores = torch.get_num_threads()
+    x, mods = O.seeded_inputs(B, H, W, mc, seed=1)
+
+    def step():
+        orc.zero_grad(set_to_none=True)
+        ys = orc(x, [m.clone() for m in mods])
+        sum(y.mean() for y in ys).backward()
+    step()                                                        # warm-up (primitive creation)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {'value': round(B / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{iters} timed train fwd+bwd iterations (after 1 warm-up) of the same {B}x3x{H}x{W} '
+                      f'+ {len(mc)} modality batch, torch CPU fp32, {cores} threads, no optimizer step',
+            'ms_per_step': round(dt * 1e3, 1)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)          # 'nccl' is RCCL on ROCm
+        group = dist.group.WORLD
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from hrfuser_amd import build_backbone, _lib
+    from hrfuser_amd.trainer import Trainer, make_cotangents
+    from hrfuser_amd import profiling
+
+    tag = args.model if world == 1 else args.model.replace('_bn', '')
+    cfg = load_cfg(tag)
+    stf = tag.startswith('t_stf')
+    H = args.height or 384
+    W = args.width or (1248 if stf else 640)
+    mc = cfg.get('mod_in_channels', [3, 3])
+    torch.manual_seed(1234)                                       # same init on every rank (DP)
+    net = build_backbone(copy.deepcopy(cfg)).to(dev)
+    with torch.no_grad():                                         # non-trivial RPB so that path is exercised
+        for n, p in net.named_parameters():
+            if n.endswith('relative_position_bias_table'):
+                p.normal_(0, 0.02)
+    net.train()
+    g = torch.Generator().manual_seed(100 + rank)                 # different data per rank
+    B = args.batch
+    x = torch.randn(B, 3, H, W, generator=g).to(dev)
+    mods = [torch.randn(B, c, H, W, generator=g).to(dev) for c in mc]
+    cots = make_cotangents(net, x, mods)
+    trainer = Trainer(net, lr=1e-3 if stf else 3e-4, group=group, world_size=world)
+
+    use_graph = not args.no_graph
+    if use_graph:
+        try:
+            trainer.capture(x, mods, cots)
+        except Exception as e:                                    # e.g. collective not capturable
+            if rank == 0:
+                print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager', file=sys.stderr)
+            use_graph = False
+            torch.cuda.synchronize()
+    run = trainer.replay if use_graph else (lambda: trainer.step(x, mods, cots))
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    # secondary metric: eval forward ms/img (BN running stats), hipGraph replay
+    fwd_ms = None
+    if rank == 0:
+        try:
+            fwd_ms = profiling.time_eval_forward(net, x, mods, use_graph=not args.no_graph)
+        except Exception as e:
+            print(f'[bench] eval-forward timing failed: {e}', file=sys.stderr)
+        net.train()
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        table = profiling.profile_step(trainer, x, mods, cots, steps=args.profile_steps)
+        roof = profiling.roofline_of_dominant(table, PEAK_F32_MFMA, PEAK_HBM)
+        if args.dump_kernels:
+            os.makedirs(os.path.dirname(os.path.abspath(args.dump_kernels)), exist_ok=True)
+            with open(args.dump_kernels, 'w') as fh:
+                json.dump(profiling.table_json(table, PEAK_F32_MFMA, PEAK_HBM), fh, indent=1)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(tag, B, H, W, mc)
+
+    if rank == 0:
+        line = {
+            'metric': 'train images/sec HRFuser-T r640 3-modal @1/2/4/8 MI355X; fwd ms/img',
+            'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{tag} backbone train step (fwd+bwd+grad exchange+AdamW), {B} img/GPU, '
+                                   f'{B}x3x{H}x{W} camera + {len(mc)} modalities, '
+                                   + ('SyncBN+RCCL all-reduce' if world > 1 else 'BN, single GPU'),
+                       'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'launch': 'hipGraph replay' if use_graph else 'eager'},
+            'fwd_ms_per_img': fwd_ms,
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

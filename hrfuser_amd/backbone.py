@@ -1,0 +1,771 @@
+"""MI355X-native HRFuser backbone: host-side mirror of the reference's module tree.
+
+Same class names, constructor keywords, error behaviour and state-dict keys as
+  /root/reference/mmdet/models/backbones/hrfuser_hrformer_based.py  (HRFuserHRFormerBased :330-628,
+      HRFuserFusionBlock :250-326, MultiWindowCrossAttention :153-248, WindowMCA :21-151)
+  /root/reference/mmdet/models/backbones/hrformer.py  (WindowMSA :18-131, LocalWindowSelfAttention
+      :134-236, CrossFFN :239-295, HRFormerBlock :298-386, HRFomerModule :389-561)
+  /root/reference/mmdet/models/backbones/hrnet.py     (stem/_make_layer/_make_transition_layer)
+  /root/reference/mmdet/models/backbones/resnet.py    (Bottleneck :100-302)
+but the modules only OWN parameters: all arithmetic is issued through `runtime.py` onto the
+hand-written gfx950 kernels behind `include/hrfuser_hip.h`.  There is no eager/CPU fallback.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import runtime as R
+from .registry import BACKBONES
+
+WIN = 7
+
+
+# ----------------------------------------------------------------------------- norm factories
+def build_bn(norm_cfg, c):
+    """mmcv.build_norm_layer subset for norm_cfg type BN / SyncBN (SyncBN = BN + RCCL stat exchange,
+    decided at run time by the engine's process group, so the module class is the same)."""
+    cfg = dict(norm_cfg or dict(type='BN'))
+    kind = cfg.pop('type')
+    if kind not in ('BN', 'SyncBN'):
+        raise KeyError(f'unsupported norm_cfg type {kind}')
+    requires_grad = cfg.pop('requires_grad', True)
+    bn = nn.BatchNorm2d(c, eps=cfg.get('eps', 1e-5), momentum=cfg.get('momentum', 0.1))
+    for p in bn.parameters():
+        p.requires_grad_(requires_grad)
+    return bn
+
+
+def build_ln(cfg, c):
+    cfg = dict(cfg or dict(type='LN', eps=1e-6))
+    if cfg.pop('type') != 'LN':
+        raise KeyError('transformer_norm_cfg must be LN')
+    return nn.LayerNorm(c, eps=cfg.get('eps', 1e-5))
+
+
+def _conv_bn_seq(cin, cout, k, stride, norm_cfg, relu, groups=1):
+    mods = [nn.Conv2d(cin, cout, k, stride, k // 2, groups=groups, bias=False), build_bn(norm_cfg, cout)]
+    if relu:
+        mods.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*mods)
+
+
+def _rel_index():
+    ys, xs = torch.meshgrid(torch.arange(WIN), torch.arange(WIN), indexing='ij')
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    return (ys[:, None] - ys[None, :] + WIN - 1) * (2 * WIN - 1) + (xs[:, None] - xs[None, :] + WIN - 1)
+
+
+# ----------------------------------------------------------------------------- engine
+class Engine:
+    """Device-side state owned by a root module: flat parameter / gradient arenas, per-BatchNorm
+    scratch slots, eval-mode BN affine cache, SyncBN group."""
+
+    def __init__(self, root):
+        self.root = root
+        self.device = None
+        self.flat_p = self.flat_g = None
+        self.slots = {}
+        self.eval_cache = {}
+        self.epoch = 0
+
+    def ready(self, device):
+        params = [p for p in self.root.parameters()]
+        if self.device != device or self.flat_p is None or (params and params[0].data_ptr() != self._p0):
+            self._setup(device, params)
+        # re-bind gradients dropped by zero_grad(set_to_none=True)
+        dirty = False
+        for p, (off, n) in zip(params, self._spans):
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self.flat_g[off:off + n].view_as(p)
+                dirty = True
+        if dirty:
+            self.flat_g.zero_()
+
+    def _setup(self, device, params):
+        total = sum(p.numel() for p in params)
+        self.flat_p = torch.empty(total, device=device, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=device, dtype=torch.float32)
+        self._spans = []
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                self.flat_p[off:off + n].copy_(p.data.reshape(-1).to(device))
+                p.data = self.flat_p[off:off + n].view(p.shape)
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+                self._spans.append((off, n))
+                off += n
+        self._p0 = params[0].data_ptr() if params else 0
+        bns = [m for m in self.root.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        csum = sum(m.num_features for m in bns)
+        self.arena_d = torch.zeros(4 * csum, device=device, dtype=torch.float64)
+        self.arena_f = torch.zeros(7 * csum, device=device, dtype=torch.float32)
+        self.slots = {}
+        od = of = 0
+        for m in bns:
+            C = m.num_features
+            d = self.arena_d
+            f = self.arena_f
+            self.slots[id(m)] = dict(
+                stats=d[od:od + 2 * C], gstats=d[od + 2 * C:od + 4 * C],
+                scale=f[of:of + C], shift=f[of + C:of + 2 * C], mean=f[of + 2 * C:of + 3 * C],
+                invstd=f[of + 3 * C:of + 4 * C], cA=f[of + 4 * C:of + 5 * C], cB=f[of + 5 * C:of + 6 * C],
+                cC=f[of + 6 * C:of + 7 * C])
+            od += 4 * C
+            of += 7 * C
+        nbt = [m.num_batches_tracked for m in bns if m.num_batches_tracked is not None]
+        self.nbt_flat = torch.zeros(len(nbt), device=device, dtype=torch.long)
+        with torch.no_grad():
+            for i, m in enumerate(b for b in bns if b.num_batches_tracked is not None):
+                self.nbt_flat[i] = m.num_batches_tracked.to(device)
+                m.num_batches_tracked = self.nbt_flat[i]          # 0-dim view: one add_ per step updates all
+        self.device = device
+        self.eval_cache = {}
+
+    def begin_forward(self, training):
+        self.arena_d.zero_()
+        if training:
+            self.nbt_flat.add_(1)
+
+    def bn_eval_affine(self, bn):
+        key = id(bn)
+        ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, self.epoch)
+        hit = self.eval_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            invstd = torch.rsqrt(bn.running_var + bn.eps)
+            scale = bn.weight * invstd
+            shift = bn.bias - bn.running_mean * scale
+            val = (scale.contiguous(), shift.contiguous(), bn.running_mean.clone(), invstd.contiguous())
+        self.eval_cache[key] = (ver, val)
+        return val
+
+
+class EngineOwner:
+    """Mixin for root modules that execute on the HIP engine."""
+    sync_group = None
+    sync_world = 1
+
+    def _engine(self):
+        eng = self.__dict__.get('_hrf_engine')
+        if eng is None:
+            eng = Engine(self)
+            self.__dict__['_hrf_engine'] = eng
+        return eng
+
+    def _lib_handle(self):
+        return _lib.lib()
+
+    def _bn_slot(self, bn):
+        return self._engine().slots[id(bn)]
+
+    def _bn_eval_affine(self, bn):
+        return self._engine().bn_eval_affine(bn)
+
+    def set_sync_group(self, group, world):
+        """Enable SyncBN semantics: BN statistics are all-reduced over `group` (RCCL)."""
+        self.sync_group, self.sync_world = group, world
+
+    def params_updated(self):
+        self._engine().epoch += 1
+
+
+# ----------------------------------------------------------------------------- blocks
+class Bottleneck(nn.Module):
+    """resnet.py:263-302 - 1x1 -> 3x3 -> 1x1 (+downsample) with BN/ReLU, residual add, ReLU."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, norm_cfg, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = build_bn(norm_cfg, planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = build_bn(norm_cfg, planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = build_bn(norm_cfg, planes * 4)
+        self.downsample = downsample
+
+    def run(self, ctx, x):
+        y = R.conv_bn(ctx, x, self.conv1, self.bn1, R.TF_RELU)
+        y = R.conv_bn(ctx, y, self.conv2, self.bn2, R.TF_RELU)
+        y = R.conv_bn(ctx, y, self.conv3, self.bn3, R.TF_AFFINE)
+        if self.downsample is not None:
+            idt = R.conv_bn(ctx, x, self.downsample[0], self.downsample[1], R.TF_AFFINE)
+            return R.materialize(ctx, y, R.ACT_RELU, lazy2=idt)
+        return R.materialize(ctx, y, R.ACT_RELU, res=x)
+
+
+class CrossFFN(nn.Module):
+    """hrformer.py:267-295.  Returns the LAZY tail BN(h3) (GELU applied by the caller's residual add)."""
+
+    def __init__(self, in_channels, hidden_channels=None, out_channels=None, norm_cfg=dict(type='SyncBN'), **kw):
+        super().__init__()
+        out_channels = out_channels or in_channels
+        hidden_channels = hidden_channels or in_channels
+        self.layers = nn.Sequential(
+            nn.Conv2d(in_channels, hidden_channels, 1), build_bn(norm_cfg, hidden_channels), nn.GELU(),
+            nn.Conv2d(hidden_channels, hidden_channels, 3, 1, 1, groups=hidden_channels),
+            build_bn(norm_cfg, hidden_channels), nn.GELU(),
+            nn.Conv2d(hidden_channels, out_channels, 1), build_bn(norm_cfg, out_channels), nn.GELU())
+
+    def run(self, ctx, ln_in):
+        l = self.layers
+        h = R.conv_bn(ctx, ln_in, l[0], l[1], R.TF_GELU)
+        h = R.dwconv_bn(ctx, h, l[3], l[4], R.TF_GELU)
+        return R.conv_bn(ctx, h, l[6], l[7], R.TF_GELU)
+
+
+class WindowMSA(nn.Module):
+    def __init__(self, embed_dims, num_heads, window_size=(WIN, WIN), **kw):
+        super().__init__()
+        if tuple(window_size) != (WIN, WIN):
+            raise NotImplementedError('the HIP attention core is specialised for 7x7 windows')
+        self.embed_dims, self.num_heads = embed_dims, num_heads
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * WIN - 1) ** 2, num_heads))
+        self.register_buffer('relative_position_index', _rel_index())
+        self.qkv = nn.Linear(embed_dims, embed_dims * 3)
+        self.out_proj = nn.Linear(embed_dims, embed_dims)
+
+
+class LocalWindowSelfAttention(nn.Module):
+    """hrformer.py:184-236 + WindowMSA.forward :96-131; returns x + out_proj(attn(LN(x)))."""
+
+    def __init__(self, embed_dims, num_heads, window_size=WIN, with_pad_mask=False, **kw):
+        super().__init__()
+        if with_pad_mask:
+            raise NotImplementedError('with_pad_mask=True is unused by every reference config')
+        ws = (window_size, window_size) if isinstance(window_size, int) else tuple(window_size)
+        self.attn = WindowMSA(embed_dims, num_heads, ws)
+
+    def run(self, ctx, x, ln, cache=None):
+        a = self.attn
+        B, H, W, C = x.t.shape
+        lin = R.ln_input(ctx, x, ln, cache)
+        qkv = R.Plain(torch.empty((B * H * W, 3 * C), device=x.t.device, dtype=torch.float32))
+        R.linear_into(ctx, lin, a.qkv, qkv, 0)
+        bq = a.qkv.bias
+        bg = bq.grad
+        o = R.window_attention(ctx, qkv, 0, qkv, C, qkv, 2 * C, bq[C:2 * C], bq[2 * C:], bg[C:2 * C], bg[2 * C:],
+                               a.relative_position_bias_table, a.num_heads, (B, H, W, C))
+        return R.linear_residual(ctx, o, a.out_proj, x)
+
+
+class HRFormerBlock(nn.Module):
+    """hrformer.py:365-373: x += LSA(LN1(x)); x += CrossFFN(LN2(x))  (DropPath is Identity, App. D-2)."""
+    expansion = 1
+
+    def __init__(self, in_channels, out_channels, num_heads, window_size=WIN, mlp_ratio=4, drop_path=0.0,
+                 norm_cfg=dict(type='SyncBN'), transformer_norm_cfg=dict(type='LN', eps=1e-6), **kw):
+        super().__init__()
+        self.norm1 = build_ln(transformer_norm_cfg, in_channels)
+        self.attn = LocalWindowSelfAttention(in_channels, num_heads, window_size,
+                                             with_pad_mask=kw.get('with_pad_mask', False))
+        self.norm2 = build_ln(transformer_norm_cfg, out_channels)
+        self.ffn = CrossFFN(in_channels, int(in_channels * mlp_ratio), out_channels, norm_cfg)
+        if drop_path > 0.0:
+            raise NotImplementedError('HRFormerBlock drop_path is always 0 on this path (SURVEY App. D-2)')
+
+    def run(self, ctx, x):
+        x = self.attn.run(ctx, x, self.norm1)
+        tail = self.ffn.run(ctx, R.ln_input(ctx, x, self.norm2))
+        return R.materialize(ctx, tail, R.ACT_GELU, res=x, act_first=True)
+
+
+class WindowMCA(nn.Module):
+    def __init__(self, embed_dim, num_heads, window_size=(WIN, WIN), proj_drop_rate=0., **kw):
+        super().__init__()
+        if tuple(window_size) != (WIN, WIN):
+            raise NotImplementedError('the HIP attention core is specialised for 7x7 windows')
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * WIN - 1) ** 2, num_heads))
+        self.register_buffer('relative_position_index', _rel_index())
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.proj_drop = nn.Dropout(proj_drop_rate)
+
+
+class MultiWindowCrossAttention(nn.Module):
+    """hrfuser_hrformer_based.py:189-248 + WindowMCA.forward :106-151."""
+
+    def __init__(self, window_size=WIN, with_pad_mask=False, **kwargs):
+        super().__init__()
+        if with_pad_mask:
+            raise NotImplementedError('with_pad_mask=True is unused by every reference config')
+        ws = (window_size, window_size) if isinstance(window_size, int) else tuple(window_size)
+        self.attn = WindowMCA(window_size=ws, **kwargs)
+
+    def run(self, ctx, q_in, kv_in, acc, z, drop_path_scale):
+        """acc + z + DropPath(Dropout(out_proj(attn(q_in, kv_in))))"""
+        a = self.attn
+        B, H, W, C = acc.t.shape
+        dev = acc.t.device
+        q = R.Plain(torch.empty((B * H * W, C), device=dev, dtype=torch.float32))
+        kv = R.Plain(torch.empty((B * H * W, 2 * C), device=dev, dtype=torch.float32))
+        R.linear_into(ctx, q_in, a.q_proj, q, 0)
+        R.linear_into(ctx, kv_in, a.k_proj, kv, 0)
+        R.linear_into(ctx, kv_in, a.v_proj, kv, C)
+        o = R.window_attention(ctx, q, 0, kv, 0, kv, C, a.k_proj.bias, a.v_proj.bias, a.k_proj.bias.grad,
+                               a.v_proj.bias.grad, a.relative_position_bias_table, a.num_heads, (B, H, W, C))
+        drop = None
+        p = a.proj_drop.p
+        if ctx.training and a.proj_drop.training and (p > 0 or drop_path_scale is not None):
+            mask = None
+            if p > 0:
+                mask = torch.empty((B, H, W, C), device=dev, dtype=torch.float32).bernoulli_(1.0 - p)
+            drop = (mask, 1.0 / (1.0 - p) if p > 0 else 1.0, drop_path_scale)
+        return R.linear_residual(ctx, o, a.out_proj, acc, res2=z, drop=drop)
+
+
+class HRFuserFusionBlock(nn.Module):
+    """hrfuser_hrformer_based.py:305-317."""
+    expansion = 1
+
+    def __init__(self, in_channels, out_channels, num_heads, window_size=WIN, mlp_ratio=4, drop_path=0.0,
+                 norm_cfg=dict(type='SyncBN'), transformer_norm_cfg=dict(type='LN', eps=1e-6), with_cp=False,
+                 num_fused_modalities=2, **kwargs):
+        super().__init__()
+        self.with_cp = with_cp
+        self.num_fused_modalities = M = num_fused_modalities
+        self.norm1 = nn.ModuleList(build_ln(transformer_norm_cfg, in_channels) for _ in range(M))
+        self.norm2 = nn.ModuleList(build_ln(transformer_norm_cfg, out_channels) for _ in range(M))
+        self.attn = nn.ModuleList(MultiWindowCrossAttention(embed_dim=in_channels, num_heads=num_heads,
+                                                            window_size=window_size, **kwargs) for _ in range(M))
+        self.norm3 = build_ln(transformer_norm_cfg, out_channels)
+        self.ffn = CrossFFN(in_channels, int(in_channels * mlp_ratio), out_channels, norm_cfg)
+        self.drop_path_prob = float(drop_path)
+
+    def _droppath_scale(self, ctx, B, dev):
+        """mmcv DropPath: per-sample floor(keep + U[0,1)) / keep (train only)."""
+        p = self.drop_path_prob
+        if not (ctx.training and self.training) or p <= 0.0:
+            return None
+        keep = 1.0 - p
+        return (torch.rand(B, device=dev) + keep).floor_().div_(keep)
+
+    def run(self, ctx, x, mods):
+        if self.with_cp and ctx.record:
+            raise Exception('with_cp is currently not possible with CA Fusion module')
+        B = x.t.shape[0]
+        dev = x.t.device
+        cache = {}
+        acc = x
+        for k in range(self.num_fused_modalities):
+            z = mods[k]
+            q_in = R.ln_input(ctx, x, self.norm1[k], cache)      # every modality queries the PRE-fusion camera
+            kv_in = R.ln_input(ctx, z, self.norm2[k])
+            acc = self.attn[k].run(ctx, q_in, kv_in, acc, z, self._droppath_scale(ctx, B, dev))
+        tail = self.ffn.run(ctx, R.ln_input(ctx, acc, self.norm3))
+        return R.materialize(ctx, tail, R.ACT_GELU, res=acc, act_first=True,
+                             rowscale=self._droppath_scale(ctx, B, dev))
+
+
+class HRFomerModule(nn.Module):
+    """hrnet.py:184-207 (HRModule.forward) with HRFormer fuse layers hrformer.py:498-561."""
+
+    def __init__(self, num_branches, block, num_blocks, num_inchannels, num_channels, num_heads,
+                 num_window_sizes, num_mlp_ratios, multiscale_output=True, drop_paths=(0.0,), with_rpe=True,
+                 with_pad_mask=False, conv_cfg=None, norm_cfg=dict(type='SyncBN', requires_grad=True),
+                 transformer_norm_cfg=dict(type='LN', eps=1e-6), with_cp=False):
+        super().__init__()
+        if num_branches != len(num_blocks):
+            raise ValueError(f'NUM_BRANCHES({num_branches}) != NUM_BLOCKS({len(num_blocks)})')
+        if num_branches != len(num_channels):
+            raise ValueError(f'NUM_BRANCHES({num_branches}) != NUM_CHANNELS({len(num_channels)})')
+        if num_branches != len(num_inchannels):
+            raise ValueError(f'NUM_BRANCHES({num_branches}) != NUM_INCHANNELS({len(num_inchannels)})')
+        if not with_rpe:
+            raise NotImplementedError('with_rpe=False is unused by every reference config')
+        self.num_branches = nb = num_branches
+        self.in_channels = list(num_inchannels)
+        self.multiscale_output = multiscale_output
+        ch = self.in_channels
+        self.branches = nn.ModuleList(
+            nn.Sequential(*[block(ch[i], num_channels[i], num_heads=num_heads[i], window_size=num_window_sizes[i],
+                                  mlp_ratio=num_mlp_ratios[i], drop_path=drop_paths[0] if drop_paths else 0.0,
+                                  norm_cfg=norm_cfg, transformer_norm_cfg=transformer_norm_cfg,
+                                  with_pad_mask=with_pad_mask)
+                            for _ in range(num_blocks[i])]) for i in range(nb))
+        self.fuse_layers = None
+        if nb > 1:
+            rows = []
+            for i in range(nb if multiscale_output else 1):
+                row = []
+                for j in range(nb):
+                    if j > i:
+                        row.append(_conv_bn_seq(ch[j], ch[i], 1, 1, norm_cfg, relu=False))
+                    elif j == i:
+                        row.append(None)
+                    else:
+                        steps = []
+                        for s in range(i - j):
+                            last = s == i - j - 1
+                            cout = ch[i] if last else ch[j]
+                            mods = [nn.Conv2d(ch[j], ch[j], 3, 2, 1, groups=ch[j], bias=False), build_bn(norm_cfg, ch[j]),
+                                    nn.Conv2d(ch[j], cout, 1, bias=False), build_bn(norm_cfg, cout)]
+                            if not last:
+                                mods.append(nn.ReLU(False))
+                            steps.append(nn.Sequential(*mods))
+                        row.append(nn.Sequential(*steps))
+                rows.append(nn.ModuleList(row))
+            self.fuse_layers = nn.ModuleList(rows)
+
+    def run(self, ctx, xs):
+        nb = self.num_branches
+        xs = list(xs)
+        for i in range(nb):
+            for blk in self.branches[i]:
+                xs[i] = blk.run(ctx, xs[i])
+        if nb == 1:
+            return [xs[0]]
+        outs = []
+        for i, row in enumerate(self.fuse_layers):
+            terms = []
+            for j in range(nb):
+                if j == i:
+                    terms.append(('id', xs[j]))
+                elif j > i:
+                    terms.append(('up', R.conv_bn(ctx, xs[j], row[j][0], row[j][1], R.TF_AFFINE)))
+                else:
+                    cur = xs[j]
+                    for step in row[j]:
+                        cur = R.dwconv_bn(ctx, cur, step[0], step[1], R.TF_AFFINE)
+                        cur = R.conv_bn(ctx, cur, step[2], step[3], R.TF_RELU if len(step) == 5 else R.TF_AFFINE)
+                    terms.append(('same', cur))
+            outs.append(R.fuse_sum(ctx, tuple(xs[i].t.shape), terms))
+        return outs
+
+
+def _make_transition(pre, cur, norm_cfg):
+    """hrnet.py:419-463."""
+    layers = []
+    for i, c in enumerate(cur):
+        if i < len(pre):
+            layers.append(_conv_bn_seq(pre[i], c, 3, 1, norm_cfg, relu=True) if c != pre[i] else None)
+        else:
+            steps = []
+            for j in range(i + 1 - len(pre)):
+                cout = c if j == i - len(pre) else pre[-1]
+                steps.append(_conv_bn_seq(pre[-1], cout, 3, 2, norm_cfg, relu=True))
+            layers.append(nn.Sequential(*steps))
+    return nn.ModuleList(layers)
+
+
+def _run_conv_chain(ctx, x, seqs):
+    """[Sequential(conv, bn, relu)]* -> materialised ReLU(BN(conv(...)))"""
+    cur = x
+    for seq in seqs:
+        cur = R.conv_bn(ctx, cur, seq[0], seq[1], R.TF_RELU)
+    return R.materialize(ctx, cur, R.ACT_RELU)
+
+
+def _make_res_layer(inplanes, planes, blocks, norm_cfg):
+    ds = None
+    if inplanes != planes * 4:
+        ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, bias=False), build_bn(norm_cfg, planes * 4))
+    layers = [Bottleneck(inplanes, planes, norm_cfg, ds)]
+    layers += [Bottleneck(planes * 4, planes, norm_cfg) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+
+# ----------------------------------------------------------------------------- autograd bridge
+class _BackboneFn(torch.autograd.Function):
+    """Bridges the explicit tape to torch.autograd at the backbone boundary only."""
+
+    @staticmethod
+    def forward(fctx, module, anchor, *inputs):
+        record = anchor is not None
+        ctx, outs, srcs = module._execute(inputs, record)
+        fctx.hrf = (ctx, outs, srcs)
+        fctx.set_materialize_grads(False)
+        return tuple(o.t.permute(0, 3, 1, 2) for o in outs)
+
+    @staticmethod
+    def backward(fctx, *gouts):
+        ctx, outs, srcs = fctx.hrf
+        for o, g in zip(outs, gouts):
+            if g is None:
+                o.grad = torch.zeros_like(o.t)
+            else:
+                o.grad = g.permute(0, 2, 3, 1).contiguous()
+                if o.grad.data_ptr() == g.data_ptr():
+                    o.grad = o.grad.clone()
+        ctx.run_backward()
+        grads = tuple(fctx_module_input_grad(s) for s in srcs)
+        fctx.hrf = None
+        return (None, None) + grads
+
+
+def fctx_module_input_grad(src):
+    if not src.needs_grad or src.grad is None:
+        return None
+    if isinstance(src, R.RawInput):
+        return src.grad                        # already NCHW
+    return src.grad.permute(0, 3, 1, 2)        # NHWC Act of a block harness -> logical NCHW
+
+
+class HipModule(nn.Module, EngineOwner):
+    """Root of a module tree executed on the HIP engine (the backbone, or a sub-block under test)."""
+
+    def _execute(self, inputs, record):
+        dev = inputs[0].device
+        if dev.type != 'cuda' and _lib.lib().require_cuda:
+            raise _lib.HRFuserHipError(
+                f'HRFuser HIP path invoked with tensors on {dev}: there is no CPU fallback '
+                '(the CPU oracle lives in oracle/ and is test infrastructure only)')
+        eng = self._engine()
+        eng.ready(dev)
+        eng.begin_forward(self.training)
+        ctx = R.Ctx(self, self.training, record)
+        with torch.no_grad():
+            srcs = self._wrap_inputs(inputs)
+            outs = self._run(ctx, srcs)
+        return ctx, outs, srcs
+
+    def _call_engine(self, inputs):
+        inputs = tuple(t.contiguous().float() for t in inputs)
+        anchor = None
+        if torch.is_grad_enabled():
+            # parameters are not autograd inputs (their grads are written by the kernels straight
+            # into param.grad); a dummy leaf makes autograd call our tape when outputs get grads
+            anchor = self.__dict__.get('_hrf_anchor')
+            if anchor is None or anchor.device != inputs[0].device:
+                anchor = torch.zeros(1, device=inputs[0].device, requires_grad=True)
+                self.__dict__['_hrf_anchor'] = anchor
+        res = _BackboneFn.apply(self, anchor, *inputs)
+        return list(res)
+
+
+@BACKBONES.register_module()
+class HRFuserHRFormerBased(HipModule):
+    """HRFuser backbone (camera HRFormer stream + M modality streams + multi-window cross-attention
+    fusion before stages 2/3/4) on hand-written gfx950 kernels.
+
+    Drop-in for mmdet's `HRFuserHRFormerBased` (hrfuser_hrformer_based.py:330-628): same registry
+    name, constructor keywords, `forward(x, x_mod) -> list[4]` contract, exceptions and state-dict.
+    """
+    blocks_dict = {'BOTTLENECK': Bottleneck, 'HRFORMER': HRFormerBlock, 'CA': HRFuserFusionBlock,
+                   'MWCA': HRFuserFusionBlock}
+
+    def __init__(self, extra, in_channels=3, conv_cfg=None, norm_cfg=dict(type='SyncBN', requires_grad=True),
+                 transformer_norm_cfg=dict(type='LN', eps=1e-6), norm_eval=False, with_cp=False,
+                 drop_path_rate=0., zero_init_residual=False, multiscale_output=True, pretrained=None,
+                 init_cfg=None, num_fused_modalities=2, mod_in_channels=[3, 3]):
+        super().__init__()
+        assert 'stage1' in extra and 'stage2' in extra and 'stage3' in extra and 'stage4' in extra
+        for i in range(4):
+            cfg = extra[f'stage{i + 1}']
+            assert len(cfg['num_blocks']) == cfg['num_branches'] and \
+                len(cfg['num_channels']) == cfg['num_branches']
+        if conv_cfg is not None:
+            raise NotImplementedError('conv_cfg must be None (plain Conv2d), as in every reference config')
+        if with_cp:
+            # the reference raises inside the fusion blocks as soon as gradients are needed (:321-322)
+            pass
+        self.extra = extra
+        self.norm_cfg, self.transformer_norm_cfg = norm_cfg, transformer_norm_cfg
+        self.norm_eval, self.with_cp = norm_eval, with_cp
+        self.num_fused_modalities = M = num_fused_modalities
+        self.pre_neck_fusion = True if extra.get('LidarStageD') else False
+        if self.pre_neck_fusion:
+            raise NotImplementedError('LidarStageD / ModFusionD (pre-neck fusion) is disabled in every reference '
+                                      'config (SURVEY 8f-4) and not built yet')
+        ncfg, lcfg = norm_cfg, transformer_norm_cfg
+        # HRFormer.__init__ :666-678 - drop_path_rate is swallowed (always 0 here)
+        for s in ('stage2', 'stage3', 'stage4'):
+            n = extra[s]['num_blocks'][0] * extra[s]['num_modules']
+            extra[s]['drop_path_rates'] = [0.0] * n
+        extra['LidarStageB']['drop_path_rates'] = extra['stage2']['drop_path_rates']
+        extra['LidarStageC']['drop_path_rates'] = extra['stage3']['drop_path_rates']
+
+        # camera stem + stage 1 (hrnet.py:337-371)
+        self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)
+        self.bn1 = build_bn(ncfg, 64)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = build_bn(ncfg, 64)
+        self.stage1_cfg = extra['stage1']
+        blk = self.blocks_dict[self.stage1_cfg['block']]
+        if blk is not Bottleneck:
+            raise NotImplementedError('stage1 block must be BOTTLENECK')
+        c1 = self.stage1_cfg['num_channels'][0]
+        self.layer1 = _make_res_layer(64, c1, self.stage1_cfg['num_blocks'][0], ncfg)
+        pre = [c1 * 4]
+        for si in (2, 3, 4):
+            cfg = extra[f'stage{si}']
+            setattr(self, f'stage{si}_cfg', cfg)
+            ch = [c * self.blocks_dict[cfg['block']].expansion for c in cfg['num_channels']]
+            setattr(self, f'transition{si - 1}', _make_transition(pre, ch, ncfg))
+            stage, pre = self._make_stage(cfg, ch, multiscale_output if si == 4 else True)
+            setattr(self, f'stage{si}', stage)
+
+        # modality stems + stage A (hrfuser_hrformer_based.py:375-412)
+        self.conv_a = nn.ModuleList(nn.Conv2d(mod_in_channels[k], 64, 3, 2, 1, bias=False) for k in range(M))
+        self.norm_a = nn.ModuleList(build_bn(ncfg, 64) for _ in range(M))
+        self.conv_b = nn.ModuleList(nn.Conv2d(64, 64, 3, 2, 1, bias=False) for _ in range(M))
+        self.norm_b = nn.ModuleList(build_bn(ncfg, 64) for _ in range(M))
+        sa = extra['LidarStageA']
+        self.stage_a_cfg = sa
+        self.layer_a = nn.ModuleList(_make_res_layer(64, sa['num_channels'][0], sa['num_blocks'][0], ncfg)
+                                     for _ in range(M))
+        pre_m = [[sa['num_channels'][0] * 4] for _ in range(M)]
+        for tag, nxt in (('a', 'b'), ('b', 'c'), ('c', None)):
+            fcfg = extra[f'ModFusion{tag.upper()}']
+            setattr(self, f'fusion_{tag}_cfg', fcfg)
+            ch = list(fcfg['num_channels'])
+            setattr(self, f'transition_{tag}',
+                    nn.ModuleList(_make_transition(pre_m[k], ch, ncfg) for k in range(M)))
+            setattr(self, f'fusion_{tag}', self._make_multimodal_fusion(fcfg, ch))
+            if nxt is not None:
+                scfg = extra[f'LidarStage{nxt.upper()}']
+                setattr(self, f'stage_{nxt}_cfg', scfg)
+                sch = list(scfg['num_channels'])
+                stages = [self._make_stage(scfg, sch)[0] for _ in range(M)]
+                setattr(self, f'stage_{nxt}', nn.ModuleList(stages))
+                pre_m = [sch for _ in range(M)]
+        self.init_weights()
+
+    # -- construction helpers -------------------------------------------------------------------
+    def _make_stage(self, cfg, in_channels, multiscale_output=True):
+        block = self.blocks_dict[cfg['block']]
+        if block is not HRFormerBlock:
+            raise NotImplementedError('stages 2-4 / LidarStage B-C must use block HRFORMER')
+        n = cfg['num_modules']
+        nb0 = cfg['num_blocks'][0]
+        dpr = cfg.get('drop_path_rates', [0.0] * (n * nb0))
+        mods = []
+        for i in range(n):
+            ms = multiscale_output or i != n - 1
+            mods.append(HRFomerModule(cfg['num_branches'], block, cfg['num_blocks'], in_channels,
+                                      cfg['num_channels'], cfg['num_heads'], cfg['window_sizes'], cfg['mlp_ratios'],
+                                      ms, drop_paths=dpr[nb0 * i:nb0 * (i + 1)],
+                                      with_rpe=self.extra.get('with_rpe', True),
+                                      with_pad_mask=self.extra.get('with_pad_mask', False),
+                                      norm_cfg=self.norm_cfg, transformer_norm_cfg=self.transformer_norm_cfg,
+                                      with_cp=self.with_cp))
+            in_channels = mods[-1].in_channels
+        return nn.Sequential(*mods), in_channels
+
+    def _make_multimodal_fusion(self, cfg, num_inchannels):
+        if cfg['block'] not in ('CA', 'MWCA'):
+            raise Exception('Not valid fusion block')
+        block = self.blocks_dict[cfg['block']]
+        return nn.ModuleList(
+            block(num_inchannels[i], cfg['num_channels'][i], num_heads=cfg['num_heads'][i],
+                  window_size=cfg['window_sizes'][i], mlp_ratio=cfg['mlp_ratios'][i], drop_path=cfg['drop_path'],
+                  norm_cfg=self.norm_cfg, transformer_norm_cfg=self.transformer_norm_cfg,
+                  num_fused_modalities=self.num_fused_modalities, proj_drop_rate=cfg['proj_drop_rate'])
+            for i in range(cfg['num_branches']))
+
+    def init_weights(self):
+        """Kaiming(conv) / constant-1 (BN) as hrnet.py:309-316; RPB tables stay zero (App. D-4)."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def train(self, mode=True):
+        """hrnet.py:588-596 (norm_eval keeps BN frozen).  Unlike the reference this returns self."""
+        super().train(mode)
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+    # -- execution ------------------------------------------------------------------------------
+    def forward(self, x, x_mod):
+        if not self.num_fused_modalities == len(x_mod):
+            raise Exception('num_fused_modalities does not fit the given input length')
+        for m in x_mod:
+            if m.shape[0] != x.shape[0] or m.shape[2:] != x.shape[2:]:
+                raise AssertionError('camera and modality inputs must share batch and spatial size')
+        return self._call_engine((x,) + tuple(x_mod))
+
+    def _wrap_inputs(self, inputs):
+        return [R.RawInput(t, bool(t.requires_grad)) for t in inputs]
+
+    def _stem(self, ctx, src, c1, b1, c2, b2, layer):
+        y = R.conv_bn(ctx, src, c1, b1, R.TF_RELU)
+        y = R.conv_bn(ctx, y, c2, b2, R.TF_RELU)
+        x = R.materialize(ctx, y, R.ACT_RELU)
+        for blk in layer:
+            x = blk.run(ctx, x)
+        return x
+
+    def _fuse_stage(self, ctx, cam_in, trans_cam, trans_mod, fusion, nb, mods, first):
+        xs, m0 = [], None
+        M = self.num_fused_modalities
+        for i in range(nb):
+            if first:
+                # reference quirk (:550-551): transition1[i][0] takes only the FIRST child:
+                #   branch 0 -> the bare conv (no BN / ReLU); branch 1 -> conv + BN + ReLU.
+                t0 = trans_cam[i][0]
+                if isinstance(t0, nn.Conv2d):
+                    cam = self._bare_conv(ctx, cam_in, t0)
+                else:
+                    cam = _run_conv_chain(ctx, cam_in, [t0])
+            elif trans_cam[i] is not None:
+                tr = trans_cam[i]
+                same = isinstance(tr[0], nn.Conv2d)          # same-index channel change (3x3 s1)
+                cam = _run_conv_chain(ctx, cam_in[i] if same else cam_in[-1], [tr] if same else list(tr))
+            else:
+                cam = cam_in[i]
+            ms = []
+            for k in range(M):
+                tr = trans_mod[k][i]
+                if tr is None:
+                    ms.append(mods[k])
+                else:
+                    ms.append(_run_conv_chain(ctx, mods[k], [tr] if isinstance(tr[0], nn.Conv2d) else list(tr)))
+            if i == 0:
+                m0 = ms
+            xs.append(fusion[i].run(ctx, cam, ms))
+        return xs, m0
+
+    def _bare_conv(self, ctx, x, conv):
+        """3x3 conv WITHOUT BatchNorm (transition1[0][0] quirk)."""
+        B, H, W, C = x.t.shape
+        out = R.Plain(torch.empty((B * H * W, conv.weight.shape[0]), device=x.t.device, dtype=torch.float32))
+        L, s = ctx.L, ctx.stream
+        w = conv.weight
+        Cout = w.shape[0]
+        strides = (H * W * C, W * C, C, 1)
+        L.hrf_conv_fwd(x.t, *strides, B, H, W, C, w, None, 3, 1, Cout, out.t, Cout, 0, None, None, 0,
+                       R.TF_NONE, None, None, None, None, s)
+        act = R.Act(out.t.view(B, H, W, Cout))
+
+        def bwd():
+            R._conv_backward(ctx, x, w, None, 3, 1, Cout, act.grad, Cout, 0, None, None)
+        ctx.push(bwd)
+        return act
+
+    @staticmethod
+    def _run_stage(ctx, stage, xs):
+        for mod in stage:
+            xs = mod.run(ctx, xs)
+        return xs
+
+    def _run(self, ctx, srcs):
+        M = self.num_fused_modalities
+        x = self._stem(ctx, srcs[0], self.conv1, self.bn1, self.conv2, self.bn2, self.layer1)
+        mods = [self._stem(ctx, srcs[1 + k], self.conv_a[k], self.norm_a[k], self.conv_b[k], self.norm_b[k],
+                           self.layer_a[k]) for k in range(M)]
+        xs, m0 = self._fuse_stage(ctx, x, self.transition1, self.transition_a, self.fusion_a,
+                                  self.stage2_cfg['num_branches'], mods, True)
+        ys = self._run_stage(ctx, self.stage2, xs)
+        mods = [self._run_stage(ctx, self.stage_b[k], [m0[k]])[0] for k in range(M)]
+        xs, m0 = self._fuse_stage(ctx, ys, self.transition2, self.transition_b, self.fusion_b,
+                                  self.stage3_cfg['num_branches'], mods, False)
+        ys = self._run_stage(ctx, self.stage3, xs)
+        mods = [self._run_stage(ctx, self.stage_c[k], [m0[k]])[0] for k in range(M)]
+        xs, _ = self._fuse_stage(ctx, ys, self.transition3, self.transition_c, self.fusion_c,
+                                 self.stage4_cfg['num_branches'], mods, False)
+        return self._run_stage(ctx, self.stage4, xs)

@@ -23,7 +23,7 @@ constexpr int LDK = 17;   // LDS row pitch: [row][k], 17 keeps MFMA fragment rea
 struct ConvFwdArgs {
   const float* x; const float* w; const float* bias;
   float* y; int ldY; int yoff;
-  const float* res; int ldR;
+  const float* res; int ldR; const float* res2;
   int tf_mode; const float* tf_scale; const float* tf_shift; const float* tf_rowstat;
   double* stats;
   int B, H, W, Cin, Ho, Wo, Cout, stride, pad;
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         if (nv && m < a.M) {
           float v = acc[i][j][r] + bv;
           if (a.res != nullptr) v += a.res[(long)m * a.ldR + n];
+          if (a.res2 != nullptr) v += a.res2[(long)m * a.ldR + n];
           a.y[(long)m * a.ldY + a.yoff + n] = v;
           s1 += v; s2 = fmaf(v, v, s2);
         }
@@ -460,14 +461,14 @@ inline int pick_nt(int C) {
 
 extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin,
                             const float* w, const float* bias, int KH, int stride, int Cout,
-                            float* y, int ldY, int yoff, const float* res, int ldR,
+                            float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
                             int tf_mode, const float* tf_scale, const float* tf_shift,
                             const float* tf_rowstat, double* stats, void* stream) {
   if ((KH != 1 && KH != 3) || (stride != 1 && stride != 2)) return HRF_ERR_ARG;
   if (tf_mode == HRF_TF_LN && (KH != 1 || stride != 1)) return HRF_ERR_ARG;
   ConvFwdArgs a;
   const int pad = KH / 2;
-  a.x = x; a.w = w; a.bias = bias; a.y = y; a.ldY = ldY; a.yoff = yoff; a.res = res; a.ldR = ldR;
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.ldY = ldY; a.yoff = yoff; a.res = res; a.res2 = res2; a.ldR = ldR;
   a.tf_mode = tf_mode; a.tf_scale = tf_scale; a.tf_shift = tf_shift; a.tf_rowstat = tf_rowstat;
   a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin;
   a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KH) / stride + 1;

@@ -37,16 +37,20 @@ __global__ void bn_finalize_kernel(const double* stats, const float* gamma, cons
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* gstats, const float* gamma, const float* mean,
-                                       const float* invstd, double count, int train,
+__global__ void bn_bwd_finalize_kernel(const double* gstats, const double* gstats_local, const float* gamma,
+                                       const float* mean, const float* invstd, double count, int train,
                                        float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double sdu = gstats[c], sdux = gstats[C + c];
   const double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.f;
   const double sduy = (sdux - mu * sdu) * is;            // sum du * yhat
-  if (dgamma) dgamma[c] += (float)sduy;
-  if (dbeta) dbeta[c] += (float)sdu;
+  // parameter grads use the rank-LOCAL moments (data-parallel grads are averaged afterwards);
+  // the dy coefficients use the (SyncBN: all-reduced) global moments.
+  const double ldu = gstats_local ? gstats_local[c] : sdu;
+  const double ldux = gstats_local ? gstats_local[C + c] : sdux;
+  if (dgamma) dgamma[c] += (float)((ldux - mu * ldu) * is);
+  if (dbeta) dbeta[c] += (float)ldu;
   if (train) {
     const double a = sdu / count, b = sduy / count;
     cA[c] = (float)(g * is);
@@ -178,6 +182,21 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* dout, const f
   }
 }
 
+// out = res + res2 + y * mask * mscale * rowscale[b]   (Dropout / DropPath arithmetic; the Bernoulli
+// draws come from torch's graph-safe Philox generator, only the arithmetic runs here)
+__global__ __launch_bounds__(256) void scale_add_kernel(const float* y, const float* mask, float mscale,
+                                                        const float* rowscale, int rows_per_sample, const float* res,
+                                                        const float* res2, float* out, long total, int C) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    float v = y[i] * mscale;
+    if (mask) v *= mask[i];
+    if (rowscale) v *= rowscale[(i / C) / rows_per_sample];
+    if (res) v += res[i];
+    if (res2) v += res2[i];
+    out[i] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------- cross-resolution exchange
 struct FuseTerm { int type; const float* p; const float* sc; const float* sh; int Hs, Ws; };
 struct FuseArgs { FuseTerm t[4]; float* out; int B, H, W, C; };
@@ -306,10 +325,11 @@ extern "C" int hrf_bn_finalize(const double* stats, const float* gamma, const fl
   return hrf_check_launch();
 }
 
-extern "C" int hrf_bn_bwd_finalize(const double* gstats, const float* gamma, const float* mean, const float* invstd,
+extern "C" int hrf_bn_bwd_finalize(const double* gstats, const double* gstats_local, const float* gamma,
+                                   const float* mean, const float* invstd,
                                    double count, int train, float* dgamma, float* dbeta, float* cA, float* cB,
                                    float* cC, int C, void* stream) {
-  HRF_LAUNCH(bn_bwd_finalize_kernel, dim3(hrf_cdiv(C, 64)), dim3(64), 0, stream, gstats, gamma, mean, invstd, count,
+  HRF_LAUNCH(bn_bwd_finalize_kernel, dim3(hrf_cdiv(C, 64)), dim3(64), 0, stream, gstats, gstats_local, gamma, mean, invstd, count,
              train, dgamma, dbeta, cA, cB, cC, C);
   return hrf_check_launch();
 }
@@ -338,6 +358,16 @@ extern "C" int hrf_affine_act_res(const float* y1, const float* sc1, const float
   if (total <= 0) return HRF_OK;
   HRF_LAUNCH(affine_act_res_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, y1, sc1, sh1, y2, sc2, sh2, res,
              rowscale, rows_per_sample, act, act_first, out, total, C);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_scale_add(const float* y, const float* mask, float mscale, const float* rowscale,
+                             int rows_per_sample, const float* res, const float* res2, float* out, long rows, int C,
+                             void* stream) {
+  const long total = rows * C;
+  if (total <= 0) return HRF_OK;
+  HRF_LAUNCH(scale_add_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, y, mask, mscale, rowscale, rows_per_sample,
+             res, res2, out, total, C);
   return hrf_check_launch();
 }
 

@@ -1,0 +1,198 @@
+"""In-process measurement helpers for bench.py: per-launch HIP-event timing of every C-ABI call,
+an algorithmic work model (FLOPs / compulsory bytes) per launch, and the roofline of the
+dominant kernel.  Pure measurement plumbing - nothing here computes results."""
+import math
+import time
+
+import torch
+
+from . import _lib
+
+
+def _pick_nt(C):
+    T = (C + 15) // 16
+    best, cost = 2, 1 << 30
+    for nt in (2, 3, 4):
+        c = ((T + nt - 1) // nt) * nt
+        if c <= cost:
+            cost, best = c, nt
+    return best
+
+
+def _out_hw(H, W, KH, s):
+    p = KH // 2
+    return (H + 2 * p - KH) // s + 1, (W + 2 * p - KH) // s + 1
+
+
+def work_model(name, a):
+    """-> (kernel key as rocprof names it, algorithmic FLOPs, compulsory HBM bytes) of one launch."""
+    f4 = 4.0
+    if name == 'hrf_conv_fwd':
+        Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
+        M, K = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']
+        tfk = 0 if a['tf_mode'] == 0 else (4 if a['tf_mode'] == 4 else 1)
+        bm = 128 if M >= 128 * 192 else 64
+        by = f4 * (a['B'] * a['H'] * a['W'] * a['Cin'] + a['Cout'] * K + M * a['Cout'] * (1 + (a['res'] is not None) + (a['res2'] is not None)))
+        return f"conv_fwd_kernel<{bm},{_pick_nt(a['Cout'])},{a['KH']},{tfk}>", 2.0 * M * a['Cout'] * K, by
+    if name == 'hrf_conv_bwd_data':
+        Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
+        M, K = a['B'] * a['H'] * a['W'], a['KH'] ** 2 * a['Cout']
+        bm = 128 if M >= 128 * 192 else 64
+        by = f4 * (a['B'] * Ho * Wo * a['Cout'] * (2 if a['cA'] is not None else 1) + a['Cin'] * K
+                   + M * a['Cin'] * (2 if a['epi'] else 1 + bool(a['accumulate'])))
+        return f"conv_bwd_data_kernel<{bm},{_pick_nt(a['Cin'])},{a['KH']}>", 2.0 * M * a['Cin'] * K, by
+    if name == 'hrf_conv_bwd_weight':
+        Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
+        Mp, Np = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']
+        by = f4 * (Mp * a['Cout'] * (2 if a['cA'] is not None else 1) + a['B'] * a['H'] * a['W'] * a['Cin'] + a['Cout'] * Np)
+        return 'conv_bwd_wgt_kernel', 2.0 * Mp * a['Cout'] * Np, by
+    if name in ('hrf_dwconv_fwd', 'hrf_dwconv_bwd_weight'):
+        Ho, Wo = _out_hw(a['H'], a['W'], 3, a['stride'])
+        n_in, n_out = a['B'] * a['H'] * a['W'] * a['C'], a['B'] * Ho * Wo * a['C']
+        if name == 'hrf_dwconv_fwd':
+            return f"dw_fwd_kernel<{a['stride']}>", 18.0 * n_out, f4 * (n_in + n_out)
+        return f"dw_bwd_wgt_kernel<{a['stride']}>", 20.0 * n_out, f4 * (n_in + n_out * (2 if a['cA'] is not None else 1))
+    if name == 'hrf_dwconv_bwd_data':
+        Ho, Wo = _out_hw(a['H'], a['W'], 3, a['stride'])
+        n_in, n_out = a['B'] * a['H'] * a['W'] * a['C'], a['B'] * Ho * Wo * a['C']
+        return (f"dw_bwd_data_kernel<{a['stride']}>", 18.0 * n_in,
+                f4 * (n_out * (2 if a['cA'] is not None else 1) + n_in * (2 if a['epi'] else 1)))
+    if name in ('hrf_window_attn_fwd', 'hrf_window_attn_bwd'):
+        nwin = a['B'] * math.ceil(a['H'] / 7) * math.ceil(a['W'] / 7)
+        D = a['C'] // a['heads']
+        P = a['B'] * a['H'] * a['W']
+        unit = 2.0 * 49 * 49 * D * nwin * a['heads']          # one 49x49xD contraction per (window, head)
+        if name == 'hrf_window_attn_fwd':
+            return f"attn_fwd_kernel<{D}>", 2 * unit, f4 * P * a['C'] * 4
+        return f"attn_bwd_kernel<{D}>", 5 * unit, f4 * P * a['C'] * 7
+    rc = None
+    if 'rows' in a and 'C' in a:
+        rc = float(a['rows']) * a['C']
+    if name == 'hrf_affine_act_res':
+        return 'affine_act_res_kernel', 4 * rc, f4 * rc * (2 + (a['res'] is not None) + (a['y2'] is not None))
+    if name == 'hrf_act_bwd':
+        n = 2 + (a['out'] is not None) + (a['y1'] is not None and a['st1'] is not None or a['mode'] == 1) \
+            + (a['y2'] is not None) + (a['y3'] is not None)
+        return 'act_bwd_kernel', 6 * rc, f4 * rc * n
+    if name == 'hrf_scale_add':
+        return 'scale_add_kernel', 3 * rc, f4 * rc * (2 + (a['mask'] is not None) + (a['res'] is not None) + (a['res2'] is not None))
+    if name == 'hrf_ln_stats':
+        return 'ln_stats_kernel', 4 * rc, f4 * rc
+    if name == 'hrf_ln_bwd':
+        return 'ln_bwd_kernel', 12 * rc, f4 * rc * (3 + bool(a['accumulate']))
+    if name == 'hrf_fuse_sum':
+        n = float(a['B']) * a['H'] * a['W'] * a['C']
+        nt = sum(1 for k in range(4) if a[f'type{k}'])
+        return 'fuse_sum_kernel', 4 * n * nt, f4 * n * (1 + nt)
+    if name == 'hrf_bilinear_up_bwd':
+        n = float(a['B']) * a['H'] * a['W'] * a['C']
+        return 'bilinear_up_bwd_kernel', 2 * n, f4 * (n + 3.0 * a['B'] * a['Hs'] * a['Ws'] * a['C'])
+    if name == 'hrf_adamw':
+        return 'adamw_kernel', 12.0 * a['n'], f4 * a['n'] * 7
+    return name.replace('hrf_', '') + '_kernel', 0.0, 0.0
+
+
+class ProfLib:
+    """Wraps the loaded library: brackets every C-ABI launch with HIP events recorded on the launch
+    stream (torch's current stream - the stream the kernels are enqueued on)."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self.require_cuda = lib.require_cuda
+        self.protos = lib.protos
+        self.records = []
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        names = [n for _, n in self._lib.protos[name]]
+
+        def call(*args):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*args)
+            e1.record()
+            self.records.append((name, dict(zip(names, args)), e0, e1))
+        return call
+
+
+def profile_step(trainer, x, mods, cots, steps=3):
+    """Run `steps` eager training steps with per-launch event timing -> {key: [n, sec, flops, bytes]}"""
+    real = _lib.lib
+    prof = ProfLib(real())
+    trainer.step(x, mods, cots)                    # eager warm-up (allocator, caches)
+    torch.cuda.synchronize()
+    _lib.lib = lambda: prof
+    try:
+        for _ in range(steps):
+            trainer.step(x, mods, cots)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib = real
+    table = {}
+    for name, a, e0, e1 in prof.records:
+        key, fl, by = work_model(name, a)
+        t = table.setdefault(key, [0, 0.0, 0.0, 0.0])
+        t[0] += 1
+        t[1] += e0.elapsed_time(e1) * 1e-3
+        t[2] += fl
+        t[3] += by
+    for t in table.values():
+        t.append(steps)
+    return table
+
+
+def _row(key, t, peak_f, peak_b):
+    n, sec, fl, by, steps = t
+    bound = 'mfma' if (fl / peak_f) > (by / peak_b) else 'hbm'
+    if bound == 'mfma':
+        ach, peak, unit = fl / sec / 1e12, peak_f / 1e12, 'TFLOP/s'
+    else:
+        ach, peak, unit = by / sec / 1e9, peak_b / 1e9, 'GB/s'
+    return {'kernel': key, 'bound': bound, 'achieved': round(ach, 3), 'peak': peak, 'unit': unit,
+            'frac': round(ach / peak, 4), 'traffic': None, 'launches_per_step': n // steps,
+            'avg_launch_us': round(sec / n * 1e6, 2), 'time_per_step_ms': round(sec / steps * 1e3, 4),
+            'flops_per_launch': fl / n, 'bytes_per_launch': by / n}
+
+
+def roofline_of_dominant(table, peak_f, peak_b):
+    key = max(table, key=lambda k: table[k][1])
+    return _row(key, table[key], peak_f, peak_b)
+
+
+def table_json(table, peak_f, peak_b):
+    rows = [_row(k, t, peak_f, peak_b) for k, t in table.items()]
+    rows.sort(key=lambda r: -r['time_per_step_ms'])
+    return rows
+
+
+def time_eval_forward(net, x, mods, iters=30, use_graph=True):
+    """Eval-mode (running-stat BN) forward latency in ms per image."""
+    net.eval()
+    B = x.shape[0]
+    with torch.no_grad():
+        for _ in range(3):
+            net(x, list(mods))
+        torch.cuda.synchronize()
+        run = lambda: net(x, list(mods))
+        if use_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    net(x, list(mods))
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    net(x, list(mods))
+                run = g.replay
+            except Exception:
+                torch.cuda.synchronize()
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run()
+        torch.cuda.synchronize()
+    return round((time.perf_counter() - t0) / iters / B * 1e3, 4)

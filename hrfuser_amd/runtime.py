@@ -1,0 +1,495 @@
+"""Execution runtime of the HRFuser HIP path: NHWC activations, a reverse-mode tape, and the op
+layer that turns the reference's ATen graph into launches of the C-ABI kernels.
+
+Design (MI355X-first):
+  * activations are NHWC fp32 end to end (= the reference's NLC), so every nchw<->nlc copy of the
+    reference (~1000 `copy_` per forward) disappears;
+  * BatchNorm / LayerNorm / activations are never materialised on their own: a conv writes its RAW
+    output plus per-channel sums, consumers apply `act(scale*raw+shift)` while loading;
+  * backward is an explicit tape of closures (no torch.autograd graph inside the backbone): every
+    gradient buffer is written exactly once or accumulated in place by the kernels themselves;
+  * parameter gradients are accumulated by the kernels straight into `param.grad` (views of one
+    flat arena owned by the backbone) so the optimizer and the RCCL all-reduce see ONE buffer.
+
+Nothing in this file computes on the CPU: every op is a launch on torch's current HIP stream.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+TF_NONE, TF_AFFINE, TF_RELU, TF_GELU, TF_LN = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+_TF2ACT = {TF_NONE: ACT_NONE, TF_AFFINE: ACT_NONE, TF_RELU: ACT_RELU, TF_GELU: ACT_GELU}
+
+
+class Act:
+    """A materialised NHWC activation (B,H,W,C) with an explicit gradient slot."""
+    __slots__ = ('t', 'grad', 'needs_grad')
+
+    def __init__(self, t, needs_grad=True):
+        self.t = t
+        self.grad = None
+        self.needs_grad = needs_grad
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def grad_target(self):
+        """-> (tensor, accumulate flag) for a kernel that writes this activation's gradient."""
+        if self.grad is None:
+            self.grad = torch.empty_like(self.t)
+            return self.grad, 0
+        return self.grad, 1
+
+    def add_grad(self, g):
+        """Accumulate a finished gradient tensor (aliasing it when it is the first one)."""
+        if self.grad is None:
+            self.grad = g
+        else:
+            self.grad.add_(g)
+
+
+class BNState:
+    """One BatchNorm application: raw conv output + the per-channel vectors around it."""
+    __slots__ = ('bn', 'C', 'raw', 'count', 'scale', 'shift', 'mean', 'invstd', 'stats', 'gstats',
+                 'coef', 'du', 'train')
+
+
+class Lazy:
+    """act(scale*raw + shift) of a conv output, applied by the consumer on load (never stored)."""
+    __slots__ = ('st', 'mode')
+
+    def __init__(self, st, mode):
+        self.st = st
+        self.mode = mode
+
+    @property
+    def raw(self):
+        return self.st.raw
+
+    @property
+    def shape(self):
+        return self.st.raw.shape
+
+
+class LNIn:
+    """LayerNorm(act) applied by the consumer on load: (x - mean[row]) * rstd[row] * gamma + beta."""
+    __slots__ = ('act', 'rowstat', 'ln')
+
+    def __init__(self, act, rowstat, ln):
+        self.act, self.rowstat, self.ln = act, rowstat, ln
+
+    @property
+    def shape(self):
+        return self.act.t.shape
+
+
+class RawInput:
+    """A network input in its native NCHW layout (read through element strides by the stem conv)."""
+    __slots__ = ('t', 'grad', 'needs_grad')
+
+    def __init__(self, t, needs_grad):
+        self.t, self.grad, self.needs_grad = t, None, needs_grad
+
+    @property
+    def shape(self):
+        B, C, H, W = self.t.shape
+        return (B, H, W, C)
+
+
+class Ctx:
+    """Per-forward execution context (library handle, stream, mode, tape, BN arenas, SyncBN group)."""
+
+    def __init__(self, owner, training, record):
+        self.L = owner._lib_handle()
+        self.stream = _lib.stream_ptr()
+        self.training = training
+        self.record = record            # build the backward tape?
+        self.tape = []
+        self.owner = owner
+        self.group = owner.sync_group if training else None
+        self.world = owner.sync_world if (training and owner.sync_group is not None) else 1
+
+    def push(self, fn):
+        if self.record:
+            self.tape.append(fn)
+
+    def run_backward(self):
+        tape = self.tape
+        self.tape = []
+        while tape:
+            tape.pop()()
+
+    def all_reduce(self, t):
+        if self.group is not None and self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.group)
+
+
+# ----------------------------------------------------------------------------- input descriptors
+def _nhwc_strides(B, H, W, C):
+    return (H * W * C, W * C, C, 1)
+
+
+def _src_desc(src):
+    """-> tensor, strides(sB,sY,sX,sC), (B,H,W,C), tf_mode, scale, shift, rowstat"""
+    if isinstance(src, Act):
+        B, H, W, C = src.t.shape
+        return src.t, _nhwc_strides(B, H, W, C), (B, H, W, C), TF_NONE, None, None, None
+    if isinstance(src, Lazy):
+        B, H, W, C = src.raw.shape
+        return src.raw, _nhwc_strides(B, H, W, C), (B, H, W, C), src.mode, src.st.scale, src.st.shift, None
+    if isinstance(src, LNIn):
+        B, H, W, C = src.act.t.shape
+        return src.act.t, _nhwc_strides(B, H, W, C), (B, H, W, C), TF_LN, src.ln.weight, src.ln.bias, src.rowstat
+    if isinstance(src, RawInput):
+        B, C, H, W = src.t.shape
+        return src.t, (C * H * W, W, 1, H * W), (B, H, W, C), TF_NONE, None, None, None
+    raise TypeError(type(src))
+
+
+def _needs_grad(src):
+    if isinstance(src, (Act, RawInput)):
+        return src.needs_grad
+    if isinstance(src, LNIn):
+        return src.act.needs_grad
+    return True
+
+
+# ----------------------------------------------------------------------------- BatchNorm plumbing
+def bn_forward(ctx, bn, raw, stats):
+    """Turn (raw conv output, accumulated sums) into a BNState with scale/shift on device."""
+    st = BNState()
+    C = raw.shape[-1]
+    st.bn, st.C, st.raw, st.du, st.coef = bn, C, raw, None, None
+    slot = ctx.owner._bn_slot(bn)
+    st.train = bool(ctx.training and bn.training)
+    if st.train:
+        st.stats, st.gstats = slot['stats'], slot['gstats']
+        st.scale, st.shift, st.mean, st.invstd = slot['scale'], slot['shift'], slot['mean'], slot['invstd']
+        rows = raw.numel() // C
+        ctx.all_reduce(st.stats)
+        st.count = float(rows * ctx.world)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        ctx.L.hrf_bn_finalize(st.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, st.count,
+                              float(bn.eps), float(mom), 1 if bn.track_running_stats else 0,
+                              st.scale, st.shift, st.mean, st.invstd, C, ctx.stream)
+    else:
+        st.stats, st.gstats = None, slot['gstats']
+        st.scale, st.shift, st.mean, st.invstd = ctx.owner._bn_eval_affine(bn)
+        st.count = float(raw.numel() // C)
+    return st
+
+
+def bn_backward_coef(ctx, st):
+    """After a consumer wrote st.du / st.gstats: dgamma/dbeta += and the on-load dy coefficients."""
+    slot = ctx.owner._bn_slot(st.bn)
+    cA, cB, cC = slot['cA'], slot['cB'], slot['cC']
+    local = None
+    if st.train and ctx.world > 1:
+        local = st.gstats.clone()
+        ctx.all_reduce(st.gstats)
+    wg = st.bn.weight.grad if st.bn.weight.requires_grad else None
+    bg = st.bn.bias.grad if st.bn.bias.requires_grad else None
+    ctx.L.hrf_bn_bwd_finalize(st.gstats, local, st.bn.weight, st.mean, st.invstd, st.count, 1 if st.train else 0,
+                              wg, bg, cA, cB, cC, st.C, ctx.stream)
+    st.coef = (cA, cB, cC)
+    return st.coef
+
+
+# ----------------------------------------------------------------------------- conv / linear ops
+def _conv_out_hw(H, W, KH, stride):
+    pad = KH // 2
+    return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KH) // stride + 1
+
+
+def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw, coef):
+    """Shared backward of every dense conv / linear: dW (+db), then dX routed by the source kind."""
+    L, s = ctx.L, ctx.stream
+    x, strides, (B, H, W, Cin), tf, sc, sh, rowstat = _src_desc(src)
+    cA, cB, cC = coef if coef is not None else (None, None, None)
+    if weight.requires_grad:
+        L.hrf_conv_bwd_weight(dy, ldD, doff, yraw, cA, cB, cC, x, *strides, B, H, W, Cin, KH, stride, Cout,
+                              tf, sc, sh, rowstat, weight.grad,
+                              bias.grad if (bias is not None and bias.requires_grad) else None, s)
+    if not _needs_grad(src):
+        return
+    if isinstance(src, Lazy):
+        st = src.st
+        st.du = torch.empty_like(st.raw)
+        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
+                            st.du, *strides, 0, 1, st.raw, Cin, st.scale, st.shift, _TF2ACT[src.mode],
+                            st.gstats, s)
+    elif isinstance(src, LNIn):
+        da = torch.empty_like(src.act.t)
+        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
+                            da, *strides, 0, 0, None, 0, None, None, 0, None, s)
+        g, acc = src.act.grad_target()
+        L.hrf_ln_bwd(da, src.act.t, src.rowstat, src.ln.weight, B * H * W, Cin, g, acc,
+                     src.ln.weight.grad, src.ln.bias.grad, s)
+    elif isinstance(src, Act):
+        g, acc = src.grad_target()
+        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
+                            g, *strides, acc, 0, None, 0, None, None, 0, None, s)
+    else:                                   # RawInput (NCHW gradient written through strides)
+        if src.grad is None:
+            src.grad = torch.empty_like(src.t)
+            acc = 0
+        else:
+            acc = 1
+        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
+                            src.grad, *strides, acc, 0, None, 0, None, None, 0, None, s)
+
+
+def conv_bn(ctx, src, conv, bn, mode):
+    """conv (k=1|3, dense) + BatchNorm (+ReLU/GELU) -> Lazy.  mode: TF_AFFINE / TF_RELU / TF_GELU."""
+    L, s = ctx.L, ctx.stream
+    x, strides, (B, H, W, Cin), tf, sc, sh, rowstat = _src_desc(src)
+    w, b = conv.weight, conv.bias
+    Cout, KH, stride = w.shape[0], w.shape[2], conv.stride[0]
+    Ho, Wo = _conv_out_hw(H, W, KH, stride)
+    y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    slot = ctx.owner._bn_slot(bn)
+    train = ctx.training and bn.training
+    stats = slot['stats'] if train else None
+    L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
+                   tf, sc, sh, rowstat, stats, s)
+    st = bn_forward(ctx, bn, y, stats)
+    out = Lazy(st, mode)
+
+    def bwd():
+        coef = bn_backward_coef(ctx, st)
+        _conv_backward(ctx, src, w, b, KH, stride, Cout, st.du, Cout, 0, st.raw, coef)
+        st.du = None
+    ctx.push(bwd)
+    return out
+
+
+class Plain:
+    """Output of a Linear without BatchNorm: (rows, ld) buffer + gradient buffer of the same shape."""
+    __slots__ = ('t', 'grad')
+
+    def __init__(self, t):
+        self.t, self.grad = t, None
+
+
+def linear_into(ctx, src, lin, out, off):
+    """out.t[:, off:off+Cout] = Linear(src).  `out` is a Plain shared by several projections."""
+    L, s = ctx.L, ctx.stream
+    x, strides, (B, H, W, Cin), tf, sc, sh, rowstat = _src_desc(src)
+    w, b = lin.weight, lin.bias
+    Cout = w.shape[0]
+    ld = out.t.shape[-1]
+    L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, 1, 1, Cout, out.t, ld, off, None, None, 0,
+                   tf, sc, sh, rowstat, None, s)
+
+    def bwd():
+        _conv_backward(ctx, src, w, b, 1, 1, Cout, out.grad, ld, off, None, None)
+    ctx.push(bwd)
+
+
+def linear_residual(ctx, o, lin, res, res2=None, drop=None):
+    """x_new = res (+ res2) + scale*Linear(o).  `drop` = (mask|None, mscale, rowscale|None) in training
+    for nn.Dropout / DropPath; otherwise the residual adds are fused into the GEMM epilogue."""
+    L, s = ctx.L, ctx.stream
+    B, H, W, C = res.t.shape
+    w, b = lin.weight, lin.bias
+    rows = B * H * W
+    out = Act(torch.empty_like(res.t))
+    strides = _nhwc_strides(B, H, W, C)
+    if drop is None:
+        L.hrf_conv_fwd(o.t, *strides, B, H, W, C, w, b, 1, 1, C, out.t, C, 0, res.t,
+                       res2.t if res2 is not None else None, C, TF_NONE, None, None, None, None, s)
+    else:
+        mask, mscale, rowscale = drop
+        y = torch.empty_like(res.t)
+        L.hrf_conv_fwd(o.t, *strides, B, H, W, C, w, b, 1, 1, C, y, C, 0, None, None, 0,
+                       TF_NONE, None, None, None, None, s)
+        L.hrf_scale_add(y, mask, mscale, rowscale, H * W, res.t, res2.t if res2 is not None else None,
+                        out.t, rows, C, s)
+
+    def bwd():
+        g = out.grad
+        if drop is None:
+            dy = g
+        else:
+            mask, mscale, rowscale = drop
+            dy = torch.empty_like(g)
+            L.hrf_scale_add(g, mask, mscale, rowscale, H * W, None, None, dy, rows, C, s)
+        if w.requires_grad:
+            L.hrf_conv_bwd_weight(dy, C, 0, None, None, None, None, o.t, *strides, B, H, W, C, 1, 1, C,
+                                  TF_NONE, None, None, None, w.grad, b.grad if b is not None else None, s)
+        og, acc = o.grad_target()
+        L.hrf_conv_bwd_data(dy, C, 0, None, None, None, None, w, 1, 1, C, B, H, W, C, og, *strides, acc,
+                            0, None, 0, None, None, 0, None, s)
+        # identity paths: the residual streams receive the output gradient unchanged
+        if res2 is not None and res2.needs_grad:
+            if res2.grad is None and res.grad is None and res.needs_grad:
+                res2.grad = g.clone()
+            else:
+                res2.add_grad(g)
+        if res.needs_grad:
+            res.add_grad(g)
+    ctx.push(bwd)
+    return out
+
+
+def ln_input(ctx, act, ln, cache=None):
+    """LayerNorm as a transform-on-load: only the (mean, rstd) row statistics are computed."""
+    B, H, W, C = act.t.shape
+    key = (id(act), float(ln.eps))
+    if cache is not None and key in cache:
+        rowstat = cache[key]
+    else:
+        rowstat = torch.empty((B * H * W, 2), device=act.t.device, dtype=torch.float32)
+        ctx.L.hrf_ln_stats(act.t, B * H * W, C, float(ln.eps), rowstat, ctx.stream)
+        if cache is not None:
+            cache[key] = rowstat
+    return LNIn(act, rowstat, ln)
+
+
+def window_attention(ctx, q, qoff, k, koff, v, voff, kpad, vpad, kpad_grad, vpad_grad, rpb, heads, dims):
+    """softmax(q k^T d^-1/2 + RPB) v per 7x7 window and head.  q/k/v are Plain projection buffers."""
+    L, s = ctx.L, ctx.stream
+    B, H, W, C = dims
+    o = Act(torch.empty((B, H, W, C), device=q.t.device, dtype=torch.float32))
+    L.hrf_window_attn_fwd(q.t, q.t.shape[-1], qoff, k.t, k.t.shape[-1], koff, v.t, v.t.shape[-1], voff,
+                          kpad, vpad, rpb, o.t, C, B, H, W, C, heads, s)
+
+    def bwd():
+        for p in (q, k, v):
+            if p.grad is None:
+                p.grad = torch.empty_like(p.t)
+        L.hrf_window_attn_bwd(q.t, q.t.shape[-1], qoff, k.t, k.t.shape[-1], koff, v.t, v.t.shape[-1], voff,
+                              kpad, vpad, rpb, o.grad, C,
+                              q.grad, q.grad.shape[-1], qoff, k.grad, k.grad.shape[-1], koff,
+                              v.grad, v.grad.shape[-1], voff, kpad_grad, vpad_grad, rpb.grad,
+                              B, H, W, C, heads, s)
+    ctx.push(bwd)
+    return o
+
+
+# ----------------------------------------------------------------------------- depthwise conv
+def dwconv_bn(ctx, src, conv, bn, mode):
+    L, s = ctx.L, ctx.stream
+    x, _, (B, H, W, C), tf, sc, sh, _ = _src_desc(src)
+    w, b = conv.weight, conv.bias
+    stride = conv.stride[0]
+    Ho, Wo = _conv_out_hw(H, W, 3, stride)
+    y = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.float32)
+    slot = ctx.owner._bn_slot(bn)
+    train = ctx.training and bn.training
+    stats = slot['stats'] if train else None
+    L.hrf_dwconv_fwd(x, B, H, W, C, w, b, stride, tf, sc, sh, y, stats, s)
+    st = bn_forward(ctx, bn, y, stats)
+    out = Lazy(st, mode)
+
+    def bwd():
+        cA, cB, cC = bn_backward_coef(ctx, st)
+        if w.requires_grad:
+            L.hrf_dwconv_bwd_weight(st.du, st.raw, cA, cB, cC, x, B, H, W, C, stride, tf, sc, sh, w.grad,
+                                    b.grad if b is not None else None, s)
+        if isinstance(src, Lazy):
+            ps = src.st
+            ps.du = torch.empty_like(ps.raw)
+            L.hrf_dwconv_bwd_data(st.du, st.raw, cA, cB, cC, w, stride, B, H, W, C, ps.du, 0, 1, ps.raw,
+                                  ps.scale, ps.shift, _TF2ACT[src.mode], ps.gstats, s)
+        elif src.needs_grad:
+            g, acc = src.grad_target()
+            L.hrf_dwconv_bwd_data(st.du, st.raw, cA, cB, cC, w, stride, B, H, W, C, g, acc, 0, None, None,
+                                  None, 0, None, s)
+        st.du = None
+    ctx.push(bwd)
+    return out
+
+
+# ----------------------------------------------------------------------------- materialisation
+def materialize(ctx, lazy, act, res=None, lazy2=None, act_first=False, rowscale=None):
+    """Store act(BN(raw)) [+res] [+BN2(raw2)] as an NHWC tensor.
+
+    act_first=True : out = res + rowscale*act(BN(raw))           (CrossFFN tail, DropPath scale)
+    act_first=False: out = act(BN(raw) + res + BN2(raw2))        (Bottleneck tail / transition ReLU)
+    """
+    L, s = ctx.L, ctx.stream
+    st = lazy.st
+    B, H, W, C = st.raw.shape
+    rows = B * H * W
+    out = Act(torch.empty_like(st.raw))
+    st2 = lazy2.st if lazy2 is not None else None
+    L.hrf_affine_act_res(st.raw, st.scale, st.shift, st2.raw if st2 else None, st2.scale if st2 else None,
+                         st2.shift if st2 else None, res.t if res is not None else None, rowscale, H * W,
+                         act, 1 if act_first else 0, out.t, rows, C, s)
+
+    def bwd():
+        g = torch.empty_like(out.t)
+        if act_first:
+            assert act == ACT_GELU and st2 is None
+            L.hrf_act_bwd(out.grad, None, st.raw, st.scale, st.shift, rowscale, H * W, 1, g, None, None,
+                          st.gstats, None, None, rows, C, s)
+            st.du = g
+            if res is not None and res.needs_grad:
+                res.add_grad(out.grad)
+        else:
+            mode = 0 if act == ACT_RELU else 2
+            L.hrf_act_bwd(out.grad, out.t, st.raw, None, None, None, 1, mode, g, st2.raw if st2 else None, None,
+                          st.gstats, st2.gstats if st2 else None, None, rows, C, s)
+            st.du = g
+            if st2 is not None:
+                st2.du = g
+            if res is not None and res.needs_grad:
+                # g stays alive as st.du for the producer conv's backward -> never alias it
+                if res.grad is None:
+                    res.grad = g.clone()
+                else:
+                    res.grad.add_(g)
+    ctx.push(bwd)
+    return out
+
+
+def fuse_sum(ctx, dims, terms):
+    """HRModule exchange for one output branch: ReLU(sum terms).  terms: list of
+    ('id', Act) | ('same', Lazy) | ('up', Lazy)   (hrnet.py:192-206)."""
+    L, s = ctx.L, ctx.stream
+    B, H, W, C = dims
+    dev = terms[0][1].t.device if isinstance(terms[0][1], Act) else terms[0][1].raw.device
+    out = Act(torch.empty((B, H, W, C), device=dev, dtype=torch.float32))
+    args = []
+    for kind, t in terms:
+        if kind == 'id':
+            args += [1, t.t, None, None, 0, 0]
+        elif kind == 'same':
+            args += [2, t.raw, t.st.scale, t.st.shift, 0, 0]
+        else:
+            args += [3, t.raw, t.st.scale, t.st.shift, t.raw.shape[1], t.raw.shape[2]]
+    for _ in range(4 - len(terms)):
+        args += [0, None, None, None, 0, 0]
+    L.hrf_fuse_sum(*args, out.t, B, H, W, C, s)
+
+    def bwd():
+        g = torch.empty_like(out.t)
+        same = [t for kind, t in terms if kind == 'same']
+        assert len(same) <= 3
+        ys = [t.raw for t in same] + [None] * (3 - len(same))
+        sts = [t.st.gstats for t in same] + [None] * (3 - len(same))
+        L.hrf_act_bwd(out.grad, out.t, ys[0], None, None, None, 1, 0, g, ys[1], ys[2], sts[0], sts[1], sts[2],
+                      B * H * W, C, s)
+        first_alias = True
+        for kind, t in terms:
+            if kind == 'id':
+                if t.needs_grad:
+                    if t.grad is None and first_alias:
+                        t.grad = g
+                        first_alias = False
+                    else:
+                        t.add_grad(g)
+            elif kind == 'same':
+                t.st.du = g
+            else:
+                st = t.st
+                st.du = torch.empty_like(st.raw)
+                L.hrf_bilinear_up_bwd(g, B, H, W, C, st.raw, st.raw.shape[1], st.raw.shape[2], st.du, st.gstats, s)
+    ctx.push(bwd)
+    return out

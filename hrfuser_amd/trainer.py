@@ -1,0 +1,115 @@
+"""Data-parallel training step for the HIP backbone (one process per GPU, RCCL over xGMI).
+
+Mirrors what the reference gets from mmdet/apis/train.py:113-121 (MMDistributedDataParallel,
+find_unused_parameters=True), nn.SyncBatchNorm and the AdamW `paramwise_cfg` of
+configs/hrfuser/*_fusion.py:37-48 - restricted to the backbone hot path:
+
+  * forward + backward run on the explicit tape (no torch.autograd graph);
+  * every parameter gradient already lives in ONE flat fp32 arena, so the gradient exchange is a
+    handful of large RCCL all-reduces on slices of that arena (no per-parameter bucketing copies,
+    unused parameters such as transition1.0.1.* are simply zeros in the arena);
+  * SyncBN = all-reduce of the per-channel fp64 (sum, sumsq) slots between the producing conv and
+    the BN-finalize kernel (runtime.bn_forward / bn_backward_coef);
+  * the optimizer is one fused AdamW launch over the flat arena with a per-element decay mask
+    (decay_mult=0 for `relative_position_bias_table` and `norm` keys) and a device-side step count;
+  * the whole step is captured into a hipGraph when possible (launch-bound regime at batch 2).
+"""
+import torch
+
+from . import _lib
+from . import runtime as R
+
+NO_DECAY_KEYS = ('absolute_pos_embed', 'relative_position_bias_table', 'norm')
+
+
+class Trainer:
+    def __init__(self, net, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, group=None,
+                 world_size=1, n_buckets=4):
+        self.net = net
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.group, self.world = group, world_size
+        self.n_buckets = n_buckets
+        if world_size > 1:
+            net.set_sync_group(group, world_size)
+        self._ready = False
+        self.graph = None
+
+    # -------------------------------------------------------------------------------------------
+    def _setup(self, device):
+        eng = self.net._engine()
+        eng.ready(device)
+        n = eng.flat_p.numel()
+        self.m = torch.zeros(n, device=device)
+        self.v = torch.zeros(n, device=device)
+        self.state = torch.zeros(4, device=device)
+        mask = torch.ones(n, device=device)
+        for (name, p), (off, cnt) in zip(self.net.named_parameters(), eng._spans):
+            # mmcv DefaultOptimizerConstructor custom_keys: substring match on the parameter name
+            if any(k in name for k in NO_DECAY_KEYS):
+                mask[off:off + cnt] = 0.0
+        self.wd_mask = mask
+        self._ready = True
+
+    def buckets(self, n):
+        """Contiguous slices of the flat gradient arena for the RCCL all-reduce (>= 1 MiB each)."""
+        nb = max(1, min(self.n_buckets, n // (256 * 1024)))
+        step = (n + nb - 1) // nb
+        return [(i, min(n, i + step)) for i in range(0, n, step)]
+
+    def _step_impl(self, x, mods, cots):
+        net = self.net
+        eng = net._engine()
+        L = net._lib_handle()
+        eng.flat_g.zero_()
+        ctx, outs, _ = net._execute((x,) + tuple(mods), True)
+        for o, c in zip(outs, cots):
+            o.grad = c.clone()              # synthetic loss  L = sum_i <out_i, cot_i>   
+        ctx.run_backward()
+        if self.world > 1:
+            import torch.distributed as dist
+            for a, b in self.buckets(eng.flat_g.numel()):
+                dist.all_reduce(eng.flat_g[a:b], group=self.group)
+        s = _lib.stream_ptr()
+        L.hrf_adamw_tick(self.state, self.betas[0], self.betas[1], s)
+        L.hrf_adamw(eng.flat_p, eng.flat_g, self.m, self.v, self.wd_mask, eng.flat_p.numel(), self.lr,
+                    self.betas[0], self.betas[1], self.eps, self.wd, self.state, 1.0 / self.world, s)
+        net.params_updated()
+        return outs
+
+    def step(self, x, mods, cots):
+        """One eager training step (forward, backward, gradient exchange, AdamW)."""
+        if not self._ready:
+            self._setup(x.device)
+        return self._step_impl(x, mods, cots)
+
+    # -------------------------------------------------------------------------------------------
+    def capture(self, x, mods, cots, warmup=2):
+        """Capture the full step into a hipGraph (static input buffers x/mods/cots)."""
+        if not self._ready:
+            self._setup(x.device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step_impl(x, mods, cots)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._graph_outs = self._step_impl(x, mods, cots)
+        self.graph = g
+        return g
+
+    def replay(self):
+        self.graph.replay()
+
+
+def make_cotangents(net, x, mods, seed=5):
+    """Fixed random output cotangents (NHWC) for the synthetic loss, shaped by a dry eval forward."""
+    was = net.training
+    net.eval()
+    with torch.no_grad():
+        ys = net(x, list(mods))
+    net.train(was)
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(tuple(y.permute(0, 2, 3, 1).shape), generator=g).to(x.device) / y.numel() for y in ys]

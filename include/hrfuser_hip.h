@@ -33,7 +33,7 @@ extern "C" {
  *   hrfuser_hrformer_based.py:92-96.  Linear = 1x1 conv over a (1,1,rows,C) view.            */
 int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin,
                  const float* w, const float* bias, int KH, int stride, int Cout,
-                 float* y, int ldY, int yoff, const float* res, int ldR,
+                 float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
                  int tf_mode, const float* tf_scale, const float* tf_shift,
                  const float* tf_rowstat, double* stats, void* stream);
 /* dX (or, epi=1, dU = dX*act'(scale*xraw+shift) plus (sum dU, sum dU*xraw) for the producer BN).
@@ -94,9 +94,10 @@ int hrf_bn_finalize(const double* stats, const float* gamma, const float* beta, 
                     float* running_var, double count, float eps, float momentum, int update_running,
                     float* scale, float* shift, float* mean_out, float* invstd_out, int C, void* stream);
 /* gstats = (sum du, sum du*yraw): dgamma += , dbeta += , and the on-load backward coefficients
- * dy = cA*du + cB*yraw + cC.  train=0: frozen statistics (eval / norm_eval).                    */
-int hrf_bn_bwd_finalize(const double* gstats, const float* gamma, const float* mean, const float* invstd,
-                        double count, int train, float* dgamma, float* dbeta, float* cA, float* cB,
+ * dy = cA*du + cB*yraw + cC.  train=0: frozen statistics (eval / norm_eval).  gstats_local
+ * (nullable) = this rank's moments for the parameter grads when gstats was all-reduced (SyncBN). */
+int hrf_bn_bwd_finalize(const double* gstats, const double* gstats_local, const float* gamma,
+                        const float* mean, const float* invstd, double count, int train, float* dgamma, float* dbeta, float* cA, float* cB,
                         float* cC, int C, void* stream);
 
 /* ---- LayerNorm over channels (F.layer_norm: hrformer.py:343,351; hrfuser_hrformer_based.py:279-291) */
@@ -112,6 +113,11 @@ int hrf_affine_act_res(const float* y1, const float* sc1, const float* sh1, cons
                        const float* sc2, const float* sh2, const float* res, const float* rowscale,
                        int rows_per_sample, int act, int act_first, float* out, long rows, int C,
                        void* stream);
+/* out = res + res2 + y*mask*mscale*rowscale[b]: nn.Dropout(proj_drop) hrfuser_hrformer_based.py:97
+ * and mmcv DropPath hrfuser_hrformer_based.py:301-315 arithmetic (mask / rowscale nullable).    */
+int hrf_scale_add(const float* y, const float* mask, float mscale, const float* rowscale,
+                  int rows_per_sample, const float* res, const float* res2, float* out, long rows, int C,
+                  void* stream);
 /* mode 0: g = dout*(out>0); 1: g = dout*rowscale*gelu'(sc*y1+sh); 2: g = dout.  st_k (nullable)
  * accumulate (sum g, sum g*y_k) for the BatchNorms whose output fed the activation.            */
 int hrf_act_bwd(const float* dout, const float* out, const float* y1, const float* sc, const float* sh,

@@ -1,0 +1,354 @@
+"""Kernel-level parity through the C ABI: every entry point of include/hrfuser_hip.h against plain
+PyTorch fp32/fp64 math of the same op (the oracle's building blocks)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import hrfuser_oracle as O
+from helpers import use_backend
+from hrfuser_amd import _lib
+
+TOL = 2e-5
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def r(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _tf_apply(x, tf, sc, sh):
+    """reference of the transform-on-load; returns (u leaf, transformed, rowstat)"""
+    if tf == 4:
+        xl = nhwc(x)
+        mean = xl.mean(-1, keepdim=True)
+        rstd = (xl.var(-1, unbiased=False, keepdim=True) + 1e-6).rsqrt()
+        rowstat = torch.cat([mean, rstd], -1).reshape(-1, 2).contiguous()
+        u = (((xl - mean) * rstd) * sc + sh).permute(0, 3, 1, 2).detach().requires_grad_(True)
+        return u, u, rowstat
+    if tf:
+        u = (x * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+        return u, (u if tf == 1 else (F.relu(u) if tf == 2 else F.gelu(u))), None
+    u = x.clone().requires_grad_(True)
+    return u, u, None
+
+
+CONV_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
+    (2, 9, 11, 18, 72, 1, 1, 4, True, False),
+    (2, 9, 11, 72, 18, 1, 1, 3, True, True),
+    (2, 10, 13, 64, 64, 3, 1, 2, True, True),
+    (2, 10, 13, 20, 36, 3, 2, 0, False, False),
+    (2, 11, 13, 20, 36, 3, 2, 2, True, True),
+    (1, 6, 5, 256, 18, 3, 1, 0, True, False),
+    (3, 40, 50, 16, 40, 1, 1, 1, False, True),
+    (2, 16, 24, 64, 256, 1, 1, 2, True, True),
+    (1, 50, 130, 64, 64, 3, 1, 2, True, True),      # M >= 128*.. exercises the BM=128 tile on GPU sizes
+]
+
+
+def run_conv(case, backend):
+    dev = use_backend(backend)
+    L = _lib.lib()
+    B, H, W, Cin, Cout, KH, stride, tf, bnb, epi = case
+    g = torch.Generator().manual_seed(sum(case[:7]))
+    rn = lambda *s: torch.randn(*s, generator=g)
+    xraw, w, bias = rn(B, Cin, H, W), rn(Cout, Cin, KH, KH) * 0.2, rn(Cout)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, rn(Cin) * 0.3
+    u, xt, rowstat = _tf_apply(xraw, tf, sc, sh)
+    wq, bq = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    y = F.conv2d(xt, wq, bq, stride, KH // 2)
+    Ho, Wo = y.shape[2:]
+    res = rn(B, Ho, Wo, Cout)
+    yref = nhwc(y.detach()) + res
+    D = lambda t: None if t is None else t.to(dev)
+    xr = nhwc(xraw)
+    st = (H * W * Cin, W * Cin, Cin, 1)
+    yk = torch.zeros(B, Ho, Wo, Cout, device=dev)
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    L.hrf_conv_fwd(D(xr), *st, B, H, W, Cin, D(w), D(bias), KH, stride, Cout, yk, Cout, 0, D(res), None, Cout,
+                   tf, D(sc) if tf else None, D(sh) if tf else None, D(rowstat), stats, _lib.stream_ptr())
+    assert r(yk, yref) < TOL
+    s1, s2 = yref.reshape(-1, Cout).double().sum(0), (yref.reshape(-1, Cout).double() ** 2).sum(0)
+    assert r(stats[:Cout], s1) < TOL and r(stats[Cout:], s2) < TOL
+    # NCHW input through strides (stem path)
+    if tf == 0:
+        yk2 = torch.zeros_like(yk)
+        L.hrf_conv_fwd(D(xraw.contiguous()), Cin * H * W, W, 1, H * W, B, H, W, Cin, D(w), D(bias), KH, stride, Cout,
+                       yk2, Cout, 0, None, None, 0, 0, None, None, None, None, _lib.stream_ptr())
+        assert r(yk2, nhwc(y.detach())) < TOL
+    # ---- backward
+    du, yraw = rn(B, Ho, Wo, Cout), rn(B, Ho, Wo, Cout)
+    cA, cB, cC = rn(Cout), rn(Cout) * 0.3, rn(Cout) * 0.1
+    dyeff = cA * du + cB * yraw + cC if bnb else du
+    y.backward(dyeff.permute(0, 3, 1, 2))
+    gu = nhwc(u.grad)
+    co = (D(cA), D(cB), D(cC)) if bnb else (None, None, None)
+    act = {0: 0, 1: 0, 2: 1, 3: 2, 4: 0}[tf]
+    dx = torch.zeros(B, H, W, Cin, device=dev)
+    if epi:
+        gst = torch.zeros(2 * Cin, dtype=torch.float64, device=dev)
+        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), *co, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 0, 1,
+                            D(xr), Cin, D(sc), D(sh), act, gst, _lib.stream_ptr())
+        assert r(dx, gu) < TOL
+        assert r(gst[:Cin], gu.reshape(-1, Cin).double().sum(0)) < TOL
+        assert r(gst[Cin:], (gu.reshape(-1, Cin).double() * xr.reshape(-1, Cin).double()).sum(0)) < TOL
+    else:
+        base = rn(B, H, W, Cin)
+        dx.copy_(base)
+        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), *co, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 1, 0,
+                            None, 0, None, None, 0, None, _lib.stream_ptr())
+        assert r(dx, gu + base) < TOL
+    dw, db = torch.zeros_like(w, device=dev), torch.zeros(Cout, device=dev)
+    L.hrf_conv_bwd_weight(D(du), Cout, 0, D(yraw), *co, D(xr), *st, B, H, W, Cin, KH, stride, Cout, tf,
+                          D(sc) if tf else None, D(sh) if tf else None, D(rowstat), dw, db, _lib.stream_ptr())
+    assert r(dw, wq.grad) < TOL and r(db, bq.grad) < TOL
+
+
+DW_CASES = [(2, 9, 11, 72, 1, 3, True, True, True), (2, 17, 35, 40, 1, 0, False, False, False),
+            (2, 10, 13, 18, 2, 0, False, True, False), (2, 11, 15, 36, 2, 2, False, True, True),
+            (1, 16, 32, 33, 2, 1, False, False, True)]
+
+
+def run_dw(case, backend):
+    dev = use_backend(backend)
+    L = _lib.lib()
+    B, H, W, C, S, tf, has_bias, bnb, epi = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    rn = lambda *s: torch.randn(*s, generator=g)
+    D = lambda t: None if t is None else t.to(dev)
+    xraw, w = rn(B, C, H, W), rn(C, 1, 3, 3) * 0.3
+    b = rn(C) if has_bias else None
+    sc, sh = torch.rand(C, generator=g) + 0.5, rn(C) * 0.3
+    u, xt, _ = _tf_apply(xraw, tf, sc, sh)
+    wq, bq = w.clone().requires_grad_(True), torch.zeros(C, requires_grad=True)
+    y = F.conv2d(xt, wq, (b + bq) if has_bias else bq, S, 1, groups=C)
+    Ho, Wo = y.shape[2:]
+    yk = torch.zeros(B, Ho, Wo, C, device=dev)
+    st = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    xr = nhwc(xraw)
+    L.hrf_dwconv_fwd(D(xr), B, H, W, C, D(w), D(b), S, tf, D(sc) if tf else None, D(sh) if tf else None, yk, st,
+                     _lib.stream_ptr())
+    yr = nhwc(y.detach())
+    assert r(yk, yr) < TOL
+    assert r(st[:C], yr.reshape(-1, C).double().sum(0)) < TOL and r(st[C:], (yr.reshape(-1, C).double() ** 2).sum(0)) < TOL
+    du, yraw = rn(B, Ho, Wo, C), rn(B, Ho, Wo, C)
+    cA, cB, cC = rn(C), rn(C) * 0.3, rn(C) * 0.1
+    y.backward((cA * du + cB * yraw + cC if bnb else du).permute(0, 3, 1, 2))
+    gu = nhwc(u.grad)
+    co = (D(cA), D(cB), D(cC)) if bnb else (None, None, None)
+    act = {0: 0, 1: 0, 2: 1, 3: 2}[tf]
+    dx = torch.zeros(B, H, W, C, device=dev)
+    if epi:
+        gst = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        L.hrf_dwconv_bwd_data(D(du), D(yraw), *co, D(w), S, B, H, W, C, dx, 0, 1, D(xr), D(sc), D(sh), act, gst,
+                              _lib.stream_ptr())
+        assert r(dx, gu) < TOL
+        assert r(gst[C:], (gu.reshape(-1, C).double() * xr.reshape(-1, C).double()).sum(0)) < TOL
+    else:
+        base = rn(B, H, W, C)
+        dx.copy_(base)
+        L.hrf_dwconv_bwd_data(D(du), D(yraw), *co, D(w), S, B, H, W, C, dx, 1, 0, None, None, None, 0, None,
+                              _lib.stream_ptr())
+        assert r(dx, gu + base) < TOL
+    dw, db = torch.zeros_like(w, device=dev), torch.zeros(C, device=dev)
+    L.hrf_dwconv_bwd_weight(D(du), D(yraw), *co, D(xr), B, H, W, C, S, tf, D(sc) if tf else None,
+                            D(sh) if tf else None, dw, db, _lib.stream_ptr())
+    assert r(dw, wq.grad) < TOL and r(db, bq.grad) < TOL
+
+
+ATTN_CASES = [(2, 10, 13, 18, 1), (1, 7, 7, 36, 2), (2, 15, 8, 72, 4), (1, 9, 16, 78, 2), (1, 6, 10, 64, 8),
+              (3, 20, 31, 18, 1)]
+
+
+def run_attn(case, backend):
+    dev = use_backend(backend)
+    L = _lib.lib()
+    B, H, W, C, heads = case
+    P = B * H * W
+    g = torch.Generator().manual_seed(sum(case))
+    rn = lambda *s: torch.randn(*s, generator=g)
+    q, kv = rn(P, C).requires_grad_(True), rn(P, 2 * C).requires_grad_(True)
+    kb, vb = rn(C).requires_grad_(True), rn(C).requires_grad_(True)
+    T = (rn(169, heads) * 0.5).requires_grad_(True)
+    idx = O.rel_pos_index()
+
+    def part(t, padval):     # padded tokens carry the projection bias (zero input after LayerNorm)
+        return O.window_partition(t.view(B, H * W, -1) - padval, H, W) + padval
+    ow = O._window_attention_core(O.window_partition(q.view(B, H * W, C), H, W), part(kv[:, :C], kb),
+                                  part(kv[:, C:], vb), heads, T, idx)
+    o_ref = O.window_merge(ow, B, H, W).reshape(P, C)
+    go = rn(P, C)
+    o_ref.backward(go)
+    D = lambda t: t.detach().to(dev)
+    qd, kvd, kbd, vbd, Td = D(q), D(kv), D(kb), D(vb), D(T)
+    o = torch.zeros(P, C, device=dev)
+    s = _lib.stream_ptr()
+    L.hrf_window_attn_fwd(qd, C, 0, kvd, 2 * C, 0, kvd, 2 * C, C, kbd, vbd, Td, o, C, B, H, W, C, heads, s)
+    assert r(o, o_ref) < TOL
+    dq, dkv = torch.zeros(P, C, device=dev), torch.zeros(P, 2 * C, device=dev)
+    dkb, dvb, dT = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(169, heads, device=dev)
+    L.hrf_window_attn_bwd(qd, C, 0, kvd, 2 * C, 0, kvd, 2 * C, C, kbd, vbd, Td, D(go), C, dq, C, 0, dkv, 2 * C, 0,
+                          dkv, 2 * C, C, dkb, dvb, dT, B, H, W, C, heads, s)
+    assert r(dq, q.grad) < TOL and r(dkv, kv.grad) < TOL and r(dT, T.grad) < TOL
+    if (H % 7) or (W % 7):
+        assert r(dkb, kb.grad) < 1e-4 and r(dvb, vb.grad) < TOL
+
+
+def run_pointwise(backend):
+    dev = use_backend(backend)
+    L = _lib.lib()
+    s = _lib.stream_ptr()
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *sh: torch.randn(*sh, generator=g)
+    D = lambda t: None if t is None else t.detach().to(dev)
+    # ---- BatchNorm train forward/backward through the finalize kernels
+    B, H, W, C = 2, 7, 9, 20
+    y = rn(B, H, W, C) * 2 + 1
+    yq = y.clone().requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(rn(C))
+        bn.running_mean.copy_(rn(C)); bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    rm, rv = D(bn.running_mean), D(bn.running_var)
+    out = F.relu(bn(yq.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+    gg = rn(B, H, W, C)
+    out.backward(gg)
+    st = torch.stack([y.reshape(-1, C).double().sum(0), (y.reshape(-1, C).double() ** 2).sum(0)]).reshape(-1).to(dev)
+    sc, sh, mean, inv = (torch.zeros(C, device=dev) for _ in range(4))
+    n = float(B * H * W)
+    L.hrf_bn_finalize(st, D(bn.weight), D(bn.bias), rm, rv, n, 1e-5, 0.1, 1, sc, sh, mean, inv, C, s)
+    o = torch.zeros(B, H, W, C, device=dev)
+    L.hrf_affine_act_res(D(y), sc, sh, None, None, None, None, None, 1, 1, 0, o, B * H * W, C, s)
+    assert r(o, out) < TOL and r(rm, bn.running_mean) < TOL and r(rv, bn.running_var) < TOL
+    gk = torch.zeros(B, H, W, C, device=dev)
+    gst = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    L.hrf_act_bwd(D(gg), o, D(y), None, None, None, 1, 0, gk, None, None, gst, None, None, B * H * W, C, s)
+    dg, db, cA, cB, cC = (torch.zeros(C, device=dev) for _ in range(5))
+    L.hrf_bn_bwd_finalize(gst, None, D(bn.weight), mean, inv, n, 1, dg, db, cA, cB, cC, C, s)
+    assert r(cA * gk + cB * D(y) + cC, yq.grad) < TOL and r(dg, bn.weight.grad) < TOL and r(db, bn.bias.grad) < TOL
+    # ---- CrossFFN tail: res + rowscale*gelu(bn(y)) and its adjoint
+    res, rs = rn(B, H, W, C), torch.tensor([0.0, 1.25])
+    L.hrf_affine_act_res(D(y), sc, sh, None, None, None, D(res), D(rs), H * W, 2, 1, o, B * H * W, C, s)
+    ref = res + rs.view(B, 1, 1, 1) * F.gelu(y * sc.cpu() + sh.cpu())
+    assert r(o, ref) < TOL
+    uq = (y * sc.cpu() + sh.cpu()).requires_grad_(True)
+    (F.gelu(uq) * rs.view(B, 1, 1, 1) * gg).sum().backward()
+    L.hrf_act_bwd(D(gg), None, D(y), sc, sh, D(rs), H * W, 1, gk, None, None, gst.zero_(), None, None, B * H * W, C, s)
+    assert r(gk, uq.grad) < TOL
+    # ---- dropout / droppath arithmetic
+    mask = torch.empty(B, H, W, C).bernoulli_(0.9, generator=g)
+    L.hrf_scale_add(D(y), D(mask), 1 / 0.9, D(rs), H * W, D(res), D(gg), o, B * H * W, C, s)
+    assert r(o, res + gg + y * mask / 0.9 * rs.view(B, 1, 1, 1)) < TOL
+    # ---- LayerNorm
+    rows, Cl = 37, 18
+    x = rn(rows, Cl) * 2 + 0.5
+    xq = x.clone().requires_grad_(True)
+    ln = torch.nn.LayerNorm(Cl, eps=1e-6)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(Cl, generator=g) + 0.5); ln.bias.copy_(rn(Cl))
+    da = rn(rows, Cl)
+    ln(xq).backward(da)
+    rsb = torch.zeros(rows, 2, device=dev)
+    L.hrf_ln_stats(D(x), rows, Cl, 1e-6, rsb, s)
+    assert r(rsb[:, 0], x.mean(-1)) < TOL and r(rsb[:, 1], (x.var(-1, unbiased=False) + 1e-6).rsqrt()) < TOL
+    base = rn(rows, Cl)
+    dx, dgl, dbl = D(base).clone(), torch.zeros(Cl, device=dev), torch.zeros(Cl, device=dev)
+    L.hrf_ln_bwd(D(da), D(x), rsb, D(ln.weight), rows, Cl, dx, 1, dgl, dbl, s)
+    assert r(dx, xq.grad + base) < TOL and r(dgl, ln.weight.grad) < TOL and r(dbl, ln.bias.grad) < TOL
+    # ---- cross-resolution exchange + bilinear adjoint (x2, x4, non-integer ratio)
+    B, H, W, C = 2, 12, 20, 10
+    x0 = rn(B, H, W, C).requires_grad_(True)
+    ylo, ylo2 = rn(B, 6, 10, C).requires_grad_(True), rn(B, 3, 5, C).requires_grad_(True)
+    ysame = rn(B, H, W, C).requires_grad_(True)
+    scs = [torch.rand(C, generator=g) + 0.5 for _ in range(3)]
+    shs = [rn(C) for _ in range(3)]
+    up = lambda t, a, b: F.interpolate((t * a + b).permute(0, 3, 1, 2), size=(H, W), mode='bilinear',
+                                       align_corners=False).permute(0, 2, 3, 1)
+    ref = F.relu(x0 + up(ylo, scs[0], shs[0]) + up(ylo2, scs[1], shs[1]) + (ysame * scs[2] + shs[2]))
+    gg = rn(B, H, W, C)
+    ref.backward(gg)
+    o = torch.zeros(B, H, W, C, device=dev)
+    L.hrf_fuse_sum(1, D(x0), None, None, 0, 0, 3, D(ylo), D(scs[0]), D(shs[0]), 6, 10, 3, D(ylo2), D(scs[1]),
+                   D(shs[1]), 3, 5, 2, D(ysame), D(scs[2]), D(shs[2]), 0, 0, o, B, H, W, C, s)
+    assert r(o, ref) < TOL
+    gk = torch.zeros(B, H, W, C, device=dev)
+    st3 = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    L.hrf_act_bwd(D(gg), o, D(ysame), None, None, None, 1, 0, gk, None, None, st3, None, None, B * H * W, C, s)
+    assert r(gk, x0.grad) < TOL
+    assert r(st3[C:], (x0.grad.reshape(-1, C).double() * ysame.detach().reshape(-1, C).double()).sum(0)) < TOL
+    du, stl = torch.zeros(B, 6, 10, C, device=dev), torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    L.hrf_bilinear_up_bwd(gk, B, H, W, C, D(ylo), 6, 10, du, stl, s)
+    assert r(du * D(scs[0]), ylo.grad) < TOL and r(stl[:C], du.reshape(-1, C).double().sum(0)) < TOL
+    du2 = torch.zeros(B, 3, 5, C, device=dev)
+    L.hrf_bilinear_up_bwd(gk, B, H, W, C, D(ylo2), 3, 5, du2, None, s)
+    assert r(du2 * D(scs[1]), ylo2.grad) < TOL
+    ylo3 = rn(1, 8, 4, C).requires_grad_(True)
+    ref3 = F.interpolate(ylo3.permute(0, 3, 1, 2), size=(15, 7), mode='bilinear', align_corners=False).permute(0, 2, 3, 1)
+    g3 = rn(1, 15, 7, C)
+    ref3.backward(g3)
+    du3 = torch.zeros(1, 8, 4, C, device=dev)
+    L.hrf_bilinear_up_bwd(D(g3), 1, 15, 7, C, D(ylo3), 8, 4, du3, None, s)
+    o3 = torch.zeros(1, 15, 7, C, device=dev)
+    one, zero = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    L.hrf_fuse_sum(3, D(ylo3), one, zero, 8, 4, 0, None, None, None, 0, 0, 0, None, None, None, 0, 0, 0, None, None,
+                   None, 0, 0, o3, 1, 15, 7, C, s)
+    assert r(o3, F.relu(ref3)) < TOL and r(du3, ylo3.grad) < TOL
+    # ---- AdamW vs torch.optim.AdamW (3 steps, device-side step counter)
+    n = 1000
+    p, gr = rn(n), rn(n)
+    pp = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([pp], lr=3e-4, weight_decay=0.01)
+    pk, gk2, m, v, state = D(p).clone(), D(gr), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(4, device=dev)
+    for _ in range(3):
+        pp.grad = gr.clone()
+        opt.step()
+        L.hrf_adamw_tick(state, 0.9, 0.999, s)
+        L.hrf_adamw(pk, gk2, m, v, None, n, 3e-4, 0.9, 0.999, 1e-8, 0.01, state, 1.0, s)
+    assert r(pk, pp.data) < TOL and float(state[2]) == 3.0
+
+
+# ------------------------------------------------------------------ emulator (CPU suite)
+@pytest.mark.parametrize('case', CONV_CASES[:8], ids=str)
+def test_conv_emul(case):
+    run_conv(case, 'emul')
+
+
+@pytest.mark.parametrize('case', DW_CASES, ids=str)
+def test_dwconv_emul(case):
+    run_dw(case, 'emul')
+
+
+@pytest.mark.parametrize('case', ATTN_CASES[:5], ids=str)
+def test_attention_emul(case):
+    run_attn(case, 'emul')
+
+
+def test_pointwise_emul():
+    run_pointwise('emul')
+
+
+# ------------------------------------------------------------------ MI355X (product path)
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', CONV_CASES, ids=str)
+def test_conv_gpu(case):
+    run_conv(case, 'hip')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', DW_CASES, ids=str)
+def test_dwconv_gpu(case):
+    run_dw(case, 'hip')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ATTN_CASES, ids=str)
+def test_attention_gpu(case):
+    run_attn(case, 'hip')
+
+
+@pytest.mark.gpu
+def test_pointwise_gpu():
+    run_pointwise('hip')

@@ -1,0 +1,98 @@
+"""Block-level parity: product blocks (HIP kernels) vs the oracle, forward + backward.
+Same cases as the reference-derived module fixtures (tests/golden/modules.npz)."""
+import copy
+
+import pytest
+import torch
+
+import hrfuser_oracle as O
+from helpers import LN, NORM, disable_stochastic, relmax, use_backend
+
+import hrfuser_amd.backbone as B
+from hrfuser_amd.testing import BlockHarness
+
+CH, HD = (8, 16, 32, 64), (1, 2, 4, 8)
+
+
+def _cases():
+    ds = lambda: torch.nn.Sequential(torch.nn.Conv2d(16, 64, 1, bias=False), torch.nn.BatchNorm2d(64))
+    c = {}
+    c['bottleneck_first'] = (lambda: B.Bottleneck(16, 16, NORM, ds()), lambda k, b, x: b.run(k, x[0]),
+                             lambda: O.Bottleneck(16, 16, NORM, ds()), lambda m, i: m(i[0]), [(2, 16, 9, 10)])
+    c['bottleneck_plain'] = (lambda: B.Bottleneck(64, 16, NORM), lambda k, b, x: b.run(k, x[0]),
+                             lambda: O.Bottleneck(64, 16, NORM), lambda m, i: m(i[0]), [(2, 64, 9, 10)])
+    c['block_c36_h2'] = (lambda: B.HRFormerBlock(36, 36, 2, norm_cfg=NORM, transformer_norm_cfg=LN),
+                         lambda k, b, x: b.run(k, x[0]), lambda: O.HRFormerBlock(36, 2, 4, NORM, LN),
+                         lambda m, i: m(i[0]), [(2, 36, 9, 12)])
+    c['block_c78_h2'] = (lambda: B.HRFormerBlock(78, 78, 2, norm_cfg=NORM, transformer_norm_cfg=LN),
+                         lambda k, b, x: b.run(k, x[0]), lambda: O.HRFormerBlock(78, 2, 4, NORM, LN),
+                         lambda m, i: m(i[0]), [(1, 78, 9, 16)])
+    for (ch, h, M, H, W) in ((18, 1, 2, 10, 13), (36, 2, 3, 8, 15)):
+        c[f'fusion_c{ch}_M{M}'] = (
+            lambda ch=ch, h=h, M=M: B.HRFuserFusionBlock(ch, ch, h, norm_cfg=NORM, transformer_norm_cfg=LN,
+                                                         num_fused_modalities=M, drop_path=0.2, proj_drop_rate=0.1),
+            lambda k, b, x: b.run(k, x[0], x[1:]),
+            lambda ch=ch, h=h, M=M: O.HRFuserFusionBlock(ch, h, 4, NORM, LN, 0.2, M, 0.1),
+            lambda m, i: m(i[0], list(i[1:])), [(2, ch, H, W)] * (M + 1))
+    for nb in (2, 3, 4):
+        c[f'hrmodule_{nb}b'] = (
+            lambda nb=nb: B.HRFomerModule(nb, B.HRFormerBlock, (1,) * nb, list(CH[:nb]), CH[:nb], HD[:nb],
+                                          (7,) * nb, (4,) * nb, norm_cfg=NORM, transformer_norm_cfg=LN),
+            lambda k, b, x: b.run(k, x),
+            lambda nb=nb: O.HRFormerModule(list(CH[:nb]), (1,) * nb, HD[:nb], (4,) * nb, NORM, LN),
+            lambda m, i: m(list(i)), [(2, CH[i], 24 >> i, 40 >> i) for i in range(nb)])
+    return c
+
+
+CASES = _cases()
+
+
+def run_case(name, train, backend):
+    dev = use_backend(backend)
+    mk_prod, runner, mk_orc, orc_call, shapes = CASES[name]
+    orc = mk_orc()
+    O.seeded_fill_(orc, 3)
+    h = BlockHarness(mk_prod(), runner)
+    h.block.load_state_dict(orc.state_dict(), strict=True)
+    h.to(dev)
+    orc = orc.double()
+    disable_stochastic(h, orc)
+    h.train(train)
+    orc.train(train)
+    ins = [torch.randn(s, generator=torch.Generator().manual_seed(40 + i)) for i, s in enumerate(shapes)]
+    a = [t.clone().to(dev).requires_grad_(True) for t in ins]
+    b = [t.clone().double().requires_grad_(True) for t in ins]
+    ya = h(*a)
+    yb = orc_call(orc, b)
+    yb = list(yb) if isinstance(yb, (list, tuple)) else [yb]
+    g = torch.Generator().manual_seed(7)
+    cots = [torch.randn(y.shape, generator=g) for y in yb]
+    sum((y * c.to(dev)).sum() for y, c in zip(ya, cots)).backward()
+    sum((y * c.double()).sum() for y, c in zip(yb, cots)).backward()
+    for p, q in zip(ya, yb):
+        assert relmax(p, q) < 1e-4, (name, 'out')            # north-star gate is 1e-3
+    for p, q in zip(a, b):
+        assert relmax(p.grad, q.grad) < 1e-3, (name, 'din')
+    pa, pb = dict(h.block.named_parameters()), dict(orc.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in pb.values() if q.grad is not None)
+    for k, q in pb.items():
+        if q.grad is None:
+            continue
+        # absolute floor covers analytically-zero grads (k-bias; biases feeding a train-mode BN)
+        scale = max(float(q.grad.abs().max()), 1e-3 * gmax)
+        err = float((pa[k].grad.double().cpu() - q.grad).abs().max()) / scale
+        assert err < 1e-3, (name, k, err)
+
+
+@pytest.mark.parametrize('train', [False, True])
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_block_emul(name, train):
+    """kernel-logic check on the CPU fiber emulator (not a product path)"""
+    run_case(name, train, 'emul')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('train', [False, True])
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_block_gpu(name, train):
+    run_case(name, train, 'hip')

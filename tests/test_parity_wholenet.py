@@ -1,0 +1,111 @@
+"""Whole-backbone parity: product (HIP) vs oracle and vs the reference-derived golden vectors."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hrfuser_oracle as O
+from helpers import ROOT, build_pair, grad_check, relmax, use_backend
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _fwd_bwd(tag, B, H, W, train, backend, check_grads=True, gold_key=None):
+    dev = use_backend(backend)
+    net, orc, cfg = build_pair(tag, dev)
+    mc = cfg.get('mod_in_channels', [3, 3])
+    x, mods = O.seeded_inputs(B, H, W, mc, seed=1)
+    net.train(train)
+    orc.train(train)
+    o64 = copy.deepcopy(orc).double()
+    xa = x.clone().to(dev).requires_grad_(check_grads)
+    ma = [m.clone().to(dev).requires_grad_(check_grads) for m in mods]
+    ya = net(xa, list(ma))
+    xb = x.double().requires_grad_(check_grads)
+    mb = [m.double().requires_grad_(check_grads) for m in mods]
+    with torch.set_grad_enabled(check_grads):
+        yb = o64(xb, list(mb))
+    assert len(ya) == 4
+    for i, (p, q) in enumerate(zip(ya, yb)):
+        assert tuple(p.shape) == tuple(q.shape)
+        assert relmax(p, q) < 1e-3, (tag, train, i, relmax(p, q))      # north-star gate: 1e-3 rel fp32
+    if gold_key is not None:
+        gold = np.load(os.path.join(GOLD, f'wholenet_{tag}.npz'))
+        mode = 'train' if train else 'eval'
+        for i, p in enumerate(ya):
+            assert relmax(p, torch.as_tensor(gold[f'{gold_key}/{mode}/out{i}'])) < 1e-3
+    if not check_grads:
+        return
+    g = torch.Generator().manual_seed(5)
+    cots = [torch.randn(t.shape, generator=g) for t in yb]
+    sum((t * c.to(dev)).sum() for t, c in zip(ya, cots)).backward()
+    sum((t * c.double()).sum() for t, c in zip(yb, cots)).backward()
+    assert relmax(xa.grad, xb.grad) < 2e-2 if train else 1e-3
+    for p, q in zip(ma, mb):
+        assert relmax(p.grad, q.grad) < (2e-2 if train else 1e-3)
+    grad_check(net.named_parameters(), o64.named_parameters(), tol=2e-2 if train else 1e-3)
+    # quirk App. D-1: transition1.0.1 never receives a gradient
+    assert float(dict(net.named_parameters())['transition1.0.1.weight'].grad.abs().max()) == 0.0
+
+
+def test_wholenet_emul_eval():
+    """T backbone, tiny input, eval BN, fwd+bwd on the CPU emulator (kernel-logic check)."""
+    _fwd_bwd('t_nus', 1, 32, 64, False, 'emul')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['t_nus', 'b_nus', 't_stf'])
+def test_wholenet_gpu_eval_small(tag):
+    _fwd_bwd(tag, 2, 64, 96, False, 'hip', gold_key='B2_64x96')
+
+
+@pytest.mark.gpu
+def test_wholenet_gpu_eval_transposed():
+    _fwd_bwd('t_nus', 1, 96, 64, False, 'hip', gold_key='B1_96x64')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['t_nus', 'b_nus', 't_stf'])
+def test_wholenet_gpu_train_small(tag):
+    # 64x96 leaves 2*2*3 = 12 BN samples at stride 32: the oracle's own fp32-vs-fp64 noise is
+    # ~1e-5 on outputs and up to 1e-2 on some gradients there, hence the wider grad gate
+    _fwd_bwd(tag, 2, 64, 96, True, 'hip', gold_key='B2_64x96')
+
+
+@pytest.mark.gpu
+def test_wholenet_gpu_train_medium():
+    _fwd_bwd('t_nus', 2, 192, 320, True, 'hip')
+
+
+@pytest.mark.gpu
+def test_fullres_digest_gpu():
+    """BASELINE config[0]/[1] shape: 384x640 + lidar + radar, eval B=1 and train B=2 digests."""
+    dev = use_backend('hip')
+    gold = np.load(os.path.join(GOLD, 'fullres_digests.npz'))
+    net, orc, cfg = build_pair('t_nus', dev)
+    for mode, B in (('eval_B1', 1), ('train_B2', 2)):
+        net.train(mode.startswith('train'))
+        x, mods = O.seeded_inputs(B, 384, 640, [3, 3], seed=1)
+        with torch.no_grad():
+            ys = net(x.to(dev), [m.to(dev) for m in mods])
+        for i, y in enumerate(ys):
+            meta = gold[f't_nus/{mode}/out{i}/meta']
+            assert list(y.shape) == [int(v) for v in meta[3:]]
+            f = y.contiguous().double().reshape(-1).cpu()
+            idx = torch.linspace(0, f.numel() - 1, min(4096, f.numel())).long()
+            assert relmax(f[idx], torch.as_tensor(gold[f't_nus/{mode}/out{i}/samples'])) < 1e-3 * max(1.0, meta[2] / float(f[idx].abs().max()))
+            assert abs(float(f.abs().sum()) - meta[1]) <= 1e-3 * meta[1]
+
+
+@pytest.mark.gpu
+def test_output_contract_gpu():
+    dev = use_backend('hip')
+    net, _, _ = build_pair('t_nus', dev)
+    net.eval()
+    x, mods = O.seeded_inputs(1, 64, 96, [3, 3], seed=1)
+    with torch.no_grad():
+        ys = net(x.to(dev), [m.to(dev) for m in mods])
+    assert isinstance(ys, list) and [tuple(y.shape) for y in ys] == [(1, 18, 16, 24), (1, 36, 8, 12), (1, 72, 4, 6), (1, 144, 2, 3)]
+    assert all(y.is_cuda and y.dtype == torch.float32 for y in ys)
