@@ -125,6 +125,7 @@ class Engine:
         self.eval_cache = {}
 
     def begin_forward(self, training):
+        R.release_step_buffers()
         self.arena_d.zero_()
         if training:
             self.nbt_flat.add_(1)
@@ -164,6 +165,16 @@ class EngineOwner:
 
     def _bn_eval_affine(self, bn):
         return self._engine().bn_eval_affine(bn)
+
+    use_lanes = True          # multi-stream execution of independent branches / modality streams
+
+    def _lane_pool(self, grow=False):
+        pool = self.__dict__.setdefault('_hrf_lanes', [])
+        if grow:
+            lane = R.Lane(torch.cuda.Stream())
+            pool.append(lane)
+            return lane
+        return pool
 
     def set_sync_group(self, group, world):
         """Enable SyncBN semantics: BN statistics are all-reduced over `group` (RCCL)."""
@@ -244,7 +255,7 @@ class LocalWindowSelfAttention(nn.Module):
         a = self.attn
         B, H, W, C = x.t.shape
         lin = R.ln_input(ctx, x, ln, cache)
-        qkv = R.Plain(torch.empty((B * H * W, 3 * C), device=x.t.device, dtype=torch.float32))
+        qkv = R.Plain(R._new((B * H * W, 3 * C), x.t.device))
         R.linear_into(ctx, lin, a.qkv, qkv, 0)
         bq = a.qkv.bias
         bg = bq.grad
@@ -304,8 +315,8 @@ class MultiWindowCrossAttention(nn.Module):
         a = self.attn
         B, H, W, C = acc.t.shape
         dev = acc.t.device
-        q = R.Plain(torch.empty((B * H * W, C), device=dev, dtype=torch.float32))
-        kv = R.Plain(torch.empty((B * H * W, 2 * C), device=dev, dtype=torch.float32))
+        q = R.Plain(R._new((B * H * W, C), dev))
+        kv = R.Plain(R._new((B * H * W, 2 * C), dev))
         R.linear_into(ctx, q_in, a.q_proj, q, 0)
         R.linear_into(ctx, kv_in, a.k_proj, kv, 0)
         R.linear_into(ctx, kv_in, a.v_proj, kv, C)
@@ -316,7 +327,7 @@ class MultiWindowCrossAttention(nn.Module):
         if ctx.training and a.proj_drop.training and (p > 0 or drop_path_scale is not None):
             mask = None
             if p > 0:
-                mask = torch.empty((B, H, W, C), device=dev, dtype=torch.float32).bernoulli_(1.0 - p)
+                mask = R._new((B, H, W, C), dev).bernoulli_(1.0 - p)
             drop = (mask, 1.0 / (1.0 - p) if p > 0 else 1.0, drop_path_scale)
         return R.linear_residual(ctx, o, a.out_proj, acc, res2=z, drop=drop)
 
@@ -417,27 +428,34 @@ class HRFomerModule(nn.Module):
     def run(self, ctx, xs):
         nb = self.num_branches
         xs = list(xs)
+        lanes = ctx.fork(nb)                       # parallel branches (hrnet.py:189-190)
         for i in range(nb):
-            for blk in self.branches[i]:
-                xs[i] = blk.run(ctx, xs[i])
+            with ctx.on(lanes[i]):
+                for blk in self.branches[i]:
+                    xs[i] = blk.run(ctx, xs[i])
+        ctx.join(lanes)
         if nb == 1:
             return [xs[0]]
-        outs = []
-        for i, row in enumerate(self.fuse_layers):
-            terms = []
-            for j in range(nb):
-                if j == i:
-                    terms.append(('id', xs[j]))
-                elif j > i:
-                    terms.append(('up', R.conv_bn(ctx, xs[j], row[j][0], row[j][1], R.TF_AFFINE)))
-                else:
-                    cur = xs[j]
-                    for step in row[j]:
-                        cur = R.dwconv_bn(ctx, cur, step[0], step[1], R.TF_AFFINE)
-                        cur = R.conv_bn(ctx, cur, step[2], step[3], R.TF_RELU if len(step) == 5 else R.TF_AFFINE)
-                    terms.append(('same', cur))
-            outs.append(R.fuse_sum(ctx, tuple(xs[i].t.shape), terms))
-        return outs
+        # exchange: one lane per SOURCE branch j computes every conv chain that reads xs[j], so the
+        # backward of a lane accumulates into xs[j].grad only (no cross-lane gradient races)
+        nrows = len(self.fuse_layers)
+        terms = [[None] * nb for _ in range(nrows)]
+        lanes = ctx.fork(nb)
+        for j in range(nb):
+            with ctx.on(lanes[j]):
+                for i, row in enumerate(self.fuse_layers):
+                    if j == i:
+                        terms[i][j] = ('id', xs[j])
+                    elif j > i:
+                        terms[i][j] = ('up', R.conv_bn(ctx, xs[j], row[j][0], row[j][1], R.TF_AFFINE))
+                    else:
+                        cur = xs[j]
+                        for step in row[j]:
+                            cur = R.dwconv_bn(ctx, cur, step[0], step[1], R.TF_AFFINE)
+                            cur = R.conv_bn(ctx, cur, step[2], step[3], R.TF_RELU if len(step) == 5 else R.TF_AFFINE)
+                        terms[i][j] = ('same', cur)
+        ctx.join(lanes)
+        return [R.fuse_sum(ctx, tuple(xs[i].t.shape), terms[i]) for i in range(nrows)]
 
 
 def _make_transition(pre, cur, norm_cfg):
@@ -701,39 +719,46 @@ class HRFuserHRFormerBased(HipModule):
         return x
 
     def _fuse_stage(self, ctx, cam_in, trans_cam, trans_mod, fusion, nb, mods, first):
-        xs, m0 = [], None
         M = self.num_fused_modalities
+        cams = [None] * nb
+        ms = [[None] * M for _ in range(nb)]
+        # phase 1 - transitions: lane 0 = camera, lane 1+k = modality k (each lane only ever
+        # back-propagates into its own source tensor)
+        lanes = ctx.fork(1 + M)
+        with ctx.on(lanes[0]):
+            for i in range(nb):
+                if first:
+                    # reference quirk (:550-551): transition1[i][0] takes only the FIRST child:
+                    #   branch 0 -> the bare conv (no BN / ReLU); branch 1 -> conv + BN + ReLU.
+                    t0 = trans_cam[i][0]
+                    cams[i] = self._bare_conv(ctx, cam_in, t0) if isinstance(t0, nn.Conv2d) \
+                        else _run_conv_chain(ctx, cam_in, [t0])
+                elif trans_cam[i] is not None:
+                    tr = trans_cam[i]
+                    same = isinstance(tr[0], nn.Conv2d)      # same-index channel change (3x3 s1)
+                    cams[i] = _run_conv_chain(ctx, cam_in[i] if same else cam_in[-1], [tr] if same else list(tr))
+                else:
+                    cams[i] = cam_in[i]
+        for k in range(M):
+            with ctx.on(lanes[1 + k]):
+                for i in range(nb):
+                    tr = trans_mod[k][i]
+                    ms[i][k] = mods[k] if tr is None else \
+                        _run_conv_chain(ctx, mods[k], [tr] if isinstance(tr[0], nn.Conv2d) else list(tr))
+        ctx.join(lanes)
+        # phase 2 - one fusion block per branch, in parallel
+        xs = [None] * nb
+        lanes = ctx.fork(nb)
         for i in range(nb):
-            if first:
-                # reference quirk (:550-551): transition1[i][0] takes only the FIRST child:
-                #   branch 0 -> the bare conv (no BN / ReLU); branch 1 -> conv + BN + ReLU.
-                t0 = trans_cam[i][0]
-                if isinstance(t0, nn.Conv2d):
-                    cam = self._bare_conv(ctx, cam_in, t0)
-                else:
-                    cam = _run_conv_chain(ctx, cam_in, [t0])
-            elif trans_cam[i] is not None:
-                tr = trans_cam[i]
-                same = isinstance(tr[0], nn.Conv2d)          # same-index channel change (3x3 s1)
-                cam = _run_conv_chain(ctx, cam_in[i] if same else cam_in[-1], [tr] if same else list(tr))
-            else:
-                cam = cam_in[i]
-            ms = []
-            for k in range(M):
-                tr = trans_mod[k][i]
-                if tr is None:
-                    ms.append(mods[k])
-                else:
-                    ms.append(_run_conv_chain(ctx, mods[k], [tr] if isinstance(tr[0], nn.Conv2d) else list(tr)))
-            if i == 0:
-                m0 = ms
-            xs.append(fusion[i].run(ctx, cam, ms))
-        return xs, m0
+            with ctx.on(lanes[i]):
+                xs[i] = fusion[i].run(ctx, cams[i], ms[i])
+        ctx.join(lanes)
+        return xs, ms[0]
 
     def _bare_conv(self, ctx, x, conv):
         """3x3 conv WITHOUT BatchNorm (transition1[0][0] quirk)."""
         B, H, W, C = x.t.shape
-        out = R.Plain(torch.empty((B * H * W, conv.weight.shape[0]), device=x.t.device, dtype=torch.float32))
+        out = R.Plain(R._new((B * H * W, conv.weight.shape[0]), x.t.device))
         L, s = ctx.L, ctx.stream
         w = conv.weight
         Cout = w.shape[0]
@@ -755,17 +780,34 @@ class HRFuserHRFormerBased(HipModule):
 
     def _run(self, ctx, srcs):
         M = self.num_fused_modalities
-        x = self._stem(ctx, srcs[0], self.conv1, self.bn1, self.conv2, self.bn2, self.layer1)
-        mods = [self._stem(ctx, srcs[1 + k], self.conv_a[k], self.norm_a[k], self.conv_b[k], self.norm_b[k],
-                           self.layer_a[k]) for k in range(M)]
+        lanes = ctx.fork(1 + M)
+        with ctx.on(lanes[0]):
+            x = self._stem(ctx, srcs[0], self.conv1, self.bn1, self.conv2, self.bn2, self.layer1)
+        mods = [None] * M
+        for k in range(M):
+            with ctx.on(lanes[1 + k]):
+                mods[k] = self._stem(ctx, srcs[1 + k], self.conv_a[k], self.norm_a[k], self.conv_b[k],
+                                     self.norm_b[k], self.layer_a[k])
+        ctx.join(lanes)
         xs, m0 = self._fuse_stage(ctx, x, self.transition1, self.transition_a, self.fusion_a,
                                   self.stage2_cfg['num_branches'], mods, True)
-        ys = self._run_stage(ctx, self.stage2, xs)
-        mods = [self._run_stage(ctx, self.stage_b[k], [m0[k]])[0] for k in range(M)]
+        ys, mods = self._stages(ctx, self.stage2, xs, self.stage_b, m0)
         xs, m0 = self._fuse_stage(ctx, ys, self.transition2, self.transition_b, self.fusion_b,
                                   self.stage3_cfg['num_branches'], mods, False)
-        ys = self._run_stage(ctx, self.stage3, xs)
-        mods = [self._run_stage(ctx, self.stage_c[k], [m0[k]])[0] for k in range(M)]
+        ys, mods = self._stages(ctx, self.stage3, xs, self.stage_c, m0)
         xs, _ = self._fuse_stage(ctx, ys, self.transition3, self.transition_c, self.fusion_c,
                                  self.stage4_cfg['num_branches'], mods, False)
         return self._run_stage(ctx, self.stage4, xs)
+
+    def _stages(self, ctx, cam_stage, xs, mod_stages, m0):
+        """camera stage and the M single-branch modality stages are independent: run them side by side"""
+        M = self.num_fused_modalities
+        lanes = ctx.fork(1 + M)
+        with ctx.on(lanes[0]):
+            ys = self._run_stage(ctx, cam_stage, xs)
+        mods = [None] * M
+        for k in range(M):
+            with ctx.on(lanes[1 + k]):
+                mods[k] = self._run_stage(ctx, mod_stages[k], [m0[k]])[0]
+        ctx.join(lanes)
+        return ys, mods

@@ -318,26 +318,29 @@ struct ConvBwdWgtArgs {
   int chunk;                     // pixels per split (multiple of 16)
 };
 
+constexpr int WK = 64;     // pixels (reduction elements) staged per step: 4 k-substeps per wave
+constexpr int WLD = 65;    // LDS pitch of the [row][pixel] tiles
+
+template <bool DENSE1>
 __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
-  // tile: 64 (co) x 64 (n' = tap*Cin+ci); K = pixels; each wave owns one k-substep of 4 pixels
-  __shared__ float As[64 * LDK];
-  __shared__ float Bs[64 * LDK];
-  __shared__ float red[64 * 65];
-  __shared__ float sBias[64];
+  // tile: 64 (co) x 64 (n' = tap*Cin+ci); reduction over pixels.  Every wave owns 16 of the 64
+  // pixels of a step (4 MFMA k-substeps) and a full 4x4 grid of 16x16 accumulators; the four
+  // partial tiles are summed through LDS (plain ld/st rounds, no atomics) and each block issues
+  // ONE fp32 atomic per output element - the split count is kept small by the launcher.
+  __shared__ float As[64 * WLD];
+  __shared__ float Bs[64 * WLD];
+  __shared__ float sBias[4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
   const int pbeg = blockIdx.z * a.chunk, pend = min(a.Mpix, pbeg + a.chunk);
-  for (int i = tid; i < 64 * 65; i += 256) red[i] = 0.f;
-  if (tid < 64) sBias[tid] = 0.f;
   const bool bnb = a.cA != nullptr;
   const int mtiles = min(4, (a.Cout - m0 + 15) / 16), ntiles = min(4, (a.Np - n0 + 15) / 16);
 
-  // thread-fixed operand coordinates
-  const int co = m0 + lane;                    // A row handled by this thread when staging
+  const int co = m0 + lane;
   const bool cov = co < a.Cout;
   float ca = 1.f, cb = 0.f, cc = 0.f;
   if (bnb && cov) { ca = a.cA[co]; cb = a.cB[co]; cc = a.cC[co]; }
-  const int np = n0 + lane;                    // B row (n') handled by this thread when staging
+  const int np = n0 + lane;
   const bool npv = np < a.Np;
   int tap = 0, ci = np;
   if (a.KH == 3) { tap = np / a.Cin; ci = np - tap * a.Cin; }
@@ -353,11 +356,13 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
 
-  float areg[4], breg[4];
+  float areg[16], breg[16];
   auto load_tile = [&](int p0) {
+    int pix = p0 + wave;                       // this thread's pixel slots: p0 + wave + 4*s
+    int b = 0, yo = 0, xo = 0;
+    if (!DENSE1) { b = pix / HoWo; const int rem = pix - b * HoWo; yo = rem / a.Wo; xo = rem - yo * a.Wo; }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int pix = p0 + wave + 4 * s;       // pixel slot (tid>>6) + 4*s
+    for (int s = 0; s < 16; ++s) {
       float av = 0.f, bv = 0.f;
       if (pix < pend) {
         if (cov) {
@@ -366,41 +371,48 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
           if (bnb) av = fmaf(ca, av, fmaf(cb, a.yraw[idx], cc));
         }
         if (npv) {
-          const int b = pix / HoWo, rem = pix - b * HoWo;
-          const int yo = rem / a.Wo, xo = rem - yo * a.Wo;
-          const int yi = yo * a.stride - a.pad + dyy, xi = xo * a.stride - a.pad + dxx;
-          if ((unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W) {
-            bv = a.x[(long)b * a.sB + (long)yi * a.sY + (long)xi * a.sX + (long)ci * a.sC];
-            if (a.tf_mode == HRF_TF_LN) {
-              const long row = (long)(b * a.H + yi) * a.W + xi;
-              bv = fmaf((bv - a.tf_rowstat[2 * row]) * a.tf_rowstat[2 * row + 1], sc, sh);
-            } else if (a.tf_mode != HRF_TF_NONE) {
-              bv = hrf_tf_affine(a.tf_mode, bv, sc, sh);
+          if (DENSE1) {
+            bv = a.x[(long)pix * a.sX + (long)ci * a.sC];
+            if (a.tf_mode == HRF_TF_LN) bv = fmaf((bv - a.tf_rowstat[2 * pix]) * a.tf_rowstat[2 * pix + 1], sc, sh);
+            else if (a.tf_mode != HRF_TF_NONE) bv = hrf_tf_affine(a.tf_mode, bv, sc, sh);
+          } else {
+            const int yi = yo * a.stride - a.pad + dyy, xi = xo * a.stride - a.pad + dxx;
+            if ((unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W) {
+              bv = a.x[(long)b * a.sB + (long)yi * a.sY + (long)xi * a.sX + (long)ci * a.sC];
+              if (a.tf_mode == HRF_TF_LN) {
+                const long row = (long)(b * a.H + yi) * a.W + xi;
+                bv = fmaf((bv - a.tf_rowstat[2 * row]) * a.tf_rowstat[2 * row + 1], sc, sh);
+              } else if (a.tf_mode != HRF_TF_NONE) {
+                bv = hrf_tf_affine(a.tf_mode, bv, sc, sh);
+              }
             }
           }
         }
       }
       areg[s] = av; breg[s] = bv;
+      pix += 4;
+      if (!DENSE1) { xo += 4; while (xo >= a.Wo) { xo -= a.Wo; if (++yo == a.Ho) { yo = 0; ++b; } } }
     }
   };
 
   if (pbeg < pend) load_tile(pbeg);
-  for (int p0 = pbeg; p0 < pend; p0 += BK) {
+  for (int p0 = pbeg; p0 < pend; p0 += WK) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      As[lane * LDK + wave + 4 * s] = areg[s];
-      Bs[lane * LDK + wave + 4 * s] = breg[s];
+    for (int s = 0; s < 16; ++s) {
+      As[lane * WLD + wave + 4 * s] = areg[s];
+      Bs[lane * WLD + wave + 4 * s] = breg[s];
       bias_part += areg[s];
     }
     __syncthreads();
-    if (p0 + BK < pend) load_tile(p0 + BK);
-    {
-      // wave w consumes k-substep w: pixel slots 4w..4w+3 of this step
+    if (p0 + WK < pend) load_tile(p0 + WK);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int kq = (wave * 4 + kk) * 4 + (lane >> 4);
       float af[4], bf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = As[(i * 16 + (lane & 15)) * LDK + wave * 4 + (lane >> 4)];
+      for (int i = 0; i < 4; ++i) af[i] = As[(i * 16 + (lane & 15)) * WLD + kq];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = Bs[(j * 16 + (lane & 15)) * LDK + wave * 4 + (lane >> 4)];
+      for (int j = 0; j < 4; ++j) bf[j] = Bs[(j * 16 + (lane & 15)) * WLD + kq];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -409,30 +421,38 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
     }
     __syncthreads();
   }
-  // cross-wave reduction in LDS, then one atomic per output element
+  // cross-wave reduction: four ordered rounds of plain LDS read-modify-write (same lane->element map)
+  float* red = As;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (i < mtiles && j < ntiles) {
+        for (int j = 0; j < 4; ++j)
+          if (i < mtiles && j < ntiles) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          hrf_atomic_add(&red[(i * 16 + (lane >> 4) * 4 + r) * 65 + j * 16 + (lane & 15)], acc[i][j][r]);
-      }
-  if (a.dbias != nullptr && blockIdx.y == 0) hrf_atomic_add(&sBias[lane], bias_part);
-  __syncthreads();
+            for (int r = 0; r < 4; ++r) {
+              const int idx = (i * 16 + (lane >> 4) * 4 + r) * WLD + j * 16 + (lane & 15);
+              red[idx] = (w == 0 ? 0.f : red[idx]) + acc[i][j][r];
+            }
+          }
+    }
+    __syncthreads();
+  }
+  sBias[wave * 64 + lane] = bias_part;
   for (int e = tid; e < 64 * 64; e += 256) {
     const int ml = e >> 6, nl = e & 63;
     const int cco = m0 + ml, nn = n0 + nl;
-    if (cco < a.Cout && nn < a.Np) {
+    if (cco < a.Cout && nn < a.Np && (ml >> 4) < mtiles && (nl >> 4) < ntiles) {
       long o;
       if (a.KH == 3) { const int t = nn / a.Cin, c = nn - t * a.Cin; o = ((long)cco * a.Cin + c) * 9 + t; }
       else o = (long)cco * a.Cin + nn;
-      hrf_atomic_add(&a.dw[o], red[ml * 65 + nl]);
+      hrf_atomic_add(&a.dw[o], red[ml * WLD + nl]);
     }
   }
+  __syncthreads();
   if (a.dbias != nullptr && blockIdx.y == 0 && tid < 64 && m0 + tid < a.Cout)
-    hrf_atomic_add(&a.dbias[m0 + tid], sBias[tid]);
+    hrf_atomic_add(&a.dbias[m0 + tid], sBias[tid] + sBias[64 + tid] + sBias[128 + tid] + sBias[192 + tid]);
 }
 
 inline int pick_nt(int C) {
@@ -540,12 +560,16 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
   a.Mpix = B * a.Ho * a.Wo; a.Np = KH * KH * Cin;
   if (a.Mpix <= 0) return HRF_OK;
   const int gx = hrf_cdiv(Cout, 64), gy = hrf_cdiv(a.Np, 64);
-  int splits = hrf_cdiv(1024, gx * gy);
-  const int maxs = hrf_cdiv(a.Mpix, 64);
-  if (splits > maxs) splits = maxs;
+  // split the pixel reduction so that ~256-512 blocks exist, but never below 4 steps (256 pixels)
+  // per block: the per-block epilogue (LDS reduce + one atomic per output) must stay amortised.
+  int splits = hrf_cdiv(a.Mpix, 256);
+  const int cap = hrf_cdiv(512, gx * gy);
+  if (splits > cap) splits = cap;
   if (splits < 1) splits = 1;
-  a.chunk = hrf_cdiv(hrf_cdiv(a.Mpix, splits), 16) * 16;
+  a.chunk = hrf_cdiv(hrf_cdiv(a.Mpix, splits), WK) * WK;
   splits = hrf_cdiv(a.Mpix, a.chunk);
-  HRF_LAUNCH(conv_bwd_wgt_kernel, dim3(gx, gy, splits), dim3(256), 0, stream, a);
+  const bool dense1 = KH == 1 && stride == 1 && sC == 1 && sY == W * sX && sB == H * sY;
+  if (dense1) { HRF_LAUNCH(conv_bwd_wgt_kernel<true>, dim3(gx, gy, splits), dim3(256), 0, stream, a); }
+  else { HRF_LAUNCH(conv_bwd_wgt_kernel<false>, dim3(gx, gy, splits), dim3(256), 0, stream, a); }
   return hrf_check_launch();
 }

@@ -40,7 +40,7 @@ class Act:
     def grad_target(self):
         """-> (tensor, accumulate flag) for a kernel that writes this activation's gradient."""
         if self.grad is None:
-            self.grad = torch.empty_like(self.t)
+            self.grad = _new_like(self.t)
             return self.grad, 0
         return self.grad, 1
 
@@ -100,33 +100,134 @@ class RawInput:
         return (B, H, W, C)
 
 
+class Lane:
+    """An execution lane = one HIP stream.  Independent parts of the network (camera branches,
+    modality streams, per-source exchange chains) run on sibling lanes so that the many small,
+    latency-bound launches of HRFuser-T overlap on the 256 CUs instead of queueing serially."""
+    __slots__ = ('stream', 'ptr')
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.ptr = stream.cuda_stream if stream is not None else 0
+
+
 class Ctx:
-    """Per-forward execution context (library handle, stream, mode, tape, BN arenas, SyncBN group)."""
+    """Per-forward execution context: library handle, current lane/stream, mode, reverse tape."""
 
     def __init__(self, owner, training, record):
         self.L = owner._lib_handle()
-        self.stream = _lib.stream_ptr()
         self.training = training
         self.record = record            # build the backward tape?
         self.tape = []
         self.owner = owner
         self.group = owner.sync_group if training else None
         self.world = owner.sync_world if (training and owner.sync_group is not None) else 1
+        self.multi = bool(torch.cuda.is_available() and getattr(owner, 'use_lanes', True))
+        self.main = Lane(torch.cuda.current_stream() if torch.cuda.is_available() else None)
+        self.cur = self.main
+        self.stream = self.main.ptr
+        self._free = list(owner._lane_pool()) if self.multi else []
 
+    # ---- tape ----------------------------------------------------------------------------------
     def push(self, fn):
         if self.record:
-            self.tape.append(fn)
+            self.tape.append((fn, self.cur))
+
+    # ---- lanes ---------------------------------------------------------------------------------
+    def fork(self, n):
+        """n sibling lanes that start after everything enqueued so far on the current lane."""
+        if not self.multi or n <= 1:
+            return [self.cur] * n
+        while len(self._free) < n:
+            self._free.append(self.owner._lane_pool(grow=True))
+        kids = [self._free.pop() for _ in range(n)]
+        for k in kids:
+            k.stream.wait_stream(self.cur.stream)
+        if self.record:
+            self.tape.append(('F', self.cur, kids))
+        return kids
+
+    def join(self, kids):
+        """The current lane continues after all sibling lanes have finished."""
+        if not self.multi or len(kids) <= 1 or kids[0] is self.cur:
+            return
+        for k in kids:
+            self.cur.stream.wait_stream(k.stream)
+        if self.record:
+            self.tape.append(('J', self.cur, kids))
+        self._free.extend(kids)
+
+    def on(self, lane):
+        return _LaneScope(self, lane)
 
     def run_backward(self):
         tape = self.tape
         self.tape = []
+        if self.multi:
+            self.main.stream.wait_stream(torch.cuda.current_stream())
         while tape:
-            tape.pop()()
+            e = tape.pop()
+            if e[0] == 'J':                     # reverse of a join = fork
+                for k in e[2]:
+                    k.stream.wait_stream(e[1].stream)
+            elif e[0] == 'F':                   # reverse of a fork = join
+                for k in e[2]:
+                    e[1].stream.wait_stream(k.stream)
+            else:
+                fn, lane = e
+                with _LaneScope(self, lane):
+                    fn()
+        if self.multi:
+            torch.cuda.current_stream().wait_stream(self.main.stream)
 
     def all_reduce(self, t):
         if self.group is not None and self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(t, group=self.group)
+
+
+class _LaneScope:
+    def __init__(self, ctx, lane):
+        self.ctx, self.lane = ctx, lane
+
+    def __enter__(self):
+        c = self.ctx
+        self.prev = c.cur
+        c.cur, c.stream = self.lane, self.lane.ptr
+        self.tctx = None
+        if c.multi and self.lane.stream is not None:
+            self.tctx = torch.cuda.stream(self.lane.stream)
+            self.tctx.__enter__()
+        return self.lane
+
+    def __exit__(self, *exc):
+        if self.tctx is not None:
+            self.tctx.__exit__(*exc)
+        c = self.ctx
+        c.cur, c.stream = self.prev, self.prev.ptr
+        return False
+
+
+# Tensors created inside ops are kept alive until the next forward of ANY engine begins: with
+# several lanes a buffer may still be read on a sibling stream after its Python owner dropped it.
+_KEEP = []
+
+
+def _keep(t):
+    _KEEP.append(t)
+    return t
+
+
+def _new_like(t):
+    return _keep(torch.empty_like(t))
+
+
+def _new(shape, device):
+    return _keep(torch.empty(shape, device=device, dtype=torch.float32))
+
+
+def release_step_buffers():
+    _KEEP.clear()
 
 
 # ----------------------------------------------------------------------------- input descriptors
@@ -190,7 +291,7 @@ def bn_backward_coef(ctx, st):
     cA, cB, cC = slot['cA'], slot['cB'], slot['cC']
     local = None
     if st.train and ctx.world > 1:
-        local = st.gstats.clone()
+        local = _keep(st.gstats.clone())
         ctx.all_reduce(st.gstats)
     wg = st.bn.weight.grad if st.bn.weight.requires_grad else None
     bg = st.bn.bias.grad if st.bn.bias.requires_grad else None
@@ -219,12 +320,12 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
         return
     if isinstance(src, Lazy):
         st = src.st
-        st.du = torch.empty_like(st.raw)
+        st.du = _new_like(st.raw)
         L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
                             st.du, *strides, 0, 1, st.raw, Cin, st.scale, st.shift, _TF2ACT[src.mode],
                             st.gstats, s)
     elif isinstance(src, LNIn):
-        da = torch.empty_like(src.act.t)
+        da = _new_like(src.act.t)
         L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
                             da, *strides, 0, 0, None, 0, None, None, 0, None, s)
         g, acc = src.act.grad_target()
@@ -236,7 +337,7 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
                             g, *strides, acc, 0, None, 0, None, None, 0, None, s)
     else:                                   # RawInput (NCHW gradient written through strides)
         if src.grad is None:
-            src.grad = torch.empty_like(src.t)
+            src.grad = _new_like(src.t)
             acc = 0
         else:
             acc = 1
@@ -251,7 +352,7 @@ def conv_bn(ctx, src, conv, bn, mode):
     w, b = conv.weight, conv.bias
     Cout, KH, stride = w.shape[0], w.shape[2], conv.stride[0]
     Ho, Wo = _conv_out_hw(H, W, KH, stride)
-    y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    y = _new((B, Ho, Wo, Cout), x.device)
     slot = ctx.owner._bn_slot(bn)
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None
@@ -298,14 +399,14 @@ def linear_residual(ctx, o, lin, res, res2=None, drop=None):
     B, H, W, C = res.t.shape
     w, b = lin.weight, lin.bias
     rows = B * H * W
-    out = Act(torch.empty_like(res.t))
+    out = Act(_new_like(res.t))
     strides = _nhwc_strides(B, H, W, C)
     if drop is None:
         L.hrf_conv_fwd(o.t, *strides, B, H, W, C, w, b, 1, 1, C, out.t, C, 0, res.t,
                        res2.t if res2 is not None else None, C, TF_NONE, None, None, None, None, s)
     else:
         mask, mscale, rowscale = drop
-        y = torch.empty_like(res.t)
+        y = _new_like(res.t)
         L.hrf_conv_fwd(o.t, *strides, B, H, W, C, w, b, 1, 1, C, y, C, 0, None, None, 0,
                        TF_NONE, None, None, None, None, s)
         L.hrf_scale_add(y, mask, mscale, rowscale, H * W, res.t, res2.t if res2 is not None else None,
@@ -317,7 +418,7 @@ def linear_residual(ctx, o, lin, res, res2=None, drop=None):
             dy = g
         else:
             mask, mscale, rowscale = drop
-            dy = torch.empty_like(g)
+            dy = _new_like(g)
             L.hrf_scale_add(g, mask, mscale, rowscale, H * W, None, None, dy, rows, C, s)
         if w.requires_grad:
             L.hrf_conv_bwd_weight(dy, C, 0, None, None, None, None, o.t, *strides, B, H, W, C, 1, 1, C,
@@ -328,7 +429,7 @@ def linear_residual(ctx, o, lin, res, res2=None, drop=None):
         # identity paths: the residual streams receive the output gradient unchanged
         if res2 is not None and res2.needs_grad:
             if res2.grad is None and res.grad is None and res.needs_grad:
-                res2.grad = g.clone()
+                res2.grad = _keep(g.clone())
             else:
                 res2.add_grad(g)
         if res.needs_grad:
@@ -344,7 +445,7 @@ def ln_input(ctx, act, ln, cache=None):
     if cache is not None and key in cache:
         rowstat = cache[key]
     else:
-        rowstat = torch.empty((B * H * W, 2), device=act.t.device, dtype=torch.float32)
+        rowstat = _new((B * H * W, 2), act.t.device)
         ctx.L.hrf_ln_stats(act.t, B * H * W, C, float(ln.eps), rowstat, ctx.stream)
         if cache is not None:
             cache[key] = rowstat
@@ -355,14 +456,14 @@ def window_attention(ctx, q, qoff, k, koff, v, voff, kpad, vpad, kpad_grad, vpad
     """softmax(q k^T d^-1/2 + RPB) v per 7x7 window and head.  q/k/v are Plain projection buffers."""
     L, s = ctx.L, ctx.stream
     B, H, W, C = dims
-    o = Act(torch.empty((B, H, W, C), device=q.t.device, dtype=torch.float32))
+    o = Act(_new((B, H, W, C), q.t.device))
     L.hrf_window_attn_fwd(q.t, q.t.shape[-1], qoff, k.t, k.t.shape[-1], koff, v.t, v.t.shape[-1], voff,
                           kpad, vpad, rpb, o.t, C, B, H, W, C, heads, s)
 
     def bwd():
         for p in (q, k, v):
             if p.grad is None:
-                p.grad = torch.empty_like(p.t)
+                p.grad = _new_like(p.t)
         L.hrf_window_attn_bwd(q.t, q.t.shape[-1], qoff, k.t, k.t.shape[-1], koff, v.t, v.t.shape[-1], voff,
                               kpad, vpad, rpb, o.grad, C,
                               q.grad, q.grad.shape[-1], qoff, k.grad, k.grad.shape[-1], koff,
@@ -379,7 +480,7 @@ def dwconv_bn(ctx, src, conv, bn, mode):
     w, b = conv.weight, conv.bias
     stride = conv.stride[0]
     Ho, Wo = _conv_out_hw(H, W, 3, stride)
-    y = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.float32)
+    y = _new((B, Ho, Wo, C), x.device)
     slot = ctx.owner._bn_slot(bn)
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None
@@ -394,7 +495,7 @@ def dwconv_bn(ctx, src, conv, bn, mode):
                                     b.grad if b is not None else None, s)
         if isinstance(src, Lazy):
             ps = src.st
-            ps.du = torch.empty_like(ps.raw)
+            ps.du = _new_like(ps.raw)
             L.hrf_dwconv_bwd_data(st.du, st.raw, cA, cB, cC, w, stride, B, H, W, C, ps.du, 0, 1, ps.raw,
                                   ps.scale, ps.shift, _TF2ACT[src.mode], ps.gstats, s)
         elif src.needs_grad:
@@ -417,14 +518,14 @@ def materialize(ctx, lazy, act, res=None, lazy2=None, act_first=False, rowscale=
     st = lazy.st
     B, H, W, C = st.raw.shape
     rows = B * H * W
-    out = Act(torch.empty_like(st.raw))
+    out = Act(_new_like(st.raw))
     st2 = lazy2.st if lazy2 is not None else None
     L.hrf_affine_act_res(st.raw, st.scale, st.shift, st2.raw if st2 else None, st2.scale if st2 else None,
                          st2.shift if st2 else None, res.t if res is not None else None, rowscale, H * W,
                          act, 1 if act_first else 0, out.t, rows, C, s)
 
     def bwd():
-        g = torch.empty_like(out.t)
+        g = _new_like(out.t)
         if act_first:
             assert act == ACT_GELU and st2 is None
             L.hrf_act_bwd(out.grad, None, st.raw, st.scale, st.shift, rowscale, H * W, 1, g, None, None,
@@ -442,7 +543,7 @@ def materialize(ctx, lazy, act, res=None, lazy2=None, act_first=False, rowscale=
             if res is not None and res.needs_grad:
                 # g stays alive as st.du for the producer conv's backward -> never alias it
                 if res.grad is None:
-                    res.grad = g.clone()
+                    res.grad = _keep(g.clone())
                 else:
                     res.grad.add_(g)
     ctx.push(bwd)
@@ -455,7 +556,7 @@ def fuse_sum(ctx, dims, terms):
     L, s = ctx.L, ctx.stream
     B, H, W, C = dims
     dev = terms[0][1].t.device if isinstance(terms[0][1], Act) else terms[0][1].raw.device
-    out = Act(torch.empty((B, H, W, C), device=dev, dtype=torch.float32))
+    out = Act(_new((B, H, W, C), dev))
     args = []
     for kind, t in terms:
         if kind == 'id':
@@ -469,27 +570,29 @@ def fuse_sum(ctx, dims, terms):
     L.hrf_fuse_sum(*args, out.t, B, H, W, C, s)
 
     def bwd():
-        g = torch.empty_like(out.t)
+        g = _new_like(out.t)
         same = [t for kind, t in terms if kind == 'same']
         assert len(same) <= 3
         ys = [t.raw for t in same] + [None] * (3 - len(same))
         sts = [t.st.gstats for t in same] + [None] * (3 - len(same))
         L.hrf_act_bwd(out.grad, out.t, ys[0], None, None, None, 1, 0, g, ys[1], ys[2], sts[0], sts[1], sts[2],
                       B * H * W, C, s)
-        first_alias = True
+        # g doubles as st.du of every 'same' term and is read later by their conv backward (possibly
+        # on another lane): it may only be aliased as the identity gradient when no such reader exists
+        can_alias = len(same) == 0
         for kind, t in terms:
             if kind == 'id':
                 if t.needs_grad:
-                    if t.grad is None and first_alias:
-                        t.grad = g
-                        first_alias = False
+                    if t.grad is None:
+                        t.grad = g if can_alias else _keep(g.clone())
+                        can_alias = False
                     else:
-                        t.add_grad(g)
+                        t.grad.add_(g)
             elif kind == 'same':
                 t.st.du = g
             else:
                 st = t.st
-                st.du = torch.empty_like(st.raw)
+                st.du = _new_like(st.raw)
                 L.hrf_bilinear_up_bwd(g, B, H, W, C, st.raw, st.raw.shape[1], st.raw.shape[2], st.du, st.gstats, s)
     ctx.push(bwd)
     return out

@@ -38,16 +38,36 @@ def _fwd_bwd(tag, B, H, W, train, backend, check_grads=True, gold_key=None):
             assert relmax(p, torch.as_tensor(gold[f'{gold_key}/{mode}/out{i}'])) < 1e-3
     if not check_grads:
         return
+    # Gradient gate: err(build, fp64) <= max(tol, 3*e_ref) where e_ref is the ORACLE's own
+    # fp32-vs-fp64 error on the same tensor (ReLU-mask flips / tiny BN sample counts make a few
+    # tensors noisy at fp32 no matter who computes them).
+    o32 = copy.deepcopy(orc)
+    xc = x.clone().requires_grad_(True)
+    mc32 = [m.clone().requires_grad_(True) for m in mods]
+    yc = o32(xc, list(mc32))
     g = torch.Generator().manual_seed(5)
     cots = [torch.randn(t.shape, generator=g) for t in yb]
     sum((t * c.to(dev)).sum() for t, c in zip(ya, cots)).backward()
     sum((t * c.double()).sum() for t, c in zip(yb, cots)).backward()
-    assert relmax(xa.grad, xb.grad) < 2e-2 if train else 1e-3
-    for p, q in zip(ma, mb):
-        assert relmax(p.grad, q.grad) < (2e-2 if train else 1e-3)
-    grad_check(net.named_parameters(), o64.named_parameters(), tol=2e-2 if train else 1e-3)
+    sum((t * c).sum() for t, c in zip(yc, cots)).backward()
+    tol = 1e-3
+    for p, q, r32 in zip([xa] + ma, [xb] + mb, [xc] + mc32):
+        e_ref = relmax(r32.grad, q.grad)
+        assert relmax(p.grad, q.grad) <= max(tol, 3 * e_ref), (tag, train, relmax(p.grad, q.grad), e_ref)
+    pa, pb, pc = dict(net.named_parameters()), dict(o64.named_parameters()), dict(o32.named_parameters())
+    gscale = max(float(v.grad.abs().max()) for v in pb.values() if v.grad is not None)
+    worst = (0.0, '')
+    for k, q in pb.items():
+        if q.grad is None:
+            continue
+        # absolute floor for analytically-zero gradients (k-bias; biases feeding a train-mode BN)
+        den = float(q.grad.norm()) + 2e-3 * gscale * (q.numel() ** 0.5)
+        e = float((pa[k].grad.detach().double().cpu() - q.grad).norm()) / den
+        e_ref = float((pc[k].grad.double() - q.grad).norm()) / den
+        assert e <= max(tol, 3 * e_ref), (tag, train, k, e, e_ref)
+        worst = max(worst, (e, k))
     # quirk App. D-1: transition1.0.1 never receives a gradient
-    assert float(dict(net.named_parameters())['transition1.0.1.weight'].grad.abs().max()) == 0.0
+    assert float(pa['transition1.0.1.weight'].grad.abs().max()) == 0.0
 
 
 def test_wholenet_emul_eval():
