@@ -11,6 +11,7 @@ but the modules only OWN parameters: all arithmetic is issued through `runtime.p
 hand-written gfx950 kernels behind `include/hrfuser_hip.h`.  There is no eager/CPU fallback.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -174,6 +175,14 @@ class EngineOwner:
             lane = R.Lane(torch.cuda.Stream())
             pool.append(lane)
             return lane
+        return pool
+
+    def _side_pool(self):
+        pool = self.__dict__.get('_hrf_side')
+        if pool is None:
+            n = int(os.environ.get('HRF_SIDE_LANES', '6'))
+            pool = [R.Lane(torch.cuda.Stream()) for _ in range(max(1, n))]
+            self.__dict__['_hrf_side'] = pool
         return pool
 
     def set_sync_group(self, group, world):
@@ -800,14 +809,15 @@ class HRFuserHRFormerBased(HipModule):
         return self._run_stage(ctx, self.stage4, xs)
 
     def _stages(self, ctx, cam_stage, xs, mod_stages, m0):
-        """camera stage and the M single-branch modality stages are independent: run them side by side"""
+        """The camera stage and the M single-branch modality stages are independent.  The modality
+        stages are enqueued on their own lanes first; the camera stage then runs from the main lane,
+        each of its modules forking branch lanes from main (flat, never nested)."""
         M = self.num_fused_modalities
-        lanes = ctx.fork(1 + M)
-        with ctx.on(lanes[0]):
-            ys = self._run_stage(ctx, cam_stage, xs)
+        lanes = ctx.fork(M)
         mods = [None] * M
         for k in range(M):
-            with ctx.on(lanes[1 + k]):
+            with ctx.on(lanes[k]):
                 mods[k] = self._run_stage(ctx, mod_stages[k], [m0[k]])[0]
+        ys = self._run_stage(ctx, cam_stage, xs)
         ctx.join(lanes)
         return ys, mods

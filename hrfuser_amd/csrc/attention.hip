@@ -10,15 +10,22 @@
 // projection bias: padded keys/values are synthesised from (k_bias, v_bias) and - as in the
 // reference (with_pad_mask=False) - are NOT masked.
 //
-// Mapping: one wave64 per (window, head); lane i = query row i (49 of 64 lanes active), K/V rows
-// of the window are staged once in LDS and read as wave-wide broadcasts (conflict-free); the
-// softmax row lives in one lane, so the row max/sum need no cross-lane traffic at all.
+// Mapping: one wave64 per (window, head); lane i = query row i (49 of 64 lanes active).  K/V rows
+// of the window are staged once in LDS (rows padded to a multiple of 4 floats, 16 B aligned) and
+// read as wave-wide ds_read_b128 broadcasts (conflict-free); the whole 49-wide logit row lives in
+// the lane's registers (fully unrolled), so softmax needs no cross-lane traffic and the 49
+// dot-product chains are independent (ILP hides the LDS latency inside a single wave).
+// head_dim is 18 (HRFuser-T) / 39 (HRFuser-B): with 49x49xD contractions padded to 64x64x20 an
+// MFMA tile would waste > 55 % of its lanes, so the contraction runs as per-lane FMA chains at the
+// same fp32 rate the f32 MFMA has ("attention core").
 #include "hrf_common.h"
 #include "../../include/hrfuser_hip.h"
 
 namespace {
 
 constexpr int NT = 49;      // tokens per window (7x7)
+
+struct alignas(16) V4 { float x, y, z, w; };
 
 struct AttnArgs {
   const float* q; int ldq, qoff;
@@ -45,10 +52,35 @@ __device__ __forceinline__ int tok_pixel(const AttnArgs& a, int b, int wy, int w
   return -1;
 }
 
+// dot(q[0..DP), row[0..DP)) + init, row read as DP/4 aligned 16-byte LDS broadcasts
+template <int DP>
+__device__ __forceinline__ float dot_row(const float* q, const float* row, float init) {
+  const V4* r4 = reinterpret_cast<const V4*>(row);
+  float acc = init;
+#pragma unroll
+  for (int c = 0; c < DP / 4; ++c) {
+    const V4 v = r4[c];
+    acc = fmaf(q[4 * c + 0], v.x, acc); acc = fmaf(q[4 * c + 1], v.y, acc);
+    acc = fmaf(q[4 * c + 2], v.z, acc); acc = fmaf(q[4 * c + 3], v.w, acc);
+  }
+  return acc;
+}
+template <int DP>
+__device__ __forceinline__ void axpy_row(float* o, float p, const float* row) {
+  const V4* r4 = reinterpret_cast<const V4*>(row);
+#pragma unroll
+  for (int c = 0; c < DP / 4; ++c) {
+    const V4 v = r4[c];
+    o[4 * c + 0] = fmaf(p, v.x, o[4 * c + 0]); o[4 * c + 1] = fmaf(p, v.y, o[4 * c + 1]);
+    o[4 * c + 2] = fmaf(p, v.z, o[4 * c + 2]); o[4 * c + 3] = fmaf(p, v.w, o[4 * c + 3]);
+  }
+}
+
 template <int D, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(AttnArgs a) {
-  __shared__ float sK[WAVES][NT * D];
-  __shared__ float sV[WAVES][NT * D];
+  constexpr int DP = (D + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float sK[WAVES][NT * DP];
+  __shared__ __attribute__((aligned(16))) float sV[WAVES][NT * DP];
   __shared__ float sT[WAVES][176];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
   const int nwin = a.B * a.nWh * a.nWw;
@@ -56,11 +88,16 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(AttnArgs a) {
   const bool active = win < nwin;
   const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
   if (active) {
-    for (int e = lane; e < NT * D; e += 64) {
-      const int j = e / D, d = e - j * D;
+    for (int e = lane; e < NT * DP; e += 64) {
+      const int j = e / DP, d = e - j * DP;
       const int pix = tok_pixel(a, b, wy, wx, j);
-      sK[wave][e] = pix >= 0 ? a.k[(long)pix * a.ldk + a.koff + h * D + d] : a.kpad[h * D + d];
-      sV[wave][e] = pix >= 0 ? a.v[(long)pix * a.ldv + a.voff + h * D + d] : a.vpad[h * D + d];
+      const bool dv = d < D;
+      const long pc = pix >= 0 ? pix : 0;       // unconditional clamped loads, select afterwards
+      const int col = h * D + (dv ? d : 0);
+      const float kx = a.k[pc * a.ldk + a.koff + col], kp = a.kpad[col];
+      const float vx = a.v[pc * a.ldv + a.voff + col], vp = a.vpad[col];
+      sK[wave][e] = dv ? (pix >= 0 ? kx : kp) : 0.f;
+      sV[wave][e] = dv ? (pix >= 0 ? vx : vp) : 0.f;
     }
     for (int e = lane; e < 169; e += 64) sT[wave][e] = a.rpb[e * a.heads + h];
   }
@@ -68,34 +105,29 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(AttnArgs a) {
   const int i = lane;
   const int pix = (active && i < NT) ? tok_pixel(a, b, wy, wx, i) : -1;
   if (pix < 0) return;                       // padded / idle query rows produce no output
-  float q[D];
+  float q[DP];
 #pragma unroll
-  for (int d = 0; d < D; ++d) q[d] = a.q[(long)pix * a.ldq + a.qoff + h * D + d] * a.scale;
+  for (int d = 0; d < DP; ++d) q[d] = d < D ? a.q[(long)pix * a.ldq + a.qoff + h * D + d] * a.scale : 0.f;
   const int yi = i / 7, xi = i - 7 * yi;
   const int bias0 = (yi + 6) * 13 + (xi + 6);
   const float* Kw = sK[wave];
   const float* Vw = sV[wave];
   const float* Tw = sT[wave];
+  float s[NT];
   float m = -3.0e38f;
-  for (int j = 0; j < NT; ++j) {
-    const int yj = j / 7, xj = j - 7 * yj;
-    float s = Tw[bias0 - yj * 13 - xj];
 #pragma unroll
-    for (int d = 0; d < D; ++d) s = fmaf(q[d], Kw[j * D + d], s);
-    m = fmaxf(m, s);
+  for (int j = 0; j < NT; ++j) {
+    s[j] = dot_row<DP>(q, Kw + j * DP, Tw[bias0 - (j / 7) * 13 - (j % 7)]);
+    m = fmaxf(m, s[j]);
   }
-  float l = 0.f, o[D];
+  float l = 0.f, o[DP];
 #pragma unroll
-  for (int d = 0; d < D; ++d) o[d] = 0.f;
+  for (int d = 0; d < DP; ++d) o[d] = 0.f;
+#pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int yj = j / 7, xj = j - 7 * yj;
-    float s = Tw[bias0 - yj * 13 - xj];
-#pragma unroll
-    for (int d = 0; d < D; ++d) s = fmaf(q[d], Kw[j * D + d], s);
-    const float p = expf(s - m);
+    const float p = __expf(s[j] - m);
     l += p;
-#pragma unroll
-    for (int d = 0; d < D; ++d) o[d] = fmaf(p, Vw[j * D + d], o[d]);
+    axpy_row<DP>(o, p, Vw + j * DP);
   }
   const float inv = 1.0f / l;
 #pragma unroll
@@ -104,18 +136,19 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(AttnArgs a) {
 
 template <int D, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attn_bwd_kernel(AttnArgs a) {
-  __shared__ float sK[WAVES][NT * D];
-  __shared__ float sV[WAVES][NT * D];
-  __shared__ float sQ[WAVES][NT * D];
-  __shared__ float sG[WAVES][NT * D];        // dO rows
+  constexpr int DP = (D + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float sK[WAVES][NT * DP];
+  __shared__ __attribute__((aligned(16))) float sV[WAVES][NT * DP];
+  __shared__ __attribute__((aligned(16))) float sQ[WAVES][NT * DP];
+  __shared__ __attribute__((aligned(16))) float sG[WAVES][NT * DP];        // dO rows
   __shared__ float sT[WAVES][176];
   __shared__ float sdT[WAVES][176];
   __shared__ float sM[WAVES][64], sL[WAVES][64], sDl[WAVES][64];
-  __shared__ float sPadK[WAVES][D], sPadV[WAVES][D];
+  __shared__ float sPadK[WAVES][DP], sPadV[WAVES][DP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
   const int nwin = a.B * a.nWh * a.nWw;
-  for (int e = lane; e < 176; e += 64) { sdT[wave][e] = 0.f; sT[wave][e] = e < 169 ? a.rpb[e * a.heads + h] : 0.f; }
-  for (int e = lane; e < D; e += 64) { sPadK[wave][e] = 0.f; sPadV[wave][e] = 0.f; }
+  for (int e = lane; e < 176; e += 64) { sdT[wave][e] = 0.f; sT[wave][e] = a.rpb[(e < 169 ? e : 0) * a.heads + h]; }
+  for (int e = lane; e < DP; e += 64) { sPadK[wave][e] = 0.f; sPadV[wave][e] = 0.f; }
   const float* Kw = sK[wave];
   const float* Vw = sV[wave];
   const float* Qw = sQ[wave];
@@ -130,14 +163,19 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_kernel(AttnArgs a) {
     const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
     __syncthreads();                           // previous iteration's readers are done
     if (active) {
-      for (int e = lane; e < NT * D; e += 64) {
-        const int j = e / D, d = e - j * D;
+      for (int e = lane; e < NT * DP; e += 64) {
+        const int j = e / DP, d = e - j * DP;
         const int pix = tok_pixel(a, b, wy, wx, j);
-        const int col = h * D + d;
-        sK[wave][e] = pix >= 0 ? a.k[(long)pix * a.ldk + a.koff + col] : a.kpad[col];
-        sV[wave][e] = pix >= 0 ? a.v[(long)pix * a.ldv + a.voff + col] : a.vpad[col];
-        sQ[wave][e] = pix >= 0 ? a.q[(long)pix * a.ldq + a.qoff + col] * a.scale : 0.f;
-        sG[wave][e] = pix >= 0 ? a.dout[(long)pix * a.lddo + col] : 0.f;
+        const bool dv = d < D;
+        const int col = h * D + (dv ? d : 0);
+        const long pc = pix >= 0 ? pix : 0;     // unconditional clamped loads, select afterwards
+        const float kx = a.k[pc * a.ldk + a.koff + col], kp = a.kpad[col];
+        const float vx = a.v[pc * a.ldv + a.voff + col], vp = a.vpad[col];
+        const float qx = a.q[pc * a.ldq + a.qoff + col] * a.scale, gx = a.dout[pc * a.lddo + col];
+        sK[wave][e] = dv ? (pix >= 0 ? kx : kp) : 0.f;
+        sV[wave][e] = dv ? (pix >= 0 ? vx : vp) : 0.f;
+        sQ[wave][e] = (dv && pix >= 0) ? qx : 0.f;
+        sG[wave][e] = (dv && pix >= 0) ? gx : 0.f;
       }
     }
     __syncthreads();
@@ -145,41 +183,30 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_kernel(AttnArgs a) {
     // ---- pass A: lane = query row i -> softmax stats, D_i, dQ_i, dRPB
     if (active && lane < NT) {
       const int i = lane;
-      float q[D], g[D];
+      float q[DP], g[DP];
 #pragma unroll
-      for (int d = 0; d < D; ++d) { q[d] = Qw[i * D + d]; g[d] = Gw[i * D + d]; }
+      for (int d = 0; d < DP; ++d) { q[d] = Qw[i * DP + d]; g[d] = Gw[i * DP + d]; }
       const int bias0 = (yl + 6) * 13 + (xl + 6);
+      float s[NT], dp[NT];
       float m = -3.0e38f;
-      for (int j = 0; j < NT; ++j) {
-        const int yj = j / 7, xj = j - 7 * yj;
-        float s = Tw[bias0 - yj * 13 - xj];
 #pragma unroll
-        for (int d = 0; d < D; ++d) s = fmaf(q[d], Kw[j * D + d], s);
-        m = fmaxf(m, s);
+      for (int j = 0; j < NT; ++j) {
+        s[j] = dot_row<DP>(q, Kw + j * DP, Tw[bias0 - (j / 7) * 13 - (j % 7)]);
+        dp[j] = dot_row<DP>(g, Vw + j * DP, 0.f);
+        m = fmaxf(m, s[j]);
       }
       float l = 0.f, acc = 0.f;
-      for (int j = 0; j < NT; ++j) {
-        const int yj = j / 7, xj = j - 7 * yj;
-        float s = Tw[bias0 - yj * 13 - xj], dp = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) { s = fmaf(q[d], Kw[j * D + d], s); dp = fmaf(g[d], Vw[j * D + d], dp); }
-        const float p = expf(s - m);
-        l += p; acc = fmaf(p, dp, acc);
-      }
+      for (int j = 0; j < NT; ++j) { s[j] = __expf(s[j] - m); l += s[j]; acc = fmaf(s[j], dp[j], acc); }
       const float inv = 1.0f / l, Dl = acc * inv;
-      float dq[D];
+      float dq[DP];
 #pragma unroll
-      for (int d = 0; d < D; ++d) dq[d] = 0.f;
+      for (int d = 0; d < DP; ++d) dq[d] = 0.f;
+#pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int yj = j / 7, xj = j - 7 * yj;
-        const int bidx = bias0 - yj * 13 - xj;
-        float s = Tw[bidx], dp = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) { s = fmaf(q[d], Kw[j * D + d], s); dp = fmaf(g[d], Vw[j * D + d], dp); }
-        const float ds = expf(s - m) * inv * (dp - Dl);
-#pragma unroll
-        for (int d = 0; d < D; ++d) dq[d] = fmaf(ds, Kw[j * D + d], dq[d]);
-        hrf_atomic_add(&sdT[wave][bidx], ds);     // distinct bins across lanes for a fixed j
+        const float ds = s[j] * inv * (dp[j] - Dl);
+        axpy_row<DP>(dq, ds, Kw + j * DP);
+        hrf_atomic_add(&sdT[wave][bias0 - (j / 7) * 13 - (j % 7)], ds);   // distinct bins across lanes
       }
       sM[wave][i] = m; sL[wave][i] = inv; sDl[wave][i] = Dl;
       if (pix >= 0) {
@@ -191,19 +218,19 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_kernel(AttnArgs a) {
     // ---- pass B: lane = key column j -> dK_j, dV_j
     if (active && lane < NT) {
       const int j = lane;
-      float kj[D], vj[D], dk[D], dv[D];
+      float kj[DP], vj[DP], dk[DP], dv[DP];
 #pragma unroll
-      for (int d = 0; d < D; ++d) { kj[d] = Kw[j * D + d]; vj[d] = Vw[j * D + d]; dk[d] = 0.f; dv[d] = 0.f; }
+      for (int d = 0; d < DP; ++d) { kj[d] = Kw[j * DP + d]; vj[d] = Vw[j * DP + d]; dk[d] = 0.f; dv[d] = 0.f; }
       const int sub = yl * 13 + xl;
+#pragma unroll 7
       for (int i = 0; i < NT; ++i) {
         const int yi = i / 7, xi = i - 7 * yi;
-        float s = Tw[(yi + 6) * 13 + (xi + 6) - sub], dp = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) { s = fmaf(Qw[i * D + d], kj[d], s); dp = fmaf(Gw[i * D + d], vj[d], dp); }
-        const float p = expf(s - sM[wave][i]) * sL[wave][i];
-        const float ds = p * (dp - sDl[wave][i]);
-#pragma unroll
-        for (int d = 0; d < D; ++d) { dk[d] = fmaf(ds, Qw[i * D + d], dk[d]); dv[d] = fmaf(p, Gw[i * D + d], dv[d]); }
+        const float s = dot_row<DP>(kj, Qw + i * DP, Tw[(yi + 6) * 13 + (xi + 6) - sub]);
+        const float dpv = dot_row<DP>(vj, Gw + i * DP, 0.f);
+        const float p = __expf(s - sM[wave][i]) * sL[wave][i];
+        const float ds = p * (dpv - sDl[wave][i]);
+        axpy_row<DP>(dk, ds, Qw + i * DP);
+        axpy_row<DP>(dv, p, Gw + i * DP);
       }
       if (pix >= 0) {
 #pragma unroll
@@ -256,7 +283,7 @@ extern "C" int hrf_window_attn_fwd(const float* q, int ldq, int qoff, const floa
   const int nwin = B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
 #define HRF_FWD_GRID(WV) hrf_cdiv(nwin, WV)
-  HRF_ATTN_DISPATCH(attn_fwd_kernel, 4, 4, HRF_FWD_GRID)
+  HRF_ATTN_DISPATCH(attn_fwd_kernel, 2, 2, HRF_FWD_GRID)
   return hrf_check_launch();
 }
 
@@ -286,6 +313,6 @@ extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const floa
     *iters = hrf_cdiv(nw, gx * wv);
     return gx;
   };
-  HRF_ATTN_DISPATCH(attn_bwd_kernel, 4, 2, HRF_BWD_GRID)
+  HRF_ATTN_DISPATCH(attn_bwd_kernel, 2, 2, HRF_BWD_GRID)
   return hrf_check_launch();
 }

@@ -56,10 +56,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
       ry[p] = yo * a.stride - a.pad;
       rx[p] = xo * a.stride - a.pad;
       rb[p] = b * a.sB + ry[p] * a.sY + rx[p] * a.sX;
-      if (TF == HRF_TF_LN) { rmean[p] = a.tf_rowstat[2 * m]; rrstd[p] = a.tf_rowstat[2 * m + 1]; }
     } else {
       ry[p] = -(1 << 20); rx[p] = 0; rb[p] = 0;
     }
+    if (TF == HRF_TF_LN) { const int mc = m < a.M ? m : 0; rmean[p] = a.tf_rowstat[2 * mc]; rrstd[p] = a.tf_rowstat[2 * mc + 1]; }
   }
 
   float areg[RP], breg[NT];
@@ -69,26 +69,36 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     int dy = 0, dx = 0, ci = k;
     if (KH == 3) { const int tap = k / a.Cin; ci = k - tap * a.Cin; dy = tap / 3; dx = tap - 3 * dy; }
     const int koff = dy * a.sY + dx * a.sX + ci * a.sC;
+    // Loads are UNCONDITIONAL (address clamped to element 0, value selected afterwards): a load under
+    // a per-element branch makes hipcc wait vmcnt(0) per element = one dependent memory round trip
+    // per tap instead of one per tile (cdna_hip_programming.md, "three .s-level traps" (c)).
     float sc = 1.f, sh = 0.f;
-    if (TF != HRF_TF_NONE && kv) { sc = a.tf_scale[ci]; sh = a.tf_shift[ci]; }
+    if (TF != HRF_TF_NONE) { const int cs = kv ? ci : 0; sc = a.tf_scale[cs]; sh = a.tf_shift[cs]; }
+    float raw[RP];
+    bool okv[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
-      const bool ok = kv && (unsigned)(ry[p] + dy) < (unsigned)a.H && (unsigned)(rx[p] + dx) < (unsigned)a.W;
-      float v = 0.f;
-      if (ok) {
-        v = a.x[rb[p] + koff];
-        if (TF == HRF_TF_LN) v = fmaf((v - rmean[p]) * rrstd[p], sc, sh);
-        else if (TF != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
-      }
-      areg[p] = v;
+      okv[p] = kv && (unsigned)(ry[p] + dy) < (unsigned)a.H && (unsigned)(rx[p] + dx) < (unsigned)a.W;
+      raw[p] = a.x[okv[p] ? rb[p] + koff : 0];
     }
+    float wraw[NT];
+    bool wok[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       const int n = n0 + r0 + 16 * q;
-      float v = 0.f;
-      if (kv && n < a.Cout) v = (KH == 3) ? a.w[(n * a.Cin + ci) * 9 + dy * 3 + dx] : a.w[n * a.Cin + k];
-      breg[q] = v;
+      wok[q] = kv && n < a.Cout;
+      const int wi = (KH == 3) ? (n * a.Cin + ci) * 9 + dy * 3 + dx : n * a.Cin + k;
+      wraw[q] = a.w[wok[q] ? wi : 0];
     }
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      float v = raw[p];
+      if (TF == HRF_TF_LN) v = fmaf((v - rmean[p]) * rrstd[p], sc, sh);
+      else if (TF != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
+      areg[p] = okv[p] ? v : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) breg[q] = wok[q] ? wraw[q] : 0.f;
   };
 
   hrf_f4 acc[MT][NT];
@@ -128,17 +138,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + j * 16 + col;
     const bool nv = n < a.Cout;
-    const float bv = (a.bias != nullptr && nv) ? a.bias[n] : 0.f;
+    const float bv = a.bias != nullptr ? a.bias[nv ? n : 0] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wave * 16 * MT + i * 16 + (lane >> 4) * 4 + r;
-        if (nv && m < a.M) {
-          float v = acc[i][j][r] + bv;
-          if (a.res != nullptr) v += a.res[(long)m * a.ldR + n];
-          if (a.res2 != nullptr) v += a.res2[(long)m * a.ldR + n];
+        const bool ok = nv && m < a.M;
+        float v = acc[i][j][r] + bv;
+        const long ro = ok ? (long)m * a.ldR + n : 0;
+        if (a.res != nullptr) v += a.res[ro];
+        if (a.res2 != nullptr) v += a.res2[ro];
+        if (ok) {
           a.y[(long)m * a.ldY + a.yoff + n] = v;
           s1 += v; s2 = fmaf(v, v, s2);
         }
@@ -174,7 +186,7 @@ struct ConvBwdDataArgs {
   int M, K;                                    // M = B*H*W, K = KH*KH*Cout
 };
 
-template <int BM, int NT, int KH>
+template <int BM, int NT, int KH, bool BNB>
 __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
   constexpr int BN = NT * 16, MT = BM / 64, RP = BM / 16;
   __shared__ float As[BM * LDK];
@@ -184,8 +196,6 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
   const int kl = tid & 15, r0 = tid >> 4;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   if (tid < 2 * BN) sStat[tid] = 0.f;
-  const bool bnb = a.cA != nullptr;
-
   int rbase[RP], ryp[RP], rxp[RP];
   const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
 #pragma unroll
@@ -206,7 +216,10 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
     int dyy = 0, dxx = 0, co = k;
     if (KH == 3) { const int tap = k / a.Cout; co = k - tap * a.Cout; dyy = tap / 3; dxx = tap - 3 * dyy; }
     float ca = 1.f, cb = 0.f, cc = 0.f;
-    if (bnb && kv) { ca = a.cA[co]; cb = a.cB[co]; cc = a.cC[co]; }
+    if (BNB) { const int cs = kv ? co : 0; ca = a.cA[cs]; cb = a.cB[cs]; cc = a.cC[cs]; }
+    // unconditional (clamped) loads, values selected afterwards - see conv_fwd_kernel::load_tile
+    float dv[RP], yv[RP];
+    bool okv[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
       const int ty = ryp[p] - dyy, tx = rxp[p] - dxx;
@@ -214,21 +227,28 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
       int yo = ty, xo = tx;
       if (a.stride == 2) { ok = ok && ((ty | tx) & 1) == 0; yo = ty >> 1; xo = tx >> 1; }
       ok = ok && yo < a.Ho && xo < a.Wo;
-      float v = 0.f;
-      if (ok) {
-        const long idx = (long)(rbase[p] + yo * a.Wo + xo) * a.ldD + a.doff + co;
-        v = a.dy[idx];
-        if (bnb) v = fmaf(ca, v, fmaf(cb, a.yraw[idx], cc));
-      }
-      areg[p] = v;
+      const long idx = ok ? (long)(rbase[p] + yo * a.Wo + xo) * a.ldD + a.doff + co : 0;
+      okv[p] = ok;
+      dv[p] = a.dy[idx];
+      yv[p] = BNB ? a.yraw[idx] : 0.f;
     }
+    float wraw[NT];
+    bool wok[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       const int n = n0 + r0 + 16 * q;   // n = ci
-      float v = 0.f;
-      if (kv && n < a.Cin) v = (KH == 3) ? a.w[(co * a.Cin + n) * 9 + dyy * 3 + dxx] : a.w[co * a.Cin + n];
-      breg[q] = v;
+      wok[q] = kv && n < a.Cin;
+      const int wi = (KH == 3) ? (co * a.Cin + n) * 9 + dyy * 3 + dxx : co * a.Cin + n;
+      wraw[q] = a.w[wok[q] ? wi : 0];
     }
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      float v = dv[p];
+      if (BNB) v = fmaf(ca, v, fmaf(cb, yv[p], cc));
+      areg[p] = okv[p] ? v : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) breg[q] = wok[q] ? wraw[q] : 0.f;
   };
 
   hrf_f4 acc[MT][NT];
@@ -268,26 +288,26 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
     const int n = n0 + j * 16 + col;
     const bool nv = n < a.Cin;
     float sc = 1.f, sh = 0.f;
-    if (a.epi == 1 && nv) { sc = a.tf_scale[n]; sh = a.tf_shift[n]; }
+    if (a.epi == 1) { sc = a.tf_scale[nv ? n : 0]; sh = a.tf_shift[nv ? n : 0]; }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wave * 16 * MT + i * 16 + (lane >> 4) * 4 + r;
-        if (nv && m < a.M) {
-          float v = acc[i][j][r];
-          const int b = m / HW, rem = m - b * HW;
-          const int yi = rem / a.W, xi = rem - yi * a.W;
-          const long o = (long)b * a.sB + (long)yi * a.sY + (long)xi * a.sX + (long)n * a.sC;
-          if (a.epi == 1) {
-            const float xr = a.xraw[(long)m * a.ldXr + n];
-            v *= hrf_act_grad(a.act, fmaf(xr, sc, sh));
-            s1 += v; s2 = fmaf(v, xr, s2);
-            a.dx[o] = v;
-          } else {
-            a.dx[o] = a.accumulate ? a.dx[o] + v : v;
-          }
+        const bool ok = nv && m < a.M;
+        const int mc = ok ? m : 0;
+        const int b = mc / HW, rem = mc - b * HW;
+        const int yi = rem / a.W, xi = rem - yi * a.W;
+        const long o = ok ? (long)b * a.sB + (long)yi * a.sY + (long)xi * a.sX + (long)n * a.sC : 0;
+        float v = acc[i][j][r];
+        if (a.epi == 1) {
+          const float xr = a.xraw[ok ? (long)m * a.ldXr + n : 0];
+          v *= hrf_act_grad(a.act, fmaf(xr, sc, sh));
+          if (ok) { s1 += v; s2 = fmaf(v, xr, s2); a.dx[o] = v; }
+        } else {
+          const float prev = a.accumulate ? a.dx[o] : 0.f;
+          if (ok) a.dx[o] = prev + v;
         }
       }
     }
@@ -316,12 +336,15 @@ struct ConvBwdWgtArgs {
   int B, H, W, Cin, Ho, Wo, Cout, stride, pad, KH;
   int Mpix, Np;                  // Mpix = B*Ho*Wo (reduction), Np = KH*KH*Cin
   int chunk;                     // pixels per split (multiple of 16)
+  int dbg_plain;                 // tuning aid: plain stores instead of atomics (WRONG results)
 };
+
+static int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 constexpr int WK = 64;     // pixels (reduction elements) staged per step: 4 k-substeps per wave
 constexpr int WLD = 65;    // LDS pitch of the [row][pixel] tiles
 
-template <bool DENSE1>
+template <bool DENSE1, bool BNB>
 __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
   // tile: 64 (co) x 64 (n' = tap*Cin+ci); reduction over pixels.  Every wave owns 16 of the 64
   // pixels of a step (4 MFMA k-substeps) and a full 4x4 grid of 16x16 accumulators; the four
@@ -333,20 +356,19 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
   const int pbeg = blockIdx.z * a.chunk, pend = min(a.Mpix, pbeg + a.chunk);
-  const bool bnb = a.cA != nullptr;
   const int mtiles = min(4, (a.Cout - m0 + 15) / 16), ntiles = min(4, (a.Np - n0 + 15) / 16);
 
   const int co = m0 + lane;
   const bool cov = co < a.Cout;
   float ca = 1.f, cb = 0.f, cc = 0.f;
-  if (bnb && cov) { ca = a.cA[co]; cb = a.cB[co]; cc = a.cC[co]; }
+  if (BNB) { const int cs = cov ? co : 0; ca = a.cA[cs]; cb = a.cB[cs]; cc = a.cC[cs]; }
   const int np = n0 + lane;
   const bool npv = np < a.Np;
   int tap = 0, ci = np;
   if (a.KH == 3) { tap = np / a.Cin; ci = np - tap * a.Cin; }
   const int dyy = tap / 3, dxx = tap - 3 * dyy;
   float sc = 1.f, sh = 0.f;
-  if (a.tf_mode != HRF_TF_NONE && npv) { sc = a.tf_scale[ci]; sh = a.tf_shift[ci]; }
+  if (a.tf_mode != HRF_TF_NONE) { sc = a.tf_scale[npv ? ci : 0]; sh = a.tf_shift[npv ? ci : 0]; }
   const int HoWo = a.Ho * a.Wo;
   float bias_part = 0.f;
 
@@ -361,37 +383,43 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
     int pix = p0 + wave;                       // this thread's pixel slots: p0 + wave + 4*s
     int b = 0, yo = 0, xo = 0;
     if (!DENSE1) { b = pix / HoWo; const int rem = pix - b * HoWo; yo = rem / a.Wo; xo = rem - yo * a.Wo; }
+    // all 32 loads of a step are issued unconditionally (clamped addresses) before any use
+    float ad[16], ay[16], bx[16], bm[16], br[16];
+    bool aok[16], bok[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      float av = 0.f, bv = 0.f;
-      if (pix < pend) {
-        if (cov) {
-          const long idx = (long)pix * a.ldD + a.doff + co;
-          av = a.dy[idx];
-          if (bnb) av = fmaf(ca, av, fmaf(cb, a.yraw[idx], cc));
-        }
-        if (npv) {
-          if (DENSE1) {
-            bv = a.x[(long)pix * a.sX + (long)ci * a.sC];
-            if (a.tf_mode == HRF_TF_LN) bv = fmaf((bv - a.tf_rowstat[2 * pix]) * a.tf_rowstat[2 * pix + 1], sc, sh);
-            else if (a.tf_mode != HRF_TF_NONE) bv = hrf_tf_affine(a.tf_mode, bv, sc, sh);
-          } else {
-            const int yi = yo * a.stride - a.pad + dyy, xi = xo * a.stride - a.pad + dxx;
-            if ((unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W) {
-              bv = a.x[(long)b * a.sB + (long)yi * a.sY + (long)xi * a.sX + (long)ci * a.sC];
-              if (a.tf_mode == HRF_TF_LN) {
-                const long row = (long)(b * a.H + yi) * a.W + xi;
-                bv = fmaf((bv - a.tf_rowstat[2 * row]) * a.tf_rowstat[2 * row + 1], sc, sh);
-              } else if (a.tf_mode != HRF_TF_NONE) {
-                bv = hrf_tf_affine(a.tf_mode, bv, sc, sh);
-              }
-            }
-          }
-        }
+      const bool pv = pix < pend;
+      aok[s] = pv && cov;
+      const long idx = aok[s] ? (long)pix * a.ldD + a.doff + co : 0;
+      ad[s] = a.dy[idx];
+      ay[s] = BNB ? a.yraw[idx] : 0.f;
+      long xo_ = 0, row = 0;
+      bool ok = pv && npv;
+      if (DENSE1) {
+        row = pix;
+        xo_ = (long)pix * a.sX + (long)ci * a.sC;
+      } else {
+        const int yi = yo * a.stride - a.pad + dyy, xi = xo * a.stride - a.pad + dxx;
+        ok = ok && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W;
+        row = (long)(b * a.H + yi) * a.W + xi;
+        xo_ = (long)b * a.sB + (long)yi * a.sY + (long)xi * a.sX + (long)ci * a.sC;
       }
-      areg[s] = av; breg[s] = bv;
+      bok[s] = ok;
+      bx[s] = a.x[ok ? xo_ : 0];
+      bm[s] = 0.f; br[s] = 0.f;
+      if (a.tf_mode == HRF_TF_LN) { bm[s] = a.tf_rowstat[ok ? 2 * row : 0]; br[s] = a.tf_rowstat[ok ? 2 * row + 1 : 0]; }
       pix += 4;
       if (!DENSE1) { xo += 4; while (xo >= a.Wo) { xo -= a.Wo; if (++yo == a.Ho) { yo = 0; ++b; } } }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      float av = ad[s];
+      if (BNB) av = fmaf(ca, av, fmaf(cb, ay[s], cc));
+      float bv = bx[s];
+      if (a.tf_mode == HRF_TF_LN) bv = fmaf((bv - bm[s]) * br[s], sc, sh);
+      else if (a.tf_mode != HRF_TF_NONE) bv = hrf_tf_affine(a.tf_mode, bv, sc, sh);
+      areg[s] = aok[s] ? av : 0.f;
+      breg[s] = bok[s] ? bv : 0.f;
     }
   };
 
@@ -447,7 +475,7 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
       long o;
       if (a.KH == 3) { const int t = nn / a.Cin, c = nn - t * a.Cin; o = ((long)cco * a.Cin + c) * 9 + t; }
       else o = (long)cco * a.Cin + nn;
-      hrf_atomic_add(&a.dw[o], red[ml * WLD + nl]);
+      if (a.dbg_plain) a.dw[o] = red[ml * WLD + nl]; else hrf_atomic_add(&a.dw[o], red[ml * WLD + nl]);
     }
   }
   __syncthreads();
@@ -506,9 +534,14 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
   return hrf_check_launch();
 }
 
-#define HRF_CONV_BD_CASE(BM_, NT_, KH_)                                                                  \
-  HRF_LAUNCH((conv_bwd_data_kernel<BM_, NT_, KH_>), dim3(hrf_cdiv(a.M, BM_), hrf_cdiv(Cin, NT_ * 16)),   \
-             dim3(256), 0, stream, a)
+#define HRF_CONV_BD_CASE(BM_, NT_, KH_)                                                                         \
+  if (cA != nullptr) {                                                                                          \
+    HRF_LAUNCH((conv_bwd_data_kernel<BM_, NT_, KH_, true>), dim3(hrf_cdiv(a.M, BM_), hrf_cdiv(Cin, NT_ * 16)),  \
+               dim3(256), 0, stream, a);                                                                        \
+  } else {                                                                                                      \
+    HRF_LAUNCH((conv_bwd_data_kernel<BM_, NT_, KH_, false>), dim3(hrf_cdiv(a.M, BM_), hrf_cdiv(Cin, NT_ * 16)), \
+               dim3(256), 0, stream, a);                                                                        \
+  }
 #define HRF_CONV_BD_NT(BM_, KH_)                       \
   switch (nt) {                                        \
     case 2: HRF_CONV_BD_CASE(BM_, 2, KH_); break;      \
@@ -542,6 +575,12 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
   return hrf_check_launch();
 }
 
+extern "C" int hrf_debug_knob(int key, int value) {
+  if (key < 0 || key >= 8) return HRF_ERR_ARG;
+  g_knob[key] = value;
+  return HRF_OK;
+}
+
 extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const float* yraw,
                                    const float* cA, const float* cB, const float* cC,
                                    const float* x, int sB, int sY, int sX, int sC,
@@ -563,13 +602,21 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
   // split the pixel reduction so that ~256-512 blocks exist, but never below 4 steps (256 pixels)
   // per block: the per-block epilogue (LDS reduce + one atomic per output) must stay amortised.
   int splits = hrf_cdiv(a.Mpix, 256);
-  const int cap = hrf_cdiv(512, gx * gy);
+  int cap = hrf_cdiv(512, gx * gy);
+  if (g_knob[0] > 0) cap = g_knob[0];
+  a.dbg_plain = g_knob[1];
   if (splits > cap) splits = cap;
   if (splits < 1) splits = 1;
   a.chunk = hrf_cdiv(hrf_cdiv(a.Mpix, splits), WK) * WK;
   splits = hrf_cdiv(a.Mpix, a.chunk);
   const bool dense1 = KH == 1 && stride == 1 && sC == 1 && sY == W * sX && sB == H * sY;
-  if (dense1) { HRF_LAUNCH(conv_bwd_wgt_kernel<true>, dim3(gx, gy, splits), dim3(256), 0, stream, a); }
-  else { HRF_LAUNCH(conv_bwd_wgt_kernel<false>, dim3(gx, gy, splits), dim3(256), 0, stream, a); }
+  const dim3 grid(gx, gy, splits);
+  if (dense1) {
+    if (cA != nullptr) { HRF_LAUNCH((conv_bwd_wgt_kernel<true, true>), grid, dim3(256), 0, stream, a); }
+    else { HRF_LAUNCH((conv_bwd_wgt_kernel<true, false>), grid, dim3(256), 0, stream, a); }
+  } else {
+    if (cA != nullptr) { HRF_LAUNCH((conv_bwd_wgt_kernel<false, true>), grid, dim3(256), 0, stream, a); }
+    else { HRF_LAUNCH((conv_bwd_wgt_kernel<false, false>), grid, dim3(256), 0, stream, a); }
+  }
   return hrf_check_launch();
 }

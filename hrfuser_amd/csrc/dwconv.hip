@@ -42,16 +42,15 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwFwdArgs a) {
     const int c = tid & 31, cg = c0 + c;
     const bool cv = cg < a.C;
     float sc = 1.f, sh = 0.f;
-    if (a.tf_mode != HRF_TF_NONE && cv) { sc = a.tf_scale[cg]; sh = a.tf_shift[cg]; }
+    if (a.tf_mode != HRF_TF_NONE) { sc = a.tf_scale[cv ? cg : 0]; sh = a.tf_shift[cv ? cg : 0]; }
+    // unconditional clamped loads (no load under a per-element branch), value selected afterwards
     for (int pix = tid >> 5; pix < IH * IW; pix += 8) {
       const int iy = pix / IW, ix = pix - iy * IW;
       const int gy = iy0 + iy, gx = ix0 + ix;
-      float v = 0.f;
-      if (cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-        v = a.x[(((long)b * a.H + gy) * a.W + gx) * a.C + cg];
-        if (a.tf_mode != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
-      }
-      sIn[pix * CB + c] = v;
+      const bool ok = cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      float v = a.x[ok ? (((long)b * a.H + gy) * a.W + gx) * a.C + cg : 0];
+      if (a.tf_mode != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
+      sIn[pix * CB + c] = ok ? v : 0.f;
     }
   }
   __syncthreads();
@@ -119,17 +118,15 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
   {
     const bool bnb = a.cA != nullptr;
     float ca = 1.f, cb = 0.f, cc = 0.f;
-    if (bnb && cv) { ca = a.cA[cg]; cb = a.cB[cg]; cc = a.cC[cg]; }
+    if (bnb) { const int cs = cv ? cg : 0; ca = a.cA[cs]; cb = a.cB[cs]; cc = a.cC[cs]; }
     for (int pix = tid >> 5; pix < RH * RW; pix += 8) {
       const int ly = pix / RW, lx = pix - ly * RW;
       const int oy = ry0 + ly, ox = rx0 + lx;
-      float v = 0.f;
-      if (cv && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo) {
-        const long idx = (((long)b * a.Ho + oy) * a.Wo + ox) * a.C + cg;
-        v = a.dy[idx];
-        if (bnb) v = fmaf(ca, v, fmaf(cb, a.yraw[idx], cc));
-      }
-      sD[pix * CB + c] = v;
+      const bool ok = cv && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
+      const long idx = ok ? (((long)b * a.Ho + oy) * a.Wo + ox) * a.C + cg : 0;
+      float v = a.dy[idx];
+      if (bnb) v = fmaf(ca, v, fmaf(cb, a.yraw[idx], cc));
+      sD[pix * CB + c] = ok ? v : 0.f;
     }
   }
   __syncthreads();
@@ -205,16 +202,15 @@ __global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) {
   const bool cv = cg < a.C;
   {
     float sc = 1.f, sh = 0.f;
-    if (a.tf_mode != HRF_TF_NONE && cv) { sc = a.tf_scale[cg]; sh = a.tf_shift[cg]; }
+    if (a.tf_mode != HRF_TF_NONE) { sc = a.tf_scale[cv ? cg : 0]; sh = a.tf_shift[cv ? cg : 0]; }
+    // unconditional clamped loads (no load under a per-element branch), value selected afterwards
     for (int pix = tid >> 5; pix < IH * IW; pix += 8) {
       const int iy = pix / IW, ix = pix - iy * IW;
       const int gy = iy0 + iy, gx = ix0 + ix;
-      float v = 0.f;
-      if (cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-        v = a.x[(((long)b * a.H + gy) * a.W + gx) * a.C + cg];
-        if (a.tf_mode != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
-      }
-      sIn[pix * CB + c] = v;
+      const bool ok = cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      float v = a.x[ok ? (((long)b * a.H + gy) * a.W + gx) * a.C + cg : 0];
+      if (a.tf_mode != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
+      sIn[pix * CB + c] = ok ? v : 0.f;
     }
   }
   __syncthreads();

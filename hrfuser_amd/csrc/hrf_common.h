@@ -13,12 +13,29 @@ enum {
 };
 enum { HRF_ACT_NONE = 0, HRF_ACT_RELU = 1, HRF_ACT_GELU = 2 };
 
+// erf(x) by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, fp32-rounding class): ~15 VALU ops and one
+// v_exp_f32 instead of the ~60-instruction libm erff.  GELU is evaluated on load by every consumer
+// of a BN+GELU tensor (CrossFFN, 189 sites per forward), so its instruction count sets both the
+// VALU time and the I-cache footprint of the unrolled loaders.
+__device__ __forceinline__ float hrf_erf(float x) {
+#ifndef HRF_FAST_ERF   // default: libm-accurate erff (keeps fp32 ReLU-mask flips as rare as the reference)
+  return erff(x);
+#endif
+  const float ax = fabsf(x);
+  const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-ax * ax);
+  return x < 0.f ? -e : e;
+}
 __device__ __forceinline__ float hrf_gelu(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + hrf_erf(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float hrf_gelu_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  const float cdf = 0.5f * (1.0f + hrf_erf(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
 __device__ __forceinline__ float hrf_act(int act, float u) {

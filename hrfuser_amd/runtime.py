@@ -14,6 +14,7 @@ Design (MI355X-first):
 Nothing in this file computes on the CPU: every op is a launch on torch's current HIP stream.
 """
 import math
+import os
 
 import torch
 
@@ -122,11 +123,14 @@ class Ctx:
         self.owner = owner
         self.group = owner.sync_group if training else None
         self.world = owner.sync_world if (training and owner.sync_group is not None) else 1
-        self.multi = bool(torch.cuda.is_available() and getattr(owner, 'use_lanes', True))
+        self.multi = bool(torch.cuda.is_available() and getattr(owner, 'use_lanes', True)
+                          and os.environ.get('HRF_LANES', '1') != '0')
         self.main = Lane(torch.cuda.current_stream() if torch.cuda.is_available() else None)
         self.cur = self.main
         self.stream = self.main.ptr
         self._free = list(owner._lane_pool()) if self.multi else []
+        self._side_i = 0
+        self._side_used = {}
 
     # ---- tape ----------------------------------------------------------------------------------
     def push(self, fn):
@@ -136,7 +140,9 @@ class Ctx:
     # ---- lanes ---------------------------------------------------------------------------------
     def fork(self, n):
         """n sibling lanes that start after everything enqueued so far on the current lane."""
-        if not self.multi or n <= 1:
+        # lanes are always direct children of the main lane: nested stream forks crash hipGraph
+        # capture on ROCm 7.x, and a flat fork/join schedule expresses all the parallelism we need
+        if not self.multi or n <= 1 or self.cur is not self.main:
             return [self.cur] * n
         while len(self._free) < n:
             self._free.append(self.owner._lane_pool(grow=True))
@@ -160,6 +166,20 @@ class Ctx:
     def on(self, lane):
         return _LaneScope(self, lane)
 
+    def side_launch(self, fn):
+        """Run `fn` (one off-critical-path launch) on a side lane that starts after the current lane's
+        work so far and is joined into the main lane at the end of the backward pass."""
+        if not self.multi:
+            fn()
+            return
+        pool = self.owner._side_pool()
+        lane = pool[self._side_i % len(pool)]
+        self._side_i += 1
+        lane.stream.wait_stream(self.cur.stream)
+        self._side_used[id(lane)] = lane
+        with _LaneScope(self, lane):
+            fn()
+
     def run_backward(self):
         tape = self.tape
         self.tape = []
@@ -178,6 +198,9 @@ class Ctx:
                 with _LaneScope(self, lane):
                     fn()
         if self.multi:
+            for lane in self._side_used.values():
+                self.main.stream.wait_stream(lane.stream)
+            self._side_used = {}
             torch.cuda.current_stream().wait_stream(self.main.stream)
 
     def all_reduce(self, t):
@@ -313,9 +336,12 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
     x, strides, (B, H, W, Cin), tf, sc, sh, rowstat = _src_desc(src)
     cA, cB, cC = coef if coef is not None else (None, None, None)
     if weight.requires_grad:
-        L.hrf_conv_bwd_weight(dy, ldD, doff, yraw, cA, cB, cC, x, *strides, B, H, W, Cin, KH, stride, Cout,
-                              tf, sc, sh, rowstat, weight.grad,
-                              bias.grad if (bias is not None and bias.requires_grad) else None, s)
+        # weight gradients are leaves of the backward graph: issue them on a side lane so they overlap
+        # the latency-bound data-gradient chain (operands are never mutated afterwards)
+        bgrad = bias.grad if (bias is not None and bias.requires_grad) else None
+        ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
+            dy, ldD, doff, yraw, cA, cB, cC, x, *strides, B, H, W, Cin, KH, stride, Cout,
+            tf, sc, sh, rowstat, weight.grad, bgrad, ctx.stream))
     if not _needs_grad(src):
         return
     if isinstance(src, Lazy):
@@ -491,8 +517,10 @@ def dwconv_bn(ctx, src, conv, bn, mode):
     def bwd():
         cA, cB, cC = bn_backward_coef(ctx, st)
         if w.requires_grad:
-            L.hrf_dwconv_bwd_weight(st.du, st.raw, cA, cB, cC, x, B, H, W, C, stride, tf, sc, sh, w.grad,
-                                    b.grad if b is not None else None, s)
+            du_ = st.du
+            ctx.side_launch(lambda: L.hrf_dwconv_bwd_weight(
+                du_, st.raw, cA, cB, cC, x, B, H, W, C, stride, tf, sc, sh, w.grad,
+                b.grad if b is not None else None, ctx.stream))
         if isinstance(src, Lazy):
             ps = src.st
             ps.du = _new_like(ps.raw)

@@ -53,6 +53,10 @@ int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const float* yraw,
                         int tf_mode, const float* tf_scale, const float* tf_shift,
                         const float* tf_rowstat, float* dw, float* dbias, void* stream);
 
+/* tuning aid for micro-benchmarks (not used by the product path): key 0 = split cap of
+ * hrf_conv_bwd_weight (0 = default), key 1 = replace its atomics by plain stores (wrong results). */
+int hrf_debug_knob(int key, int value);
+
 /* ---- depthwise 3x3 convolution, pad 1, stride 1|2, NHWC (F.conv2d groups=C) -----------------
  * CrossFFN hrformer.py:271-277 (bias, stride 1, input = GELU(BN(h1)) applied on load) and the
  * fuse-down chains hrformer.py:532-541 (stride 2, no bias).  w is (C,1,3,3).                    */

@@ -124,6 +124,7 @@ inline void hrf_atomic_add(double* p, double v) {
 inline float atomicAdd(float* p, float v) { hrf_atomic_add(p, v); return 0.f; }
 
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline float __expf(float x) { return expf(x); }
 using std::max;
 using std::min;
 

@@ -47,6 +47,19 @@ def rel_l2(a, b, floor=0.0):
     return float((a - b).norm() / (b.norm() + floor))
 
 
+def grad_close(a, b, tol=1e-3, max_flip_frac=0.02):
+    """Gradient comparison robust to fp32 ReLU-mask flips: a pre-activation within fp32 noise of 0
+    may land on either side in two correct fp32 implementations, which changes the gradient inside
+    ONE receptive field.  Pass if max-rel error <= tol, or if the elements beyond tol are a small
+    localized fraction of the tensor (and the tensor-wide rel-L2 stays small)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = float(b.abs().max()) + 1e-30
+    bad = ((a - b).abs() > tol * scale).double().mean().item()
+    if bad == 0.0:
+        return True
+    return bad <= max_flip_frac and float((a - b).norm() / (b.norm() + 1e-30)) < 0.1
+
+
 def disable_stochastic(*nets):
     for net in nets:
         for m in net.modules():
