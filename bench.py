@@ -10,10 +10,13 @@ radar; BASELINE.json configs[1]; SyncBN + RCCL all-reduce when N > 1; weak scali
 the timed region runs on the hand-written HIP kernels (no oracle, no CPU fallback).
 
 The JSON line also carries
-  roofline      dominant kernel: algorithmic FLOPs (or bytes) per launch / measured launch time,
-                measured in-process with HIP events on the launch stream (an instrumented eager
-                pass right after the timed region - events cannot bracket kernels inside a
-                captured hipGraph); cross-checked by profiles/*.csv (rocprofv3 --kernel-trace --stats)
+  roofline      dominant kernel (largest share of GPU time per step): algorithmic FLOPs (or bytes)
+                per launch / average launch duration.  Durations are measured in-process with HIP
+                events on the launch stream: every distinct (entry point, shape) of one training step
+                is re-issued 20x back-to-back inside a captured hipGraph right after the timed region
+                (events cannot bracket single kernels inside the step's own graph, and an event pair
+                around one eager launch measures the ~10 us host gap, not the kernel);
+                cross-checked by profiles/*.csv (rocprofv3 --kernel-trace --stats)
   cpu_baseline  the PyTorch-CPU oracle (kind "port": bit-exact restatement of the reference
                 backbone) timed on the host cores on a bounded sample of the same workload.
 """
@@ -45,7 +48,7 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--profile-steps', type=int, default=3)
+    ap.add_argument('--profile-steps', type=int, default=1)
     ap.add_argument('--dump-kernels', default='', help='write the per-kernel table (JSON) to this path')
     return ap.parse_args()
 
@@ -167,10 +170,10 @@ def main():
         net.train()
 
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:          # every rank runs it (the step contains collectives when N > 1)
         table = profiling.profile_step(trainer, x, mods, cots, steps=args.profile_steps)
         roof = profiling.roofline_of_dominant(table, PEAK_F32_MFMA, PEAK_HBM)
-        if args.dump_kernels:
+        if args.dump_kernels and rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(args.dump_kernels)), exist_ok=True)
             with open(args.dump_kernels, 'w') as fh:
                 json.dump(profiling.table_json(table, PEAK_F32_MFMA, PEAK_HBM), fh, indent=1)

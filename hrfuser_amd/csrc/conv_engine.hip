@@ -6,9 +6,17 @@
 //   conv_bwd_wgt  dW[co][n'] += sum_pix bnbwd(dY)[pix][co] * tf(X)[pix@n']  (split-K, atomics)
 // All contractions run on v_mfma_f32_16x16x4_f32 (exact fp32: parity with the fp32 reference is a
 // hard requirement - SURVEY.md 7 "hard parts": bf16/fp16 inputs fail the 1e-3 gate).
-// BatchNorm / LayerNorm / activation are never materialised: the loaders read the producer's
-// RAW output and apply the affine(+act) on the fly ("transform on load"), the epilogues emit
-// the per-channel sums the next BatchNorm needs.
+// BatchNorm / LayerNorm / activation are never materialised: the loaders read the producer's RAW
+// output, apply the per-channel affine while staging into LDS and the (expensive, erf-based)
+// activation when the MFMA fragment is read - off the global-load -> LDS critical path; the
+// epilogues emit the per-channel sums the next BatchNorm needs.
+//
+// Shape of the problem (HRFuser-T, 2 images/GPU): M = 480..30720 pixels, K = 18..2304, N = 18..576,
+// ~1200 launches per training step, each far too small to fill 256 CUs.  The kernels are therefore
+// built for LATENCY: 64-row tiles (many blocks), 64-deep K steps (few barrier/latency round trips),
+// all global loads of a step issued unconditionally and back-to-back (clamped addresses - a load
+// under a per-element branch costs one dependent memory round trip each), next step prefetched
+// into registers under the current step's MFMAs.
 //
 // Reference ops replaced: every nn.Conv2d(k=1|3, groups=1) + nn.Linear reached from
 // mmdet/models/backbones/{hrfuser_hrformer_based,hrformer,hrnet,resnet}.py.
@@ -17,14 +25,22 @@
 
 namespace {
 
-constexpr int BK = 16;    // K elements staged per step (4 MFMA k-substeps)
-constexpr int LDK = 17;   // LDS row pitch: [row][k], 17 keeps MFMA fragment reads conflict-free
+constexpr int BM = 64;      // output rows (pixels) per block: one 16-row MFMA tile per wave
+constexpr int BK = 64;      // K elements staged per step (16 MFMA k-substeps)
+constexpr int LDK = 65;     // LDS pitch of the [row][k] tiles: bank = (row + k) % 32
+constexpr float SENT = -1.0e30f;   // staged pre-activation of a zero-padded tap: relu/gelu(SENT) == 0
+
+static int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+__device__ __forceinline__ float act_at_read(int tf, float u) {
+  return tf == HRF_TF_AFFINE_RELU ? fmaxf(u, 0.f) : (tf == HRF_TF_AFFINE_GELU ? hrf_gelu(u) : u);
+}
 
 struct ConvFwdArgs {
   const float* x; const float* w; const float* bias;
   float* y; int ldY; int yoff;
   const float* res; int ldR; const float* res2;
-  int tf_mode; const float* tf_scale; const float* tf_shift; const float* tf_rowstat;
+  const float* tf_scale; const float* tf_shift; const float* tf_rowstat;
   double* stats;
   int B, H, W, Cin, Ho, Wo, Cout, stride, pad;
   int sB, sY, sX, sC;
@@ -32,107 +48,107 @@ struct ConvFwdArgs {
 };
 
 // --------------------------------------------------------------------------------- forward
-template <int BM, int NT, int KH, int TF>
+template <int NT, int KH, int TF>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
-  constexpr int BN = NT * 16, MT = BM / 64, RP = BM / 16;
+  constexpr int BN = NT * 16, RP = BM / 4, RQ = BN / 4;
   __shared__ float As[BM * LDK];
   __shared__ float Bs[BN * LDK];
-  __shared__ float sStat[2 * BN];
+  __shared__ float sStat[4 * 2 * BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kl = tid & 15, r0 = tid >> 4;
+  const int kl = tid & 63, r0 = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  if (tid < 2 * BN) sStat[tid] = 0.f;
 
-  int rb[RP], ry[RP], rx[RP];
-  float rmean[RP], rrstd[RP];
+  // per-thread row bookkeeping for its 16 staged rows (r0 + 4p)
+  int rb[RP];
+  unsigned ryx[KH == 3 ? RP : 1];
+  float rmean[TF == HRF_TF_LN ? RP : 1], rrstd[TF == HRF_TF_LN ? RP : 1];
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int p = 0; p < RP; ++p) {
-    const int m = m0 + r0 + 16 * p;
-    rmean[p] = 0.f; rrstd[p] = 0.f;
-    if (m < a.M) {
-      const int b = m / HoWo, rem = m - b * HoWo;
-      const int yo = rem / a.Wo, xo = rem - yo * a.Wo;
-      ry[p] = yo * a.stride - a.pad;
-      rx[p] = xo * a.stride - a.pad;
-      rb[p] = b * a.sB + ry[p] * a.sY + rx[p] * a.sX;
+    const int m = m0 + r0 + 4 * p;
+    const bool mv = m < a.M;
+    const int mc = mv ? m : 0;
+    const int b = mc / HoWo, rem = mc - b * HoWo;
+    const int yo = rem / a.Wo, xo = rem - yo * a.Wo;
+    const int ry = yo * a.stride - a.pad, rx = xo * a.stride - a.pad;
+    if (KH == 3) {
+      rb[p] = b * a.sB + ry * a.sY + rx * a.sX;
+      ryx[p] = mv ? ((unsigned)(ry + 1) << 16) | (unsigned)(rx + 1) : 0xFFFF0000u;
     } else {
-      ry[p] = -(1 << 20); rx[p] = 0; rb[p] = 0;
+      rb[p] = mv ? b * a.sB + ry * a.sY + rx * a.sX : -1;
     }
-    if (TF == HRF_TF_LN) { const int mc = m < a.M ? m : 0; rmean[p] = a.tf_rowstat[2 * mc]; rrstd[p] = a.tf_rowstat[2 * mc + 1]; }
+    if (TF == HRF_TF_LN) { rmean[p] = a.tf_rowstat[2 * mc]; rrstd[p] = a.tf_rowstat[2 * mc + 1]; }
   }
 
-  float areg[RP], breg[NT];
+  float areg[RP], breg[RQ];
   auto load_tile = [&](int k0) {
     const int k = k0 + kl;
     const bool kv = k < a.K;
-    int dy = 0, dx = 0, ci = k;
-    if (KH == 3) { const int tap = k / a.Cin; ci = k - tap * a.Cin; dy = tap / 3; dx = tap - 3 * dy; }
+    int dy = 0, dx = 0, ci = kv ? k : 0;
+    if (KH == 3) { const int tap = ci / a.Cin; ci -= tap * a.Cin; dy = tap / 3; dx = tap - 3 * dy; }
     const int koff = dy * a.sY + dx * a.sX + ci * a.sC;
-    // Loads are UNCONDITIONAL (address clamped to element 0, value selected afterwards): a load under
-    // a per-element branch makes hipcc wait vmcnt(0) per element = one dependent memory round trip
-    // per tap instead of one per tile (cdna_hip_programming.md, "three .s-level traps" (c)).
     float sc = 1.f, sh = 0.f;
-    if (TF != HRF_TF_NONE) { const int cs = kv ? ci : 0; sc = a.tf_scale[cs]; sh = a.tf_shift[cs]; }
+    if (TF != HRF_TF_NONE) { sc = a.tf_scale[ci]; sh = a.tf_shift[ci]; }
     float raw[RP];
     bool okv[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
-      okv[p] = kv && (unsigned)(ry[p] + dy) < (unsigned)a.H && (unsigned)(rx[p] + dx) < (unsigned)a.W;
-      raw[p] = a.x[okv[p] ? rb[p] + koff : 0];
+      bool ok;
+      if (KH == 3) {
+        const int yy = (int)(ryx[p] >> 16) - 1 + dy, xx = (int)(ryx[p] & 0xFFFFu) - 1 + dx;
+        ok = kv && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      } else {
+        ok = kv && rb[p] >= 0;
+      }
+      okv[p] = ok;
+      raw[p] = a.x[ok ? rb[p] + koff : 0];
     }
-    float wraw[NT];
-    bool wok[NT];
+    const int wk = (KH == 3) ? ci * 9 + dy * 3 + dx : ci;
+    const int wrow = (KH == 3) ? a.Cin * 9 : a.Cin;
+    float wraw[RQ];
+    bool wok[RQ];
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-      const int n = n0 + r0 + 16 * q;
+    for (int q = 0; q < RQ; ++q) {
+      const int n = n0 + r0 + 4 * q;
       wok[q] = kv && n < a.Cout;
-      const int wi = (KH == 3) ? (n * a.Cin + ci) * 9 + dy * 3 + dx : n * a.Cin + k;
-      wraw[q] = a.w[wok[q] ? wi : 0];
+      wraw[q] = a.w[wok[q] ? n * wrow + wk : 0];
     }
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
       float v = raw[p];
       if (TF == HRF_TF_LN) v = fmaf((v - rmean[p]) * rrstd[p], sc, sh);
-      else if (TF != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
-      areg[p] = okv[p] ? v : 0.f;
+      else if (TF != HRF_TF_NONE) v = fmaf(v, sc, sh);
+      const float zero = (TF == HRF_TF_AFFINE_RELU || TF == HRF_TF_AFFINE_GELU) ? SENT : 0.f;
+      areg[p] = okv[p] ? v : zero;
     }
 #pragma unroll
-    for (int q = 0; q < NT; ++q) breg[q] = wok[q] ? wraw[q] : 0.f;
+    for (int q = 0; q < RQ; ++q) breg[q] = wok[q] ? wraw[q] : 0.f;
   };
 
-  hrf_f4 acc[MT][NT];
+  hrf_f4 acc[NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NT; ++j) acc[j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
 
   load_tile(0);
   for (int k0 = 0; k0 < a.K; k0 += BK) {
 #pragma unroll
-    for (int p = 0; p < RP; ++p) As[(r0 + 16 * p) * LDK + kl] = areg[p];
+    for (int p = 0; p < RP; ++p) As[(r0 + 4 * p) * LDK + kl] = areg[p];
 #pragma unroll
-    for (int q = 0; q < NT; ++q) Bs[(r0 + 16 * q) * LDK + kl] = breg[q];
+    for (int q = 0; q < RQ; ++q) Bs[(r0 + 4 * q) * LDK + kl] = breg[q];
     __syncthreads();
     if (k0 + BK < a.K) load_tile(k0 + BK);
+    const int ksub = min(16, (a.K - k0 + 3) >> 2);
+#pragma unroll 4
+    for (int kk = 0; kk < ksub; ++kk) {
+      const int kc = kk * 4 + (lane >> 4);
+      const float af = act_at_read(TF, As[(wave * 16 + (lane & 15)) * LDK + kc]);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (k0 + kk * 4 < a.K) {
-        float af[MT], bf[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = As[(wave * 16 * MT + i * 16 + (lane & 15)) * LDK + kk * 4 + (lane >> 4)];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = Bs[(j * 16 + (lane & 15)) * LDK + kk * 4 + (lane >> 4)];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = hrf_mfma16(af[i], bf[j], acc[i][j]);
-      }
+      for (int j = 0; j < NT; ++j) acc[j] = hrf_mfma16(af, Bs[(j * 16 + (lane & 15)) * LDK + kc], acc[j]);
     }
     __syncthreads();
   }
 
-  // epilogue: bias, residual, store, per-channel (sum, sumsq) for the following BatchNorm
+  // epilogue: bias, residual(s), store, per-channel (sum, sumsq) for the following BatchNorm
   const int col = lane & 15;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -141,32 +157,32 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     const float bv = a.bias != nullptr ? a.bias[nv ? n : 0] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wave * 16 * MT + i * 16 + (lane >> 4) * 4 + r;
-        const bool ok = nv && m < a.M;
-        float v = acc[i][j][r] + bv;
-        const long ro = ok ? (long)m * a.ldR + n : 0;
-        if (a.res != nullptr) v += a.res[ro];
-        if (a.res2 != nullptr) v += a.res2[ro];
-        if (ok) {
-          a.y[(long)m * a.ldY + a.yoff + n] = v;
-          s1 += v; s2 = fmaf(v, v, s2);
-        }
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 16 + (lane >> 4) * 4 + r;
+      const bool ok = nv && m < a.M;
+      float v = acc[j][r] + bv;
+      const int ro = ok ? m * a.ldR + n : 0;
+      if (a.res != nullptr) v += a.res[ro];
+      if (a.res2 != nullptr) v += a.res2[ro];
+      if (ok) {
+        a.y[m * a.ldY + a.yoff + n] = v;
+        s1 += v; s2 = fmaf(v, v, s2);
       }
     }
     if (a.stats != nullptr) {
       s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-      if (lane < 16) { hrf_atomic_add(&sStat[j * 16 + lane], s1); hrf_atomic_add(&sStat[BN + j * 16 + lane], s2); }
+      if (lane < 16) { sStat[wave * 2 * BN + j * 16 + lane] = s1; sStat[wave * 2 * BN + BN + j * 16 + lane] = s2; }
     }
   }
   if (a.stats != nullptr) {
     __syncthreads();
-    if (tid < BN && n0 + tid < a.Cout) {
-      hrf_atomic_add(&a.stats[n0 + tid], (double)sStat[tid]);
-      hrf_atomic_add(&a.stats[a.Cout + n0 + tid], (double)sStat[BN + tid]);
+    if (tid < 2 * BN) {
+      const int c = tid < BN ? tid : tid - BN;
+      if (n0 + c < a.Cout) {
+        const float s = sStat[tid] + sStat[2 * BN + tid] + sStat[4 * BN + tid] + sStat[6 * BN + tid];
+        hrf_atomic_add(&a.stats[(tid < BN ? 0 : a.Cout) + n0 + c], (double)s);
+      }
     }
   }
 }
@@ -186,57 +202,56 @@ struct ConvBwdDataArgs {
   int M, K;                                    // M = B*H*W, K = KH*KH*Cout
 };
 
-template <int BM, int NT, int KH, bool BNB>
+template <int NT, int KH, bool BNB>
 __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
-  constexpr int BN = NT * 16, MT = BM / 64, RP = BM / 16;
+  constexpr int BN = NT * 16, RP = BM / 4, RQ = BN / 4;
   __shared__ float As[BM * LDK];
   __shared__ float Bs[BN * LDK];
-  __shared__ float sStat[2 * BN];
+  __shared__ float sStat[4 * 2 * BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kl = tid & 15, r0 = tid >> 4;
+  const int kl = tid & 63, r0 = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  if (tid < 2 * BN) sStat[tid] = 0.f;
-  int rbase[RP], ryp[RP], rxp[RP];
+
+  int rbase[RP];
+  unsigned ryx[RP];
   const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int p = 0; p < RP; ++p) {
-    const int m = m0 + r0 + 16 * p;
-    if (m < a.M) {
-      const int b = m / HW, rem = m - b * HW;
-      const int yi = rem / a.W, xi = rem - yi * a.W;
-      rbase[p] = b * HoWo; ryp[p] = yi + a.pad; rxp[p] = xi + a.pad;
-    } else {
-      rbase[p] = 0; ryp[p] = -(1 << 20); rxp[p] = 0;
-    }
+    const int m = m0 + r0 + 4 * p;
+    const bool mv = m < a.M;
+    const int mc = mv ? m : 0;
+    const int b = mc / HW, rem = mc - b * HW;
+    const int yi = rem / a.W, xi = rem - yi * a.W;
+    rbase[p] = b * HoWo;
+    ryx[p] = mv ? ((unsigned)(yi + a.pad) << 16) | (unsigned)(xi + a.pad) : 0xFFFFFFFFu;
   }
-  float areg[RP], breg[NT];
+  float areg[RP], breg[RQ];
   auto load_tile = [&](int k0) {
     const int k = k0 + kl;
     const bool kv = k < a.K;
-    int dyy = 0, dxx = 0, co = k;
-    if (KH == 3) { const int tap = k / a.Cout; co = k - tap * a.Cout; dyy = tap / 3; dxx = tap - 3 * dyy; }
+    int dyy = 0, dxx = 0, co = kv ? k : 0;
+    if (KH == 3) { const int tap = co / a.Cout; co -= tap * a.Cout; dyy = tap / 3; dxx = tap - 3 * dyy; }
     float ca = 1.f, cb = 0.f, cc = 0.f;
-    if (BNB) { const int cs = kv ? co : 0; ca = a.cA[cs]; cb = a.cB[cs]; cc = a.cC[cs]; }
-    // unconditional (clamped) loads, values selected afterwards - see conv_fwd_kernel::load_tile
+    if (BNB) { ca = a.cA[co]; cb = a.cB[co]; cc = a.cC[co]; }
     float dv[RP], yv[RP];
     bool okv[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
-      const int ty = ryp[p] - dyy, tx = rxp[p] - dxx;
-      bool ok = kv && ty >= 0 && tx >= 0;
+      const int ty = (int)(ryx[p] >> 16) - dyy, tx = (int)(ryx[p] & 0xFFFFu) - dxx;
+      bool ok = kv && ryx[p] != 0xFFFFFFFFu && ty >= 0 && tx >= 0;
       int yo = ty, xo = tx;
       if (a.stride == 2) { ok = ok && ((ty | tx) & 1) == 0; yo = ty >> 1; xo = tx >> 1; }
       ok = ok && yo < a.Ho && xo < a.Wo;
-      const long idx = ok ? (long)(rbase[p] + yo * a.Wo + xo) * a.ldD + a.doff + co : 0;
+      const int idx = ok ? (rbase[p] + yo * a.Wo + xo) * a.ldD + a.doff + co : 0;
       okv[p] = ok;
       dv[p] = a.dy[idx];
       yv[p] = BNB ? a.yraw[idx] : 0.f;
     }
-    float wraw[NT];
-    bool wok[NT];
+    float wraw[RQ];
+    bool wok[RQ];
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-      const int n = n0 + r0 + 16 * q;   // n = ci
+    for (int q = 0; q < RQ; ++q) {
+      const int n = n0 + r0 + 4 * q;   // n = ci
       wok[q] = kv && n < a.Cin;
       const int wi = (KH == 3) ? (co * a.Cin + n) * 9 + dyy * 3 + dxx : co * a.Cin + n;
       wraw[q] = a.w[wok[q] ? wi : 0];
@@ -248,41 +263,44 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
       areg[p] = okv[p] ? v : 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < NT; ++q) breg[q] = wok[q] ? wraw[q] : 0.f;
+    for (int q = 0; q < RQ; ++q) breg[q] = wok[q] ? wraw[q] : 0.f;
   };
 
-  hrf_f4 acc[MT][NT];
+  hrf_f4 acc[NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NT; ++j) acc[j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
 
   load_tile(0);
   for (int k0 = 0; k0 < a.K; k0 += BK) {
 #pragma unroll
-    for (int p = 0; p < RP; ++p) As[(r0 + 16 * p) * LDK + kl] = areg[p];
+    for (int p = 0; p < RP; ++p) As[(r0 + 4 * p) * LDK + kl] = areg[p];
 #pragma unroll
-    for (int q = 0; q < NT; ++q) Bs[(r0 + 16 * q) * LDK + kl] = breg[q];
+    for (int q = 0; q < RQ; ++q) Bs[(r0 + 4 * q) * LDK + kl] = breg[q];
     __syncthreads();
     if (k0 + BK < a.K) load_tile(k0 + BK);
+    const int ksub = min(16, (a.K - k0 + 3) >> 2);
+#pragma unroll 4
+    for (int kk = 0; kk < ksub; ++kk) {
+      const int kc = kk * 4 + (lane >> 4);
+      const float af = As[(wave * 16 + (lane & 15)) * LDK + kc];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (k0 + kk * 4 < a.K) {
-        float af[MT], bf[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = As[(wave * 16 * MT + i * 16 + (lane & 15)) * LDK + kk * 4 + (lane >> 4)];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = Bs[(j * 16 + (lane & 15)) * LDK + kk * 4 + (lane >> 4)];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = hrf_mfma16(af[i], bf[j], acc[i][j]);
-      }
+      for (int j = 0; j < NT; ++j) acc[j] = hrf_mfma16(af, Bs[(j * 16 + (lane & 15)) * LDK + kc], acc[j]);
     }
     __syncthreads();
   }
 
   const int col = lane & 15;
+  int orow[4];
+  bool rowok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + wave * 16 + (lane >> 4) * 4 + r;
+    rowok[r] = m < a.M;
+    const int mc = rowok[r] ? m : 0;
+    const int b = mc / HW, rem = mc - b * HW;
+    const int yi = rem / a.W, xi = rem - yi * a.W;
+    orow[r] = b * a.sB + yi * a.sY + xi * a.sX;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + j * 16 + col;
@@ -291,37 +309,34 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
     if (a.epi == 1) { sc = a.tf_scale[nv ? n : 0]; sh = a.tf_shift[nv ? n : 0]; }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wave * 16 * MT + i * 16 + (lane >> 4) * 4 + r;
-        const bool ok = nv && m < a.M;
-        const int mc = ok ? m : 0;
-        const int b = mc / HW, rem = mc - b * HW;
-        const int yi = rem / a.W, xi = rem - yi * a.W;
-        const long o = ok ? (long)b * a.sB + (long)yi * a.sY + (long)xi * a.sX + (long)n * a.sC : 0;
-        float v = acc[i][j][r];
-        if (a.epi == 1) {
-          const float xr = a.xraw[ok ? (long)m * a.ldXr + n : 0];
-          v *= hrf_act_grad(a.act, fmaf(xr, sc, sh));
-          if (ok) { s1 += v; s2 = fmaf(v, xr, s2); a.dx[o] = v; }
-        } else {
-          const float prev = a.accumulate ? a.dx[o] : 0.f;
-          if (ok) a.dx[o] = prev + v;
-        }
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 16 + (lane >> 4) * 4 + r;
+      const bool ok = nv && rowok[r];
+      const int o = ok ? orow[r] + n * a.sC : 0;
+      float v = acc[j][r];
+      if (a.epi == 1) {
+        const float xr = a.xraw[ok ? m * a.ldXr + n : 0];
+        v *= hrf_act_grad(a.act, fmaf(xr, sc, sh));
+        if (ok) { s1 += v; s2 = fmaf(v, xr, s2); a.dx[o] = v; }
+      } else {
+        const float prev = a.accumulate ? a.dx[o] : 0.f;
+        if (ok) a.dx[o] = prev + v;
       }
     }
     if (a.epi == 1 && a.stats != nullptr) {
       s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-      if (lane < 16) { hrf_atomic_add(&sStat[j * 16 + lane], s1); hrf_atomic_add(&sStat[BN + j * 16 + lane], s2); }
+      if (lane < 16) { sStat[wave * 2 * BN + j * 16 + lane] = s1; sStat[wave * 2 * BN + BN + j * 16 + lane] = s2; }
     }
   }
   if (a.epi == 1 && a.stats != nullptr) {
     __syncthreads();
-    if (tid < BN && n0 + tid < a.Cin) {
-      hrf_atomic_add(&a.stats[n0 + tid], (double)sStat[tid]);
-      hrf_atomic_add(&a.stats[a.Cin + n0 + tid], (double)sStat[BN + tid]);
+    if (tid < 2 * BN) {
+      const int c = tid < BN ? tid : tid - BN;
+      if (n0 + c < a.Cin) {
+        const float s = sStat[tid] + sStat[2 * BN + tid] + sStat[4 * BN + tid] + sStat[6 * BN + tid];
+        hrf_atomic_add(&a.stats[(tid < BN ? 0 : a.Cin) + n0 + c], (double)s);
+      }
     }
   }
 }
@@ -335,16 +350,15 @@ struct ConvBwdWgtArgs {
   float* dw; float* dbias;
   int B, H, W, Cin, Ho, Wo, Cout, stride, pad, KH;
   int Mpix, Np;                  // Mpix = B*Ho*Wo (reduction), Np = KH*KH*Cin
-  int chunk;                     // pixels per split (multiple of 16)
+  int chunk;                     // pixels per split (multiple of WK)
   int dbg_plain;                 // tuning aid: plain stores instead of atomics (WRONG results)
 };
-
-static int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 constexpr int WK = 64;     // pixels (reduction elements) staged per step: 4 k-substeps per wave
 constexpr int WLD = 65;    // LDS pitch of the [row][pixel] tiles
 
-template <bool DENSE1, bool BNB>
+// TFA: activation applied to the X operand when its MFMA fragment is read (0 none, 2 relu, 3 gelu)
+template <bool DENSE1, bool BNB, int TFA>
 __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
   // tile: 64 (co) x 64 (n' = tap*Cin+ci); reduction over pixels.  Every wave owns 16 of the 64
   // pixels of a step (4 MFMA k-substeps) and a full 4x4 grid of 16x16 accumulators; the four
@@ -364,11 +378,12 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
   if (BNB) { const int cs = cov ? co : 0; ca = a.cA[cs]; cb = a.cB[cs]; cc = a.cC[cs]; }
   const int np = n0 + lane;
   const bool npv = np < a.Np;
-  int tap = 0, ci = np;
-  if (a.KH == 3) { tap = np / a.Cin; ci = np - tap * a.Cin; }
+  int tap = 0, ci = npv ? np : 0;
+  if (a.KH == 3) { tap = ci / a.Cin; ci -= tap * a.Cin; }
   const int dyy = tap / 3, dxx = tap - 3 * dyy;
   float sc = 1.f, sh = 0.f;
-  if (a.tf_mode != HRF_TF_NONE) { sc = a.tf_scale[npv ? ci : 0]; sh = a.tf_shift[npv ? ci : 0]; }
+  if (a.tf_mode != HRF_TF_NONE) { sc = a.tf_scale[ci]; sh = a.tf_shift[ci]; }
+  const bool ln = a.tf_mode == HRF_TF_LN;
   const int HoWo = a.Ho * a.Wo;
   float bias_part = 0.f;
 
@@ -383,31 +398,31 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
     int pix = p0 + wave;                       // this thread's pixel slots: p0 + wave + 4*s
     int b = 0, yo = 0, xo = 0;
     if (!DENSE1) { b = pix / HoWo; const int rem = pix - b * HoWo; yo = rem / a.Wo; xo = rem - yo * a.Wo; }
-    // all 32 loads of a step are issued unconditionally (clamped addresses) before any use
+    // all loads of a step are issued unconditionally (clamped addresses) before any use
     float ad[16], ay[16], bx[16], bm[16], br[16];
     bool aok[16], bok[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const bool pv = pix < pend;
       aok[s] = pv && cov;
-      const long idx = aok[s] ? (long)pix * a.ldD + a.doff + co : 0;
+      const int idx = aok[s] ? pix * a.ldD + a.doff + co : 0;
       ad[s] = a.dy[idx];
       ay[s] = BNB ? a.yraw[idx] : 0.f;
-      long xo_ = 0, row = 0;
+      int xo_ = 0, row = 0;
       bool ok = pv && npv;
       if (DENSE1) {
         row = pix;
-        xo_ = (long)pix * a.sX + (long)ci * a.sC;
+        xo_ = pix * a.sX + ci * a.sC;
       } else {
         const int yi = yo * a.stride - a.pad + dyy, xi = xo * a.stride - a.pad + dxx;
         ok = ok && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W;
-        row = (long)(b * a.H + yi) * a.W + xi;
-        xo_ = (long)b * a.sB + (long)yi * a.sY + (long)xi * a.sX + (long)ci * a.sC;
+        row = (b * a.H + yi) * a.W + xi;
+        xo_ = b * a.sB + yi * a.sY + xi * a.sX + ci * a.sC;
       }
       bok[s] = ok;
       bx[s] = a.x[ok ? xo_ : 0];
       bm[s] = 0.f; br[s] = 0.f;
-      if (a.tf_mode == HRF_TF_LN) { bm[s] = a.tf_rowstat[ok ? 2 * row : 0]; br[s] = a.tf_rowstat[ok ? 2 * row + 1 : 0]; }
+      if (ln) { bm[s] = a.tf_rowstat[ok ? 2 * row : 0]; br[s] = a.tf_rowstat[ok ? 2 * row + 1 : 0]; }
       pix += 4;
       if (!DENSE1) { xo += 4; while (xo >= a.Wo) { xo -= a.Wo; if (++yo == a.Ho) { yo = 0; ++b; } } }
     }
@@ -416,10 +431,10 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
       float av = ad[s];
       if (BNB) av = fmaf(ca, av, fmaf(cb, ay[s], cc));
       float bv = bx[s];
-      if (a.tf_mode == HRF_TF_LN) bv = fmaf((bv - bm[s]) * br[s], sc, sh);
-      else if (a.tf_mode != HRF_TF_NONE) bv = hrf_tf_affine(a.tf_mode, bv, sc, sh);
+      if (ln) bv = fmaf((bv - bm[s]) * br[s], sc, sh);
+      else bv = fmaf(bv, sc, sh);               // (sc, sh) = (1, 0) when no transform
       areg[s] = aok[s] ? av : 0.f;
-      breg[s] = bok[s] ? bv : 0.f;
+      breg[s] = bok[s] ? bv : (TFA != 0 ? SENT : 0.f);
     }
   };
 
@@ -433,14 +448,14 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
     }
     __syncthreads();
     if (p0 + WK < pend) load_tile(p0 + WK);
-#pragma unroll
+#pragma unroll 2
     for (int kk = 0; kk < 4; ++kk) {
       const int kq = (wave * 4 + kk) * 4 + (lane >> 4);
       float af[4], bf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = As[(i * 16 + (lane & 15)) * WLD + kq];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = Bs[(j * 16 + (lane & 15)) * WLD + kq];
+      for (int j = 0; j < 4; ++j) bf[j] = act_at_read(TFA, Bs[(j * 16 + (lane & 15)) * WLD + kq]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -472,9 +487,9 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
     const int ml = e >> 6, nl = e & 63;
     const int cco = m0 + ml, nn = n0 + nl;
     if (cco < a.Cout && nn < a.Np && (ml >> 4) < mtiles && (nl >> 4) < ntiles) {
-      long o;
-      if (a.KH == 3) { const int t = nn / a.Cin, c = nn - t * a.Cin; o = ((long)cco * a.Cin + c) * 9 + t; }
-      else o = (long)cco * a.Cin + nn;
+      int o;
+      if (a.KH == 3) { const int t = nn / a.Cin, c = nn - t * a.Cin; o = (cco * a.Cin + c) * 9 + t; }
+      else o = cco * a.Cin + nn;
       if (a.dbg_plain) a.dw[o] = red[ml * WLD + nl]; else hrf_atomic_add(&a.dw[o], red[ml * WLD + nl]);
     }
   }
@@ -495,17 +510,21 @@ inline int pick_nt(int C) {
 
 }  // namespace
 
-#define HRF_CONV_FWD_CASE(BM_, NT_, KH_, TF_)                                                        \
-  HRF_LAUNCH((conv_fwd_kernel<BM_, NT_, KH_, TF_>), dim3(hrf_cdiv(a.M, BM_), hrf_cdiv(Cout, NT_ * 16)), \
-             dim3(256), 0, stream, a)
-#define HRF_CONV_FWD_NT(BM_, KH_, TF_)                       \
-  switch (nt) {                                              \
-    case 2: HRF_CONV_FWD_CASE(BM_, 2, KH_, TF_); break;      \
-    case 3: HRF_CONV_FWD_CASE(BM_, 3, KH_, TF_); break;      \
-    default: HRF_CONV_FWD_CASE(BM_, 4, KH_, TF_); break;     \
+#define HRF_CF_LAUNCH(NT_, KH_, TF_) \
+  HRF_LAUNCH((conv_fwd_kernel<NT_, KH_, TF_>), dim3(hrf_cdiv(a.M, BM), hrf_cdiv(Cout, NT_ * 16)), dim3(256), 0, stream, a)
+#define HRF_CF_NT(KH_, TF_)                          \
+  switch (nt) {                                      \
+    case 2: HRF_CF_LAUNCH(2, KH_, TF_); break;       \
+    case 3: HRF_CF_LAUNCH(3, KH_, TF_); break;       \
+    default: HRF_CF_LAUNCH(4, KH_, TF_); break;      \
   }
-#define HRF_CONV_FWD_BM(KH_, TF_)                                          \
-  if (bm == 128) { HRF_CONV_FWD_NT(128, KH_, TF_) } else { HRF_CONV_FWD_NT(64, KH_, TF_) }
+#define HRF_CF_TF(KH_)                                            \
+  switch (tf_mode) {                                              \
+    case HRF_TF_NONE: HRF_CF_NT(KH_, HRF_TF_NONE) break;          \
+    case HRF_TF_AFFINE: HRF_CF_NT(KH_, HRF_TF_AFFINE) break;      \
+    case HRF_TF_AFFINE_RELU: HRF_CF_NT(KH_, HRF_TF_AFFINE_RELU) break; \
+    default: HRF_CF_NT(KH_, HRF_TF_AFFINE_GELU) break;            \
+  }
 
 extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin,
                             const float* w, const float* bias, int KH, int stride, int Cout,
@@ -513,43 +532,34 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
                             int tf_mode, const float* tf_scale, const float* tf_shift,
                             const float* tf_rowstat, double* stats, void* stream) {
   if ((KH != 1 && KH != 3) || (stride != 1 && stride != 2)) return HRF_ERR_ARG;
+  if (tf_mode < 0 || tf_mode > 4) return HRF_ERR_ARG;
   if (tf_mode == HRF_TF_LN && (KH != 1 || stride != 1)) return HRF_ERR_ARG;
   ConvFwdArgs a;
   const int pad = KH / 2;
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.ldY = ldY; a.yoff = yoff; a.res = res; a.res2 = res2; a.ldR = ldR;
-  a.tf_mode = tf_mode; a.tf_scale = tf_scale; a.tf_shift = tf_shift; a.tf_rowstat = tf_rowstat;
+  a.tf_scale = tf_scale; a.tf_shift = tf_shift; a.tf_rowstat = tf_rowstat;
   a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin;
   a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KH) / stride + 1;
   a.Cout = Cout; a.stride = stride; a.pad = pad; a.sB = sB; a.sY = sY; a.sX = sX; a.sC = sC;
   a.M = B * a.Ho * a.Wo; a.K = KH * KH * Cin;
   if (a.M <= 0) return HRF_OK;
   const int nt = pick_nt(Cout);
-  const int bm = a.M >= 128 * 192 ? 128 : 64;
-  const int tfk = tf_mode == HRF_TF_NONE ? 0 : (tf_mode == HRF_TF_LN ? 4 : 1);
   if (KH == 1) {
-    if (tfk == 0) { HRF_CONV_FWD_BM(1, 0) } else if (tfk == 1) { HRF_CONV_FWD_BM(1, 1) } else { HRF_CONV_FWD_BM(1, 4) }
+    if (tf_mode == HRF_TF_LN) { HRF_CF_NT(1, HRF_TF_LN) } else { HRF_CF_TF(1) }
   } else {
-    if (tfk == 0) { HRF_CONV_FWD_BM(3, 0) } else { HRF_CONV_FWD_BM(3, 1) }
+    HRF_CF_TF(3)
   }
   return hrf_check_launch();
 }
 
-#define HRF_CONV_BD_CASE(BM_, NT_, KH_)                                                                         \
-  if (cA != nullptr) {                                                                                          \
-    HRF_LAUNCH((conv_bwd_data_kernel<BM_, NT_, KH_, true>), dim3(hrf_cdiv(a.M, BM_), hrf_cdiv(Cin, NT_ * 16)),  \
-               dim3(256), 0, stream, a);                                                                        \
-  } else {                                                                                                      \
-    HRF_LAUNCH((conv_bwd_data_kernel<BM_, NT_, KH_, false>), dim3(hrf_cdiv(a.M, BM_), hrf_cdiv(Cin, NT_ * 16)), \
-               dim3(256), 0, stream, a);                                                                        \
+#define HRF_BD_LAUNCH(NT_, KH_, BNB_) \
+  HRF_LAUNCH((conv_bwd_data_kernel<NT_, KH_, BNB_>), dim3(hrf_cdiv(a.M, BM), hrf_cdiv(Cin, NT_ * 16)), dim3(256), 0, stream, a)
+#define HRF_BD_NT(KH_, BNB_)                         \
+  switch (nt) {                                      \
+    case 2: HRF_BD_LAUNCH(2, KH_, BNB_); break;      \
+    case 3: HRF_BD_LAUNCH(3, KH_, BNB_); break;      \
+    default: HRF_BD_LAUNCH(4, KH_, BNB_); break;     \
   }
-#define HRF_CONV_BD_NT(BM_, KH_)                       \
-  switch (nt) {                                        \
-    case 2: HRF_CONV_BD_CASE(BM_, 2, KH_); break;      \
-    case 3: HRF_CONV_BD_CASE(BM_, 3, KH_); break;      \
-    default: HRF_CONV_BD_CASE(BM_, 4, KH_); break;     \
-  }
-#define HRF_CONV_BD_BM(KH_) \
-  if (bm == 128) { HRF_CONV_BD_NT(128, KH_) } else { HRF_CONV_BD_NT(64, KH_) }
 
 extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float* yraw,
                                  const float* cA, const float* cB, const float* cC,
@@ -570,8 +580,11 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
   a.M = B * H * W; a.K = KH * KH * Cout;
   if (a.M <= 0) return HRF_OK;
   const int nt = pick_nt(Cin);
-  const int bm = a.M >= 128 * 192 ? 128 : 64;
-  if (KH == 1) { HRF_CONV_BD_BM(1) } else { HRF_CONV_BD_BM(3) }
+  if (KH == 1) {
+    if (cA != nullptr) { HRF_BD_NT(1, true) } else { HRF_BD_NT(1, false) }
+  } else {
+    if (cA != nullptr) { HRF_BD_NT(3, true) } else { HRF_BD_NT(3, false) }
+  }
   return hrf_check_launch();
 }
 
@@ -580,6 +593,13 @@ extern "C" int hrf_debug_knob(int key, int value) {
   g_knob[key] = value;
   return HRF_OK;
 }
+
+#define HRF_BW_LAUNCH(D1_, BNB_, TFA_) \
+  HRF_LAUNCH((conv_bwd_wgt_kernel<D1_, BNB_, TFA_>), grid, dim3(256), 0, stream, a)
+#define HRF_BW_TFA(D1_, BNB_)                                       \
+  if (tfa == 2) { HRF_BW_LAUNCH(D1_, BNB_, 2); }                    \
+  else if (tfa == 3) { HRF_BW_LAUNCH(D1_, BNB_, 3); }               \
+  else { HRF_BW_LAUNCH(D1_, BNB_, 0); }
 
 extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const float* yraw,
                                    const float* cA, const float* cB, const float* cC,
@@ -610,13 +630,12 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
   a.chunk = hrf_cdiv(hrf_cdiv(a.Mpix, splits), WK) * WK;
   splits = hrf_cdiv(a.Mpix, a.chunk);
   const bool dense1 = KH == 1 && stride == 1 && sC == 1 && sY == W * sX && sB == H * sY;
+  const int tfa = tf_mode == HRF_TF_AFFINE_RELU ? 2 : (tf_mode == HRF_TF_AFFINE_GELU ? 3 : 0);
   const dim3 grid(gx, gy, splits);
   if (dense1) {
-    if (cA != nullptr) { HRF_LAUNCH((conv_bwd_wgt_kernel<true, true>), grid, dim3(256), 0, stream, a); }
-    else { HRF_LAUNCH((conv_bwd_wgt_kernel<true, false>), grid, dim3(256), 0, stream, a); }
+    if (cA != nullptr) { HRF_BW_TFA(true, true) } else { HRF_BW_TFA(true, false) }
   } else {
-    if (cA != nullptr) { HRF_LAUNCH((conv_bwd_wgt_kernel<false, true>), grid, dim3(256), 0, stream, a); }
-    else { HRF_LAUNCH((conv_bwd_wgt_kernel<false, false>), grid, dim3(256), 0, stream, a); }
+    if (cA != nullptr) { HRF_BW_TFA(false, true) } else { HRF_BW_TFA(false, false) }
   }
   return hrf_check_launch();
 }

@@ -2,6 +2,7 @@
 an algorithmic work model (FLOPs / compulsory bytes) per launch, and the roofline of the
 dominant kernel.  Pure measurement plumbing - nothing here computes results."""
 import math
+import os
 import time
 
 import torch
@@ -30,17 +31,14 @@ def work_model(name, a):
     if name == 'hrf_conv_fwd':
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         M, K = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']
-        tfk = 0 if a['tf_mode'] == 0 else (4 if a['tf_mode'] == 4 else 1)
-        bm = 128 if M >= 128 * 192 else 64
         by = f4 * (a['B'] * a['H'] * a['W'] * a['Cin'] + a['Cout'] * K + M * a['Cout'] * (1 + (a['res'] is not None) + (a['res2'] is not None)))
-        return f"conv_fwd_kernel<{bm},{_pick_nt(a['Cout'])},{a['KH']},{tfk}>", 2.0 * M * a['Cout'] * K, by
+        return f"conv_fwd_kernel<{_pick_nt(a['Cout'])},{a['KH']},{a['tf_mode']}>", 2.0 * M * a['Cout'] * K, by
     if name == 'hrf_conv_bwd_data':
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         M, K = a['B'] * a['H'] * a['W'], a['KH'] ** 2 * a['Cout']
-        bm = 128 if M >= 128 * 192 else 64
         by = f4 * (a['B'] * Ho * Wo * a['Cout'] * (2 if a['cA'] is not None else 1) + a['Cin'] * K
                    + M * a['Cin'] * (2 if a['epi'] else 1 + bool(a['accumulate'])))
-        return f"conv_bwd_data_kernel<{bm},{_pick_nt(a['Cin'])},{a['KH']}>", 2.0 * M * a['Cin'] * K, by
+        return f"conv_bwd_data_kernel<{_pick_nt(a['Cin'])},{a['KH']},{int(a['cA'] is not None)}>", 2.0 * M * a['Cin'] * K, by
     if name == 'hrf_conv_bwd_weight':
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         Mp, Np = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']
@@ -96,17 +94,22 @@ class ProfLib:
     """Wraps the loaded library: brackets every C-ABI launch with HIP events recorded on the launch
     stream (torch's current stream - the stream the kernels are enqueued on)."""
 
-    def __init__(self, lib):
+    def __init__(self, lib, timing=True):
         self._lib = lib
         self.require_cuda = lib.require_cuda
         self.protos = lib.protos
         self.records = []
+        self.timing = timing
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
         names = [n for _, n in self._lib.protos[name]]
 
         def call(*args):
+            if not self.timing:
+                fn(*args)
+                self.records.append((name, dict(zip(names, args)), args))
+                return
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -116,27 +119,86 @@ class ProfLib:
         return call
 
 
-def profile_step(trainer, x, mods, cots, steps=3):
-    """Run `steps` eager training steps with per-launch event timing -> {key: [n, sec, flops, bytes]}"""
+def _signature(name, a):
+    return (name,) + tuple(v for v in a.values() if isinstance(v, (int, float)) and not isinstance(v, bool))
+
+
+def _graph_time(fn, reps=20, replays=5):
+    """GPU-side average duration of one launch: `reps` back-to-back launches captured into a hipGraph
+    on the launch stream, replayed and bracketed by HIP events (no host launch overhead inside)."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / (reps * replays)
+
+
+def profile_step(trainer, x, mods, cots, steps=1):
+    """Per-kernel table of one training step -> {key: [launches, seconds, flops, bytes, steps]}.
+
+    Pass 1 records every C-ABI call of an eager step (arguments only).  Pass 2 re-issues one
+    representative call per distinct (entry point, shape) signature inside a captured hipGraph and
+    times it with HIP events on the launch stream, so the per-launch duration is measured on the GPU
+    (an event pair around a single eager launch mostly measures the ~10 us host/ctypes gap).
+    Re-issuing accumulating kernels perturbs gradients: call this after the timed region only."""
     real = _lib.lib
-    prof = ProfLib(real())
+    base = real()
+    prof = ProfLib(base, timing=False)
     trainer.step(x, mods, cots)                    # eager warm-up (allocator, caches)
     torch.cuda.synchronize()
     _lib.lib = lambda: prof
+    os_lanes = os.environ.get('HRF_LANES')
+    os.environ['HRF_LANES'] = '0'                  # record on one stream; replay order is irrelevant
     try:
         for _ in range(steps):
             trainer.step(x, mods, cots)
         torch.cuda.synchronize()
     finally:
         _lib.lib = real
+        if os_lanes is None:
+            os.environ.pop('HRF_LANES', None)
+        else:
+            os.environ['HRF_LANES'] = os_lanes
+    sigs = {}
+    for name, a, args in prof.records:
+        sg = _signature(name, a)
+        ent = sigs.get(sg)
+        if ent is None:
+            sigs[sg] = [1, name, a, args]
+        else:
+            ent[0] += 1
     table = {}
-    for name, a, e0, e1 in prof.records:
+    for sg, (cnt, name, a, args) in sigs.items():
+        fn = getattr(base, name)
+        sptr = [None]
+
+        def call(fn=fn, args=args):
+            fn(*args[:-1], _lib.stream_ptr())
+        try:
+            dt = _graph_time(call)
+        except Exception:
+            torch.cuda.synchronize()
+            continue
         key, fl, by = work_model(name, a)
         t = table.setdefault(key, [0, 0.0, 0.0, 0.0])
-        t[0] += 1
-        t[1] += e0.elapsed_time(e1) * 1e-3
-        t[2] += fl
-        t[3] += by
+        t[0] += cnt
+        t[1] += dt * cnt
+        t[2] += fl * cnt
+        t[3] += by * cnt
     for t in table.values():
         t.append(steps)
     return table

@@ -169,7 +169,7 @@ class Ctx:
     def side_launch(self, fn):
         """Run `fn` (one off-critical-path launch) on a side lane that starts after the current lane's
         work so far and is joined into the main lane at the end of the backward pass."""
-        if not self.multi:
+        if not self.multi or os.environ.get('HRF_SIDE_LANES', '0') == '0':
             fn()
             return
         pool = self.owner._side_pool()
