@@ -180,7 +180,7 @@ class EngineOwner:
     def _side_pool(self):
         pool = self.__dict__.get('_hrf_side')
         if pool is None:
-            n = int(os.environ.get('HRF_SIDE_LANES', '0') or 0)
+            n = int(os.environ.get('HRF_SIDE_LANES', '6') or 6)
             pool = [R.Lane(torch.cuda.Stream()) for _ in range(max(1, n))]
             self.__dict__['_hrf_side'] = pool
         return pool

@@ -387,11 +387,22 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
   const int HoWo = a.Ho * a.Wo;
   float bias_part = 0.f;
 
-  hrf_f4 acc[4][4];
+  // Output tiles (16x16) are dealt round-robin to the four waves (tile t -> wave t % 4), so every
+  // wave reduces its own tiles over ALL 64 pixels of a step: no cross-wave reduction, the epilogue
+  // is one fp32 atomic per owned element straight from the accumulator registers.
+  const int ntl = mtiles * ntiles;
+  int ti[4], tj[4];
+  bool tv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int q = 0; q < 4; ++q) {
+    const int t = wave + 4 * q;
+    tv[q] = t < ntl;
+    ti[q] = tv[q] ? t / ntiles : 0;
+    tj[q] = tv[q] ? t - ti[q] * ntiles : 0;
+  }
+  hrf_f4 acc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < 4; ++q) acc[q] = hrf_f4{0.f, 0.f, 0.f, 0.f};
 
   float areg[16], breg[16];
   auto load_tile = [&](int p0) {
@@ -449,50 +460,37 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
     __syncthreads();
     if (p0 + WK < pend) load_tile(p0 + WK);
 #pragma unroll 2
-    for (int kk = 0; kk < 4; ++kk) {
-      const int kq = (wave * 4 + kk) * 4 + (lane >> 4);
-      float af[4], bf[4];
+    for (int kk = 0; kk < 16; ++kk) {
+      const int kq = kk * 4 + (lane >> 4);
+      const float bf0 = act_at_read(TFA, Bs[(tj[0] * 16 + (lane & 15)) * WLD + kq]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = As[(i * 16 + (lane & 15)) * WLD + kq];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = act_at_read(TFA, Bs[(j * 16 + (lane & 15)) * WLD + kq]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (i < mtiles && j < ntiles) acc[i][j] = hrf_mfma16(af[i], bf[j], acc[i][j]);
+      for (int q = 0; q < 4; ++q) {
+        if (tv[q]) {
+          const float af = As[(ti[q] * 16 + (lane & 15)) * WLD + kq];
+          const float bf = (q == 0 || tj[q] == tj[0]) ? bf0 : act_at_read(TFA, Bs[(tj[q] * 16 + (lane & 15)) * WLD + kq]);
+          acc[q] = hrf_mfma16(af, bf, acc[q]);
+        }
+      }
     }
     __syncthreads();
   }
-  // cross-wave reduction: four ordered rounds of plain LDS read-modify-write (same lane->element map)
-  float* red = As;
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+  for (int q = 0; q < 4; ++q) {
+    if (tv[q]) {
+      const int nn = n0 + tj[q] * 16 + (lane & 15);
+      int t9 = 0, c9 = nn;
+      if (a.KH == 3) { t9 = nn / a.Cin; c9 = nn - t9 * a.Cin; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (i < mtiles && j < ntiles) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int idx = (i * 16 + (lane >> 4) * 4 + r) * WLD + j * 16 + (lane & 15);
-              red[idx] = (w == 0 ? 0.f : red[idx]) + acc[i][j][r];
-            }
-          }
+      for (int r = 0; r < 4; ++r) {
+        const int cco = m0 + ti[q] * 16 + (lane >> 4) * 4 + r;
+        if (cco < a.Cout && nn < a.Np) {
+          const int o = a.KH == 3 ? (cco * a.Cin + c9) * 9 + t9 : cco * a.Cin + nn;
+          if (a.dbg_plain) a.dw[o] = acc[q][r]; else hrf_atomic_add(&a.dw[o], acc[q][r]);
+        }
+      }
     }
-    __syncthreads();
   }
   sBias[wave * 64 + lane] = bias_part;
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int ml = e >> 6, nl = e & 63;
-    const int cco = m0 + ml, nn = n0 + nl;
-    if (cco < a.Cout && nn < a.Np && (ml >> 4) < mtiles && (nl >> 4) < ntiles) {
-      int o;
-      if (a.KH == 3) { const int t = nn / a.Cin, c = nn - t * a.Cin; o = (cco * a.Cin + c) * 9 + t; }
-      else o = cco * a.Cin + nn;
-      if (a.dbg_plain) a.dw[o] = red[ml * WLD + nl]; else hrf_atomic_add(&a.dw[o], red[ml * WLD + nl]);
-    }
-  }
   __syncthreads();
   if (a.dbias != nullptr && blockIdx.y == 0 && tid < 64 && m0 + tid < a.Cout)
     hrf_atomic_add(&a.dbias[m0 + tid], sBias[tid] + sBias[64 + tid] + sBias[128 + tid] + sBias[192 + tid]);

@@ -131,6 +131,7 @@ class Ctx:
         self._free = list(owner._lane_pool()) if self.multi else []
         self._side_i = 0
         self._side_used = {}
+        self._deferred = []
 
     # ---- tape ----------------------------------------------------------------------------------
     def push(self, fn):
@@ -169,8 +170,14 @@ class Ctx:
     def side_launch(self, fn):
         """Run `fn` (one off-critical-path launch) on a side lane that starts after the current lane's
         work so far and is joined into the main lane at the end of the backward pass."""
-        if not self.multi or os.environ.get('HRF_SIDE_LANES', '0') == '0':
+        mode = os.environ.get('HRF_WGRAD', 'defer')
+        if not self.multi or mode == 'inline':
             fn()
+            return
+        if mode == 'defer':
+            # weight-gradient launches are leaves of the backward graph: collect them and issue them
+            # as one wide, fully parallel phase after the (serial, latency-bound) data-gradient chain
+            self._deferred.append(fn)
             return
         pool = self.owner._side_pool()
         lane = pool[self._side_i % len(pool)]
@@ -197,6 +204,14 @@ class Ctx:
                 fn, lane = e
                 with _LaneScope(self, lane):
                     fn()
+        if self._deferred:
+            fns, self._deferred = self._deferred, []
+            k = int(os.environ.get('HRF_WGRAD_LANES', '8'))
+            lanes = self.fork(k)
+            for i, fn in enumerate(fns):
+                with _LaneScope(self, lanes[i % k]):
+                    fn()
+            self.join(lanes)
         if self.multi:
             for lane in self._side_used.values():
                 self.main.stream.wait_stream(lane.stream)
