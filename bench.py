@@ -96,9 +96,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     group = None
-    if world > 1:
+    force_coll = os.environ.get('HRF_FORCE_COLLECTIVES', '0') == '1'
+    if world > 1 or force_coll:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)          # 'nccl' is RCCL on ROCm
         group = dist.group.WORLD
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -107,7 +111,7 @@ def main():
     from hrfuser_amd.trainer import Trainer, make_cotangents
     from hrfuser_amd import profiling
 
-    tag = args.model if world == 1 else args.model.replace('_bn', '')
+    tag = args.model if (world == 1 and not force_coll) else args.model.replace('_bn', '')
     cfg = load_cfg(tag)
     stf = tag.startswith('t_stf')
     H = args.height or 384
@@ -197,9 +201,17 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if world > 1 or force_coll:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+        except Exception:
+            pass
+        # RCCL/HIP teardown of a process that holds captured graphs with collectives can abort at
+        # interpreter exit on ROCm 7.0; the result line is already out, so leave without destructors.
+        os._exit(0)
 
 
 if __name__ == '__main__':

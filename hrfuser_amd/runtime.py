@@ -20,6 +20,7 @@ import torch
 
 from . import _lib
 
+_FORCE_COLL = os.environ.get('HRF_FORCE_COLLECTIVES', '0') == '1'
 TF_NONE, TF_AFFINE, TF_RELU, TF_GELU, TF_LN = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 _TF2ACT = {TF_NONE: ACT_NONE, TF_AFFINE: ACT_NONE, TF_RELU: ACT_RELU, TF_GELU: ACT_GELU}
@@ -219,7 +220,9 @@ class Ctx:
             torch.cuda.current_stream().wait_stream(self.main.stream)
 
     def all_reduce(self, t):
-        if self.group is not None and self.world > 1:
+        # HRF_FORCE_COLLECTIVES=1: issue the collectives even in a 1-rank group (lets a single-GPU box
+        # exercise RCCL inside the lanes / hipGraph capture exactly as an 8-GPU run would)
+        if self.group is not None and (self.world > 1 or _FORCE_COLL):
             import torch.distributed as dist
             dist.all_reduce(t, group=self.group)
 
@@ -328,7 +331,7 @@ def bn_backward_coef(ctx, st):
     slot = ctx.owner._bn_slot(st.bn)
     cA, cB, cC = slot['cA'], slot['cB'], slot['cC']
     local = None
-    if st.train and ctx.world > 1:
+    if st.train and ctx.group is not None and (ctx.world > 1 or _FORCE_COLL):
         local = _keep(st.gstats.clone())
         ctx.all_reduce(st.gstats)
     wg = st.bn.weight.grad if st.bn.weight.requires_grad else None

@@ -29,7 +29,8 @@ class Trainer:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.group, self.world = group, world_size
         self.n_buckets = n_buckets
-        if world_size > 1:
+        self.force = R._FORCE_COLL and group is not None
+        if world_size > 1 or self.force:
             net.set_sync_group(group, world_size)
         self._ready = False
         self.graph = None
@@ -65,7 +66,7 @@ class Trainer:
         for o, c in zip(outs, cots):
             o.grad = c.clone()              # synthetic loss  L = sum_i <out_i, cot_i>   
         ctx.run_backward()
-        if self.world > 1:
+        if self.world > 1 or self.force:
             import torch.distributed as dist
             for a, b in self.buckets(eng.flat_g.numel()):
                 dist.all_reduce(eng.flat_g[a:b], group=self.group)
