@@ -14,6 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'hrfuser_hip.h')
 LIB_PATH = os.path.join(_HERE, 'libhrfuser_hip.so')
 
+def _header_int(name, default):
+    m = re.search(r'#define\s+' + name + r'\s+(\d+)', open(HEADER).read())
+    return int(m.group(1)) if m else default
+
+
+STAT_COPIES = _header_int('HRF_STAT_COPIES', 16)   # replication of cross-block accumulators (see header)
+
 _ERR = {1: 'HRF_ERR_ARG (bad argument)', 2: 'HRF_ERR_LAUNCH (kernel launch failed)'}
 
 

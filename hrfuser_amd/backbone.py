@@ -101,7 +101,8 @@ class Engine:
         self._p0 = params[0].data_ptr() if params else 0
         bns = [m for m in self.root.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
         csum = sum(m.num_features for m in bns)
-        self.arena_d = torch.zeros(4 * csum, device=device, dtype=torch.float64)
+        K = _lib.STAT_COPIES                       # replicated accumulators: see include/hrfuser_hip.h
+        self.arena_d = torch.zeros(4 * csum * K, device=device, dtype=torch.float64)
         self.arena_f = torch.zeros(7 * csum, device=device, dtype=torch.float32)
         self.slots = {}
         od = of = 0
@@ -110,12 +111,30 @@ class Engine:
             d = self.arena_d
             f = self.arena_f
             self.slots[id(m)] = dict(
-                stats=d[od:od + 2 * C], gstats=d[od + 2 * C:od + 4 * C],
+                stats=d[od:od + 2 * C * K], gstats=d[od + 2 * C * K:od + 4 * C * K],
                 scale=f[of:of + C], shift=f[of + C:of + 2 * C], mean=f[of + 2 * C:of + 3 * C],
                 invstd=f[of + 3 * C:of + 4 * C], cA=f[of + 4 * C:of + 5 * C], cB=f[of + 5 * C:of + 6 * C],
                 cC=f[of + 6 * C:of + 7 * C])
-            od += 4 * C
+            od += 4 * C * K
             of += 7 * C
+        # parameter gradients that MANY blocks add into (LayerNorm gamma/beta, depthwise weights/bias)
+        # accumulate in K replicated fp32 copies and are folded into the arena once per backward
+        offs = {id(p): o for p, (o, _) in zip(params, self._spans)}
+        self.pslot, cols, ps = {}, [], 0
+        for m in self.root.modules():
+            hit = isinstance(m, nn.LayerNorm) or (isinstance(m, nn.Conv2d) and m.groups == m.in_channels and m.groups > 1)
+            if not hit:
+                continue
+            for q in (m.weight, m.bias):
+                if q is None or id(q) not in offs or id(q) in self.pslot:
+                    continue
+                self.pslot[id(q)] = ps
+                cols.append(torch.arange(offs[id(q)], offs[id(q)] + q.numel(), dtype=torch.int32))
+                ps += q.numel()
+        self.ps_n = ps
+        self.ps_map = (torch.cat(cols) if cols else torch.zeros(0, dtype=torch.int32)).to(device)
+        self.ps_scratch = torch.zeros(max(1, K * ps), device=device, dtype=torch.float32)
+        self.ps_dirty = False
         nbt = [m.num_batches_tracked for m in bns if m.num_batches_tracked is not None]
         self.nbt_flat = torch.zeros(len(nbt), device=device, dtype=torch.long)
         with torch.no_grad():
@@ -124,6 +143,21 @@ class Engine:
                 m.num_batches_tracked = self.nbt_flat[i]          # 0-dim view: one add_ per step updates all
         self.device = device
         self.eval_cache = {}
+
+    def grad_acc(self, p):
+        """-> (accumulator tensor, copy_stride) for a parameter gradient written by many blocks."""
+        o = self.pslot.get(id(p))
+        if o is None:
+            return p.grad, 0
+        self.ps_dirty = True
+        return self.ps_scratch[o:o + p.numel()], self.ps_n
+
+    def fold_grads(self, L, stream):
+        """Sum the replicated accumulators into the gradient arena (one launch per backward)."""
+        if self.ps_dirty and self.ps_n:
+            L.hrf_fold_copies(self.ps_scratch, self.ps_n, self.ps_map, self.flat_g, self.ps_n, stream)
+            self.ps_scratch.zero_()
+        self.ps_dirty = False
 
     def begin_forward(self, training):
         R.release_step_buffers()

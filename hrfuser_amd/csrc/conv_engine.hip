@@ -21,6 +21,7 @@
 // Reference ops replaced: every nn.Conv2d(k=1|3, groups=1) + nn.Linear reached from
 // mmdet/models/backbones/{hrfuser_hrformer_based,hrformer,hrnet,resnet}.py.
 #include "hrf_common.h"
+#include "hrf_lin.h"
 #include "../../include/hrfuser_hip.h"
 
 namespace {
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
       const int c = tid < BN ? tid : tid - BN;
       if (n0 + c < a.Cout) {
         const float s = sStat[tid] + sStat[2 * BN + tid] + sStat[4 * BN + tid] + sStat[6 * BN + tid];
-        hrf_atomic_add(&a.stats[(tid < BN ? 0 : a.Cout) + n0 + c], (double)s);
+        hrf_atomic_add(&a.stats[(size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.Cout + (tid < BN ? 0 : a.Cout) + n0 + c], (double)s);
       }
     }
   }
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
       const int c = tid < BN ? tid : tid - BN;
       if (n0 + c < a.Cin) {
         const float s = sStat[tid] + sStat[2 * BN + tid] + sStat[4 * BN + tid] + sStat[6 * BN + tid];
-        hrf_atomic_add(&a.stats[(tid < BN ? 0 : a.Cin) + n0 + c], (double)s);
+        hrf_atomic_add(&a.stats[(size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.Cin + (tid < BN ? 0 : a.Cin) + n0 + c], (double)s);
       }
     }
   }
@@ -496,6 +497,140 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
     hrf_atomic_add(&a.dbias[m0 + tid], sBias[tid] + sBias[64 + tid] + sBias[128 + tid] + sBias[192 + tid]);
 }
 
+// ----------------------------------------------------------- backward weight, dense 1x1 (no LDS)
+// dW[co][ci] += sum_pix bnbwd(dY)[pix][co] * tf(X)[pix][ci] for stride-1 1x1 convs / Linears on
+// channel-contiguous rows (95 % of the weight-gradient launches).  Both operands are "pixel-major",
+// which is exactly the v_mfma_f32_16x16x4_f32 fragment layout (A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15] with k = pixel): fragments are loaded STRAIGHT from global memory, one
+// dword per lane, no LDS staging, no barrier in the reduction loop.  Every wave streams its own
+// pixels with WU k-steps (4 pixels each) of loads in flight, keeps a <= 4x4 grid of 16x16
+// accumulators, the WNW waves of a block are merged through LDS atomics and each block issues ONE
+// coalesced fp32 atomic per output element.
+struct WgradDenseArgs {
+  const float* dy; int ldD; int doff; const float* yraw;
+  const float* cA; const float* cB; const float* cC;
+  const float* x; int ldX;
+  const float* tf_scale; const float* tf_shift; const float* tf_rowstat;
+  float* dw; float* dbias;
+  int Cout, Cin, Mpix, chunk;
+  int dbg;                        // tuning aid (hrf_debug_knob 5): 1 plain stores, 2 no pixel loop, 4 no epilogue
+};
+
+constexpr int WU = 8;      // k-steps (of 4 pixels) whose loads are issued before the first use
+constexpr int WNW = 8;     // waves per block (512 threads): few blocks per output element, because
+                           // same-address global atomics serialise at ~25 ns each (fan-in <= 32)
+
+template <bool BNB, int TF>
+__global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a) {
+  __shared__ float sAcc[64 * 64];
+  __shared__ float sBias[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int mt = min(4, (a.Cout - m0 + 15) >> 4), nt = min(4, (a.Cin - n0 + 15) >> 4);
+  const int pbeg = blockIdx.z * a.chunk, pend = min(a.Mpix, pbeg + a.chunk);
+
+  int aoff[4], boff[4];
+  bool aval[4], bval[4];
+  float ca[4], cb[4], cc[4], sc[4], sh[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int co = m0 + 16 * i + c;
+    aval[i] = co < a.Cout;
+    aoff[i] = a.doff + (aval[i] ? co : 0);
+    ca[i] = 1.f; cb[i] = 0.f; cc[i] = 0.f;
+    if (BNB) { const int cs = aval[i] ? co : 0; ca[i] = a.cA[cs]; cb[i] = a.cB[cs]; cc[i] = a.cC[cs]; }
+    const int ci = n0 + 16 * i + c;
+    bval[i] = ci < a.Cin;
+    boff[i] = bval[i] ? ci : 0;
+    sc[i] = 1.f; sh[i] = 0.f;
+    if (TF != HRF_TF_NONE) { sc[i] = a.tf_scale[boff[i]]; sh[i] = a.tf_shift[boff[i]]; }
+  }
+
+  hrf_f4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  for (int sjj = 0; sjj < 64 * 64; sjj += 64 * WNW) sAcc[sjj + tid] = 0.f;
+  if (tid < 64) sBias[tid] = 0.f;
+
+  // wave w owns k-steps w, w+WNW, ... of the block's chunk: neighbouring waves read neighbouring rows
+  for (int p0 = pbeg + 4 * wave; p0 < ((a.dbg & 2) ? pbeg : pend); p0 += 4 * WNW * WU) {
+    float ar[WU][4], yr[WU][4], br[WU][4], rm[WU], rr[WU];
+    bool pv[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const int pix = p0 + 4 * WNW * u + kq;
+      pv[u] = pix < pend;
+      const int pc = pv[u] ? pix : pbeg;
+      const long arow = (long)pc * a.ldD, brow = (long)pc * a.ldX;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ar[u][i] = 0.f; yr[u][i] = 0.f; br[u][i] = 0.f;
+        if (i < mt) {
+          ar[u][i] = a.dy[arow + aoff[i]];
+          if (BNB) yr[u][i] = a.yraw[arow + aoff[i]];
+        }
+        if (i < nt) br[u][i] = a.x[brow + boff[i]];
+      }
+      rm[u] = 0.f; rr[u] = 1.f;
+      if (TF == HRF_TF_LN) { rm[u] = a.tf_rowstat[2 * pc]; rr[u] = a.tf_rowstat[2 * pc + 1]; }
+    }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = ar[u][i];
+        if (BNB) v = fmaf(ca[i], v, fmaf(cb[i], yr[u][i], cc[i]));
+        av[i] = (pv[u] && aval[i]) ? v : 0.f;
+        bsum[i] += av[i];
+        float w = br[u][i];
+        if (TF == HRF_TF_LN) w = fmaf((w - rm[u]) * rr[u], sc[i], sh[i]);
+        else if (TF != HRF_TF_NONE) w = fmaf(w, sc[i], sh[i]);
+        bv[i] = w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < nt) {
+          const float bf = act_at_read(TF, bv[j]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (i < mt) acc[i][j] = hrf_mfma16(av[i], bf, acc[i][j]);
+        }
+      }
+    }
+  }
+
+  __syncthreads();                       // sAcc / sBias zeroed by every thread before the merges
+  if (a.dbg & 4) { if (acc[0][0][0] == 12345.f) a.dw[0] = 1.f; return; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < mt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hrf_atomic_add(&sAcc[(16 * i + 4 * kq + r) * 64 + 16 * j + c], acc[i][j][r]);
+        }
+      }
+      float b = bsum[i];
+      b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+      if (lane < 16) hrf_atomic_add(&sBias[16 * i + lane], b);
+    }
+  }
+  __syncthreads();
+  const int ncol = min(64, a.Cin - n0), nrow = min(64, a.Cout - m0);
+  for (int e = tid; e < nrow * 64; e += 64 * WNW) {
+    const int row = e >> 6, col = e & 63;
+    if (col < ncol) { if (a.dbg & 1) a.dw[(long)(m0 + row) * a.Cin + n0 + col] = sAcc[e]; else hrf_atomic_add(&a.dw[(long)(m0 + row) * a.Cin + n0 + col], sAcc[e]); }
+  }
+  if (a.dbias != nullptr && blockIdx.y == 0 && tid < nrow) hrf_atomic_add(&a.dbias[m0 + tid], sBias[tid]);
+}
+
 inline int pick_nt(int C) {
   const int T = (C + 15) / 16;
   int best = 2, cost = 1 << 30;
@@ -541,6 +676,15 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
   a.Cout = Cout; a.stride = stride; a.pad = pad; a.sB = sB; a.sY = sY; a.sX = sX; a.sC = sC;
   a.M = B * a.Ho * a.Wo; a.K = KH * KH * Cin;
   if (a.M <= 0) return HRF_OK;
+  if (KH == 1 && stride == 1 && sC == 1 && sY == W * sX && sB == H * sY && g_knob[4] == 0) {
+    // channel-contiguous rows: LDS-free row-GEMM kernel (lin_engine.hip)
+    LinFwdArgs l;
+    l.x = x; l.ldX = sX; l.w = w; l.bias = bias; l.y = y; l.ldY = ldY; l.yoff = yoff;
+    l.res = res; l.res2 = res2; l.ldR = ldR; l.tf_mode = tf_mode; l.tf_scale = tf_scale; l.tf_shift = tf_shift;
+    l.tf_rowstat = tf_rowstat; l.stats = stats; l.M = a.M; l.K = Cin; l.N = Cout;
+    const int rc = hrf_lin_fwd_launch(l, stream);
+    if (rc >= 0) return rc;
+  }
   const int nt = pick_nt(Cout);
   if (KH == 1) {
     if (tf_mode == HRF_TF_LN) { HRF_CF_NT(1, HRF_TF_LN) } else { HRF_CF_TF(1) }
@@ -577,6 +721,15 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
   a.Cout = Cout; a.stride = stride; a.pad = pad;
   a.M = B * H * W; a.K = KH * KH * Cout;
   if (a.M <= 0) return HRF_OK;
+  if (KH == 1 && stride == 1 && sC == 1 && sY == W * sX && sB == H * sY && g_knob[4] == 0) {
+    LinBwdDataArgs l;
+    l.dy = dy; l.ldD = ldD; l.doff = doff; l.yraw = yraw; l.cA = cA; l.cB = cB; l.cC = cC; l.w = w;
+    l.dx = dx; l.ldDx = sX; l.accumulate = accumulate; l.epi = epi; l.xraw = xraw; l.ldXr = ldXr;
+    l.tf_scale = tf_scale; l.tf_shift = tf_shift; l.act = act; l.stats = stats;
+    l.M = a.M; l.K = Cout; l.N = Cin;
+    const int rc = hrf_lin_bwd_data_launch(l, stream);
+    if (rc >= 0) return rc;
+  }
   const int nt = pick_nt(Cin);
   if (KH == 1) {
     if (cA != nullptr) { HRF_BD_NT(1, true) } else { HRF_BD_NT(1, false) }
@@ -621,6 +774,7 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
   // per block: the per-block epilogue (LDS reduce + one atomic per output) must stay amortised.
   int splits = hrf_cdiv(a.Mpix, 256);
   int cap = hrf_cdiv(512, gx * gy);
+  if (cap > 64) cap = 64;                                  // atomic fan-in per output element
   if (g_knob[0] > 0) cap = g_knob[0];
   a.dbg_plain = g_knob[1];
   if (splits > cap) splits = cap;
@@ -629,6 +783,31 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
   splits = hrf_cdiv(a.Mpix, a.chunk);
   const bool dense1 = KH == 1 && stride == 1 && sC == 1 && sY == W * sX && sB == H * sY;
   const int tfa = tf_mode == HRF_TF_AFFINE_RELU ? 2 : (tf_mode == HRF_TF_AFFINE_GELU ? 3 : 0);
+  if (dense1 && g_knob[2] == 0) {
+    WgradDenseArgs d;
+    d.dy = dy; d.ldD = ldD; d.doff = doff; d.yraw = yraw; d.cA = cA; d.cB = cB; d.cC = cC;
+    d.x = x; d.ldX = sX; d.tf_scale = tf_scale; d.tf_shift = tf_shift; d.tf_rowstat = tf_rowstat;
+    d.dw = dw; d.dbias = dbias; d.Cout = Cout; d.Cin = Cin; d.Mpix = a.Mpix; d.dbg = g_knob[5];
+    // one block = WNW waves x >= 1 unrolled batch (WU k-steps of 4 pixels each)
+    int sp = hrf_cdiv(a.Mpix, 4 * WNW * WU);
+    const int cap2 = g_knob[3] > 0 ? g_knob[3] : 32;        // atomic fan-in per output element
+    if (sp > cap2) sp = cap2;
+    if (sp < 1) sp = 1;
+    d.chunk = hrf_cdiv(hrf_cdiv(a.Mpix, sp), 4 * WNW) * 4 * WNW;
+    sp = hrf_cdiv(a.Mpix, d.chunk);
+    const dim3 g2(gx, gy, sp);
+#define HRF_WD_LAUNCH(BNB_, TF_) HRF_LAUNCH((wgrad_dense_kernel<BNB_, TF_>), g2, dim3(64 * WNW), 0, stream, d)
+#define HRF_WD_TF(BNB_)                                               \
+    switch (tf_mode) {                                                \
+      case HRF_TF_NONE: HRF_WD_LAUNCH(BNB_, HRF_TF_NONE); break;      \
+      case HRF_TF_AFFINE: HRF_WD_LAUNCH(BNB_, HRF_TF_AFFINE); break;  \
+      case HRF_TF_AFFINE_RELU: HRF_WD_LAUNCH(BNB_, HRF_TF_AFFINE_RELU); break; \
+      case HRF_TF_AFFINE_GELU: HRF_WD_LAUNCH(BNB_, HRF_TF_AFFINE_GELU); break; \
+      default: HRF_WD_LAUNCH(BNB_, HRF_TF_LN); break;                 \
+    }
+    if (cA != nullptr) { HRF_WD_TF(true) } else { HRF_WD_TF(false) }
+    return hrf_check_launch();
+  }
   const dim3 grid(gx, gy, splits);
   if (dense1) {
     if (cA != nullptr) { HRF_BW_TFA(true, true) } else { HRF_BW_TFA(true, false) }

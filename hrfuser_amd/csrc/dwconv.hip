@@ -44,13 +44,25 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwFwdArgs a) {
     float sc = 1.f, sh = 0.f;
     if (a.tf_mode != HRF_TF_NONE) { sc = a.tf_scale[cv ? cg : 0]; sh = a.tf_shift[cv ? cg : 0]; }
     // unconditional clamped loads (no load under a per-element branch), value selected afterwards
-    for (int pix = tid >> 5; pix < IH * IW; pix += 8) {
+    constexpr int NIT = (IH * IW + 7) / 8;
+    float raw[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pix = it * 8 + (tid >> 5);
+      const int iy = pix / IW, ix = pix - iy * IW;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      const bool ok = cv && pix < IH * IW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      raw[it] = a.x[ok ? (((long)b * a.H + gy) * a.W + gx) * a.C + cg : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pix = it * 8 + (tid >> 5);
       const int iy = pix / IW, ix = pix - iy * IW;
       const int gy = iy0 + iy, gx = ix0 + ix;
       const bool ok = cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      float v = a.x[ok ? (((long)b * a.H + gy) * a.W + gx) * a.C + cg : 0];
+      float v = raw[it];
       if (a.tf_mode != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
-      sIn[pix * CB + c] = ok ? v : 0.f;
+      if (pix < IH * IW) sIn[pix * CB + c] = ok ? v : 0.f;
     }
   }
   __syncthreads();
@@ -84,8 +96,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwFwdArgs a) {
     hrf_atomic_add(&sStat[CB + c], s2);
     __syncthreads();
     if (tid < CB && c0 + tid < a.C) {
-      hrf_atomic_add(&a.stats[c0 + tid], (double)sStat[tid]);
-      hrf_atomic_add(&a.stats[a.C + c0 + tid], (double)sStat[CB + tid]);
+      double* st = a.stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.C;
+      hrf_atomic_add(&st[c0 + tid], (double)sStat[tid]);
+      hrf_atomic_add(&st[a.C + c0 + tid], (double)sStat[CB + tid]);
     }
   }
 }
@@ -119,14 +132,27 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
     const bool bnb = a.cA != nullptr;
     float ca = 1.f, cb = 0.f, cc = 0.f;
     if (bnb) { const int cs = cv ? cg : 0; ca = a.cA[cs]; cb = a.cB[cs]; cc = a.cC[cs]; }
-    for (int pix = tid >> 5; pix < RH * RW; pix += 8) {
+    constexpr int NIT = (RH * RW + 7) / 8;
+    float rd[NIT], ry[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pix = it * 8 + (tid >> 5);
+      const int ly = pix / RW, lx = pix - ly * RW;
+      const int oy = ry0 + ly, ox = rx0 + lx;
+      const bool ok = cv && pix < RH * RW && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
+      const long idx = ok ? (((long)b * a.Ho + oy) * a.Wo + ox) * a.C + cg : 0;
+      rd[it] = a.dy[idx];
+      ry[it] = bnb ? a.yraw[idx] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pix = it * 8 + (tid >> 5);
       const int ly = pix / RW, lx = pix - ly * RW;
       const int oy = ry0 + ly, ox = rx0 + lx;
       const bool ok = cv && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
-      const long idx = ok ? (((long)b * a.Ho + oy) * a.Wo + ox) * a.C + cg : 0;
-      float v = a.dy[idx];
-      if (bnb) v = fmaf(ca, v, fmaf(cb, a.yraw[idx], cc));
-      sD[pix * CB + c] = ok ? v : 0.f;
+      float v = rd[it];
+      if (bnb) v = fmaf(ca, v, fmaf(cb, ry[it], cc));
+      if (pix < RH * RW) sD[pix * CB + c] = ok ? v : 0.f;
     }
   }
   __syncthreads();
@@ -138,32 +164,37 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
   if (a.epi == 1 && cv) { sc = a.tf_scale[cg]; sh = a.tf_shift[cg]; }
   const int yi = y0 + r;
   float s1 = 0.f, s2 = 0.f;
-  if (cv && yi < a.H) {
-    for (int q = 0; q < TW; ++q) {
-      const int xi = x0 + q;
-      if (xi >= a.W) break;
-      float acc = 0.f;
+  float pre[TW];                                          // epi 1: raw producer output; else previous dx
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+  for (int q = 0; q < TW; ++q) {
+    const bool ok = cv && yi < a.H && x0 + q < a.W;
+    const long o = ok ? (((long)b * a.H + yi) * a.W + x0 + q) * a.C + cg : 0;
+    pre[q] = a.epi == 1 ? a.xraw[o] : (a.accumulate ? a.dx[o] : 0.f);
+  }
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          if (S == 1) {
-            acc = fmaf(sD[((r + 2 - dy) * RW + (q + 2 - dx)) * CB + c], wr[dy * 3 + dx], acc);
-          } else {
-            const int ty2 = r + 1 - dy, tx2 = q + 1 - dx;   // relative to (y0, x0), both even
-            if (ty2 >= 0 && tx2 >= 0 && ((ty2 | tx2) & 1) == 0)
-              acc = fmaf(sD[((ty2 >> 1) * RW + (tx2 >> 1)) * CB + c], wr[dy * 3 + dx], acc);
-          }
+  for (int q = 0; q < TW; ++q) {
+    const int xi = x0 + q;
+    const bool ok = cv && yi < a.H && xi < a.W;
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        if (S == 1) {
+          acc = fmaf(sD[((r + 2 - dy) * RW + (q + 2 - dx)) * CB + c], wr[dy * 3 + dx], acc);
+        } else {
+          const int ty2 = r + 1 - dy, tx2 = q + 1 - dx;   // relative to (y0, x0), both even
+          if (ty2 >= 0 && tx2 >= 0 && ((ty2 | tx2) & 1) == 0)
+            acc = fmaf(sD[((ty2 >> 1) * RW + (tx2 >> 1)) * CB + c], wr[dy * 3 + dx], acc);
         }
-      const long o = (((long)b * a.H + yi) * a.W + xi) * a.C + cg;
-      if (a.epi == 1) {
-        const float xr = a.xraw[o];
-        acc *= hrf_act_grad(a.act, fmaf(xr, sc, sh));
-        s1 += acc; s2 = fmaf(acc, xr, s2);
-        a.dx[o] = acc;
-      } else {
-        a.dx[o] = a.accumulate ? a.dx[o] + acc : acc;
       }
+    const long o = (((long)b * a.H + yi) * a.W + xi) * a.C + cg;
+    if (a.epi == 1) {
+      const float xr = pre[q];
+      acc *= hrf_act_grad(a.act, fmaf(xr, sc, sh));
+      if (ok) { s1 += acc; s2 = fmaf(acc, xr, s2); a.dx[o] = acc; }
+    } else {
+      if (ok) a.dx[o] = pre[q] + acc;
     }
   }
   if (a.epi == 1 && a.stats) {
@@ -171,8 +202,9 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
     hrf_atomic_add(&sStat[CB + c], s2);
     __syncthreads();
     if (tid < CB && c0 + tid < a.C) {
-      hrf_atomic_add(&a.stats[c0 + tid], (double)sStat[tid]);
-      hrf_atomic_add(&a.stats[a.C + c0 + tid], (double)sStat[CB + tid]);
+      double* st = a.stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.C;
+      hrf_atomic_add(&st[c0 + tid], (double)sStat[tid]);
+      hrf_atomic_add(&st[a.C + c0 + tid], (double)sStat[CB + tid]);
     }
   }
 }
@@ -181,7 +213,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
 struct DwBwdWgtArgs {
   const float* dy; const float* yraw; const float* cA; const float* cB; const float* cC;
   const float* x; int tf_mode; const float* tf_scale; const float* tf_shift;
-  float* dw; float* dbias;
+  float* dw; float* dbias; long copy_stride;
   int B, H, W, C, Ho, Wo, tilesX, tilesY;
 };
 
@@ -200,53 +232,75 @@ __global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) {
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   const int c = tid & 31, cg = c0 + c;
   const bool cv = cg < a.C;
+  const int rg = tid >> 5;
+  const int row = S == 1 ? rg : (rg >> 1);
+  constexpr int XC = S == 1 ? 16 : 8;
+  const int xbeg = S == 1 ? 0 : (rg & 1) * 8;
+  const int oy = oy0 + row;
+  const bool bnb = a.cA != nullptr;
+  float gq[XC], yq[XC];
+#pragma unroll
+  for (int q = 0; q < XC; ++q) {                          // this thread's dY row: issued before the halo loads
+    const int ox = ox0 + xbeg + q;
+    const bool ok = cv && oy < a.Ho && ox < a.Wo;
+    const long idx = ok ? (((long)b * a.Ho + oy) * a.Wo + ox) * a.C + cg : 0;
+    gq[q] = a.dy[idx];
+    yq[q] = bnb ? a.yraw[idx] : 0.f;
+  }
   {
     float sc = 1.f, sh = 0.f;
     if (a.tf_mode != HRF_TF_NONE) { sc = a.tf_scale[cv ? cg : 0]; sh = a.tf_shift[cv ? cg : 0]; }
     // unconditional clamped loads (no load under a per-element branch), value selected afterwards
-    for (int pix = tid >> 5; pix < IH * IW; pix += 8) {
+    constexpr int NIT = (IH * IW + 7) / 8;
+    float raw[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pix = it * 8 + (tid >> 5);
+      const int iy = pix / IW, ix = pix - iy * IW;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      const bool ok = cv && pix < IH * IW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      raw[it] = a.x[ok ? (((long)b * a.H + gy) * a.W + gx) * a.C + cg : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pix = it * 8 + (tid >> 5);
       const int iy = pix / IW, ix = pix - iy * IW;
       const int gy = iy0 + iy, gx = ix0 + ix;
       const bool ok = cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      float v = a.x[ok ? (((long)b * a.H + gy) * a.W + gx) * a.C + cg : 0];
+      float v = raw[it];
       if (a.tf_mode != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
-      sIn[pix * CB + c] = ok ? v : 0.f;
+      if (pix < IH * IW) sIn[pix * CB + c] = ok ? v : 0.f;
     }
   }
   __syncthreads();
-  const int rg = tid >> 5;
-  const int row = S == 1 ? rg : (rg >> 1);
-  const int xbeg = S == 1 ? 0 : (rg & 1) * 8, xcnt = S == 1 ? 16 : 8;
-  const int oy = oy0 + row;
-  const bool bnb = a.cA != nullptr;
   float ca = 1.f, cb = 0.f, cc = 0.f;
   if (bnb && cv) { ca = a.cA[cg]; cb = a.cB[cg]; cc = a.cC[cg]; }
   float acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-  if (cv && oy < a.Ho) {
-    for (int q = 0; q < xcnt; ++q) {
-      const int oxl = xbeg + q, ox = ox0 + oxl;
-      if (ox >= a.Wo) break;
-      const long idx = (((long)b * a.Ho + oy) * a.Wo + ox) * a.C + cg;
-      float g = a.dy[idx];
-      if (bnb) g = fmaf(ca, g, fmaf(cb, a.yraw[idx], cc));
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+  for (int q = 0; q < XC; ++q) {
+    const int oxl = xbeg + q, ox = ox0 + oxl;
+    const bool ok = cv && oy < a.Ho && ox < a.Wo;
+    float g = gq[q];
+    if (bnb) g = fmaf(ca, g, fmaf(cb, yq[q], cc));
+    g = ok ? g : 0.f;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-          acc[dy * 3 + dx] = fmaf(g, sIn[((row * S + dy) * IW + oxl * S + dx) * CB + c], acc[dy * 3 + dx]);
-      acc[9] += g;
-    }
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+        acc[dy * 3 + dx] = fmaf(g, sIn[((row * S + dy) * IW + oxl * S + dx) * CB + c], acc[dy * 3 + dx]);
+    acc[9] += g;
   }
 #pragma unroll
   for (int k = 0; k < 10; ++k) hrf_atomic_add(&sAcc[k * CB + c], acc[k]);
   __syncthreads();
+  const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride;
   for (int i = tid; i < 10 * CB; i += 256) {
     const int k = i / CB, cc2 = c0 + (i % CB);
     if (cc2 < a.C) {
-      if (k < 9) hrf_atomic_add(&a.dw[cc2 * 9 + k], sAcc[i]);
-      else if (a.dbias) hrf_atomic_add(&a.dbias[cc2], sAcc[i]);
+      if (k < 9) hrf_atomic_add(&a.dw[cp + cc2 * 9 + k], sAcc[i]);
+      else if (a.dbias) hrf_atomic_add(&a.dbias[cp + cc2], sAcc[i]);
     }
   }
 }
@@ -290,11 +344,11 @@ extern "C" int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const flo
 extern "C" int hrf_dwconv_bwd_weight(const float* dy, const float* yraw, const float* cA, const float* cB,
                                      const float* cC, const float* x, int B, int H, int W, int C, int stride,
                                      int tf_mode, const float* tf_scale, const float* tf_shift, float* dw,
-                                     float* dbias, void* stream) {
+                                     float* dbias, long copy_stride, void* stream) {
   if (stride != 1 && stride != 2) return HRF_ERR_ARG;
   DwBwdWgtArgs a;
   a.dy = dy; a.yraw = yraw; a.cA = cA; a.cB = cB; a.cC = cC; a.x = x; a.tf_mode = tf_mode;
-  a.tf_scale = tf_scale; a.tf_shift = tf_shift; a.dw = dw; a.dbias = dbias;
+  a.tf_scale = tf_scale; a.tf_shift = tf_shift; a.dw = dw; a.dbias = dbias; a.copy_stride = copy_stride;
   a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
   const int th = stride == 1 ? 8 : 4;
   a.tilesX = hrf_cdiv(a.Wo, TW); a.tilesY = hrf_cdiv(a.Ho, th);

@@ -22,6 +22,11 @@ __device__ __forceinline__ hrf_f4 hrf_mfma16(float a, float b, hrf_f4 c) {
   // C/D: col = lane&15, row = (lane>>4)*4 + reg.
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// 16-byte global access on 4-byte aligned addresses (gfx950 global_load/store_dwordx4 do not need
+// natural alignment; NHWC rows of C = 18, 54, 78 ... floats are only 8-byte aligned)
+typedef float hrf_f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ hrf_f4 hrf_ld4(const float* p) { return *reinterpret_cast<const hrf_f4u*>(p); }
+__device__ __forceinline__ void hrf_st4(float* p, hrf_f4 v) { *reinterpret_cast<hrf_f4u*>(p) = v; }
 __device__ __forceinline__ void hrf_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void hrf_atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 #endif

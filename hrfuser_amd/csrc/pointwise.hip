@@ -20,8 +20,11 @@ __global__ void bn_finalize_kernel(const double* stats, const float* gamma, cons
                                    float* mean_out, float* invstd_out, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mean = stats[c] / count;
-  double var = stats[C + c] / count - mean * mean;     // biased variance (train-mode normalisation)
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < HRF_STAT_COPIES; ++k) { s1 += stats[(size_t)k * 2 * C + c]; s2 += stats[(size_t)k * 2 * C + C + c]; }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;               // biased variance (train-mode normalisation)
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -42,13 +45,17 @@ __global__ void bn_bwd_finalize_kernel(const double* gstats, const double* gstat
                                        float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double sdu = gstats[c], sdux = gstats[C + c];
+  double sdu = 0.0, sdux = 0.0, ldu = 0.0, ldux = 0.0;
+#pragma unroll
+  for (int k = 0; k < HRF_STAT_COPIES; ++k) {
+    sdu += gstats[(size_t)k * 2 * C + c]; sdux += gstats[(size_t)k * 2 * C + C + c];
+    if (gstats_local) { ldu += gstats_local[(size_t)k * 2 * C + c]; ldux += gstats_local[(size_t)k * 2 * C + C + c]; }
+  }
+  if (!gstats_local) { ldu = sdu; ldux = sdux; }
   const double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.f;
   const double sduy = (sdux - mu * sdu) * is;            // sum du * yhat
   // parameter grads use the rank-LOCAL moments (data-parallel grads are averaged afterwards);
   // the dy coefficients use the (SyncBN: all-reduced) global moments.
-  const double ldu = gstats_local ? gstats_local[c] : sdu;
-  const double ldux = gstats_local ? gstats_local[C + c] : sdux;
   if (dgamma) dgamma[c] += (float)((ldux - mu * ldu) * is);
   if (dbeta) dbeta[c] += (float)ldu;
   if (train) {
@@ -82,45 +89,73 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* x, int rows,
 }
 
 // dx (+)= rstd*(g - mean_c(g) - xhat*mean_c(g*xhat)),  g = da*gamma;  dgamma += sum da*xhat; dbeta += sum da
+// 16 lanes per row; lane `sub` owns channels sub, sub+16, ... (NCH of them) for every row it visits,
+// so the per-channel sums live in registers across the row loop (one LDS atomic per channel per
+// thread at the very end) and each element of da / x is loaded exactly once, all loads of a row
+// issued before the first use.
+template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* da, const float* x, const float* rowstat,
                                                      const float* gamma, int rows, int C, float* dx,
-                                                     int accumulate, float* dgamma, float* dbeta) {
-  HRF_DYN_SMEM(float, sacc);                              // [2*C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) sacc[i] = 0.f;
-  __syncthreads();
+                                                     int accumulate, float* dgamma, float* dbeta, long copy_stride) {
+  __shared__ float sacc[2 * 16 * NCH];
+  for (int i = threadIdx.x; i < 2 * 16 * NCH; i += 256) sacc[i] = 0.f;
   const int sub = threadIdx.x & 15;
+  float gam[NCH], ag[NCH], ab[NCH];
+  bool cv[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = sub + 16 * k;
+    cv[k] = c < C;
+    gam[k] = gamma[cv[k] ? c : 0];
+    ag[k] = 0.f; ab[k] = 0.f;
+  }
   const int nrb = (rows + 15) / 16;
+  const float invC = 1.0f / (float)C;
   for (int rbk = blockIdx.x; rbk < nrb; rbk += gridDim.x) {
     const int row = rbk * 16 + (threadIdx.x >> 4);
     const bool rv = row < rows;
-    const long base = (long)(rv ? row : 0) * C;
-    const float mean = rv ? rowstat[2 * row] : 0.f, rstd = rv ? rowstat[2 * row + 1] : 0.f;
+    const int rc = rv ? row : 0;
+    const long base = (long)rc * C;
+    const float mean = rowstat[2 * rc], rstd = rowstat[2 * rc + 1];
+    float d[NCH], xh[NCH], pv[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const long idx = (rv && cv[k]) ? base + sub + 16 * k : 0;
+      d[k] = da[idx];
+      xh[k] = x[idx];
+      pv[k] = accumulate ? dx[idx] : 0.f;
+    }
     float s1 = 0.f, s2 = 0.f;
-    for (int c = sub; c < C; c += 16) {
-      if (rv) {
-        const float g = da[base + c] * gamma[c];
-        const float xh = (x[base + c] - mean) * rstd;
-        s1 += g; s2 = fmaf(g, xh, s2);
-      }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const bool ok = rv && cv[k];
+      d[k] = ok ? d[k] : 0.f;
+      xh[k] = ok ? (xh[k] - mean) * rstd : 0.f;
+      const float g = d[k] * gam[k];
+      s1 += g; s2 = fmaf(g, xh[k], s2);
     }
     s1 += __shfl_xor(s1, 8); s1 += __shfl_xor(s1, 4); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 1);
     s2 += __shfl_xor(s2, 8); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 1);
-    const float m1 = s1 / (float)C, m2 = s2 / (float)C;
-    for (int c = sub; c < C; c += 16) {
-      if (rv) {
-        const float d = da[base + c];
-        const float xh = (x[base + c] - mean) * rstd;
-        const float v = rstd * (d * gamma[c] - m1 - xh * m2);
-        dx[base + c] = accumulate ? dx[base + c] + v : v;
-        hrf_atomic_add(&sacc[c], d * xh);
-        hrf_atomic_add(&sacc[C + c], d);
-      }
+    const float m1 = s1 * invC, m2 = s2 * invC;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const float v = rstd * (d[k] * gam[k] - m1 - xh[k] * m2);
+      if (rv && cv[k]) dx[base + sub + 16 * k] = pv[k] + v;
+      ag[k] = fmaf(d[k], xh[k], ag[k]);
+      ab[k] += d[k];
     }
   }
   __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    hrf_atomic_add(&sacc[sub + 16 * k], ag[k]);
+    hrf_atomic_add(&sacc[16 * NCH + sub + 16 * k], ab[k]);
+  }
+  __syncthreads();
+  const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * copy_stride;
   for (int i = threadIdx.x; i < C; i += 256) {
-    hrf_atomic_add(&dgamma[i], sacc[i]);
-    hrf_atomic_add(&dbeta[i], sacc[C + i]);
+    hrf_atomic_add(&dgamma[cp + i], sacc[i]);
+    hrf_atomic_add(&dbeta[cp + i], sacc[16 * NCH + i]);
   }
 }
 
@@ -151,34 +186,76 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(const float* y1, co
 //   mode 0: mask = out > 0            (ReLU applied last: uses the saved output)
 //   mode 1: g = dout*rowscale*gelu'(sc*y1+sh)   (GELU applied first)
 //   mode 2: g = dout                  (no activation)
+// A thread keeps ONE channel for its whole life (C <= 256: 256/C rows per pass, thread = (row, c);
+// wider rows: channels c, c+256, c+512 of one row per pass), so the moments accumulate in registers
+// and LDS/global atomics are paid once per thread / block, not per element.
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* dout, const float* out, const float* y1,
                                                       const float* sc, const float* sh, const float* rowscale,
                                                       int rows_per_sample, int mode, float* g, const float* y2,
                                                       const float* y3, double* st1, double* st2, double* st3,
-                                                      long total, int C) {
+                                                      long rows, int C) {
   HRF_DYN_SMEM(float, sacc);                              // [4*C]: sum g, sum g*y1, sum g*y2, sum g*y3
   for (int i = threadIdx.x; i < 4 * C; i += 256) sacc[i] = 0.f;
-  __syncthreads();
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    float v = dout[i];
-    if (mode == 0) v = out[i] > 0.f ? v : 0.f;
-    else if (mode == 1) {
-      v *= hrf_gelu_grad(fmaf(y1[i], sc[c], sh[c]));
-      if (rowscale) v *= rowscale[(i / C) / rows_per_sample];
+  const int cw = C <= 256 ? C : 256, R = C <= 256 ? 256 / C : 1;
+  const int r = threadIdx.x / cw, c = threadIdx.x - r * cw;
+  const bool active = r < R;
+  const int nj = (C + 255) / 256;                          // <= 3 (C <= 768)
+  float a0[3], a1[3], a2[3], a3[3], scj[3], shj[3];
+  bool vj[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    a0[j] = a1[j] = a2[j] = a3[j] = 0.f;
+    const int cj = c + 256 * j;
+    vj[j] = active && j < nj && cj < C;
+    scj[j] = 1.f; shj[j] = 0.f;
+    if (mode == 1) { scj[j] = sc[vj[j] ? cj : 0]; shj[j] = sh[vj[j] ? cj : 0]; }
+  }
+  const bool need1 = mode == 1 || st1 != nullptr;
+#pragma unroll 2
+  for (long row0 = (long)blockIdx.x * R; row0 < rows; row0 += (long)gridDim.x * R) {
+    const long row = row0 + r;
+    const bool rv = row < rows;
+    float rs = 1.f;
+    if (rowscale) rs = rowscale[(rv ? row : 0) / rows_per_sample];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (j < nj) {
+        const bool ok = rv && vj[j];
+        const long idx = ok ? row * C + c + 256 * j : 0;
+        float v = dout[idx];
+        const float ov = mode == 0 ? out[idx] : 1.f;
+        const float y1v = need1 ? y1[idx] : 0.f;
+        const float y2v = st2 ? y2[idx] : 0.f;
+        const float y3v = st3 ? y3[idx] : 0.f;
+        if (mode == 0) v = ov > 0.f ? v : 0.f;
+        else if (mode == 1) v *= hrf_gelu_grad(fmaf(y1v, scj[j], shj[j])) * rs;
+        v = ok ? v : 0.f;
+        if (ok) g[idx] = v;
+        a0[j] += v;
+        a1[j] = fmaf(v, y1v, a1[j]);
+        a2[j] = fmaf(v, y2v, a2[j]);
+        a3[j] = fmaf(v, y3v, a3[j]);
+      }
     }
-    g[i] = v;
-    hrf_atomic_add(&sacc[c], v);
-    if (st1) hrf_atomic_add(&sacc[C + c], v * y1[i]);
-    if (st2) hrf_atomic_add(&sacc[2 * C + c], v * y2[i]);
-    if (st3) hrf_atomic_add(&sacc[3 * C + c], v * y3[i]);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const double s = (double)sacc[c];
-    if (st1) { hrf_atomic_add(&st1[c], s); hrf_atomic_add(&st1[C + c], (double)sacc[C + c]); }
-    if (st2) { hrf_atomic_add(&st2[c], s); hrf_atomic_add(&st2[C + c], (double)sacc[2 * C + c]); }
-    if (st3) { hrf_atomic_add(&st3[c], s); hrf_atomic_add(&st3[C + c], (double)sacc[3 * C + c]); }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (vj[j]) {
+      const int cj = c + 256 * j;
+      hrf_atomic_add(&sacc[cj], a0[j]);
+      if (st1) hrf_atomic_add(&sacc[C + cj], a1[j]);
+      if (st2) hrf_atomic_add(&sacc[2 * C + cj], a2[j]);
+      if (st3) hrf_atomic_add(&sacc[3 * C + cj], a3[j]);
+    }
+  }
+  __syncthreads();
+  const size_t cp = (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
+  for (int cc = threadIdx.x; cc < C; cc += 256) {
+    const double s = (double)sacc[cc];
+    if (st1) { hrf_atomic_add(&st1[cp + cc], s); hrf_atomic_add(&st1[cp + C + cc], (double)sacc[C + cc]); }
+    if (st2) { hrf_atomic_add(&st2[cp + cc], s); hrf_atomic_add(&st2[cp + C + cc], (double)sacc[2 * C + cc]); }
+    if (st3) { hrf_atomic_add(&st3[cp + cc], s); hrf_atomic_add(&st3[cp + C + cc], (double)sacc[3 * C + cc]); }
   }
 }
 
@@ -278,9 +355,22 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const float* g, in
   __syncthreads();
   if (stats)
     for (int c = threadIdx.x; c < C; c += 256) {
-      hrf_atomic_add(&stats[c], (double)sacc[c]);
-      hrf_atomic_add(&stats[C + c], (double)sacc[C + c]);
+      const size_t cp = (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
+      hrf_atomic_add(&stats[cp + c], (double)sacc[c]);
+      hrf_atomic_add(&stats[cp + C + c], (double)sacc[C + c]);
     }
+}
+
+// dst[map[i]] += sum_k scratch[k*copy_stride + i]: folds the replicated parameter-gradient accumulators
+// (LayerNorm gamma/beta, depthwise weights/bias) into the flat gradient arena, once per step.
+__global__ __launch_bounds__(256) void fold_copies_kernel(const float* scratch, long copy_stride, const int* map,
+                                                          float* dst, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < HRF_STAT_COPIES; ++k) s += scratch[(long)k * copy_stride + i];
+    dst[map[i]] += s;
+  }
 }
 
 // ------------------------------------------------------------------------------- optimizer
@@ -341,12 +431,16 @@ extern "C" int hrf_ln_stats(const float* x, int rows, int C, float eps, float* r
 }
 
 extern "C" int hrf_ln_bwd(const float* da, const float* x, const float* rowstat, const float* gamma, int rows, int C,
-                          float* dx, int accumulate, float* dgamma, float* dbeta, void* stream) {
+                          float* dx, int accumulate, float* dgamma, float* dbeta, long copy_stride, void* stream) {
   if (rows <= 0) return HRF_OK;
-  int grid = hrf_cdiv(rows, 16 * 8);
+  if (C > 640) return HRF_ERR_ARG;
+  int grid = hrf_cdiv(hrf_cdiv(rows, 16), 2);
   if (grid > 1024) grid = 1024;
-  HRF_LAUNCH(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), stream, da, x, rowstat, gamma, rows,
-             C, dx, accumulate, dgamma, dbeta);
+  const int nch = hrf_cdiv(C, 16);
+#define HRF_LNB(N_) HRF_LAUNCH(ln_bwd_kernel<N_>, dim3(grid), dim3(256), 0, stream, da, x, rowstat, gamma, rows, C, dx, \
+                               accumulate, dgamma, dbeta, copy_stride)
+  if (nch <= 2) { HRF_LNB(2); } else if (nch <= 3) { HRF_LNB(3); } else if (nch <= 5) { HRF_LNB(5); }
+  else if (nch <= 10) { HRF_LNB(10); } else if (nch <= 20) { HRF_LNB(20); } else { HRF_LNB(40); }
   return hrf_check_launch();
 }
 
@@ -374,11 +468,13 @@ extern "C" int hrf_scale_add(const float* y, const float* mask, float mscale, co
 extern "C" int hrf_act_bwd(const float* dout, const float* out, const float* y1, const float* sc, const float* sh,
                            const float* rowscale, int rows_per_sample, int mode, float* g, const float* y2,
                            const float* y3, double* st1, double* st2, double* st3, long rows, int C, void* stream) {
-  const long total = rows * C;
-  if (total <= 0) return HRF_OK;
-  int grid = ew_grid(total / 4 + 1);
+  if (rows * C <= 0) return HRF_OK;
+  if (C > 768) return HRF_ERR_ARG;
+  const int R = C <= 256 ? 256 / C : 1;
+  int grid = hrf_cdiv(hrf_cdiv(rows, R), 4);               // ~4 passes per block
+  if (grid > 1024) grid = 1024;
   HRF_LAUNCH(act_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), stream, dout, out, y1, sc, sh,
-             rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, total, C);
+             rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, rows, C);
   return hrf_check_launch();
 }
 
@@ -405,6 +501,13 @@ extern "C" int hrf_bilinear_up_bwd(const float* g, int B, int H, int W, int C, c
   if (total <= 0) return HRF_OK;
   HRF_LAUNCH(bilinear_up_bwd_kernel, dim3(ew_grid(total / 2 + 1)), dim3(256), (size_t)2 * C * sizeof(float), stream, g,
              B, H, W, C, ylow, Hs, Ws, du, stats);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_fold_copies(const float* scratch, long copy_stride, const int* map, float* dst, long n,
+                               void* stream) {
+  if (n <= 0) return HRF_OK;
+  HRF_LAUNCH(fold_copies_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, scratch, copy_stride, map, dst, n);
   return hrf_check_launch();
 }
 

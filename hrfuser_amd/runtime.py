@@ -217,6 +217,9 @@ class Ctx:
             for lane in self._side_used.values():
                 self.main.stream.wait_stream(lane.stream)
             self._side_used = {}
+        with _LaneScope(self, self.main):
+            self.owner._engine().fold_grads(self.L, self.main.ptr)
+        if self.multi:
             torch.cuda.current_stream().wait_stream(self.main.stream)
 
     def all_reduce(self, t):
@@ -373,8 +376,10 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
         L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
                             da, *strides, 0, 0, None, 0, None, None, 0, None, s)
         g, acc = src.act.grad_target()
-        L.hrf_ln_bwd(da, src.act.t, src.rowstat, src.ln.weight, B * H * W, Cin, g, acc,
-                     src.ln.weight.grad, src.ln.bias.grad, s)
+        eng = ctx.owner._engine()
+        gacc, cs = eng.grad_acc(src.ln.weight)
+        bacc, _ = eng.grad_acc(src.ln.bias)
+        L.hrf_ln_bwd(da, src.act.t, src.rowstat, src.ln.weight, B * H * W, Cin, g, acc, gacc, bacc, cs, s)
     elif isinstance(src, Act):
         g, acc = src.grad_target()
         L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
@@ -536,9 +541,11 @@ def dwconv_bn(ctx, src, conv, bn, mode):
         cA, cB, cC = bn_backward_coef(ctx, st)
         if w.requires_grad:
             du_ = st.du
+            eng = ctx.owner._engine()
+            wacc, cs = eng.grad_acc(w)
+            bacc = eng.grad_acc(b)[0] if b is not None else None
             ctx.side_launch(lambda: L.hrf_dwconv_bwd_weight(
-                du_, st.raw, cA, cB, cC, x, B, H, W, C, stride, tf, sc, sh, w.grad,
-                b.grad if b is not None else None, ctx.stream))
+                du_, st.raw, cA, cB, cC, x, B, H, W, C, stride, tf, sc, sh, wacc, bacc, cs, ctx.stream))
         if isinstance(src, Lazy):
             ps = src.st
             ps.du = _new_like(ps.raw)

@@ -21,6 +21,16 @@
 #ifndef HRFUSER_HIP_H_
 #define HRFUSER_HIP_H_
 
+/* Cross-block reductions (BatchNorm moments, LayerNorm / depthwise parameter gradients).
+ * Same-address global atomics serialise at ~25 ns each on MI355X (measured: 512 blocks -> 13.5 us),
+ * so every accumulator that many blocks add into is REPLICATED: a block adds into copy
+ * (block index % HRF_STAT_COPIES) and the (tiny) consumer kernel sums the copies.
+ *   - every `stats` / `gstats` argument points to [HRF_STAT_COPIES][2*C] doubles (zeroed by the caller);
+ *   - hrf_ln_bwd / hrf_dwconv_bwd_weight take `copy_stride`: element distance between the copies of
+ *     their fp32 parameter-gradient accumulators (0 = one copy, plain accumulation into the grads);
+ *     hrf_fold_copies adds the summed copies into the gradient arena. */
+#define HRF_STAT_COPIES 16
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -70,7 +80,7 @@ int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const float* cA, con
 int hrf_dwconv_bwd_weight(const float* dy, const float* yraw, const float* cA, const float* cB,
                           const float* cC, const float* x, int B, int H, int W, int C, int stride,
                           int tf_mode, const float* tf_scale, const float* tf_shift, float* dw,
-                          float* dbias, void* stream);
+                          float* dbias, long copy_stride, void* stream);
 
 /* ---- 7x7 windowed attention core (per window x head: q k^T*d^-1/2 + RPB, softmax, @v) --------
  * WindowMSA hrformer.py:103-128 / WindowMCA hrfuser_hrformer_based.py:115-148 incl. the centre
@@ -107,7 +117,7 @@ int hrf_bn_bwd_finalize(const double* gstats, const double* gstats_local, const 
 /* ---- LayerNorm over channels (F.layer_norm: hrformer.py:343,351; hrfuser_hrformer_based.py:279-291) */
 int hrf_ln_stats(const float* x, int rows, int C, float eps, float* rowstat, void* stream);
 int hrf_ln_bwd(const float* da, const float* x, const float* rowstat, const float* gamma, int rows, int C,
-               float* dx, int accumulate, float* dgamma, float* dbeta, void* stream);
+               float* dx, int accumulate, float* dgamma, float* dbeta, long copy_stride, void* stream);
 
 /* ---- BN-apply + activation + residual materialisation and its adjoint ---------------------
  * act: 0 none, 1 ReLU, 2 GELU.  act_first=1: out = res + rowscale[b]*act(sc1*y1+sh1)
@@ -145,6 +155,9 @@ int hrf_bilinear_up_bwd(const float* g, int B, int H, int W, int C, const float*
  * state = float[4] on device: {1-b1^t, 1-b2^t, t, -}; hrf_adamw_tick advances t on device so a
  * captured hipGraph replays correct bias corrections.                                           */
 int hrf_adamw_tick(float* state, float beta1, float beta2, void* stream);
+/* dst[map[i]] += sum_k scratch[k*copy_stride + i], k < HRF_STAT_COPIES (see top of file)          */
+int hrf_fold_copies(const float* scratch, long copy_stride, const int* map, float* dst, long n,
+                    void* stream);
 int hrf_adamw(float* p, const float* g, float* m, float* v, const float* wd_mask, long n, float lr,
               float beta1, float beta2, float eps, float weight_decay, const float* state,
               float grad_scale, void* stream);

@@ -85,6 +85,8 @@ struct hrf_f4 {
   float& operator[](int i) { return d[i]; }
   const float& operator[](int i) const { return d[i]; }
 };
+inline hrf_f4 hrf_ld4(const float* p) { hrf_f4 v; std::memcpy(v.d, p, 16); return v; }
+inline void hrf_st4(float* p, hrf_f4 v) { std::memcpy(p, v.d, 16); }
 // v_mfma_f32_16x16x4_f32 semantics: D = A(16x4) * B(4x16) + C, exact fp32 fmaf chain in k order.
 // lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; result reg r of lane l = D[(l>>4)*4+r][l&15].
 inline hrf_f4 hrf_mfma16(float a, float b, hrf_f4 c) {

@@ -9,6 +9,16 @@ from helpers import use_backend
 from hrfuser_amd import _lib
 
 TOL = 2e-5
+KC = _lib.STAT_COPIES      # cross-block accumulators are replicated (include/hrfuser_hip.h)
+
+
+def zstat(C, dev):
+    return torch.zeros(KC * 2 * C, dtype=torch.float64, device=dev)
+
+
+def fold(st):
+    """sum of the replicated copies -> [2*C]"""
+    return st.view(KC, -1).sum(0)
 
 
 def nhwc(t):
@@ -45,6 +55,8 @@ CONV_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
     (1, 6, 5, 256, 18, 3, 1, 0, True, False),
     (3, 40, 50, 16, 40, 1, 1, 1, False, True),
     (2, 16, 24, 64, 256, 1, 1, 2, True, True),
+    (2, 7, 9, 144, 80, 1, 1, 0, False, False),     # several 64-wide tile groups in both dims, ragged
+    (1, 5, 3, 78, 78, 1, 1, 4, False, True),       # HRFuser-B width, fewer pixels than one batch
     (1, 50, 130, 64, 64, 3, 1, 2, True, True),      # M >= 128*.. exercises the BM=128 tile on GPU sizes
 ]
 
@@ -67,12 +79,12 @@ def run_conv(case, backend):
     xr = nhwc(xraw)
     st = (H * W * Cin, W * Cin, Cin, 1)
     yk = torch.zeros(B, Ho, Wo, Cout, device=dev)
-    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    stats = zstat(Cout, dev)
     L.hrf_conv_fwd(D(xr), *st, B, H, W, Cin, D(w), D(bias), KH, stride, Cout, yk, Cout, 0, D(res), None, Cout,
                    tf, D(sc) if tf else None, D(sh) if tf else None, D(rowstat), stats, _lib.stream_ptr())
     assert r(yk, yref) < TOL
     s1, s2 = yref.reshape(-1, Cout).double().sum(0), (yref.reshape(-1, Cout).double() ** 2).sum(0)
-    assert r(stats[:Cout], s1) < TOL and r(stats[Cout:], s2) < TOL
+    assert r(fold(stats)[:Cout], s1) < TOL and r(fold(stats)[Cout:], s2) < TOL
     # NCHW input through strides (stem path)
     if tf == 0:
         yk2 = torch.zeros_like(yk)
@@ -89,12 +101,12 @@ def run_conv(case, backend):
     act = {0: 0, 1: 0, 2: 1, 3: 2, 4: 0}[tf]
     dx = torch.zeros(B, H, W, Cin, device=dev)
     if epi:
-        gst = torch.zeros(2 * Cin, dtype=torch.float64, device=dev)
+        gst = zstat(Cin, dev)
         L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), *co, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 0, 1,
                             D(xr), Cin, D(sc), D(sh), act, gst, _lib.stream_ptr())
         assert r(dx, gu) < TOL
-        assert r(gst[:Cin], gu.reshape(-1, Cin).double().sum(0)) < TOL
-        assert r(gst[Cin:], (gu.reshape(-1, Cin).double() * xr.reshape(-1, Cin).double()).sum(0)) < TOL
+        assert r(fold(gst)[:Cin], gu.reshape(-1, Cin).double().sum(0)) < TOL
+        assert r(fold(gst)[Cin:], (gu.reshape(-1, Cin).double() * xr.reshape(-1, Cin).double()).sum(0)) < TOL
     else:
         base = rn(B, H, W, Cin)
         dx.copy_(base)
@@ -127,13 +139,13 @@ def run_dw(case, backend):
     y = F.conv2d(xt, wq, (b + bq) if has_bias else bq, S, 1, groups=C)
     Ho, Wo = y.shape[2:]
     yk = torch.zeros(B, Ho, Wo, C, device=dev)
-    st = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    st = zstat(C, dev)
     xr = nhwc(xraw)
     L.hrf_dwconv_fwd(D(xr), B, H, W, C, D(w), D(b), S, tf, D(sc) if tf else None, D(sh) if tf else None, yk, st,
                      _lib.stream_ptr())
     yr = nhwc(y.detach())
     assert r(yk, yr) < TOL
-    assert r(st[:C], yr.reshape(-1, C).double().sum(0)) < TOL and r(st[C:], (yr.reshape(-1, C).double() ** 2).sum(0)) < TOL
+    assert r(fold(st)[:C], yr.reshape(-1, C).double().sum(0)) < TOL and r(fold(st)[C:], (yr.reshape(-1, C).double() ** 2).sum(0)) < TOL
     du, yraw = rn(B, Ho, Wo, C), rn(B, Ho, Wo, C)
     cA, cB, cC = rn(C), rn(C) * 0.3, rn(C) * 0.1
     y.backward((cA * du + cB * yraw + cC if bnb else du).permute(0, 3, 1, 2))
@@ -142,11 +154,11 @@ def run_dw(case, backend):
     act = {0: 0, 1: 0, 2: 1, 3: 2}[tf]
     dx = torch.zeros(B, H, W, C, device=dev)
     if epi:
-        gst = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        gst = zstat(C, dev)
         L.hrf_dwconv_bwd_data(D(du), D(yraw), *co, D(w), S, B, H, W, C, dx, 0, 1, D(xr), D(sc), D(sh), act, gst,
                               _lib.stream_ptr())
         assert r(dx, gu) < TOL
-        assert r(gst[C:], (gu.reshape(-1, C).double() * xr.reshape(-1, C).double()).sum(0)) < TOL
+        assert r(fold(gst)[C:], (gu.reshape(-1, C).double() * xr.reshape(-1, C).double()).sum(0)) < TOL
     else:
         base = rn(B, H, W, C)
         dx.copy_(base)
@@ -155,8 +167,18 @@ def run_dw(case, backend):
         assert r(dx, gu + base) < TOL
     dw, db = torch.zeros_like(w, device=dev), torch.zeros(C, device=dev)
     L.hrf_dwconv_bwd_weight(D(du), D(yraw), *co, D(xr), B, H, W, C, S, tf, D(sc) if tf else None,
-                            D(sh) if tf else None, dw, db, _lib.stream_ptr())
+                            D(sh) if tf else None, dw, db, 0, _lib.stream_ptr())
     assert r(dw, wq.grad) < TOL and r(db, bq.grad) < TOL
+    # replicated accumulators (copy_stride > 0) + hrf_fold_copies into a "gradient arena"
+    n = 10 * C
+    scr = torch.zeros(KC * n, device=dev)
+    L.hrf_dwconv_bwd_weight(D(du), D(yraw), *co, D(xr), B, H, W, C, S, tf, D(sc) if tf else None,
+                            D(sh) if tf else None, scr, scr[9 * C:], n, _lib.stream_ptr())
+    arena = torch.ones(n + 5, device=dev)
+    amap = (torch.arange(n, dtype=torch.int32) + 5).to(dev)
+    L.hrf_fold_copies(scr, n, amap, arena, n, _lib.stream_ptr())
+    assert r(arena[5:5 + 9 * C] - 1, wq.grad.reshape(-1)) < TOL and r(arena[5 + 9 * C:] - 1, bq.grad) < TOL
+    assert float(arena[:5].sum()) == 5.0
 
 
 ATTN_CASES = [(2, 10, 13, 18, 1), (1, 7, 7, 36, 2), (2, 15, 8, 72, 4), (1, 9, 16, 78, 2), (1, 6, 10, 64, 8),
@@ -216,7 +238,9 @@ def run_pointwise(backend):
     out = F.relu(bn(yq.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
     gg = rn(B, H, W, C)
     out.backward(gg)
-    st = torch.stack([y.reshape(-1, C).double().sum(0), (y.reshape(-1, C).double() ** 2).sum(0)]).reshape(-1).to(dev)
+    st = zstat(C, dev)
+    st[:2 * C] = torch.stack([y.reshape(-1, C).double().sum(0), (y.reshape(-1, C).double() ** 2).sum(0)]).reshape(-1).to(dev) * 0.75
+    st[6 * C:8 * C] = st[:2 * C] / 3          # the finalize kernels sum the copies
     sc, sh, mean, inv = (torch.zeros(C, device=dev) for _ in range(4))
     n = float(B * H * W)
     L.hrf_bn_finalize(st, D(bn.weight), D(bn.bias), rm, rv, n, 1e-5, 0.1, 1, sc, sh, mean, inv, C, s)
@@ -224,7 +248,7 @@ def run_pointwise(backend):
     L.hrf_affine_act_res(D(y), sc, sh, None, None, None, None, None, 1, 1, 0, o, B * H * W, C, s)
     assert r(o, out) < TOL and r(rm, bn.running_mean) < TOL and r(rv, bn.running_var) < TOL
     gk = torch.zeros(B, H, W, C, device=dev)
-    gst = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    gst = zstat(C, dev)
     L.hrf_act_bwd(D(gg), o, D(y), None, None, None, 1, 0, gk, None, None, gst, None, None, B * H * W, C, s)
     dg, db, cA, cB, cC = (torch.zeros(C, device=dev) for _ in range(5))
     L.hrf_bn_bwd_finalize(gst, None, D(bn.weight), mean, inv, n, 1, dg, db, cA, cB, cC, C, s)
@@ -242,22 +266,39 @@ def run_pointwise(backend):
     mask = torch.empty(B, H, W, C).bernoulli_(0.9, generator=g)
     L.hrf_scale_add(D(y), D(mask), 1 / 0.9, D(rs), H * W, D(res), D(gg), o, B * H * W, C, s)
     assert r(o, res + gg + y * mask / 0.9 * rs.view(B, 1, 1, 1)) < TOL
-    # ---- LayerNorm
-    rows, Cl = 37, 18
-    x = rn(rows, Cl) * 2 + 0.5
-    xq = x.clone().requires_grad_(True)
-    ln = torch.nn.LayerNorm(Cl, eps=1e-6)
-    with torch.no_grad():
-        ln.weight.copy_(torch.rand(Cl, generator=g) + 0.5); ln.bias.copy_(rn(Cl))
-    da = rn(rows, Cl)
-    ln(xq).backward(da)
-    rsb = torch.zeros(rows, 2, device=dev)
-    L.hrf_ln_stats(D(x), rows, Cl, 1e-6, rsb, s)
-    assert r(rsb[:, 0], x.mean(-1)) < TOL and r(rsb[:, 1], (x.var(-1, unbiased=False) + 1e-6).rsqrt()) < TOL
-    base = rn(rows, Cl)
-    dx, dgl, dbl = D(base).clone(), torch.zeros(Cl, device=dev), torch.zeros(Cl, device=dev)
-    L.hrf_ln_bwd(D(da), D(x), rsb, D(ln.weight), rows, Cl, dx, 1, dgl, dbl, s)
-    assert r(dx, xq.grad + base) < TOL and r(dgl, ln.weight.grad) < TOL and r(dbl, ln.bias.grad) < TOL
+    # ---- LayerNorm (every channel-slot template: C/16 <= 2, 3, 5, 10, 20, 40)
+    for rows, Cl in ((37, 18), (33, 36), (21, 78), (19, 144), (9, 312), (5, 624)):
+        x = rn(rows, Cl) * 2 + 0.5
+        xq = x.clone().requires_grad_(True)
+        ln = torch.nn.LayerNorm(Cl, eps=1e-6)
+        with torch.no_grad():
+            ln.weight.copy_(torch.rand(Cl, generator=g) + 0.5); ln.bias.copy_(rn(Cl))
+        da = rn(rows, Cl)
+        ln(xq).backward(da)
+        rsb = torch.zeros(rows, 2, device=dev)
+        L.hrf_ln_stats(D(x), rows, Cl, 1e-6, rsb, s)
+        assert r(rsb[:, 0], x.mean(-1)) < TOL and r(rsb[:, 1], (x.var(-1, unbiased=False) + 1e-6).rsqrt()) < TOL
+        base = rn(rows, Cl)
+        dx, dgl, dbl = D(base).clone(), torch.zeros(Cl, device=dev), torch.zeros(Cl, device=dev)
+        L.hrf_ln_bwd(D(da), D(x), rsb, D(ln.weight), rows, Cl, dx, 1, dgl, dbl, 0, s)
+        assert r(dx, xq.grad + base) < TOL and r(dgl, ln.weight.grad) < TOL and r(dbl, ln.bias.grad) < TOL
+        dx2 = torch.full((rows, Cl), 7.0, device=dev)
+        L.hrf_ln_bwd(D(da), D(x), rsb, D(ln.weight), rows, Cl, dx2, 0, dgl, dbl, 0, s)
+        assert r(dx2, xq.grad) < TOL and r(dgl, 2 * ln.weight.grad) < TOL
+        scr = torch.zeros(KC * 2 * Cl, device=dev)                      # replicated accumulators
+        L.hrf_ln_bwd(D(da), D(x), rsb, D(ln.weight), rows, Cl, dx2, 0, scr, scr[Cl:], 2 * Cl, s)
+        tot = scr.view(KC, 2 * Cl).sum(0)
+        assert r(tot[:Cl], ln.weight.grad) < TOL and r(tot[Cl:], ln.bias.grad) < TOL
+    # ---- act_bwd with three moment sets, narrow and > 256-channel rows
+    for rows, Ca in ((45, 20), (301, 18), (7, 300), (3, 600)):
+        dd, oo, ya, yb, yc = rn(rows, Ca), rn(rows, Ca), rn(rows, Ca), rn(rows, Ca), rn(rows, Ca)
+        gk = torch.zeros(rows, Ca, device=dev)
+        sa, sb, sc3 = (zstat(Ca, dev) for _ in range(3))
+        L.hrf_act_bwd(D(dd), D(oo), D(ya), None, None, None, 1, 0, gk, D(yb), D(yc), sa, sb, sc3, rows, Ca, s)
+        gref = (dd * (oo > 0)).double()
+        assert r(gk, gref) < TOL
+        for st_, y_ in ((sa, ya), (sb, yb), (sc3, yc)):
+            assert r(fold(st_)[:Ca], gref.sum(0)) < TOL and r(fold(st_)[Ca:], (gref * y_.double()).sum(0)) < TOL
     # ---- cross-resolution exchange + bilinear adjoint (x2, x4, non-integer ratio)
     B, H, W, C = 2, 12, 20, 10
     x0 = rn(B, H, W, C).requires_grad_(True)
@@ -275,13 +316,13 @@ def run_pointwise(backend):
                    D(shs[1]), 3, 5, 2, D(ysame), D(scs[2]), D(shs[2]), 0, 0, o, B, H, W, C, s)
     assert r(o, ref) < TOL
     gk = torch.zeros(B, H, W, C, device=dev)
-    st3 = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    st3 = zstat(C, dev)
     L.hrf_act_bwd(D(gg), o, D(ysame), None, None, None, 1, 0, gk, None, None, st3, None, None, B * H * W, C, s)
     assert r(gk, x0.grad) < TOL
-    assert r(st3[C:], (x0.grad.reshape(-1, C).double() * ysame.detach().reshape(-1, C).double()).sum(0)) < TOL
-    du, stl = torch.zeros(B, 6, 10, C, device=dev), torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    assert r(fold(st3)[C:], (x0.grad.reshape(-1, C).double() * ysame.detach().reshape(-1, C).double()).sum(0)) < TOL
+    du, stl = torch.zeros(B, 6, 10, C, device=dev), zstat(C, dev)
     L.hrf_bilinear_up_bwd(gk, B, H, W, C, D(ylo), 6, 10, du, stl, s)
-    assert r(du * D(scs[0]), ylo.grad) < TOL and r(stl[:C], du.reshape(-1, C).double().sum(0)) < TOL
+    assert r(du * D(scs[0]), ylo.grad) < TOL and r(fold(stl)[:C], du.reshape(-1, C).double().sum(0)) < TOL
     du2 = torch.zeros(B, 3, 5, C, device=dev)
     L.hrf_bilinear_up_bwd(gk, B, H, W, C, D(ylo2), 3, 5, du2, None, s)
     assert r(du2 * D(scs[1]), ylo2.grad) < TOL
