@@ -497,69 +497,72 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
     hrf_atomic_add(&a.dbias[m0 + tid], sBias[tid] + sBias[64 + tid] + sBias[128 + tid] + sBias[192 + tid]);
 }
 
-// ----------------------------------------------------------- backward weight, dense 1x1 (no LDS)
+// ----------------------------------------------------------- backward weight, dense 1x1 (no LDS staging)
 // dW[co][ci] += sum_pix bnbwd(dY)[pix][co] * tf(X)[pix][ci] for stride-1 1x1 convs / Linears on
-// channel-contiguous rows (95 % of the weight-gradient launches).  Both operands are "pixel-major",
+// channel-contiguous rows (90 % of the weight-gradient launches).  Both operands are "pixel-major",
 // which is exactly the v_mfma_f32_16x16x4_f32 fragment layout (A[i = l&15][k = l>>4],
 // B[k = l>>4][j = l&15] with k = pixel): fragments are loaded STRAIGHT from global memory, one
 // dword per lane, no LDS staging, no barrier in the reduction loop.  Every wave streams its own
-// pixels with WU k-steps (4 pixels each) of loads in flight, keeps a <= 4x4 grid of 16x16
-// accumulators, the WNW waves of a block are merged through LDS atomics and each block issues ONE
-// coalesced fp32 atomic per output element.
+// pixels with WU k-steps (4 pixels each) of loads in flight and keeps an MT x NT grid of 16x16
+// accumulators (compile-time: no guards in the unrolled code - executed code size and scalar
+// branches, not FLOPs or bytes, set the duration of these ~5 us kernels: the instruction cache
+// is cold at every launch).  The 8 waves of a block are merged through LDS with plain ld/st rounds
+// (LDS float atomics run at ~1 lane/clk: measured 45 us for a 64x64 tile) and the block issues ONE
+// coalesced fp32 atomic per output element; the split count is capped at 32 because same-address
+// global atomics serialise at ~25 ns each.
 struct WgradDenseArgs {
   const float* dy; int ldD; int doff; const float* yraw;
   const float* cA; const float* cB; const float* cC;
   const float* x; int ldX;
-  const float* tf_scale; const float* tf_shift; const float* tf_rowstat;
+  const float* tf_scale; const float* tf_shift; const float* tf_rowstat;   // rowstat != null: LayerNorm
   float* dw; float* dbias;
   int Cout, Cin, Mpix, chunk;
-  int dbg;                        // tuning aid (hrf_debug_knob 5): 1 plain stores, 2 no pixel loop, 4 no epilogue
 };
 
 constexpr int WU = 8;      // k-steps (of 4 pixels) whose loads are issued before the first use
-constexpr int WNW = 8;     // waves per block (512 threads): few blocks per output element, because
-                           // same-address global atomics serialise at ~25 ns each (fan-in <= 32)
+constexpr int WNW = 8;     // waves per block (512 threads)
+constexpr int WSP = 68;    // LDS pitch of the merge tile (2-way bank aliasing = the 64-lane minimum)
 
-template <bool BNB, int TF>
+// ACT: activation applied to the X operand (0 none, 1 ReLU, 2 GELU)
+template <int MT, int NT, bool BNB, int ACT>
 __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a) {
-  __shared__ float sAcc[64 * 64];
-  __shared__ float sBias[64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float sAcc[2 * MT * 16 * WSP];
+  __shared__ float sBias[WNW * MT * 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-  const int mt = min(4, (a.Cout - m0 + 15) >> 4), nt = min(4, (a.Cin - n0 + 15) >> 4);
+  const int m0 = blockIdx.x * (16 * MT), n0 = blockIdx.y * (16 * NT);
   const int pbeg = blockIdx.z * a.chunk, pend = min(a.Mpix, pbeg + a.chunk);
+  const bool ln = a.tf_rowstat != nullptr;
 
-  int aoff[4], boff[4];
-  bool aval[4], bval[4];
-  float ca[4], cb[4], cc[4], sc[4], sh[4];
+  int aoff[MT], boff[NT];
+  bool aval[MT];
+  float ca[MT], cb[MT], cc[MT], sc[NT], sh[NT], bsum[MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MT; ++i) {
     const int co = m0 + 16 * i + c;
     aval[i] = co < a.Cout;
     aoff[i] = a.doff + (aval[i] ? co : 0);
-    ca[i] = 1.f; cb[i] = 0.f; cc[i] = 0.f;
+    ca[i] = 1.f; cb[i] = 0.f; cc[i] = 0.f; bsum[i] = 0.f;
     if (BNB) { const int cs = aval[i] ? co : 0; ca[i] = a.cA[cs]; cb[i] = a.cB[cs]; cc[i] = a.cC[cs]; }
-    const int ci = n0 + 16 * i + c;
-    bval[i] = ci < a.Cin;
-    boff[i] = bval[i] ? ci : 0;
-    sc[i] = 1.f; sh[i] = 0.f;
-    if (TF != HRF_TF_NONE) { sc[i] = a.tf_scale[boff[i]]; sh[i] = a.tf_shift[boff[i]]; }
   }
-
-  hrf_f4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < NT; ++j) {
+    const int ci = n0 + 16 * j + c;
+    boff[j] = ci < a.Cin ? ci : 0;
+    sc[j] = 1.f; sh[j] = 0.f;
+    if (a.tf_scale != nullptr) { sc[j] = a.tf_scale[boff[j]]; sh[j] = a.tf_shift[boff[j]]; }
+  }
+  hrf_f4 acc[MT][NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-
-  for (int sjj = 0; sjj < 64 * 64; sjj += 64 * WNW) sAcc[sjj + tid] = 0.f;
-  if (tid < 64) sBias[tid] = 0.f;
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
 
   // wave w owns k-steps w, w+WNW, ... of the block's chunk: neighbouring waves read neighbouring rows
-  for (int p0 = pbeg + 4 * wave; p0 < ((a.dbg & 2) ? pbeg : pend); p0 += 4 * WNW * WU) {
-    float ar[WU][4], yr[WU][4], br[WU][4], rm[WU], rr[WU];
+#pragma unroll 1
+  for (int p0 = pbeg + 4 * wave; p0 < pend; p0 += 4 * WNW * WU) {
+    float ar[WU][MT], yr[WU][MT], br[WU][NT], rm[WU], rr[WU];
     bool pv[WU];
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
@@ -568,67 +571,73 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a)
       const int pc = pv[u] ? pix : pbeg;
       const long arow = (long)pc * a.ldD, brow = (long)pc * a.ldX;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ar[u][i] = 0.f; yr[u][i] = 0.f; br[u][i] = 0.f;
-        if (i < mt) {
-          ar[u][i] = a.dy[arow + aoff[i]];
-          if (BNB) yr[u][i] = a.yraw[arow + aoff[i]];
-        }
-        if (i < nt) br[u][i] = a.x[brow + boff[i]];
+      for (int i = 0; i < MT; ++i) {
+        ar[u][i] = a.dy[arow + aoff[i]];
+        yr[u][i] = BNB ? a.yraw[arow + aoff[i]] : 0.f;
       }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) br[u][j] = a.x[brow + boff[j]];
       rm[u] = 0.f; rr[u] = 1.f;
-      if (TF == HRF_TF_LN) { rm[u] = a.tf_rowstat[2 * pc]; rr[u] = a.tf_rowstat[2 * pc + 1]; }
+      if (ln) { rm[u] = a.tf_rowstat[2 * pc]; rr[u] = a.tf_rowstat[2 * pc + 1]; }
     }
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
-      float av[4], bv[4];
+      float av[MT], bv[NT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MT; ++i) {
         float v = ar[u][i];
         if (BNB) v = fmaf(ca[i], v, fmaf(cb[i], yr[u][i], cc[i]));
         av[i] = (pv[u] && aval[i]) ? v : 0.f;
         bsum[i] += av[i];
-        float w = br[u][i];
-        if (TF == HRF_TF_LN) w = fmaf((w - rm[u]) * rr[u], sc[i], sh[i]);
-        else if (TF != HRF_TF_NONE) w = fmaf(w, sc[i], sh[i]);
-        bv[i] = w;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j < nt) {
-          const float bf = act_at_read(TF, bv[j]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (i < mt) acc[i][j] = hrf_mfma16(av[i], bf, acc[i][j]);
-        }
+      for (int j = 0; j < NT; ++j) {
+        const float w = fmaf((br[u][j] - rm[u]) * rr[u], sc[j], sh[j]);    // (mean, rstd, sc, sh) = (0, 1, 1, 0) when unused
+        bv[j] = ACT == 1 ? fmaxf(w, 0.f) : (ACT == 2 ? hrf_gelu(w) : w);
       }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = hrf_mfma16(av[i], bv[j], acc[i][j]);
     }
   }
 
-  __syncthreads();                       // sAcc / sBias zeroed by every thread before the merges
-  if (a.dbg & 4) { if (acc[0][0][0] == 12345.f) a.dw[0] = 1.f; return; }
+  // merge the 8 waves: region = wave >> 2, four ld/add/st rounds (waves r and r+4 work in parallel)
+  float* S = sAcc + (wave >> 2) * (MT * 16 * WSP);
+#pragma unroll 1
+  for (int round = 0; round < 4; ++round) {
+    if ((wave & 3) == round) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < mt) {
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j < nt) {
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hrf_atomic_add(&sAcc[(16 * i + 4 * kq + r) * 64 + 16 * j + c], acc[i][j][r]);
-        }
-      }
-      float b = bsum[i];
-      b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-      if (lane < 16) hrf_atomic_add(&sBias[16 * i + lane], b);
+          for (int r = 0; r < 4; ++r) {
+            float* q = &S[(16 * i + 4 * kq + r) * WSP + 16 * j + c];
+            const float old = *q;
+            *q = round == 0 ? acc[i][j][r] : old + acc[i][j][r];
+          }
     }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    float bsm = bsum[i];
+    bsm += __shfl_xor(bsm, 16); bsm += __shfl_xor(bsm, 32);
+    if (lane < 16) sBias[wave * (MT * 16) + 16 * i + lane] = bsm;
+  }
+  for (int e = tid; e < MT * 16 * 64; e += 64 * WNW) {
+    const int row = e >> 6, col = e & 63;
+    if (col < NT * 16 && m0 + row < a.Cout && n0 + col < a.Cin)
+      hrf_atomic_add(&a.dw[(long)(m0 + row) * a.Cin + n0 + col], sAcc[row * WSP + col] + sAcc[MT * 16 * WSP + row * WSP + col]);
   }
   __syncthreads();
-  const int ncol = min(64, a.Cin - n0), nrow = min(64, a.Cout - m0);
-  for (int e = tid; e < nrow * 64; e += 64 * WNW) {
-    const int row = e >> 6, col = e & 63;
-    if (col < ncol) { if (a.dbg & 1) a.dw[(long)(m0 + row) * a.Cin + n0 + col] = sAcc[e]; else hrf_atomic_add(&a.dw[(long)(m0 + row) * a.Cin + n0 + col], sAcc[e]); }
+  if (a.dbias != nullptr && blockIdx.y == 0 && tid < MT * 16 && m0 + tid < a.Cout) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WNW; ++w) t += sBias[w * (MT * 16) + tid];
+    hrf_atomic_add(&a.dbias[m0 + tid], t);
   }
-  if (a.dbias != nullptr && blockIdx.y == 0 && tid < nrow) hrf_atomic_add(&a.dbias[m0 + tid], sBias[tid]);
 }
 
 inline int pick_nt(int C) {
@@ -786,26 +795,30 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
   if (dense1 && g_knob[2] == 0) {
     WgradDenseArgs d;
     d.dy = dy; d.ldD = ldD; d.doff = doff; d.yraw = yraw; d.cA = cA; d.cB = cB; d.cC = cC;
-    d.x = x; d.ldX = sX; d.tf_scale = tf_scale; d.tf_shift = tf_shift; d.tf_rowstat = tf_rowstat;
-    d.dw = dw; d.dbias = dbias; d.Cout = Cout; d.Cin = Cin; d.Mpix = a.Mpix; d.dbg = g_knob[5];
-    // one block = WNW waves x >= 1 unrolled batch (WU k-steps of 4 pixels each)
+    d.x = x; d.ldX = sX; d.tf_scale = tf_mode != HRF_TF_NONE ? tf_scale : nullptr; d.tf_shift = tf_shift;
+    d.tf_rowstat = tf_mode == HRF_TF_LN ? tf_rowstat : nullptr;
+    d.dw = dw; d.dbias = dbias; d.Cout = Cout; d.Cin = Cin; d.Mpix = a.Mpix;
+    const int mt = Cout <= 32 ? 2 : 4, nt = Cin <= 32 ? 2 : 4;      // 16x16 tiles per wave (masked when ragged)
     int sp = hrf_cdiv(a.Mpix, 4 * WNW * WU);
     const int cap2 = g_knob[3] > 0 ? g_knob[3] : 32;        // atomic fan-in per output element
     if (sp > cap2) sp = cap2;
     if (sp < 1) sp = 1;
     d.chunk = hrf_cdiv(hrf_cdiv(a.Mpix, sp), 4 * WNW) * 4 * WNW;
     sp = hrf_cdiv(a.Mpix, d.chunk);
-    const dim3 g2(gx, gy, sp);
-#define HRF_WD_LAUNCH(BNB_, TF_) HRF_LAUNCH((wgrad_dense_kernel<BNB_, TF_>), g2, dim3(64 * WNW), 0, stream, d)
-#define HRF_WD_TF(BNB_)                                               \
-    switch (tf_mode) {                                                \
-      case HRF_TF_NONE: HRF_WD_LAUNCH(BNB_, HRF_TF_NONE); break;      \
-      case HRF_TF_AFFINE: HRF_WD_LAUNCH(BNB_, HRF_TF_AFFINE); break;  \
-      case HRF_TF_AFFINE_RELU: HRF_WD_LAUNCH(BNB_, HRF_TF_AFFINE_RELU); break; \
-      case HRF_TF_AFFINE_GELU: HRF_WD_LAUNCH(BNB_, HRF_TF_AFFINE_GELU); break; \
-      default: HRF_WD_LAUNCH(BNB_, HRF_TF_LN); break;                 \
-    }
-    if (cA != nullptr) { HRF_WD_TF(true) } else { HRF_WD_TF(false) }
+    const dim3 g2(hrf_cdiv(Cout, 16 * mt), hrf_cdiv(Cin, 16 * nt), sp);
+    const int act = tf_mode == HRF_TF_AFFINE_RELU ? 1 : (tf_mode == HRF_TF_AFFINE_GELU ? 2 : 0);
+#define HRF_WD_LAUNCH(MT_, NT_, BNB_, ACT_) \
+    HRF_LAUNCH((wgrad_dense_kernel<MT_, NT_, BNB_, ACT_>), g2, dim3(64 * WNW), 0, stream, d)
+#define HRF_WD_ACT(MT_, NT_, BNB_)                           \
+    if (act == 1) { HRF_WD_LAUNCH(MT_, NT_, BNB_, 1); }      \
+    else if (act == 2) { HRF_WD_LAUNCH(MT_, NT_, BNB_, 2); } \
+    else { HRF_WD_LAUNCH(MT_, NT_, BNB_, 0); }
+#define HRF_WD_BNB(MT_, NT_) \
+    if (cA != nullptr) { HRF_WD_ACT(MT_, NT_, true) } else { HRF_WD_ACT(MT_, NT_, false) }
+    if (mt == 2 && nt == 2) { HRF_WD_BNB(2, 2) }
+    else if (mt == 2) { HRF_WD_BNB(2, 4) }
+    else if (nt == 2) { HRF_WD_BNB(4, 2) }
+    else { HRF_WD_BNB(4, 4) }
     return hrf_check_launch();
   }
   const dim3 grid(gx, gy, splits);

@@ -27,6 +27,14 @@ __device__ __forceinline__ hrf_f4 hrf_mfma16(float a, float b, hrf_f4 c) {
 typedef float hrf_f4u __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ hrf_f4 hrf_ld4(const float* p) { return *reinterpret_cast<const hrf_f4u*>(p); }
 __device__ __forceinline__ void hrf_st4(float* p, hrf_f4 v) { *reinterpret_cast<hrf_f4u*>(p) = v; }
+// sum over each 16-lane row (lanes sharing lane>>4) with four DPP adds - no LDS, no ds_bpermute
+__device__ __forceinline__ float hrf_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
 __device__ __forceinline__ void hrf_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void hrf_atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 #endif

@@ -22,271 +22,274 @@
 
 namespace {
 
-constexpr int NTM = 9;    // 16-channel output tiles per wave (<= 144 channels per channel group)
 constexpr int SB = 2;     // 16-deep K slabs whose loads are issued before the first use
 
-// Elements base..base+3 of a row of which only the first `nvalid` exist (nvalid <= 0: none, >= 4: all);
-// missing elements read as 0.  Never touches memory outside the row: a partial group is fetched as
-// the 4 elements ENDING at the row end and rotated into place (rows have >= 4 elements).
-__device__ __forceinline__ hrf_f4 ld4_guard(const float* p, long base, int nvalid) {
-  const int sh = (nvalid >= 4 || nvalid <= 0) ? 0 : 4 - nvalid;
-  const hrf_f4 v = hrf_ld4(p + (nvalid > 0 ? base - sh : 0));
+// Out-of-range fragment groups are read from this zero block instead of being masked after the
+// load: `cond ? loaded : 0` makes the compiler sink the load into an exec-masked branch with its own
+// s_waitcnt (one dependent round trip per load); a select between two ADDRESSES keeps every load
+// unconditional and back-to-back.
+__device__ float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+
+// 4 consecutive elements p[off..off+3]; V4: one 16-byte load (all-or-nothing validity: row lengths are
+// multiples of 4), otherwise four dword loads with per-element validity (nvalid of them exist).
+template <bool V4>
+__device__ __forceinline__ hrf_f4 ld_group(const float* p, long off, int nvalid) {
+  if (V4) return hrf_ld4(nvalid > 0 ? p + off : g_zero4);
   hrf_f4 r;
-  r[0] = nvalid > 0 ? (sh == 0 ? v[0] : (sh == 1 ? v[1] : (sh == 2 ? v[2] : v[3]))) : 0.f;
-  r[1] = nvalid > 1 ? (sh == 0 ? v[1] : (sh == 1 ? v[2] : v[3])) : 0.f;
-  r[2] = nvalid > 2 ? (sh == 0 ? v[2] : v[3]) : 0.f;
-  r[3] = nvalid > 3 ? v[3] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = *(e < nvalid ? p + off + e : g_zero4);
   return r;
 }
 
-__device__ __forceinline__ void st4_guard(float* p, hrf_f4 v, int nvalid) {
-  if (nvalid >= 4) {
-    hrf_st4(p, v);
+template <bool V4>
+__device__ __forceinline__ void st_group(float* p, hrf_f4 v, int nvalid) {
+  if (V4) {
+    if (nvalid > 0) hrf_st4(p, v);
   } else {
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-      if (r < nvalid) p[r] = v[r];
+    for (int e = 0; e < 4; ++e)
+      if (e < nvalid) p[e] = v[e];
   }
 }
 
-// per-channel (sum, sum*w) of one accumulator tile into the block's LDS moments
-__device__ __forceinline__ void tile_moments(float* sStat, int t, int q, bool pixv, int nval, hrf_f4 v, hrf_f4 w) {
+// per-channel (sum v, sum v*w) of the NT accumulator tiles of one wave -> sStat[wave][2][NT*16]
+template <int NT>
+__device__ __forceinline__ void wave_moments(float* sStat, int wave, int j, int q, bool pixv, int n0w, int N,
+                                             const hrf_f4* v, const hrf_f4* w) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (pixv && r < nval) {
-      hrf_atomic_add(&sStat[16 * t + 4 * q + r], v[r]);
-      hrf_atomic_add(&sStat[16 * NTM + 16 * t + 4 * q + r], v[r] * w[r]);
+  for (int t = 0; t < NT; ++t) {
+    const int nval = N - (n0w + 16 * t + 4 * q);
+    float s1[4], s2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float m = (pixv && r < nval) ? 1.f : 0.f;
+      s1[r] = hrf_row16_sum(v[t][r] * m);
+      s2[r] = hrf_row16_sum(v[t][r] * w[t][r] * m);
+    }
+    if (j == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sStat[(wave * 2 + 0) * (NT * 16) + 16 * t + 4 * q + r] = s1[r];
+        sStat[(wave * 2 + 1) * (NT * 16) + 16 * t + 4 * q + r] = s2[r];
+      }
     }
   }
 }
 
-__device__ __forceinline__ void flush_moments(const float* sStat, double* stats, int nt, int t0, int N) {
+template <int NT>
+__device__ __forceinline__ void flush_moments(const float* sStat, double* stats, int n0w, int N) {
   double* st = stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * N;
-  for (int i = threadIdx.x; i < 16 * nt; i += 256) {
-    const int ch = 16 * t0 + i;
+  for (int i = threadIdx.x; i < 2 * NT * 16; i += 256) {
+    const int which = i / (NT * 16), cidx = i - which * (NT * 16);
+    const int ch = n0w + cidx;
     if (ch < N) {
-      hrf_atomic_add(&st[ch], (double)sStat[i]);
-      hrf_atomic_add(&st[N + ch], (double)sStat[16 * NTM + i]);
+      const float s = sStat[(0 * 2 + which) * (NT * 16) + cidx] + sStat[(1 * 2 + which) * (NT * 16) + cidx] +
+                      sStat[(2 * 2 + which) * (NT * 16) + cidx] + sStat[(3 * 2 + which) * (NT * 16) + cidx];
+      hrf_atomic_add(&st[which * N + ch], (double)s);
     }
   }
 }
 
 // --------------------------------------------------------------------------------- forward
-template <int TF>
-__global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a, int ntw) {
-  __shared__ float sStat[2 * 16 * NTM];
+// NT = 16-channel output tiles per wave (compile time: the unrolled code carries no guards);
+// V4 = K and N are multiples of 4 (16-byte fragment loads), else dword loads.
+template <int NT, int TF, bool V4>
+__global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
+  __shared__ float sStat[4 * 2 * NT * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
-  const int T = (a.N + 15) >> 4;
-  const int t0 = blockIdx.y * ntw;
-  const int nt = min(ntw, T - t0);
+  const int n0w = blockIdx.y * (NT * 16);
   const int pix = blockIdx.x * 64 + wave * 16 + j;
   const bool pixv = pix < a.M;
   const long pc = pixv ? pix : a.M - 1;
-  if (a.stats != nullptr)
-    for (int i = tid; i < 2 * 16 * NTM; i += 256) sStat[i] = 0.f;
 
   // accumulators start as bias + residual rows (D = A*B + C): no separate epilogue loads
-  hrf_f4 acc[NTM];
+  hrf_f4 acc[NT];
 #pragma unroll
-  for (int t = 0; t < NTM; ++t) {
-    acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-    if (t < nt) {
-      const int chb = 16 * (t0 + t) + 4 * q, nval = a.N - chb;
-      if (a.bias != nullptr) acc[t] = ld4_guard(a.bias, chb, nval);
-      if (a.res != nullptr) {
-        const hrf_f4 rv = ld4_guard(a.res, pc * a.ldR + chb, nval);
+  for (int t = 0; t < NT; ++t) {
+    const int chb = n0w + 16 * t + 4 * q, nval = a.N - chb;
+    acc[t] = ld_group<V4>(a.bias, chb, a.bias != nullptr ? nval : 0);
+    const hrf_f4 r1 = ld_group<V4>(a.res, pc * a.ldR + chb, a.res != nullptr ? nval : 0);
+    const hrf_f4 r2 = ld_group<V4>(a.res2, pc * a.ldR + chb, a.res2 != nullptr ? nval : 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] += rv[r];
-      }
-      if (a.res2 != nullptr) {
-        const hrf_f4 rv = ld4_guard(a.res2, pc * a.ldR + chb, nval);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] += rv[r];
-      }
-    }
+    for (int r = 0; r < 4; ++r) acc[t][r] += r1[r] + r2[r];
   }
   float mean = 0.f, rstd = 1.f;
   if (TF == HRF_TF_LN) { mean = a.tf_rowstat[2 * pc]; rstd = a.tf_rowstat[2 * pc + 1]; }
 
   const int nslab = (a.K + 15) >> 4;
   const long xrow = pc * a.ldX;
+#pragma unroll 1
   for (int kb = 0; kb < nslab; kb += SB) {
-    hrf_f4 xa[SB], sc[SB], sh[SB], wv[SB][NTM];
+    hrf_f4 xa[SB], sc[SB], sh[SB], wv[SB][NT];
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
       const int kbase = 16 * (kb + s) + 4 * q, kval = a.K - kbase;
-      xa[s] = ld4_guard(a.x, xrow + kbase, kval);
-      if (TF != HRF_TF_NONE) { sc[s] = ld4_guard(a.tf_scale, kbase, kval); sh[s] = ld4_guard(a.tf_shift, kbase, kval); }
+      xa[s] = ld_group<V4>(a.x, xrow + kbase, kval);
+      if (TF != HRF_TF_NONE) { sc[s] = ld_group<V4>(a.tf_scale, kbase, kval); sh[s] = ld_group<V4>(a.tf_shift, kbase, kval); }
 #pragma unroll
-      for (int t = 0; t < NTM; ++t) {
-        if (t < nt) {
-          const int n = 16 * (t0 + t) + j;
-          wv[s][t] = ld4_guard(a.w, (long)n * a.K + kbase, n < a.N ? kval : 0);
-        }
+      for (int t = 0; t < NT; ++t) {
+        const int n = n0w + 16 * t + j;
+        wv[s][t] = ld_group<V4>(a.w, (long)n * a.K + kbase, n < a.N ? kval : 0);
       }
     }
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
-      float xt[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = xa[s][r];
         if (TF == HRF_TF_LN) v = fmaf((v - mean) * rstd, sc[s][r], sh[s][r]);
         else if (TF != HRF_TF_NONE) v = fmaf(v, sc[s][r], sh[s][r]);
-        xt[r] = TF == HRF_TF_AFFINE_RELU ? fmaxf(v, 0.f) : (TF == HRF_TF_AFFINE_GELU ? hrf_gelu(v) : v);
-      }
+        v = TF == HRF_TF_AFFINE_RELU ? fmaxf(v, 0.f) : (TF == HRF_TF_AFFINE_GELU ? hrf_gelu(v) : v);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (16 * (kb + s) + r < a.K) {           // uniform: MFMA r of this slab holds at least one valid k
-#pragma unroll
-          for (int t = 0; t < NTM; ++t)
-            if (t < nt) acc[t] = hrf_mfma16(wv[s][t][r], xt[r], acc[t]);
-        }
+        for (int t = 0; t < NT; ++t) acc[t] = hrf_mfma16(wv[s][t][r], v, acc[t]);   // k beyond K: W == 0
       }
     }
   }
 
-  if (a.stats != nullptr) __syncthreads();
 #pragma unroll
-  for (int t = 0; t < NTM; ++t) {
-    if (t < nt) {
-      const int chb = 16 * (t0 + t) + 4 * q, nval = a.N - chb;
-      if (pixv) st4_guard(a.y + (long)pix * a.ldY + a.yoff + chb, acc[t], nval);
-      if (a.stats != nullptr) tile_moments(sStat, t, q, pixv, nval, acc[t], acc[t]);
-    }
+  for (int t = 0; t < NT; ++t) {
+    const int chb = n0w + 16 * t + 4 * q;
+    st_group<V4>(a.y + (long)pc * a.ldY + a.yoff + chb, acc[t], pixv ? a.N - chb : 0);
   }
   if (a.stats != nullptr) {
+    wave_moments<NT>(sStat, wave, j, q, pixv, n0w, a.N, acc, acc);
     __syncthreads();
-    flush_moments(sStat, a.stats, nt, t0, a.N);
+    flush_moments<NT>(sStat, a.stats, n0w, a.N);
   }
 }
 
 // --------------------------------------------------------------------------------- backward data
-template <bool BNB>
-__global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataArgs a, int ntw) {
-  __shared__ float sStat[2 * 16 * NTM];
+template <int NT, bool BNB, bool V4>
+__global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataArgs a) {
+  __shared__ float sStat[4 * 2 * NT * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
-  const int T = (a.N + 15) >> 4;
-  const int t0 = blockIdx.y * ntw;
-  const int nt = min(ntw, T - t0);
+  const int n0w = blockIdx.y * (NT * 16);
   const int pix = blockIdx.x * 64 + wave * 16 + j;
   const bool pixv = pix < a.M;
   const long pc = pixv ? pix : a.M - 1;
-  const bool want_stats = a.epi == 1 && a.stats != nullptr;
-  if (want_stats)
-    for (int i = tid; i < 2 * 16 * NTM; i += 256) sStat[i] = 0.f;
 
-  hrf_f4 acc[NTM], xr[NTM];
+  hrf_f4 acc[NT], xr[NT];
 #pragma unroll
-  for (int t = 0; t < NTM; ++t) {
-    acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-    xr[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-    if (t < nt) {
-      const int chb = 16 * (t0 + t) + 4 * q, nval = a.N - chb;
-      if (a.epi == 1) xr[t] = ld4_guard(a.xraw, pc * a.ldXr + chb, nval);
-      else if (a.accumulate) acc[t] = ld4_guard(a.dx, pc * a.ldDx + chb, nval);
-    }
+  for (int t = 0; t < NT; ++t) {
+    const int chb = n0w + 16 * t + 4 * q, nval = a.N - chb;
+    xr[t] = ld_group<V4>(a.xraw, pc * a.ldXr + chb, a.epi == 1 ? nval : 0);
+    acc[t] = ld_group<V4>(a.dx, pc * a.ldDx + chb, (a.epi != 1 && a.accumulate) ? nval : 0);
   }
 
   const int nslab = (a.K + 15) >> 4;
   const long drow = pc * a.ldD + a.doff;
+#pragma unroll 1
   for (int kb = 0; kb < nslab; kb += SB) {
-    hrf_f4 dv[SB], yv[SB], ca[SB], cb[SB], cc[SB], wv[SB][NTM];
+    hrf_f4 dv[SB], yv[SB], ca[SB], cb[SB], cc[SB], wv[SB][NT];
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
       const int kbase = 16 * (kb + s) + 4 * q, kval = a.K - kbase;
-      dv[s] = ld4_guard(a.dy, drow + kbase, kval);
+      dv[s] = ld_group<V4>(a.dy, drow + kbase, kval);
       if (BNB) {
-        yv[s] = ld4_guard(a.yraw, drow + kbase, kval);
-        ca[s] = ld4_guard(a.cA, kbase, kval); cb[s] = ld4_guard(a.cB, kbase, kval); cc[s] = ld4_guard(a.cC, kbase, kval);
+        yv[s] = ld_group<V4>(a.yraw, drow + kbase, kval);
+        ca[s] = ld_group<V4>(a.cA, kbase, kval); cb[s] = ld_group<V4>(a.cB, kbase, kval); cc[s] = ld_group<V4>(a.cC, kbase, kval);
       }
 #pragma unroll
-      for (int t = 0; t < NTM; ++t) {
-        if (t < nt) {
-          const int ci = 16 * (t0 + t) + j;
+      for (int t = 0; t < NT; ++t) {
+        const int ci = n0w + 16 * t + j;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {              // W[co][ci]: the contraction index is the ROW here
-            const bool ok = r < kval && ci < a.N;
-            const float wr = a.w[ok ? (long)(kbase + r) * a.N + ci : 0];
-            wv[s][t][r] = ok ? wr : 0.f;
-          }
-        }
+        for (int r = 0; r < 4; ++r)                  // W[co][ci]: the contraction index is the ROW here
+          wv[s][t][r] = *((r < kval && ci < a.N) ? a.w + (long)(kbase + r) * a.N + ci : g_zero4);
       }
     }
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
-      float d[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d[r] = BNB ? fmaf(ca[s][r], dv[s][r], fmaf(cb[s][r], yv[s][r], cc[s][r])) : dv[s][r];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (16 * (kb + s) + r < a.K) {
+        const float d = BNB ? fmaf(ca[s][r], dv[s][r], fmaf(cb[s][r], yv[s][r], cc[s][r])) : dv[s][r];
 #pragma unroll
-          for (int t = 0; t < NTM; ++t)
-            if (t < nt) acc[t] = hrf_mfma16(wv[s][t][r], d[r], acc[t]);
-        }
+        for (int t = 0; t < NT; ++t) acc[t] = hrf_mfma16(wv[s][t][r], d, acc[t]);
       }
     }
   }
 
-  if (want_stats) __syncthreads();
+  if (a.epi == 1) {
 #pragma unroll
-  for (int t = 0; t < NTM; ++t) {
-    if (t < nt) {
-      const int chb = 16 * (t0 + t) + 4 * q, nval = a.N - chb;
-      hrf_f4 v = acc[t];
-      if (a.epi == 1) {
-        const hrf_f4 sc = ld4_guard(a.tf_scale, chb, nval), sh = ld4_guard(a.tf_shift, chb, nval);
+    for (int t = 0; t < NT; ++t) {
+      const int chb = n0w + 16 * t + 4 * q, nval = a.N - chb;
+      const hrf_f4 sc = ld_group<V4>(a.tf_scale, chb, nval), sh = ld_group<V4>(a.tf_shift, chb, nval);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= hrf_act_grad(a.act, fmaf(xr[t][r], sc[r], sh[r]));
-        if (want_stats) tile_moments(sStat, t, q, pixv, nval, v, xr[t]);
-      }
-      if (pixv) st4_guard(a.dx + (long)pix * a.ldDx + chb, v, nval);
+      for (int r = 0; r < 4; ++r) acc[t][r] *= hrf_act_grad(a.act, fmaf(xr[t][r], sc[r], sh[r]));
     }
   }
-  if (want_stats) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int chb = n0w + 16 * t + 4 * q;
+    st_group<V4>(a.dx + (long)pc * a.ldDx + chb, acc[t], pixv ? a.N - chb : 0);
+  }
+  if (a.epi == 1 && a.stats != nullptr) {
+    wave_moments<NT>(sStat, wave, j, q, pixv, n0w, a.N, acc, xr);
     __syncthreads();
-    flush_moments(sStat, a.stats, nt, t0, a.N);
+    flush_moments<NT>(sStat, a.stats, n0w, a.N);
   }
 }
 
-// tiles per wave: as many as fit (X fragment reuse) while keeping >= ~768 waves in flight
+// tiles per wave: as many as fit (X fragment reuse, <= 9) while keeping >= ~768 waves in flight;
+// rounded up to an instantiated size (masked tiles cost MFMA issue slots only)
 inline int pick_ntw(int M, int T) {
   const long ptiles = (M + 15) / 16;
-  int ntw = T < NTM ? T : NTM;
-  while (ntw > 1 && ptiles * ((T + ntw - 1) / ntw) < 768) --ntw;
-  const int groups = (T + ntw - 1) / ntw;
-  return (T + groups - 1) / groups;
+  long groups = (768 + ptiles - 1) / ptiles;               // channel groups wanted for parallelism
+  if (groups > T) groups = T;
+  const long gmin = (T + 8) / 9;
+  if (groups < gmin) groups = gmin;
+  const int need = (int)((T + groups - 1) / groups);
+  return need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 3 ? 3 : (need <= 5 ? 5 : 9)));
 }
 
 }  // namespace
 
-#define HRF_LF_LAUNCH(TF_) HRF_LAUNCH((lin_fwd_kernel<TF_>), grid, dim3(256), 0, stream, a, ntw)
+#define HRF_LF_LAUNCH(NT_, TF_, V4_) HRF_LAUNCH((lin_fwd_kernel<NT_, TF_, V4_>), grid, dim3(256), 0, stream, a)
+#define HRF_LF_NT(TF_, V4_)                          \
+  switch (ntw) {                                     \
+    case 1: HRF_LF_LAUNCH(1, TF_, V4_); break;       \
+    case 2: HRF_LF_LAUNCH(2, TF_, V4_); break;       \
+    case 3: HRF_LF_LAUNCH(3, TF_, V4_); break;       \
+    case 5: HRF_LF_LAUNCH(5, TF_, V4_); break;       \
+    default: HRF_LF_LAUNCH(9, TF_, V4_); break;      \
+  }
+#define HRF_LF_V4(TF_) if (v4) { HRF_LF_NT(TF_, true) } else { HRF_LF_NT(TF_, false) }
 
 int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return -1;
   const int T = (a.N + 15) / 16;
   const int ntw = pick_ntw(a.M, T);
+  const bool v4 = (a.K % 4 == 0) && (a.N % 4 == 0);
   const dim3 grid(hrf_cdiv(a.M, 64), hrf_cdiv(T, ntw));
   switch (a.tf_mode) {
-    case HRF_TF_NONE: HRF_LF_LAUNCH(HRF_TF_NONE); break;
-    case HRF_TF_AFFINE: HRF_LF_LAUNCH(HRF_TF_AFFINE); break;
-    case HRF_TF_AFFINE_RELU: HRF_LF_LAUNCH(HRF_TF_AFFINE_RELU); break;
-    case HRF_TF_AFFINE_GELU: HRF_LF_LAUNCH(HRF_TF_AFFINE_GELU); break;
-    case HRF_TF_LN: HRF_LF_LAUNCH(HRF_TF_LN); break;
+    case HRF_TF_NONE: HRF_LF_V4(HRF_TF_NONE) break;
+    case HRF_TF_AFFINE: HRF_LF_V4(HRF_TF_AFFINE) break;
+    case HRF_TF_AFFINE_RELU: HRF_LF_V4(HRF_TF_AFFINE_RELU) break;
+    case HRF_TF_AFFINE_GELU: HRF_LF_V4(HRF_TF_AFFINE_GELU) break;
+    case HRF_TF_LN: HRF_LF_V4(HRF_TF_LN) break;
     default: return -1;
   }
   return hrf_check_launch();
 }
 
+#define HRF_LB_LAUNCH(NT_, BNB_, V4_) HRF_LAUNCH((lin_bwd_data_kernel<NT_, BNB_, V4_>), grid, dim3(256), 0, stream, a)
+#define HRF_LB_NT(BNB_, V4_)                         \
+  switch (ntw) {                                     \
+    case 1: HRF_LB_LAUNCH(1, BNB_, V4_); break;      \
+    case 2: HRF_LB_LAUNCH(2, BNB_, V4_); break;      \
+    case 3: HRF_LB_LAUNCH(3, BNB_, V4_); break;      \
+    case 5: HRF_LB_LAUNCH(5, BNB_, V4_); break;      \
+    default: HRF_LB_LAUNCH(9, BNB_, V4_); break;     \
+  }
+#define HRF_LB_V4(BNB_) if (v4) { HRF_LB_NT(BNB_, true) } else { HRF_LB_NT(BNB_, false) }
+
 int hrf_lin_bwd_data_launch(const LinBwdDataArgs& a, void* stream) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return -1;
   const int T = (a.N + 15) / 16;
   const int ntw = pick_ntw(a.M, T);
+  const bool v4 = (a.K % 4 == 0) && (a.N % 4 == 0);
   const dim3 grid(hrf_cdiv(a.M, 64), hrf_cdiv(T, ntw));
-  if (a.cA != nullptr) { HRF_LAUNCH((lin_bwd_data_kernel<true>), grid, dim3(256), 0, stream, a, ntw); }
-  else { HRF_LAUNCH((lin_bwd_data_kernel<false>), grid, dim3(256), 0, stream, a, ntw); }
+  if (a.cA != nullptr) { HRF_LB_V4(true) } else { HRF_LB_V4(false) }
   return hrf_check_launch();
 }

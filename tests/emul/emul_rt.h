@@ -125,6 +125,11 @@ inline void hrf_atomic_add(double* p, double v) {
 }
 inline float atomicAdd(float* p, float v) { hrf_atomic_add(p, v); return 0.f; }
 
+inline float hrf_row16_sum(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // wave-uniform by construction at the call sites
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __expf(float x) { return expf(x); }
 using std::max;
