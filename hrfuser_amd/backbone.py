@@ -123,9 +123,11 @@ class Engine:
         self.pslot, cols, ps = {}, [], 0
         for m in self.root.modules():
             hit = isinstance(m, nn.LayerNorm) or (isinstance(m, nn.Conv2d) and m.groups == m.in_channels and m.groups > 1)
-            if not hit:
-                continue
-            for q in (m.weight, m.bias):
+            cand = (m.weight, m.bias) if hit else ()
+            if hasattr(m, 'relative_position_bias_table'):        # window attention: dRPB + pad-key/value bias grads
+                cand = (m.relative_position_bias_table,) + tuple(
+                    getattr(m, n).bias for n in ('qkv', 'k_proj', 'v_proj') if hasattr(m, n))
+            for q in cand:
                 if q is None or id(q) not in offs or id(q) in self.pslot:
                     continue
                 self.pslot[id(q)] = ps
@@ -301,8 +303,7 @@ class LocalWindowSelfAttention(nn.Module):
         qkv = R.Plain(R._new((B * H * W, 3 * C), x.t.device))
         R.linear_into(ctx, lin, a.qkv, qkv, 0)
         bq = a.qkv.bias
-        bg = bq.grad
-        o = R.window_attention(ctx, qkv, 0, qkv, C, qkv, 2 * C, bq[C:2 * C], bq[2 * C:], bg[C:2 * C], bg[2 * C:],
+        o = R.window_attention(ctx, qkv, 0, qkv, C, qkv, 2 * C, bq[C:2 * C], bq[2 * C:], bq, C, bq, 2 * C,
                                a.relative_position_bias_table, a.num_heads, (B, H, W, C))
         return R.linear_residual(ctx, o, a.out_proj, x)
 
@@ -363,8 +364,8 @@ class MultiWindowCrossAttention(nn.Module):
         R.linear_into(ctx, q_in, a.q_proj, q, 0)
         R.linear_into(ctx, kv_in, a.k_proj, kv, 0)
         R.linear_into(ctx, kv_in, a.v_proj, kv, C)
-        o = R.window_attention(ctx, q, 0, kv, 0, kv, C, a.k_proj.bias, a.v_proj.bias, a.k_proj.bias.grad,
-                               a.v_proj.bias.grad, a.relative_position_bias_table, a.num_heads, (B, H, W, C))
+        o = R.window_attention(ctx, q, 0, kv, 0, kv, C, a.k_proj.bias, a.v_proj.bias, a.k_proj.bias, 0,
+                               a.v_proj.bias, 0, a.relative_position_bias_table, a.num_heads, (B, H, W, C))
         drop = None
         p = a.proj_drop.p
         if ctx.training and a.proj_drop.training and (p > 0 or drop_path_scale is not None):

@@ -41,7 +41,7 @@ struct AttnArgs {
   float* dq; int lddq, dqoff;
   float* dk; int lddk, dkoff;
   float* dv; int lddv, dvoff;
-  float* dkpad; float* dvpad; float* drpb;
+  float* dkpad; float* dvpad; float* drpb; long copy_stride;
   int iters;
 };
 
@@ -76,11 +76,17 @@ __device__ __forceinline__ void axpy_row(float* o, float p, const float* row) {
   }
 }
 
+constexpr int SP = 65;      // pitch of the per-wave [key j][query i] score planes: lane = i or lane = j both <= 2-way
+
+// Forward.  The 49-wide logit row of a query lives in a per-wave LDS plane ([j][i], pitch 65) instead
+// of 49 registers of a fully unrolled body: the loops stay rolled (7 x unrolled-7), the kernel is
+// ~3 KB instead of 16 KB - at 20 us per launch the cold instruction cache was the main cost.
 template <int D, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(AttnArgs a) {
   constexpr int DP = (D + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float sK[WAVES][NT * DP];
   __shared__ __attribute__((aligned(16))) float sV[WAVES][NT * DP];
+  __shared__ float sS[WAVES][NT * SP];
   __shared__ float sT[WAVES][176];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
   const int nwin = a.B * a.nWh * a.nWw;
@@ -113,27 +119,40 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(AttnArgs a) {
   const float* Kw = sK[wave];
   const float* Vw = sV[wave];
   const float* Tw = sT[wave];
-  float s[NT];
+  float* Sw = sS[wave];
   float m = -3.0e38f;
+#pragma unroll 1
+  for (int jy = 0; jy < 7; ++jy) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    s[j] = dot_row<DP>(q, Kw + j * DP, Tw[bias0 - (j / 7) * 13 - (j % 7)]);
-    m = fmaxf(m, s[j]);
+    for (int jx = 0; jx < 7; ++jx) {
+      const int j = jy * 7 + jx;
+      const float sv = dot_row<DP>(q, Kw + j * DP, Tw[bias0 - jy * 13 - jx]);
+      Sw[j * SP + i] = sv;
+      m = fmaxf(m, sv);
+    }
   }
   float l = 0.f, o[DP];
 #pragma unroll
   for (int d = 0; d < DP; ++d) o[d] = 0.f;
+#pragma unroll 1
+  for (int jy = 0; jy < 7; ++jy) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const float p = __expf(s[j] - m);
-    l += p;
-    axpy_row<DP>(o, p, Vw + j * DP);
+    for (int jx = 0; jx < 7; ++jx) {
+      const int j = jy * 7 + jx;
+      const float p = __expf(Sw[j * SP + i] - m);
+      l += p;
+      axpy_row<DP>(o, p, Vw + j * DP);
+    }
   }
   const float inv = 1.0f / l;
 #pragma unroll
   for (int d = 0; d < D; ++d) a.o[(long)pix * a.ldo + h * D + d] = o[d] * inv;
 }
 
+// Backward.  Pass A (lane = query i) leaves the softmax P and dS = P*(dP - D_i) in two LDS planes;
+// pass B (lane = key j) only READS them (no recomputation of logits / exp), the relative-position
+// bias gradient is a gather over the dS plane (no LDS atomics: ds_add_f32 runs at ~1 lane/clk),
+// pad-key gradients are wave sums.  All loops rolled (7 x 7-unrolled): ~6 KB of code, < 128 VGPRs.
 template <int D, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attn_bwd_kernel(AttnArgs a) {
   constexpr int DP = (D + 3) & ~3;
@@ -141,21 +160,23 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sV[WAVES][NT * DP];
   __shared__ __attribute__((aligned(16))) float sQ[WAVES][NT * DP];
   __shared__ __attribute__((aligned(16))) float sG[WAVES][NT * DP];        // dO rows
+  __shared__ float sP[WAVES][NT * SP];
+  __shared__ float sD[WAVES][NT * SP];
   __shared__ float sT[WAVES][176];
-  __shared__ float sdT[WAVES][176];
-  __shared__ float sM[WAVES][64], sL[WAVES][64], sDl[WAVES][64];
-  __shared__ float sPadK[WAVES][DP], sPadV[WAVES][DP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
   const int nwin = a.B * a.nWh * a.nWw;
-  for (int e = lane; e < 176; e += 64) { sdT[wave][e] = 0.f; sT[wave][e] = a.rpb[(e < 169 ? e : 0) * a.heads + h]; }
-  for (int e = lane; e < DP; e += 64) { sPadK[wave][e] = 0.f; sPadV[wave][e] = 0.f; }
+  for (int e = lane; e < 176; e += 64) sT[wave][e] = a.rpb[(e < 169 ? e : 0) * a.heads + h];
   const float* Kw = sK[wave];
   const float* Vw = sV[wave];
   const float* Qw = sQ[wave];
   const float* Gw = sG[wave];
   const float* Tw = sT[wave];
+  float* Pw = sP[wave];
+  float* Dw = sD[wave];
   const int li = lane < NT ? lane : 0;
   const int yl = li / 7, xl = li - 7 * yl;
+  float bin[3] = {0.f, 0.f, 0.f};              // dRPB bins lane, lane+64, lane+128
+  float padk = 0.f, padv = 0.f;                // lane d < D: pad-key / pad-value gradient of channel d
 
   for (int it = 0; it < a.iters; ++it) {
     const int win = (it * gridDim.x + blockIdx.x) * WAVES + wave;
@@ -180,57 +201,70 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_kernel(AttnArgs a) {
     }
     __syncthreads();
     const int pix = (active && lane < NT) ? tok_pixel(a, b, wy, wx, lane) : -1;
-    // ---- pass A: lane = query row i -> softmax stats, D_i, dQ_i, dRPB
+    // ---- pass A: lane = query row i -> P, dS planes and dQ_i
     if (active && lane < NT) {
       const int i = lane;
       float q[DP], g[DP];
 #pragma unroll
       for (int d = 0; d < DP; ++d) { q[d] = Qw[i * DP + d]; g[d] = Gw[i * DP + d]; }
       const int bias0 = (yl + 6) * 13 + (xl + 6);
-      float s[NT], dp[NT];
       float m = -3.0e38f;
+#pragma unroll 1
+      for (int jy = 0; jy < 7; ++jy) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        s[j] = dot_row<DP>(q, Kw + j * DP, Tw[bias0 - (j / 7) * 13 - (j % 7)]);
-        dp[j] = dot_row<DP>(g, Vw + j * DP, 0.f);
-        m = fmaxf(m, s[j]);
+        for (int jx = 0; jx < 7; ++jx) {
+          const int j = jy * 7 + jx;
+          const float sv = dot_row<DP>(q, Kw + j * DP, Tw[bias0 - jy * 13 - jx]);
+          Pw[j * SP + i] = sv;
+          Dw[j * SP + i] = dot_row<DP>(g, Vw + j * DP, 0.f);
+          m = fmaxf(m, sv);
+        }
       }
       float l = 0.f, acc = 0.f;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) { s[j] = __expf(s[j] - m); l += s[j]; acc = fmaf(s[j], dp[j], acc); }
+#pragma unroll 7
+      for (int j = 0; j < NT; ++j) {
+        const float p = __expf(Pw[j * SP + i] - m);
+        Pw[j * SP + i] = p;
+        l += p;
+        acc = fmaf(p, Dw[j * SP + i], acc);
+      }
       const float inv = 1.0f / l, Dl = acc * inv;
       float dq[DP];
 #pragma unroll
       for (int d = 0; d < DP; ++d) dq[d] = 0.f;
+#pragma unroll 1
+      for (int jy = 0; jy < 7; ++jy) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float ds = s[j] * inv * (dp[j] - Dl);
-        axpy_row<DP>(dq, ds, Kw + j * DP);
-        hrf_atomic_add(&sdT[wave][bias0 - (j / 7) * 13 - (j % 7)], ds);   // distinct bins across lanes
+        for (int jx = 0; jx < 7; ++jx) {
+          const int j = jy * 7 + jx;
+          const float p = Pw[j * SP + i] * inv;
+          const float ds = p * (Dw[j * SP + i] - Dl);
+          Pw[j * SP + i] = p;
+          Dw[j * SP + i] = ds;
+          axpy_row<DP>(dq, ds, Kw + j * DP);
+        }
       }
-      sM[wave][i] = m; sL[wave][i] = inv; sDl[wave][i] = Dl;
       if (pix >= 0) {
 #pragma unroll
         for (int d = 0; d < D; ++d) a.dq[(long)pix * a.lddq + a.dqoff + h * D + d] = dq[d] * a.scale;
       }
     }
     __syncthreads();
-    // ---- pass B: lane = key column j -> dK_j, dV_j
-    if (active && lane < NT) {
-      const int j = lane;
-      float kj[DP], vj[DP], dk[DP], dv[DP];
+    // ---- pass B: lane = key column j -> dK_j, dV_j from the stored planes
+    float dk[DP], dv[DP];
 #pragma unroll
-      for (int d = 0; d < DP; ++d) { kj[d] = Kw[j * DP + d]; vj[d] = Vw[j * DP + d]; dk[d] = 0.f; dv[d] = 0.f; }
-      const int sub = yl * 13 + xl;
-#pragma unroll 7
-      for (int i = 0; i < NT; ++i) {
-        const int yi = i / 7, xi = i - 7 * yi;
-        const float s = dot_row<DP>(kj, Qw + i * DP, Tw[(yi + 6) * 13 + (xi + 6) - sub]);
-        const float dpv = dot_row<DP>(vj, Gw + i * DP, 0.f);
-        const float p = __expf(s - sM[wave][i]) * sL[wave][i];
-        const float ds = p * (dpv - sDl[wave][i]);
-        axpy_row<DP>(dk, ds, Qw + i * DP);
-        axpy_row<DP>(dv, p, Gw + i * DP);
+    for (int d = 0; d < DP; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    const bool keyl = active && lane < NT;
+    if (keyl) {
+      const int j = lane;
+#pragma unroll 1
+      for (int iy = 0; iy < 7; ++iy) {
+#pragma unroll
+        for (int ix = 0; ix < 7; ++ix) {
+          const int i = iy * 7 + ix;
+          axpy_row<DP>(dk, Dw[j * SP + i], Qw + i * DP);
+          axpy_row<DP>(dv, Pw[j * SP + i], Gw + i * DP);
+        }
       }
       if (pix >= 0) {
 #pragma unroll
@@ -238,17 +272,45 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_kernel(AttnArgs a) {
           a.dk[(long)pix * a.lddk + a.dkoff + h * D + d] = dk[d];
           a.dv[(long)pix * a.lddv + a.dvoff + h * D + d] = dv[d];
         }
-      } else {                                     // padded key: gradient flows to the projection bias only
+      }
+    }
+    // padded keys: their gradient flows to the projection bias only (wave sums, boundary windows only)
+    const bool padl = keyl && pix < 0;
+    if (__any(padl)) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) { hrf_atomic_add(&sPadK[wave][d], dk[d]); hrf_atomic_add(&sPadV[wave][d], dv[d]); }
+      for (int d = 0; d < D; ++d) {
+        const float sk = hrf_wave_sum(padl ? dk[d] : 0.f), sv = hrf_wave_sum(padl ? dv[d] : 0.f);
+        if (lane == d) { padk += sk; padv += sv; }
+      }
+    }
+    // dRPB[(yi-yj+6)*13 + (xi-xj+6)] += dS[i][j]: gather over the dS plane
+    if (active) {
+#pragma unroll
+      for (int kbin = 0; kbin < 3; ++kbin) {
+        const int e = lane + 64 * kbin;
+        if (e < 169) {
+          const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
+          const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
+          const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
+          float sacc = 0.f;
+          for (int yj = y0; yj <= y1; ++yj)
+            for (int xj = x0; xj <= x1; ++xj)
+              sacc += Dw[(yj * 7 + xj) * SP + (yj + dy) * 7 + xj + dx];
+          bin[kbin] += sacc;
+        }
       }
     }
   }
-  __syncthreads();
-  for (int e = lane; e < 169; e += 64) hrf_atomic_add(&a.drpb[e * a.heads + h], sdT[wave][e]);
-  for (int e = lane; e < D; e += 64) {
-    hrf_atomic_add(&a.dkpad[h * D + e], sPadK[wave][e]);
-    hrf_atomic_add(&a.dvpad[h * D + e], sPadV[wave][e]);
+  // one atomic per bin per wave into the (replicated) parameter-gradient accumulators
+  const long cp = (long)((blockIdx.x * WAVES + wave) % HRF_STAT_COPIES) * a.copy_stride;
+#pragma unroll
+  for (int kbin = 0; kbin < 3; ++kbin) {
+    const int e = lane + 64 * kbin;
+    if (e < 169) hrf_atomic_add(&a.drpb[cp + e * a.heads + h], bin[kbin]);
+  }
+  if (lane < D) {
+    hrf_atomic_add(&a.dkpad[cp + h * D + lane], padk);
+    hrf_atomic_add(&a.dvpad[cp + h * D + lane], padv);
   }
 }
 
@@ -292,7 +354,7 @@ extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const floa
                                    const float* rpb, const float* dout, int lddo,
                                    float* dq, int lddq, int dqoff, float* dk, int lddk, int dkoff,
                                    float* dv, int lddv, int dvoff, float* dkpad, float* dvpad, float* drpb,
-                                   int B, int H, int W, int C, int heads, void* stream) {
+                                   long copy_stride, int B, int H, int W, int C, int heads, void* stream) {
   if (heads <= 0 || C % heads) return HRF_ERR_ARG;
   const int D = C / heads;
   AttnArgs a{};
@@ -300,7 +362,7 @@ extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const floa
   a.kpad = kpad; a.vpad = vpad; a.rpb = rpb; a.B = B; a.H = H; a.W = W; a.heads = heads;
   a.scale = 1.0f / sqrtf((float)D);
   a.dout = dout; a.lddo = lddo; a.dq = dq; a.lddq = lddq; a.dqoff = dqoff; a.dk = dk; a.lddk = lddk; a.dkoff = dkoff;
-  a.dv = dv; a.lddv = lddv; a.dvoff = dvoff; a.dkpad = dkpad; a.dvpad = dvpad; a.drpb = drpb;
+  a.dv = dv; a.lddv = lddv; a.dvoff = dvoff; a.dkpad = dkpad; a.dvpad = dvpad; a.drpb = drpb; a.copy_stride = copy_stride;
   window_geom(a);
   const int nwin = B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;

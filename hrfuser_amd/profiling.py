@@ -32,12 +32,16 @@ def work_model(name, a):
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         M, K = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']
         by = f4 * (a['B'] * a['H'] * a['W'] * a['Cin'] + a['Cout'] * K + M * a['Cout'] * (1 + (a['res'] is not None) + (a['res2'] is not None)))
+        if a['KH'] == 1 and a['stride'] == 1 and a['sC'] == 1 and a['Cin'] >= 4 and a['Cout'] >= 4:
+            return 'lin_fwd_kernel', 2.0 * M * a['Cout'] * K, by
         return f"conv_fwd_kernel<{_pick_nt(a['Cout'])},{a['KH']},{a['tf_mode']}>", 2.0 * M * a['Cout'] * K, by
     if name == 'hrf_conv_bwd_data':
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         M, K = a['B'] * a['H'] * a['W'], a['KH'] ** 2 * a['Cout']
         by = f4 * (a['B'] * Ho * Wo * a['Cout'] * (2 if a['cA'] is not None else 1) + a['Cin'] * K
                    + M * a['Cin'] * (2 if a['epi'] else 1 + bool(a['accumulate'])))
+        if a['KH'] == 1 and a['stride'] == 1 and a['sC'] == 1 and a['Cin'] >= 4 and a['Cout'] >= 4:
+            return 'lin_bwd_data_kernel', 2.0 * M * a['Cin'] * K, by
         return f"conv_bwd_data_kernel<{_pick_nt(a['Cin'])},{a['KH']},{int(a['cA'] is not None)}>", 2.0 * M * a['Cin'] * K, by
     if name == 'hrf_conv_bwd_weight':
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])

@@ -205,6 +205,8 @@ class Ctx:
                 fn, lane = e
                 with _LaneScope(self, lane):
                     fn()
+        if self._deferred and os.environ.get('HRF_DEBUG_SKIP_WGRAD') == '1':
+            self._deferred = []                 # timing experiments only: drops the weight-gradient phase
         if self._deferred:
             fns, self._deferred = self._deferred, []
             k = int(os.environ.get('HRF_WGRAD_LANES', '8'))
@@ -501,8 +503,9 @@ def ln_input(ctx, act, ln, cache=None):
     return LNIn(act, rowstat, ln)
 
 
-def window_attention(ctx, q, qoff, k, koff, v, voff, kpad, vpad, kpad_grad, vpad_grad, rpb, heads, dims):
-    """softmax(q k^T d^-1/2 + RPB) v per 7x7 window and head.  q/k/v are Plain projection buffers."""
+def window_attention(ctx, q, qoff, k, koff, v, voff, kpad, vpad, kbias, kboff, vbias, vboff, rpb, heads, dims):
+    """softmax(q k^T d^-1/2 + RPB) v per 7x7 window and head.  q/k/v are Plain projection buffers.
+    (kbias, kboff) / (vbias, vboff): bias parameter and element offset receiving the pad-key/value grads."""
     L, s = ctx.L, ctx.stream
     B, H, W, C = dims
     o = Act(_new((B, H, W, C), q.t.device))
@@ -513,11 +516,16 @@ def window_attention(ctx, q, qoff, k, koff, v, voff, kpad, vpad, kpad_grad, vpad
         for p in (q, k, v):
             if p.grad is None:
                 p.grad = _new_like(p.t)
+        eng = ctx.owner._engine()
+        kacc, cs = eng.grad_acc(kbias)
+        vacc, cs2 = eng.grad_acc(vbias)
+        racc, cs3 = eng.grad_acc(rpb)
+        assert cs == cs2 == cs3
         L.hrf_window_attn_bwd(q.t, q.t.shape[-1], qoff, k.t, k.t.shape[-1], koff, v.t, v.t.shape[-1], voff,
                               kpad, vpad, rpb, o.grad, C,
                               q.grad, q.grad.shape[-1], qoff, k.grad, k.grad.shape[-1], koff,
-                              v.grad, v.grad.shape[-1], voff, kpad_grad, vpad_grad, rpb.grad,
-                              B, H, W, C, heads, s)
+                              v.grad, v.grad.shape[-1], voff, kacc.reshape(-1)[kboff:], vacc.reshape(-1)[vboff:],
+                              racc, cs, B, H, W, C, heads, s)
     ctx.push(bwd)
     return o
 

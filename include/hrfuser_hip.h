@@ -97,7 +97,7 @@ int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const float* k, int l
                         const float* v, int ldv, int voff, const float* kpad, const float* vpad,
                         const float* rpb, const float* dout, int lddo,
                         float* dq, int lddq, int dqoff, float* dk, int lddk, int dkoff,
-                        float* dv, int lddv, int dvoff, float* dkpad, float* dvpad, float* drpb,
+                        float* dv, int lddv, int dvoff, float* dkpad, float* dvpad, float* drpb, long copy_stride,
                         int B, int H, int W, int C, int heads, void* stream);
 
 /* ---- BatchNorm bookkeeping (F.batch_norm, 329 call sites: every build_norm_layer(norm_cfg)) ---

@@ -125,6 +125,11 @@ inline void hrf_atomic_add(double* p, double v) {
 }
 inline float atomicAdd(float* p, float v) { hrf_atomic_add(p, v); return 0.f; }
 
+inline bool __any(bool p) {
+  int v = p ? 1 : 0;
+  for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m);
+  return v != 0;
+}
 inline float hrf_row16_sum(float v) {
   v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
   return v;

@@ -213,10 +213,20 @@ def run_attn(case, backend):
     dq, dkv = torch.zeros(P, C, device=dev), torch.zeros(P, 2 * C, device=dev)
     dkb, dvb, dT = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(169, heads, device=dev)
     L.hrf_window_attn_bwd(qd, C, 0, kvd, 2 * C, 0, kvd, 2 * C, C, kbd, vbd, Td, D(go), C, dq, C, 0, dkv, 2 * C, 0,
-                          dkv, 2 * C, C, dkb, dvb, dT, B, H, W, C, heads, s)
+                          dkv, 2 * C, C, dkb, dvb, dT, 0, B, H, W, C, heads, s)
     assert r(dq, q.grad) < TOL and r(dkv, kv.grad) < TOL and r(dT, T.grad) < TOL
     if (H % 7) or (W % 7):
         assert r(dkb, kb.grad) < 1e-4 and r(dvb, vb.grad) < TOL
+    # replicated parameter-gradient accumulators: [copies][dT | dkb | dvb]
+    n = 169 * heads + 2 * C
+    scr = torch.zeros(KC * n, device=dev)
+    dq2, dkv2 = torch.zeros_like(dq), torch.zeros_like(dkv)
+    L.hrf_window_attn_bwd(qd, C, 0, kvd, 2 * C, 0, kvd, 2 * C, C, kbd, vbd, Td, D(go), C, dq2, C, 0, dkv2, 2 * C, 0,
+                          dkv2, 2 * C, C, scr[169 * heads:], scr[169 * heads + C:], scr, n, B, H, W, C, heads, s)
+    tot = scr.view(KC, n).sum(0)
+    assert r(dq2, q.grad) < TOL and r(tot[:169 * heads].view(169, heads), T.grad) < TOL
+    if (H % 7) or (W % 7):
+        assert r(tot[169 * heads:169 * heads + C], kb.grad) < 1e-4 and r(tot[169 * heads + C:], vb.grad) < TOL
 
 
 def run_pointwise(backend):
