@@ -517,6 +517,7 @@ struct WgradDenseArgs {
   const float* tf_scale; const float* tf_shift; const float* tf_rowstat;   // rowstat != null: LayerNorm
   float* dw; float* dbias;
   int Cout, Cin, Mpix, chunk;
+  int H, W, Ho, Wo, stride, gyc;   // TAP (3x3) only: input / output grids, stride, channel groups per tap
 };
 
 constexpr int WU = 8;      // k-steps (of 4 pixels) whose loads are issued before the first use
@@ -524,7 +525,10 @@ constexpr int WNW = 8;     // waves per block (512 threads)
 constexpr int WSP = 68;    // LDS pitch of the merge tile (2-way bank aliasing = the 64-lane minimum)
 
 // ACT: activation applied to the X operand (0 none, 1 ReLU, 2 GELU)
-template <int MT, int NT, bool BNB, int ACT>
+// TAP: 3x3 convolution (pad 1): the N index is n' = ci*9 + tap (the OIHW memory order, so the block's
+// output atomics stay coalesced); every lane owns its own (ci, tap) and gathers the X operand from
+// the correspondingly shifted input pixel (exact zero outside the image).
+template <int MT, int NT, bool BNB, int ACT, bool TAP>
 __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a) {
   __shared__ float sAcc[2 * MT * 16 * WSP];
   __shared__ float sBias[WNW * MT * 16];
@@ -532,11 +536,12 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * (16 * MT), n0 = blockIdx.y * (16 * NT);
+  const int Np = TAP ? a.Cin * 9 : a.Cin;
   const int pbeg = blockIdx.z * a.chunk, pend = min(a.Mpix, pbeg + a.chunk);
   const bool ln = a.tf_rowstat != nullptr;
 
-  int aoff[MT], boff[NT];
-  bool aval[MT];
+  int aoff[MT], boff[NT], tdy[NT], tdx[NT];
+  bool aval[MT], bval[NT];
   float ca[MT], cb[MT], cc[MT], sc[NT], sh[NT], bsum[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -548,10 +553,14 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a)
   }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int ci = n0 + 16 * j + c;
-    boff[j] = ci < a.Cin ? ci : 0;
+    const int np = n0 + 16 * j + c;
+    bval[j] = np < Np;
+    int ci = bval[j] ? np : 0;
+    tdy[j] = 0; tdx[j] = 0;
+    if (TAP) { const int tp = ci % 9; ci /= 9; tdy[j] = tp / 3 - 1; tdx[j] = tp - (tp / 3) * 3 - 1; }
+    boff[j] = TAP ? (tdy[j] * a.W + tdx[j]) * a.ldX + ci : ci;     // TAP: + offset of the shifted input pixel
     sc[j] = 1.f; sh[j] = 0.f;
-    if (a.tf_scale != nullptr) { sc[j] = a.tf_scale[boff[j]]; sh[j] = a.tf_shift[boff[j]]; }
+    if (a.tf_scale != nullptr) { sc[j] = a.tf_scale[ci]; sh[j] = a.tf_shift[ci]; }
   }
   hrf_f4 acc[MT][NT];
 #pragma unroll
@@ -564,19 +573,44 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a)
   for (int p0 = pbeg + 4 * wave; p0 < pend; p0 += 4 * WNW * WU) {
     float ar[WU][MT], yr[WU][MT], br[WU][NT], rm[WU], rr[WU];
     bool pv[WU];
+    unsigned bmask[WU];
+    // TAP: (image, row, column) of this lane's first pixel, advanced by 4*WNW pixels per k-step
+    int bi = 0, yo = 0, xo = 0;
+    if (TAP) {
+      const int pf = min(p0 + kq, a.Mpix - 1), HoWo = a.Ho * a.Wo;
+      bi = pf / HoWo;
+      const int rem = pf - bi * HoWo;
+      yo = rem / a.Wo; xo = rem - yo * a.Wo;
+    }
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
       const int pix = p0 + 4 * WNW * u + kq;
       pv[u] = pix < pend;
       const int pc = pv[u] ? pix : pbeg;
-      const long arow = (long)pc * a.ldD, brow = (long)pc * a.ldX;
+      const unsigned arow = (unsigned)pc * (unsigned)a.ldD;          // 32-bit offsets: tensors are < 2^31 elements
+      const unsigned brow = (unsigned)pc * (unsigned)a.ldX;
+      const int yb = yo * a.stride, xb = xo * a.stride;
+      const int tbase = ((bi * a.H + yb) * a.W + xb) * a.ldX;        // TAP: centre input pixel of this output pixel
+      bmask[u] = 0u;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        ar[u][i] = a.dy[arow + aoff[i]];
-        yr[u][i] = BNB ? a.yraw[arow + aoff[i]] : 0.f;
+        ar[u][i] = a.dy[arow + (unsigned)aoff[i]];
+        yr[u][i] = BNB ? a.yraw[arow + (unsigned)aoff[i]] : 0.f;
       }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) br[u][j] = a.x[brow + boff[j]];
+      for (int j = 0; j < NT; ++j) {
+        if (TAP) {
+          const bool inb = pv[u] && bval[j] && (unsigned)(yb + tdy[j]) < (unsigned)a.H && (unsigned)(xb + tdx[j]) < (unsigned)a.W;
+          bmask[u] |= inb ? (1u << j) : 0u;
+          br[u][j] = a.x[inb ? (unsigned)(tbase + boff[j]) : 0u];
+        } else {
+          br[u][j] = a.x[brow + (unsigned)boff[j]];
+        }
+      }
+      if (TAP) {                               // next k-step of this lane: 4*WNW pixels further
+        xo += 4 * WNW;
+        while (xo >= a.Wo) { xo -= a.Wo; if (++yo == a.Ho) { yo = 0; ++bi; } }
+      }
       rm[u] = 0.f; rr[u] = 1.f;
       if (ln) { rm[u] = a.tf_rowstat[2 * pc]; rr[u] = a.tf_rowstat[2 * pc + 1]; }
     }
@@ -594,6 +628,7 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a)
       for (int j = 0; j < NT; ++j) {
         const float w = fmaf((br[u][j] - rm[u]) * rr[u], sc[j], sh[j]);    // (mean, rstd, sc, sh) = (0, 1, 1, 0) when unused
         bv[j] = ACT == 1 ? fmaxf(w, 0.f) : (ACT == 2 ? hrf_gelu(w) : w);
+        if (TAP) bv[j] = (bmask[u] >> j) & 1u ? bv[j] : 0.f;      // zero padding applies AFTER the activation
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -628,8 +663,8 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a)
   }
   for (int e = tid; e < MT * 16 * 64; e += 64 * WNW) {
     const int row = e >> 6, col = e & 63;
-    if (col < NT * 16 && m0 + row < a.Cout && n0 + col < a.Cin)
-      hrf_atomic_add(&a.dw[(long)(m0 + row) * a.Cin + n0 + col], sAcc[row * WSP + col] + sAcc[MT * 16 * WSP + row * WSP + col]);
+    if (col < NT * 16 && m0 + row < a.Cout && n0 + col < Np)
+      hrf_atomic_add(&a.dw[(long)(m0 + row) * Np + n0 + col], sAcc[row * WSP + col] + sAcc[MT * 16 * WSP + row * WSP + col]);
   }
   __syncthreads();
   if (a.dbias != nullptr && blockIdx.y == 0 && tid < MT * 16 && m0 + tid < a.Cout) {
@@ -694,6 +729,13 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     const int rc = hrf_lin_fwd_launch(l, stream);
     if (rc >= 0) return rc;
   }
+  if (KH == 3 && stride == 1 && Cin >= 32 && sC == 1 && sY == W * sX && sB == H * sY && g_knob[6] == 0) {
+    Conv3Args c{};
+    c.in = x; c.ldIn = sX; c.t0 = tf_scale; c.t1 = tf_shift; c.tf_mode = tf_mode; c.w = w; c.wCin = Cin; c.bias = bias;
+    c.out = y; c.ldOut = ldY; c.ooff = yoff; c.res = res; c.res2 = res2; c.ldR = ldR; c.stats = stats;
+    c.B = B; c.H = H; c.W = W; c.Cin = Cin; c.Cout = Cout;
+    return hrf_conv3_fwd_launch(c, stream);
+  }
   const int nt = pick_nt(Cout);
   if (KH == 1) {
     if (tf_mode == HRF_TF_LN) { HRF_CF_NT(1, HRF_TF_LN) } else { HRF_CF_TF(1) }
@@ -738,6 +780,14 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
     l.M = a.M; l.K = Cout; l.N = Cin;
     const int rc = hrf_lin_bwd_data_launch(l, stream);
     if (rc >= 0) return rc;
+  }
+  if (KH == 3 && stride == 1 && Cout >= 32 && sC == 1 && sY == W * sX && sB == H * sY && g_knob[6] == 0) {
+    Conv3Args c{};
+    c.in = dy + doff; c.ldIn = ldD; c.in2 = cA != nullptr ? yraw + doff : nullptr; c.t0 = cA; c.t1 = cB; c.t2 = cC;
+    c.w = w; c.wCin = Cin; c.out = dx; c.ldOut = sX; c.accumulate = accumulate; c.epi = epi; c.xraw = xraw; c.ldXr = ldXr;
+    c.esc = tf_scale; c.esh = tf_shift; c.act = act; c.stats = stats;
+    c.B = B; c.H = H; c.W = W; c.Cin = Cout; c.Cout = Cin;
+    return hrf_conv3_bwd_data_launch(c, stream);
   }
   const int nt = pick_nt(Cin);
   if (KH == 1) {
@@ -792,27 +842,34 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
   splits = hrf_cdiv(a.Mpix, a.chunk);
   const bool dense1 = KH == 1 && stride == 1 && sC == 1 && sY == W * sX && sB == H * sY;
   const int tfa = tf_mode == HRF_TF_AFFINE_RELU ? 2 : (tf_mode == HRF_TF_AFFINE_GELU ? 3 : 0);
-  if (dense1 && g_knob[2] == 0) {
+  const bool tap3 = KH == 3 && sC == 1 && sY == W * sX && sB == H * sY && tf_mode != HRF_TF_LN;
+  if ((dense1 || tap3) && g_knob[2] == 0) {
     WgradDenseArgs d;
     d.dy = dy; d.ldD = ldD; d.doff = doff; d.yraw = yraw; d.cA = cA; d.cB = cB; d.cC = cC;
     d.x = x; d.ldX = sX; d.tf_scale = tf_mode != HRF_TF_NONE ? tf_scale : nullptr; d.tf_shift = tf_shift;
     d.tf_rowstat = tf_mode == HRF_TF_LN ? tf_rowstat : nullptr;
     d.dw = dw; d.dbias = dbias; d.Cout = Cout; d.Cin = Cin; d.Mpix = a.Mpix;
-    const int mt = Cout <= 32 ? 2 : 4, nt = Cin <= 32 ? 2 : 4;      // 16x16 tiles per wave (masked when ragged)
+    d.H = H; d.W = W; d.Ho = a.Ho; d.Wo = a.Wo; d.stride = stride;
+    const int mt = Cout <= 32 ? 2 : 4, nt = (tap3 ? Cin * 9 : Cin) <= 32 ? 2 : 4;   // 16x16 tiles per wave (masked when ragged)
+    d.gyc = hrf_cdiv(tap3 ? Cin * 9 : Cin, 16 * nt);
     int sp = hrf_cdiv(a.Mpix, 4 * WNW * WU);
     const int cap2 = g_knob[3] > 0 ? g_knob[3] : 32;        // atomic fan-in per output element
     if (sp > cap2) sp = cap2;
     if (sp < 1) sp = 1;
+    const int gxy = hrf_cdiv(Cout, 16 * mt) * d.gyc;
+    if (gxy * sp > 256 && gxy * sp < 512 && 256 / gxy >= 8) sp = 256 / gxy;   // one full round of blocks instead of 1.x
     d.chunk = hrf_cdiv(hrf_cdiv(a.Mpix, sp), 4 * WNW) * 4 * WNW;
     sp = hrf_cdiv(a.Mpix, d.chunk);
-    const dim3 g2(hrf_cdiv(Cout, 16 * mt), hrf_cdiv(Cin, 16 * nt), sp);
+    const dim3 g2(hrf_cdiv(Cout, 16 * mt), d.gyc, sp);
     const int act = tf_mode == HRF_TF_AFFINE_RELU ? 1 : (tf_mode == HRF_TF_AFFINE_GELU ? 2 : 0);
-#define HRF_WD_LAUNCH(MT_, NT_, BNB_, ACT_) \
-    HRF_LAUNCH((wgrad_dense_kernel<MT_, NT_, BNB_, ACT_>), g2, dim3(64 * WNW), 0, stream, d)
-#define HRF_WD_ACT(MT_, NT_, BNB_)                           \
-    if (act == 1) { HRF_WD_LAUNCH(MT_, NT_, BNB_, 1); }      \
-    else if (act == 2) { HRF_WD_LAUNCH(MT_, NT_, BNB_, 2); } \
-    else { HRF_WD_LAUNCH(MT_, NT_, BNB_, 0); }
+#define HRF_WD_LAUNCH(MT_, NT_, BNB_, ACT_, TAP_) \
+    HRF_LAUNCH((wgrad_dense_kernel<MT_, NT_, BNB_, ACT_, TAP_>), g2, dim3(64 * WNW), 0, stream, d)
+#define HRF_WD_TAP(MT_, NT_, BNB_, ACT_) \
+    if (tap3) { HRF_WD_LAUNCH(MT_, NT_, BNB_, ACT_, true); } else { HRF_WD_LAUNCH(MT_, NT_, BNB_, ACT_, false); }
+#define HRF_WD_ACT(MT_, NT_, BNB_)                        \
+    if (act == 1) { HRF_WD_TAP(MT_, NT_, BNB_, 1) }       \
+    else if (act == 2) { HRF_WD_TAP(MT_, NT_, BNB_, 2) }  \
+    else { HRF_WD_TAP(MT_, NT_, BNB_, 0) }
 #define HRF_WD_BNB(MT_, NT_) \
     if (cA != nullptr) { HRF_WD_ACT(MT_, NT_, true) } else { HRF_WD_ACT(MT_, NT_, false) }
     if (mt == 2 && nt == 2) { HRF_WD_BNB(2, 2) }

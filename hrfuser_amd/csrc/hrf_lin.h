@@ -26,3 +26,22 @@ struct LinBwdDataArgs {
 // back to the LDS-tiled implicit-GEMM kernels).
 int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream);
 int hrf_lin_bwd_data_launch(const LinBwdDataArgs& a, void* stream);
+
+// ---- conv3_engine.hip: 3x3 / stride-1 / pad-1 convolution (forward and backward-data) on NHWC rows,
+// input halo tile staged ONCE per channel slab (no im2col re-reads), weights streamed through LDS.
+struct Conv3Args {
+  const float* in; int ldIn;                 // fwd: x rows; bwd: dY rows (column offset already added)
+  const float* in2;                          // bwd + BatchNorm-backward: raw conv output (same indexing) or null
+  const float* t0; const float* t1; const float* t2;   // fwd: tf_scale, tf_shift, - ; bwd: cA, cB, cC
+  int tf_mode;                               // fwd: HRF_TF_* applied while staging the halo
+  const float* w; int wCin;                  // OIHW weights, wCin = the convolution's Cin
+  const float* bias;
+  float* out; int ldOut; int ooff;
+  const float* res; const float* res2; int ldR;
+  int accumulate, epi; const float* xraw; int ldXr; const float* esc; const float* esh; int act;
+  double* stats;                             // [HRF_STAT_COPIES][2*Cout] or null
+  int B, H, W, Cin, Cout;                    // channels of `in` / of `out`
+  int tilesX, tilesY;
+};
+int hrf_conv3_fwd_launch(const Conv3Args& a, void* stream);
+int hrf_conv3_bwd_data_launch(const Conv3Args& a, void* stream);

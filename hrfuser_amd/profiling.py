@@ -47,7 +47,7 @@ def work_model(name, a):
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         Mp, Np = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']
         by = f4 * (Mp * a['Cout'] * (2 if a['cA'] is not None else 1) + a['B'] * a['H'] * a['W'] * a['Cin'] + a['Cout'] * Np)
-        dense = a['KH'] == 1 and a['stride'] == 1 and a['sC'] == 1
+        dense = a['sC'] == 1 and (a['KH'] == 3 or a['stride'] == 1)
         return ('wgrad_dense_kernel' if dense else 'conv_bwd_wgt_kernel'), 2.0 * Mp * a['Cout'] * Np, by
     if name in ('hrf_dwconv_fwd', 'hrf_dwconv_bwd_weight'):
         Ho, Wo = _out_hw(a['H'], a['W'], 3, a['stride'])
