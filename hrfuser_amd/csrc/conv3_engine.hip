@@ -26,8 +26,17 @@ __device__ float g_zero1[4] = {0.f, 0.f, 0.f, 0.f};
 
 // MODE 0: forward (in = x, transform-on-load, bias/res epilogue, (sum, sumsq) moments)
 // MODE 1: backward data (in = dY [+ BN-backward], flipped/transposed weights, += | act' epilogue)
-template <int NT, int MODE>
+// MODE 2: backward data of a STRIDE-2 convolution, one input-parity class (Y%2, X%2) per block: the
+//         16 pixels of an MFMA row tile share their parity, so the set of contributing taps is uniform
+//         (1, 2, 2 or 4 of the 9) and no masked/zero work is issued (the generic kernel ran all 9).
+// KH = 1 (not instantiated): the same engine on wide 1x1 convolutions measured no better than the
+//         register-only row-GEMM kernel (64<->256 channels at 30720 pixels: 30.6 vs 30.3 us).
+template <int NT, int MODE, int KH>
 __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
+  constexpr int IWm = KH == 1 ? TW : (MODE == 2 ? TW + 1 : IW);     // staged source tile width / pixel count
+  constexpr int NPm = KH == 1 ? TH * TW : (MODE == 2 ? (TH + 1) * (TW + 1) : NPIX);
+  constexpr int ORG = (KH == 1 || MODE == 2) ? 0 : -1;              // source tile origin relative to (y0, x0)
+  constexpr int KK = KH * KH;
   __shared__ float sIn[NPIX * CP];
   __shared__ float sB[NT * 16 * BP];
   __shared__ float sStat[NWV * 2 * NT * 16];
@@ -35,7 +44,10 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
   const int i = lane & 15, q = lane >> 4;
   int t = blockIdx.x;
   const int tx = t % a.tilesX; t /= a.tilesX;
-  const int ty = t % a.tilesY; const int b = t / a.tilesY;
+  const int ty = t % a.tilesY; t /= a.tilesY;
+  const int cls = MODE == 2 ? (t & 3) : 0, b = MODE == 2 ? (t >> 2) : t;
+  const int cpy = cls >> 1, cpx = cls & 1;                          // MODE 2: parity class of the output pixels
+  const int Hs = MODE == 2 ? a.Hs : a.H, Ws = MODE == 2 ? a.Ws : a.W;   // source (staged) grid
   const int y0 = ty * TH, x0 = tx * TW;
   const int n0 = blockIdx.y * (NT * 16);
 
@@ -45,12 +57,13 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
 
   const int hc = tid & 63, hg = tid >> 6;          // halo staging: channel, pixel group
   const int bk = tid & 63, bc = tid >> 6;          // weight staging: k within step, row group
-  const int aBase = (wave * IW + i) * CP;          // halo address of (output row `wave`, pixel i, tap (0,0))
+  const int aBase = (wave * IWm + i) * CP;         // staged address of (output row `wave`, pixel i, tap (0,0))
 
   for (int c0 = 0; c0 < a.Cin; c0 += CS) {
     // K order inside a slab is TAP-major (k = tap*64 + ci): the tap of a 64-deep step is uniform, so the
     // halo address of an A fragment is (uniform tap offset) + 4*kk + q - no per-lane index walk at all.
-    const int csz = min(CS, a.Cin - c0), nsteps = 9;
+    const int csz = min(CS, a.Cin - c0);
+    const int nsx = MODE == 2 ? 1 + cpx : KH, nsteps = MODE == 2 ? (1 + cpy) * nsx : KK;
     // ---- stage the halo slab (all loads first, transform afterwards)
     float hv[NHL], hv2[NHL];
     const bool cv = hc < csz;
@@ -60,24 +73,28 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
 #pragma unroll
     for (int e = 0; e < NHL; ++e) {
       const int pix = e * NWV + hg;
-      const int py = pix / IW, px = pix - py * IW;
-      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-      const bool ok = cv && pix < NPIX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      const long off = ((long)(b * a.H + gy) * a.W + gx) * a.ldIn + c0 + hc;
+      const int py = pix / IWm, px = pix - py * IWm;
+      const int gy = y0 + ORG + py, gx = x0 + ORG + px;
+      const bool ok = cv && pix < NPm && (unsigned)gy < (unsigned)Hs && (unsigned)gx < (unsigned)Ws;
+      const long off = ((long)(b * Hs + gy) * Ws + gx) * a.ldIn + c0 + hc;
       hv[e] = *(ok ? a.in + off : g_zero1);
-      hv2[e] = (MODE == 1 && a.in2 != nullptr) ? *(ok ? a.in2 + off : g_zero1) : 0.f;
+      hv2[e] = (MODE != 0 && a.in2 != nullptr) ? *(ok ? a.in2 + off : g_zero1) : 0.f;
     }
     // ---- first weight tile of the slab
     float bw[64 / NWV];
-    auto load_b = [&](int k0) {
-      const int tp = k0 >> 6;                       // tap of this step, bk = channel within the slab
+    auto load_b = [&](int step) {
+      int tp = step;                                // tap of this step, bk = channel within the slab
+      if (MODE == 2) {
+        const int iy = step / nsx, ix = step - iy * nsx;
+        tp = (cpy ? 2 * iy : 1) * 3 + (cpx ? 2 * ix : 1);
+      }
 #pragma unroll
       for (int e = 0; e < 64 / NWV; ++e) {
         const int j = bc + NWV * e;                 // output channel within the block column
         const bool ok = bk < csz && j < NT * 16 && n0 + j < a.Cout;
         long off;
-        if (MODE == 0) off = ((long)(n0 + j) * a.wCin + c0 + bk) * 9 + tp;
-        else off = ((long)(c0 + bk) * a.wCin + n0 + j) * 9 + 8 - tp;     // W[co = in ch][ci = out ch][8 - tap']
+        if (MODE == 0) off = ((long)(n0 + j) * a.wCin + c0 + bk) * KK + tp;
+        else off = ((long)(c0 + bk) * a.wCin + n0 + j) * KK + (MODE == 1 ? KK - 1 - tp : tp);   // W[co = in ch][ci = out ch][.]
         bw[e] = *(ok ? a.w + off : g_zero1);
       }
     };
@@ -89,24 +106,24 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
     for (int e = 0; e < NHL; ++e) {
       const int pix = e * NWV + hg;
       float v = hv[e];
-      if (MODE == 1 && a.t0 != nullptr) {
-        const int py = pix / IW, px = pix - py * IW;
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool ok = cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      if (MODE != 0 && a.t0 != nullptr) {
+        const int py = pix / IWm, px = pix - py * IWm;
+        const int gy = y0 + ORG + py, gx = x0 + ORG + px;
+        const bool ok = cv && (unsigned)gy < (unsigned)Hs && (unsigned)gx < (unsigned)Ws;
         v = ok ? fmaf(p0, v, fmaf(p1, hv2[e], p2)) : 0.f;
       }
-      if (pix < NPIX) sIn[pix * CP + hc] = v;
+      if (pix < NPm) sIn[pix * CP + hc] = v;
     }
     if (MODE == 0 && a.tf_mode != HRF_TF_NONE) {
 #pragma unroll 1
       for (int e = 0; e < NHL; ++e) {
         const int pix = e * NWV + hg;
-        const int py = pix / IW, px = pix - py * IW;
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool ok = cv && pix < NPIX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        const int li = min(pix, NPIX - 1) * CP + hc;
+        const int py = pix / IWm, px = pix - py * IWm;
+        const int gy = y0 + ORG + py, gx = x0 + ORG + px;
+        const bool ok = cv && pix < NPm && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const int li = min(pix, NPm - 1) * CP + hc;
         const float v = hrf_tf_affine(a.tf_mode, sIn[li], p0, p1);      // own element: no barrier needed
-        if (pix < NPIX) sIn[li] = ok ? v : 0.f;
+        if (pix < NPm) sIn[li] = ok ? v : 0.f;
       }
     }
     const int nkk = (csz + 3) >> 2;
@@ -115,9 +132,13 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
       for (int e = 0; e < 64 / NWV; ++e)
         if (bc + NWV * e < NT * 16) sB[(bc + NWV * e) * BP + bk] = bw[e];
       __syncthreads();
-      if (step + 1 < nsteps) load_b((step + 1) << 6);
-      const int dy = step / 3, dx = step - 3 * dy;
-      const float* ap = sIn + aBase + (dy * IW + dx) * CP + q;
+      if (step + 1 < nsteps) load_b(step + 1);
+      int dy = step / KH, dx = step - KH * dy;                       // source offset of this tap
+      if (MODE == 2) {
+        const int iy = step / nsx, ix = step - iy * nsx;
+        dy = cpy ? 1 - iy : 0; dx = cpx ? 1 - ix : 0;                // tap dy = 2*iy reads source row y' + 1 - iy
+      }
+      const float* ap = sIn + aBase + (dy * IWm + dx) * CP + q;
       const float* bp = sB + i * BP + q;
 #pragma unroll 4
       for (int kk = 0; kk < nkk; ++kk) {
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) { s1[tt] = 0.f; s2[tt] = 0.f; }
   {
-    const int y = y0 + wave;
+    const int y = MODE == 2 ? 2 * (y0 + wave) + cpy : y0 + wave;
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       const int ch = n0 + tt * 16 + i;
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
       else if (a.epi == 1) { esc = a.esc[chc]; esh = a.esh[chc]; }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int x = xq + r;
+        const int x = MODE == 2 ? 2 * (xq + r) + cpx : xq + r;
         const bool ok = chv && y < a.H && x < a.W;
         const long prow = (long)(b * a.H + y) * a.W + x;
         float v = acc[tt][r];
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
       }
     }
   }
-  if (a.stats != nullptr && (MODE == 0 || a.epi == 1)) {
+  if (a.stats != nullptr && (MODE == 0 || a.epi == 1)) {   // (uniform condition)
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       float u1 = s1[tt], u2 = s2[tt];
@@ -193,16 +214,18 @@ inline int conv3_nt(int C) { return C <= 32 ? 2 : 4; }
 
 }  // namespace
 
-template <int MODE>
+template <int MODE, int KH>
 static int conv3_launch(Conv3Args a, void* stream) {
   if (a.B <= 0 || a.H <= 0 || a.W <= 0) return HRF_OK;
-  a.tilesX = hrf_cdiv(a.W, TW); a.tilesY = hrf_cdiv(a.H, TH);
+  a.tilesX = hrf_cdiv(MODE == 2 ? (a.W + 1) / 2 : a.W, TW); a.tilesY = hrf_cdiv(MODE == 2 ? (a.H + 1) / 2 : a.H, TH);
   const int nt = conv3_nt(a.Cout);
-  const dim3 grid(a.tilesX * a.tilesY * a.B, hrf_cdiv(a.Cout, nt * 16));
-  if (nt == 2) { HRF_LAUNCH((conv3_kernel<2, MODE>), grid, dim3(64 * NWV), 0, stream, a); }
-  else { HRF_LAUNCH((conv3_kernel<4, MODE>), grid, dim3(64 * NWV), 0, stream, a); }
+  const dim3 grid(a.tilesX * a.tilesY * a.B * (MODE == 2 ? 4 : 1), hrf_cdiv(a.Cout, nt * 16));
+  if (nt == 2) { HRF_LAUNCH((conv3_kernel<2, MODE, KH>), grid, dim3(64 * NWV), 0, stream, a); }
+  else { HRF_LAUNCH((conv3_kernel<4, MODE, KH>), grid, dim3(64 * NWV), 0, stream, a); }
   return hrf_check_launch();
 }
 
-int hrf_conv3_fwd_launch(const Conv3Args& a, void* stream) { return conv3_launch<0>(a, stream); }
-int hrf_conv3_bwd_data_launch(const Conv3Args& a, void* stream) { return conv3_launch<1>(a, stream); }
+int hrf_conv3_fwd_launch(const Conv3Args& a, void* stream) { return conv3_launch<0, 3>(a, stream); }
+int hrf_conv3_bwd_data_launch(const Conv3Args& a, void* stream) { return conv3_launch<1, 3>(a, stream); }
+int hrf_conv3s2_bwd_data_launch(const Conv3Args& a, void* stream) { return conv3_launch<2, 3>(a, stream); }
+

@@ -789,6 +789,14 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
     c.B = B; c.H = H; c.W = W; c.Cin = Cout; c.Cout = Cin;
     return hrf_conv3_bwd_data_launch(c, stream);
   }
+  if (KH == 3 && stride == 2 && Cout >= 32 && sC == 1 && sY == W * sX && sB == H * sY && g_knob[6] == 0) {
+    Conv3Args c{};
+    c.in = dy + doff; c.ldIn = ldD; c.in2 = cA != nullptr ? yraw + doff : nullptr; c.t0 = cA; c.t1 = cB; c.t2 = cC;
+    c.w = w; c.wCin = Cin; c.out = dx; c.ldOut = sX; c.accumulate = accumulate; c.epi = epi; c.xraw = xraw; c.ldXr = ldXr;
+    c.esc = tf_scale; c.esh = tf_shift; c.act = act; c.stats = stats;
+    c.B = B; c.H = H; c.W = W; c.Cin = Cout; c.Cout = Cin; c.Hs = a.Ho; c.Ws = a.Wo;
+    return hrf_conv3s2_bwd_data_launch(c, stream);
+  }
   const int nt = pick_nt(Cin);
   if (KH == 1) {
     if (cA != nullptr) { HRF_BD_NT(1, true) } else { HRF_BD_NT(1, false) }

@@ -40,8 +40,10 @@ struct Conv3Args {
   const float* res; const float* res2; int ldR;
   int accumulate, epi; const float* xraw; int ldXr; const float* esc; const float* esh; int act;
   double* stats;                             // [HRF_STAT_COPIES][2*Cout] or null
-  int B, H, W, Cin, Cout;                    // channels of `in` / of `out`
+  int B, H, W, Cin, Cout;                    // output grid; channels of `in` / of `out`
+  int Hs, Ws;                                // stride-2 backward only: grid of `in` (the conv's output)
   int tilesX, tilesY;
 };
 int hrf_conv3_fwd_launch(const Conv3Args& a, void* stream);
 int hrf_conv3_bwd_data_launch(const Conv3Args& a, void* stream);
+int hrf_conv3s2_bwd_data_launch(const Conv3Args& a, void* stream);   // stride-2 conv, parity-class blocks

@@ -57,7 +57,10 @@ CONV_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
     (2, 16, 24, 64, 256, 1, 1, 2, True, True),
     (2, 7, 9, 144, 80, 1, 1, 0, False, False),     # several 64-wide tile groups in both dims, ragged
     (1, 5, 3, 78, 78, 1, 1, 4, False, True),       # HRFuser-B width, fewer pixels than one batch
-    (1, 50, 130, 64, 64, 3, 1, 2, True, True),      # M >= 128*.. exercises the BM=128 tile on GPU sizes
+    (1, 50, 130, 64, 64, 3, 1, 2, True, True),
+    (1, 18, 35, 64, 64, 3, 2, 2, True, True),      # stride-2 backward: parity-class kernel, ragged tiles
+    (1, 70, 66, 64, 256, 1, 1, 2, True, True),     # wide 1x1 on the LDS-tiled engine (M >= 4096)
+    (1, 66, 70, 256, 64, 1, 1, 1, True, False),      # M >= 128*.. exercises the BM=128 tile on GPU sizes
 ]
 
 
@@ -362,7 +365,7 @@ def run_pointwise(backend):
 
 
 # ------------------------------------------------------------------ emulator (CPU suite)
-@pytest.mark.parametrize('case', CONV_CASES[:8], ids=str)
+@pytest.mark.parametrize('case', CONV_CASES[:8] + CONV_CASES[-3:], ids=str)
 def test_conv_emul(case):
     run_conv(case, 'emul')
 
