@@ -76,241 +76,238 @@ __device__ __forceinline__ void axpy_row(float* o, float p, const float* row) {
   }
 }
 
-constexpr int SP = 65;      // pitch of the per-wave [key j][query i] score planes: lane = i or lane = j both <= 2-way
+constexpr int SP = 65;      // pitch of the [key j][query i] score planes: lane = i or lane = j both <= 2-way
+constexpr int NJ = 13;      // keys (pass A) / queries (pass B) per wave: token 4*jj + wave, jj < 13
 
-// Forward.  The 49-wide logit row of a query lives in a per-wave LDS plane ([j][i], pitch 65) instead
-// of 49 registers of a fully unrolled body: the loops stay rolled (7 x unrolled-7), the kernel is
-// ~3 KB instead of 16 KB - at 20 us per launch the cold instruction cache was the main cost.
-template <int D, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(AttnArgs a) {
+// One 256-thread block per (window, head).  The four waves split the 49 KEYS (pass A, lane = query)
+// or the 49 QUERIES (pass B, lane = key): a quarter of the serial FMA/LDS chain per wave and 4x the
+// waves in flight compared with one wave per window (the kernel is latency-bound: 644 windows on
+// 1024 SIMDs left every SIMD with a single, dependency-stalled wave).  Softmax max / sum and the
+// output rows are combined across the waves through small LDS arrays; no atomics anywhere.
+template <int D>
+__device__ __forceinline__ void stage_rows(const AttnArgs& a, int b, int wy, int wx, int h, float* sK, float* sV,
+                                           float* sQ, float* sG) {
   constexpr int DP = (D + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) float sK[WAVES][NT * DP];
-  __shared__ __attribute__((aligned(16))) float sV[WAVES][NT * DP];
-  __shared__ float sS[WAVES][NT * SP];
-  __shared__ float sT[WAVES][176];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
-  const int nwin = a.B * a.nWh * a.nWw;
-  const int win = blockIdx.x * WAVES + wave;
-  const bool active = win < nwin;
-  const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
-  if (active) {
-    for (int e = lane; e < NT * DP; e += 64) {
-      const int j = e / DP, d = e - j * DP;
-      const int pix = tok_pixel(a, b, wy, wx, j);
-      const bool dv = d < D;
-      const long pc = pix >= 0 ? pix : 0;       // unconditional clamped loads, select afterwards
-      const int col = h * D + (dv ? d : 0);
-      const float kx = a.k[pc * a.ldk + a.koff + col], kp = a.kpad[col];
-      const float vx = a.v[pc * a.ldv + a.voff + col], vp = a.vpad[col];
-      sK[wave][e] = dv ? (pix >= 0 ? kx : kp) : 0.f;
-      sV[wave][e] = dv ? (pix >= 0 ? vx : vp) : 0.f;
+  for (int e = threadIdx.x; e < NT * DP; e += 256) {
+    const int j = e / DP, d = e - j * DP;
+    const int pix = tok_pixel(a, b, wy, wx, j);
+    const bool dv = d < D;
+    const long pc = pix >= 0 ? pix : 0;           // unconditional clamped loads, select afterwards
+    const int col = h * D + (dv ? d : 0);
+    const float kx = a.k[pc * a.ldk + a.koff + col], kp = a.kpad[col];
+    const float vx = a.v[pc * a.ldv + a.voff + col], vp = a.vpad[col];
+    sK[e] = dv ? (pix >= 0 ? kx : kp) : 0.f;
+    sV[e] = dv ? (pix >= 0 ? vx : vp) : 0.f;
+    if (sQ != nullptr) {
+      const float qx = a.q[pc * a.ldq + a.qoff + col] * a.scale, gx = a.dout[pc * a.lddo + col];
+      sQ[e] = (dv && pix >= 0) ? qx : 0.f;
+      sG[e] = (dv && pix >= 0) ? gx : 0.f;
     }
-    for (int e = lane; e < 169; e += 64) sT[wave][e] = a.rpb[e * a.heads + h];
   }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int DP = (D + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float sK[NT * DP];
+  __shared__ __attribute__((aligned(16))) float sV[NT * DP];
+  __shared__ float sO[4][NT * DP];
+  __shared__ float sT[176];
+  __shared__ float sM[4][64], sL[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
+  const int win = blockIdx.x;
+  const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
+  stage_rows<D>(a, b, wy, wx, h, sK, sV, nullptr, nullptr);
+  for (int e = threadIdx.x; e < 169; e += 256) sT[e] = a.rpb[e * a.heads + h];
   __syncthreads();
-  const int i = lane;
-  const int pix = (active && i < NT) ? tok_pixel(a, b, wy, wx, i) : -1;
-  if (pix < 0) return;                       // padded / idle query rows produce no output
+  const int i = lane < NT ? lane : 0;
+  const int pix = lane < NT ? tok_pixel(a, b, wy, wx, i) : -1;
+  const long pc = pix >= 0 ? pix : 0;
   float q[DP];
 #pragma unroll
-  for (int d = 0; d < DP; ++d) q[d] = d < D ? a.q[(long)pix * a.ldq + a.qoff + h * D + d] * a.scale : 0.f;
+  for (int d = 0; d < DP; ++d) q[d] = (d < D && pix >= 0) ? a.q[pc * a.ldq + a.qoff + h * D + d] * a.scale : 0.f;
   const int yi = i / 7, xi = i - 7 * yi;
   const int bias0 = (yi + 6) * 13 + (xi + 6);
-  const float* Kw = sK[wave];
-  const float* Vw = sV[wave];
-  const float* Tw = sT[wave];
-  float* Sw = sS[wave];
+  float sc[NJ];
   float m = -3.0e38f;
-#pragma unroll 1
-  for (int jy = 0; jy < 7; ++jy) {
 #pragma unroll
-    for (int jx = 0; jx < 7; ++jx) {
-      const int j = jy * 7 + jx;
-      const float sv = dot_row<DP>(q, Kw + j * DP, Tw[bias0 - jy * 13 - jx]);
-      Sw[j * SP + i] = sv;
-      m = fmaxf(m, sv);
-    }
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int j = min(4 * jj + wave, NT - 1);
+    const bool jv = 4 * jj + wave < NT;
+    const float sv = dot_row<DP>(q, sK + j * DP, sT[bias0 - (j / 7) * 13 - (j % 7)]);
+    sc[jj] = jv ? sv : -3.0e38f;
+    m = fmaxf(m, sc[jj]);
   }
+  sM[wave][lane] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sM[0][lane], sM[1][lane]), fmaxf(sM[2][lane], sM[3][lane]));
   float l = 0.f, o[DP];
 #pragma unroll
   for (int d = 0; d < DP; ++d) o[d] = 0.f;
-#pragma unroll 1
-  for (int jy = 0; jy < 7; ++jy) {
 #pragma unroll
-    for (int jx = 0; jx < 7; ++jx) {
-      const int j = jy * 7 + jx;
-      const float p = __expf(Sw[j * SP + i] - m);
-      l += p;
-      axpy_row<DP>(o, p, Vw + j * DP);
-    }
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int j = min(4 * jj + wave, NT - 1);
+    const float p = __expf(sc[jj] - m);           // exp(-huge) == 0 for the (at most one) padding slot
+    l += p;
+    axpy_row<DP>(o, p, sV + j * DP);
   }
-  const float inv = 1.0f / l;
+  sL[wave][lane] = l;
+  if (lane < NT) {
 #pragma unroll
-  for (int d = 0; d < D; ++d) a.o[(long)pix * a.ldo + h * D + d] = o[d] * inv;
+    for (int d = 0; d < DP; ++d) sO[wave][lane * DP + d] = o[d];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NT * D; e += 256) {
+    const int ii = e / D, d = e - ii * D;
+    const int px = tok_pixel(a, b, wy, wx, ii);
+    const float lt = sL[0][ii] + sL[1][ii] + sL[2][ii] + sL[3][ii];
+    const float ot = sO[0][ii * DP + d] + sO[1][ii * DP + d] + sO[2][ii * DP + d] + sO[3][ii * DP + d];
+    if (px >= 0) a.o[(long)px * a.ldo + h * D + d] = ot / lt;
+  }
 }
 
-// Backward.  Pass A (lane = query i) leaves the softmax P and dS = P*(dP - D_i) in two LDS planes;
-// pass B (lane = key j) only READS them (no recomputation of logits / exp), the relative-position
-// bias gradient is a gather over the dS plane (no LDS atomics: ds_add_f32 runs at ~1 lane/clk),
-// pad-key gradients are wave sums.  All loops rolled (7 x 7-unrolled): ~6 KB of code, < 128 VGPRs.
-template <int D, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void attn_bwd_kernel(AttnArgs a) {
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   constexpr int DP = (D + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) float sK[WAVES][NT * DP];
-  __shared__ __attribute__((aligned(16))) float sV[WAVES][NT * DP];
-  __shared__ __attribute__((aligned(16))) float sQ[WAVES][NT * DP];
-  __shared__ __attribute__((aligned(16))) float sG[WAVES][NT * DP];        // dO rows
-  __shared__ float sP[WAVES][NT * SP];
-  __shared__ float sD[WAVES][NT * SP];
-  __shared__ float sT[WAVES][176];
+  __shared__ __attribute__((aligned(16))) float sK[NT * DP];
+  __shared__ __attribute__((aligned(16))) float sV[NT * DP];
+  __shared__ __attribute__((aligned(16))) float sQ[NT * DP];
+  __shared__ __attribute__((aligned(16))) float sG[NT * DP];        // dO rows
+  __shared__ float sP[NT * SP];
+  __shared__ float sD[NT * SP];
+  __shared__ float sX[4][NT * DP];                                  // per-wave partial rows (dQ, then dK)
+  __shared__ float sY[4][NT * DP];                                  // per-wave partial rows (dV)
+  __shared__ float sT[176];
+  __shared__ float sM[4][64], sL[4][64], sA[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
-  const int nwin = a.B * a.nWh * a.nWw;
-  for (int e = lane; e < 176; e += 64) sT[wave][e] = a.rpb[(e < 169 ? e : 0) * a.heads + h];
-  const float* Kw = sK[wave];
-  const float* Vw = sV[wave];
-  const float* Qw = sQ[wave];
-  const float* Gw = sG[wave];
-  const float* Tw = sT[wave];
-  float* Pw = sP[wave];
-  float* Dw = sD[wave];
+  const int win = blockIdx.x;
+  const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
+  stage_rows<D>(a, b, wy, wx, h, sK, sV, sQ, sG);
+  for (int e = threadIdx.x; e < 169; e += 256) sT[e] = a.rpb[e * a.heads + h];
+  __syncthreads();
   const int li = lane < NT ? lane : 0;
   const int yl = li / 7, xl = li - 7 * yl;
-  float bin[3] = {0.f, 0.f, 0.f};              // dRPB bins lane, lane+64, lane+128
-  float padk = 0.f, padv = 0.f;                // lane d < D: pad-key / pad-value gradient of channel d
-
-  for (int it = 0; it < a.iters; ++it) {
-    const int win = (it * gridDim.x + blockIdx.x) * WAVES + wave;
-    const bool active = win < nwin;
-    const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
-    __syncthreads();                           // previous iteration's readers are done
-    if (active) {
-      for (int e = lane; e < NT * DP; e += 64) {
-        const int j = e / DP, d = e - j * DP;
-        const int pix = tok_pixel(a, b, wy, wx, j);
-        const bool dv = d < D;
-        const int col = h * D + (dv ? d : 0);
-        const long pc = pix >= 0 ? pix : 0;     // unconditional clamped loads, select afterwards
-        const float kx = a.k[pc * a.ldk + a.koff + col], kp = a.kpad[col];
-        const float vx = a.v[pc * a.ldv + a.voff + col], vp = a.vpad[col];
-        const float qx = a.q[pc * a.ldq + a.qoff + col] * a.scale, gx = a.dout[pc * a.lddo + col];
-        sK[wave][e] = dv ? (pix >= 0 ? kx : kp) : 0.f;
-        sV[wave][e] = dv ? (pix >= 0 ? vx : vp) : 0.f;
-        sQ[wave][e] = (dv && pix >= 0) ? qx : 0.f;
-        sG[wave][e] = (dv && pix >= 0) ? gx : 0.f;
-      }
+  // ---- pass A: lane = query row i, wave = key subset
+  {
+    const int i = li;
+    float q[DP], g[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) { q[d] = sQ[i * DP + d]; g[d] = sG[i * DP + d]; }
+    const int bias0 = (yl + 6) * 13 + (xl + 6);
+    // scores / dP of this wave's keys live in the (own-column, conflict-free) LDS planes, not in
+    // registers: the loops stay partially rolled and the kernel fits 128 VGPRs without spills
+    float m = -3.0e38f;
+    const int nj = (NT - wave + 3) >> 2;            // keys 4*jj + wave < 49
+#pragma unroll 2
+    for (int jj = 0; jj < nj; ++jj) {
+      const int j = 4 * jj + wave;
+      const float sv = dot_row<DP>(q, sK + j * DP, sT[bias0 - (j / 7) * 13 - (j % 7)]);
+      sP[j * SP + lane] = sv;
+      sD[j * SP + lane] = dot_row<DP>(g, sV + j * DP, 0.f);
+      m = fmaxf(m, sv);
     }
+    sM[wave][lane] = m;
     __syncthreads();
-    const int pix = (active && lane < NT) ? tok_pixel(a, b, wy, wx, lane) : -1;
-    // ---- pass A: lane = query row i -> P, dS planes and dQ_i
-    if (active && lane < NT) {
-      const int i = lane;
-      float q[DP], g[DP];
-#pragma unroll
-      for (int d = 0; d < DP; ++d) { q[d] = Qw[i * DP + d]; g[d] = Gw[i * DP + d]; }
-      const int bias0 = (yl + 6) * 13 + (xl + 6);
-      float m = -3.0e38f;
-#pragma unroll 1
-      for (int jy = 0; jy < 7; ++jy) {
-#pragma unroll
-        for (int jx = 0; jx < 7; ++jx) {
-          const int j = jy * 7 + jx;
-          const float sv = dot_row<DP>(q, Kw + j * DP, Tw[bias0 - jy * 13 - jx]);
-          Pw[j * SP + i] = sv;
-          Dw[j * SP + i] = dot_row<DP>(g, Vw + j * DP, 0.f);
-          m = fmaxf(m, sv);
-        }
-      }
-      float l = 0.f, acc = 0.f;
-#pragma unroll 7
-      for (int j = 0; j < NT; ++j) {
-        const float p = __expf(Pw[j * SP + i] - m);
-        Pw[j * SP + i] = p;
-        l += p;
-        acc = fmaf(p, Dw[j * SP + i], acc);
-      }
-      const float inv = 1.0f / l, Dl = acc * inv;
-      float dq[DP];
-#pragma unroll
-      for (int d = 0; d < DP; ++d) dq[d] = 0.f;
-#pragma unroll 1
-      for (int jy = 0; jy < 7; ++jy) {
-#pragma unroll
-        for (int jx = 0; jx < 7; ++jx) {
-          const int j = jy * 7 + jx;
-          const float p = Pw[j * SP + i] * inv;
-          const float ds = p * (Dw[j * SP + i] - Dl);
-          Pw[j * SP + i] = p;
-          Dw[j * SP + i] = ds;
-          axpy_row<DP>(dq, ds, Kw + j * DP);
-        }
-      }
-      if (pix >= 0) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) a.dq[(long)pix * a.lddq + a.dqoff + h * D + d] = dq[d] * a.scale;
-      }
+    m = fmaxf(fmaxf(sM[0][lane], sM[1][lane]), fmaxf(sM[2][lane], sM[3][lane]));
+    float l = 0.f, acc = 0.f;
+#pragma unroll 4
+    for (int jj = 0; jj < nj; ++jj) {
+      const int j = 4 * jj + wave;
+      const float p = __expf(sP[j * SP + lane] - m);
+      sP[j * SP + lane] = p;
+      l += p;
+      acc = fmaf(p, sD[j * SP + lane], acc);
     }
+    sL[wave][lane] = l; sA[wave][lane] = acc;
     __syncthreads();
-    // ---- pass B: lane = key column j -> dK_j, dV_j from the stored planes
+    l = sL[0][lane] + sL[1][lane] + sL[2][lane] + sL[3][lane];
+    acc = sA[0][lane] + sA[1][lane] + sA[2][lane] + sA[3][lane];
+    const float inv = 1.0f / l, Dl = acc * inv;
+    float dq[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) dq[d] = 0.f;
+#pragma unroll 2
+    for (int jj = 0; jj < nj; ++jj) {
+      const int j = 4 * jj + wave;
+      const float p = sP[j * SP + lane] * inv;
+      const float ds = p * (sD[j * SP + lane] - Dl);
+      sP[j * SP + lane] = p;
+      sD[j * SP + lane] = ds;
+      axpy_row<DP>(dq, ds, sK + j * DP);
+    }
+    if (lane < NT) {
+#pragma unroll
+      for (int d = 0; d < DP; ++d) sX[wave][lane * DP + d] = dq[d];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NT * D; e += 256) {
+    const int ii = e / D, d = e - ii * D;
+    const int px = tok_pixel(a, b, wy, wx, ii);
+    const float t = sX[0][ii * DP + d] + sX[1][ii * DP + d] + sX[2][ii * DP + d] + sX[3][ii * DP + d];
+    if (px >= 0) a.dq[(long)px * a.lddq + a.dqoff + h * D + d] = t * a.scale;
+  }
+  __syncthreads();
+  // ---- pass B: lane = key column j, wave = query subset
+  {
+    const int j = li;
     float dk[DP], dv[DP];
 #pragma unroll
     for (int d = 0; d < DP; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-    const bool keyl = active && lane < NT;
-    if (keyl) {
-      const int j = lane;
-#pragma unroll 1
-      for (int iy = 0; iy < 7; ++iy) {
-#pragma unroll
-        for (int ix = 0; ix < 7; ++ix) {
-          const int i = iy * 7 + ix;
-          axpy_row<DP>(dk, Dw[j * SP + i], Qw + i * DP);
-          axpy_row<DP>(dv, Pw[j * SP + i], Gw + i * DP);
-        }
-      }
-      if (pix >= 0) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          a.dk[(long)pix * a.lddk + a.dkoff + h * D + d] = dk[d];
-          a.dv[(long)pix * a.lddv + a.dvoff + h * D + d] = dv[d];
-        }
-      }
+    const int ni = (NT - wave + 3) >> 2;
+#pragma unroll 2
+    for (int ii = 0; ii < ni; ++ii) {
+      const int i = 4 * ii + wave;
+      axpy_row<DP>(dk, sD[j * SP + i], sQ + i * DP);
+      axpy_row<DP>(dv, sP[j * SP + i], sG + i * DP);
     }
-    // padded keys: their gradient flows to the projection bias only (wave sums, boundary windows only)
-    const bool padl = keyl && pix < 0;
-    if (__any(padl)) {
+    if (lane < NT) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const float sk = hrf_wave_sum(padl ? dk[d] : 0.f), sv = hrf_wave_sum(padl ? dv[d] : 0.f);
-        if (lane == d) { padk += sk; padv += sv; }
-      }
+      for (int d = 0; d < DP; ++d) { sX[wave][lane * DP + d] = dk[d]; sY[wave][lane * DP + d] = dv[d]; }
     }
-    // dRPB[(yi-yj+6)*13 + (xi-xj+6)] += dS[i][j]: gather over the dS plane
-    if (active) {
-#pragma unroll
-      for (int kbin = 0; kbin < 3; ++kbin) {
-        const int e = lane + 64 * kbin;
-        if (e < 169) {
-          const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
-          const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
-          const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
-          float sacc = 0.f;
-          for (int yj = y0; yj <= y1; ++yj)
-            for (int xj = x0; xj <= x1; ++xj)
-              sacc += Dw[(yj * 7 + xj) * SP + (yj + dy) * 7 + xj + dx];
-          bin[kbin] += sacc;
+  }
+  __syncthreads();
+  const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride;
+  bool anypad = false;
+  for (int e = threadIdx.x; e < NT * D; e += 256) {
+    const int jj = e / D, d = e - jj * D;
+    const int px = tok_pixel(a, b, wy, wx, jj);
+    const float tk = sX[0][jj * DP + d] + sX[1][jj * DP + d] + sX[2][jj * DP + d] + sX[3][jj * DP + d];
+    const float tv = sY[0][jj * DP + d] + sY[1][jj * DP + d] + sY[2][jj * DP + d] + sY[3][jj * DP + d];
+    if (px >= 0) {
+      a.dk[(long)px * a.lddk + a.dkoff + h * D + d] = tk;
+      a.dv[(long)px * a.lddv + a.dvoff + h * D + d] = tv;
+    }
+  }
+  // padded keys (boundary windows only): their gradient flows to the projection bias
+  if (wy == 0 || wx == 0 || wy == a.nWh - 1 || wx == a.nWw - 1) {
+    if (threadIdx.x < D) {
+      const int d = threadIdx.x;
+      float pk = 0.f, pv = 0.f;
+      for (int jj = 0; jj < NT; ++jj) {
+        if (tok_pixel(a, b, wy, wx, jj) < 0) {
+          pk += sX[0][jj * DP + d] + sX[1][jj * DP + d] + sX[2][jj * DP + d] + sX[3][jj * DP + d];
+          pv += sY[0][jj * DP + d] + sY[1][jj * DP + d] + sY[2][jj * DP + d] + sY[3][jj * DP + d];
+          anypad = true;
         }
+      }
+      if (anypad) {
+        hrf_atomic_add(&a.dkpad[cp + h * D + d], pk);
+        hrf_atomic_add(&a.dvpad[cp + h * D + d], pv);
       }
     }
   }
-  // one atomic per bin per wave into the (replicated) parameter-gradient accumulators
-  const long cp = (long)((blockIdx.x * WAVES + wave) % HRF_STAT_COPIES) * a.copy_stride;
-#pragma unroll
-  for (int kbin = 0; kbin < 3; ++kbin) {
-    const int e = lane + 64 * kbin;
-    if (e < 169) hrf_atomic_add(&a.drpb[cp + e * a.heads + h], bin[kbin]);
-  }
-  if (lane < D) {
-    hrf_atomic_add(&a.dkpad[cp + h * D + lane], padk);
-    hrf_atomic_add(&a.dvpad[cp + h * D + lane], padv);
+  // dRPB[(yi-yj+6)*13 + (xi-xj+6)] += dS[i][j]: gather over the dS plane, one bin per thread
+  if (threadIdx.x < 169) {
+    const int e = threadIdx.x;
+    const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
+    const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
+    const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
+    float sacc = 0.f;
+    for (int yj = y0; yj <= y1; ++yj)
+      for (int xj = x0; xj <= x1; ++xj)
+        sacc += sD[(yj * 7 + xj) * SP + (yj + dy) * 7 + xj + dx];
+    hrf_atomic_add(&a.drpb[cp + e * a.heads + h], sacc);
   }
 }
 
@@ -321,14 +318,14 @@ inline void window_geom(AttnArgs& a) {
 
 }  // namespace
 
-#define HRF_ATTN_DISPATCH(KERN, WV_SMALL, WV_BIG, GRIDX)                                             \
-  switch (D) {                                                                                       \
-    case 8:  HRF_LAUNCH((KERN<8, WV_SMALL>), dim3(GRIDX(WV_SMALL), heads), dim3(WV_SMALL * 64), 0, stream, a); break;  \
-    case 16: HRF_LAUNCH((KERN<16, WV_SMALL>), dim3(GRIDX(WV_SMALL), heads), dim3(WV_SMALL * 64), 0, stream, a); break; \
-    case 18: HRF_LAUNCH((KERN<18, WV_SMALL>), dim3(GRIDX(WV_SMALL), heads), dim3(WV_SMALL * 64), 0, stream, a); break; \
-    case 32: HRF_LAUNCH((KERN<32, WV_BIG>), dim3(GRIDX(WV_BIG), heads), dim3(WV_BIG * 64), 0, stream, a); break;       \
-    case 39: HRF_LAUNCH((KERN<39, WV_BIG>), dim3(GRIDX(WV_BIG), heads), dim3(WV_BIG * 64), 0, stream, a); break;       \
-    default: return HRF_ERR_ARG;                                                                     \
+#define HRF_ATTN_DISPATCH(KERN)                                                              \
+  switch (D) {                                                                               \
+    case 8:  HRF_LAUNCH((KERN<8>), dim3(nwin, heads), dim3(256), 0, stream, a); break;       \
+    case 16: HRF_LAUNCH((KERN<16>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
+    case 18: HRF_LAUNCH((KERN<18>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
+    case 32: HRF_LAUNCH((KERN<32>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
+    case 39: HRF_LAUNCH((KERN<39>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
+    default: return HRF_ERR_ARG;                                                             \
   }
 
 extern "C" int hrf_window_attn_fwd(const float* q, int ldq, int qoff, const float* k, int ldk, int koff,
@@ -344,8 +341,7 @@ extern "C" int hrf_window_attn_fwd(const float* q, int ldq, int qoff, const floa
   window_geom(a);
   const int nwin = B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
-#define HRF_FWD_GRID(WV) hrf_cdiv(nwin, WV)
-  HRF_ATTN_DISPATCH(attn_fwd_kernel, 2, 2, HRF_FWD_GRID)
+  HRF_ATTN_DISPATCH(attn_fwd_kernel)
   return hrf_check_launch();
 }
 
@@ -366,15 +362,6 @@ extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const floa
   window_geom(a);
   const int nwin = B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
-  // windows per wave: enough blocks to fill 256 CUs, few enough that the dRPB flush stays cheap
-#define HRF_BWD_GRID(WV) bwd_grid(nwin, WV, heads, &a.iters)
-  auto bwd_grid = [](int nw, int wv, int hd, int* iters) {
-    int gx = hrf_cdiv(nw, wv);
-    const int cap = hrf_cdiv(512, hd);
-    if (gx > cap) gx = cap;
-    *iters = hrf_cdiv(nw, gx * wv);
-    return gx;
-  };
-  HRF_ATTN_DISPATCH(attn_bwd_kernel, 2, 2, HRF_BWD_GRID)
+  HRF_ATTN_DISPATCH(attn_bwd_kernel)
   return hrf_check_launch();
 }
