@@ -116,6 +116,10 @@ def lib():
     global _LIB
     if _LIB is None:
         _LIB = Lib(LIB_PATH, require_cuda=True)
+        for kv in os.environ.get('HRF_KNOBS', '').split(','):      # tuning experiments: "key=value,..."
+            if '=' in kv:
+                k, v = kv.split('=')
+                _LIB.hrf_debug_knob(int(k), int(v))
     return _LIB
 
 

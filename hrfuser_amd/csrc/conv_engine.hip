@@ -518,6 +518,7 @@ struct WgradDenseArgs {
   float* dw; float* dbias;
   int Cout, Cin, Mpix, chunk;
   int H, W, Ho, Wo, stride, gyc;   // TAP (3x3) only: input / output grids, stride, channel groups per tap
+  int gx, gy, sp;                  // logical grid (co groups, n groups, pixel splits), see the XCD mapping below
 };
 
 constexpr int WU = 8;      // k-steps (of 4 pixels) whose loads are issued before the first use
@@ -535,9 +536,18 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.x * (16 * MT), n0 = blockIdx.y * (16 * NT);
+  // XCD-aware block mapping: workgroups are dealt round-robin to the 8 XCDs (private 4 MB L2 each).
+  // All (co group, n group) blocks that reduce the SAME pixel chunk are placed on one XCD and run
+  // back-to-back there, so the chunk's dY / X rows are fetched from the fabric once, not once per
+  // block (measured on the 3x3 64->64 weight gradient: 206 MB of fabric reads for 24 MB of data).
+  const int G = a.gx * a.gy;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int grp = slot % G, bz = (slot / G) * 8 + xcd;
+  if (bz >= a.sp) return;                                   // padding blocks (sp rounded up to 8)
+  const int bx = grp % a.gx, by = grp / a.gx;
+  const int m0 = bx * (16 * MT), n0 = by * (16 * NT);
   const int Np = TAP ? a.Cin * 9 : a.Cin;
-  const int pbeg = blockIdx.z * a.chunk, pend = min(a.Mpix, pbeg + a.chunk);
+  const int pbeg = bz * a.chunk, pend = min(a.Mpix, pbeg + a.chunk);
   const bool ln = a.tf_rowstat != nullptr;
 
   int aoff[MT], boff[NT], tdy[NT], tdx[NT];
@@ -667,7 +677,7 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a)
       hrf_atomic_add(&a.dw[(long)(m0 + row) * Np + n0 + col], sAcc[row * WSP + col] + sAcc[MT * 16 * WSP + row * WSP + col]);
   }
   __syncthreads();
-  if (a.dbias != nullptr && blockIdx.y == 0 && tid < MT * 16 && m0 + tid < a.Cout) {
+  if (a.dbias != nullptr && by == 0 && tid < MT * 16 && m0 + tid < a.Cout) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < WNW; ++w) t += sBias[w * (MT * 16) + tid];
@@ -865,10 +875,15 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     if (sp > cap2) sp = cap2;
     if (sp < 1) sp = 1;
     const int gxy = hrf_cdiv(Cout, 16 * mt) * d.gyc;
-    if (gxy * sp > 256 && gxy * sp < 512 && 256 / gxy >= 8) sp = 256 / gxy;   // one full round of blocks instead of 1.x
+    if (sp > 8) {                                            // whole pixel chunks per XCD (32 CUs): one round if possible
+      int c = hrf_cdiv(sp, 8);
+      if (gxy * c > 32 && gxy <= 32) c = 32 / gxy;
+      sp = 8 * c;
+    }
     d.chunk = hrf_cdiv(hrf_cdiv(a.Mpix, sp), 4 * WNW) * 4 * WNW;
     sp = hrf_cdiv(a.Mpix, d.chunk);
-    const dim3 g2(hrf_cdiv(Cout, 16 * mt), d.gyc, sp);
+    d.gx = hrf_cdiv(Cout, 16 * mt); d.gy = d.gyc; d.sp = sp;
+    const dim3 g2(d.gx * d.gy * hrf_cdiv(sp, 8) * 8);
     const int act = tf_mode == HRF_TF_AFFINE_RELU ? 1 : (tf_mode == HRF_TF_AFFINE_GELU ? 2 : 0);
 #define HRF_WD_LAUNCH(MT_, NT_, BNB_, ACT_, TAP_) \
     HRF_LAUNCH((wgrad_dense_kernel<MT_, NT_, BNB_, ACT_, TAP_>), g2, dim3(64 * WNW), 0, stream, d)
