@@ -176,11 +176,17 @@ def main():
     roof = None
     if not args.no_roofline:          # every rank runs it (the step contains collectives when N > 1)
         table = profiling.profile_step(trainer, x, mods, cots, steps=args.profile_steps)
-        roof = profiling.roofline_of_dominant(table, PEAK_F32_MFMA, PEAK_HBM)
+        traffic = {}
+        tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')     # PMC-measured bytes per launch by shape
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = {k: v['bytes_per_launch'] for k, v in json.load(fh).get('shapes', {}).items()}
+        roof = profiling.roofline_of_dominant(table, PEAK_F32_MFMA, PEAK_HBM, traffic)
         if args.dump_kernels and rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(args.dump_kernels)), exist_ok=True)
             with open(args.dump_kernels, 'w') as fh:
-                json.dump(profiling.table_json(table, PEAK_F32_MFMA, PEAK_HBM), fh, indent=1)
+                json.dump({'kernels': profiling.table_json(table, PEAK_F32_MFMA, PEAK_HBM),
+                           'signatures': profiling.profile_step.last_signatures[:60]}, fh, indent=1)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -128,6 +128,16 @@ def _signature(name, a):
     return (name,) + tuple(v for v in a.values() if isinstance(v, (int, float)) and not isinstance(v, bool))
 
 
+def shape_tag(name, a):
+    """Human-readable signature of one launch: entry point + the shape/mode integers that select the
+    kernel variant (pointer arguments reduced to present/absent).  Also the key of profiles/*traffic*.json."""
+    keep = ('B', 'H', 'W', 'C', 'Cin', 'Cout', 'KH', 'stride', 'rows', 'heads', 'tf_mode', 'epi', 'mode', 'accumulate')
+    parts = [f'{k}={a[k]}' for k in keep if k in a and isinstance(a[k], (int, float))]
+    if 'cA' in a:
+        parts.append(f"bnb={int(a['cA'] is not None)}")
+    return name.replace('hrf_', '') + '[' + ','.join(parts) + ']'
+
+
 def _graph_time(fn, reps=20, replays=5):
     """GPU-side average duration of one launch: `reps` back-to-back launches captured into a hipGraph
     on the launch stream, replayed and bracketed by HIP events (no host launch overhead inside)."""
@@ -187,6 +197,7 @@ def profile_step(trainer, x, mods, cots, steps=1):
         else:
             ent[0] += 1
     table = {}
+    sig_rows = []
     for sg, (cnt, name, a, args) in sigs.items():
         fn = getattr(base, name)
         sptr = [None]
@@ -199,6 +210,9 @@ def profile_step(trainer, x, mods, cots, steps=1):
             torch.cuda.synchronize()
             continue
         key, fl, by = work_model(name, a)
+        sig_rows.append({'shape': shape_tag(name, a), 'kernel': key, 'launches_per_step': cnt // steps,
+                         'avg_launch_us': dt * 1e6, 'time_per_step_ms': dt * cnt / steps * 1e3,
+                         'flops_per_launch': fl, 'bytes_per_launch': by})
         t = table.setdefault(key, [0, 0.0, 0.0, 0.0])
         t[0] += cnt
         t[1] += dt * cnt
@@ -206,6 +220,8 @@ def profile_step(trainer, x, mods, cots, steps=1):
         t[3] += by * cnt
     for t in table.values():
         t.append(steps)
+    sig_rows.sort(key=lambda r: -r['time_per_step_ms'])
+    profile_step.last_signatures = sig_rows       # per-(entry point, shape) rows of the same measurement
     return table
 
 
@@ -222,9 +238,29 @@ def _row(key, t, peak_f, peak_b):
             'flops_per_launch': fl / n, 'bytes_per_launch': by / n}
 
 
-def roofline_of_dominant(table, peak_f, peak_b):
+def roofline_of_dominant(table, peak_f, peak_b, traffic=None):
+    """Roofline entry of the dominant kernel (largest share of GPU time per step).  `achieved` is the
+    family's algorithmic bytes (or flops) per launch over its average launch duration; the heaviest
+    single signature of the family is reported next to it, with the PMC-measured fabric/HBM traffic of
+    exactly that signature when profiles/*hbm_traffic*.json holds one (`traffic`, bytes per launch)."""
     key = max(table, key=lambda k: table[k][1])
-    return _row(key, table[key], peak_f, peak_b)
+    row = _row(key, table[key], peak_f, peak_b)
+    sigs = [r for r in getattr(profile_step, 'last_signatures', []) if r['kernel'] == key]
+    if sigs:
+        top = sigs[0]
+        bound_b = (top['flops_per_launch'] / peak_f) <= (top['bytes_per_launch'] / peak_b)
+        ach = top['bytes_per_launch'] / (top['avg_launch_us'] * 1e-6) / 1e9 if bound_b else \
+            top['flops_per_launch'] / (top['avg_launch_us'] * 1e-6) / 1e12
+        row['dominant_shape'] = {'shape': top['shape'], 'launches_per_step': top['launches_per_step'],
+                                 'avg_launch_us': round(top['avg_launch_us'], 2),
+                                 'bytes_per_launch': top['bytes_per_launch'], 'flops_per_launch': top['flops_per_launch'],
+                                 'achieved': round(ach, 3), 'unit': 'GB/s' if bound_b else 'TFLOP/s',
+                                 'frac': round(ach / ((peak_b / 1e9) if bound_b else (peak_f / 1e12)), 4),
+                                 'traffic': (traffic or {}).get(top['shape'])}
+        if row['dominant_shape']['traffic'] is not None:
+            row['traffic'] = row['dominant_shape']['traffic']
+            row['traffic_note'] = 'PMC (FETCH_SIZE x2 + WRITE_SIZE) of dominant_shape, bytes per launch'
+    return row
 
 
 def table_json(table, peak_f, peak_b):

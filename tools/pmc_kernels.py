@@ -21,7 +21,10 @@ dx=R(B,H,W,Cin)
 C=18; P=B*H*W; qkv=R(P,3*C); o=R(P,C); Tt=R(169,1); bq=R(3*C); dqkv=R(P,3*C); dT=torch.zeros(169,1,device=dev); dbq=torch.zeros(3*C,device=dev)
 # dense wgrad 18->72 LN bnb ; lin fwd 18->72
 x18=R(B,H,W,18); dy72=R(B,H,W,72); yr72=R(B,H,W,72); dw2=torch.zeros(72,18,device=dev); rs=R(P,2); s18=R(18); c72=[R(72) for _ in range(3)]; w2=R(72,18,1,1); y72=R(B,H,W,72); st72=torch.zeros(32*72,dtype=torch.float64,device=dev)
+x72=R(B,H,W,72); dy18=R(B,H,W,18); yr18=R(B,H,W,18); dw3=torch.zeros(18,72,device=dev); s72=R(72); c18=[R(18) for _ in range(3)]
 for it in range(4):
+    # dominant signature of the step: fc3 weight gradient (GELU(BN(.)) operand, BatchNorm-backward on dY)
+    L.hrf_conv_bwd_weight(dy18,18,0,yr18,*c18,x72,H*W*72,W*72,72,1,B,H,W,72,1,1,18,3,s72,s72,None,dw3,None,sp())
     L.hrf_conv_bwd_weight(dy,Cout,0,yr,cA,cB,cC,x,H*W*Cin,W*Cin,Cin,1,B,H,W,Cin,3,1,Cout,2,sc,sh,None,dw,None,sp())
     L.hrf_conv_fwd(x,H*W*Cin,W*Cin,Cin,1,B,H,W,Cin,w,None,3,1,Cout,y,Cout,0,None,None,0,2,sc,sh,None,st,sp())
     L.hrf_conv_bwd_data(dy,Cout,0,yr,cA,cB,cC,w,3,1,Cout,B,H,W,Cin,dx,H*W*Cin,W*Cin,Cin,1,0,1,x,Cin,sc,sh,1,st,sp())
