@@ -521,9 +521,8 @@ struct WgradDenseArgs {
   int gx, gy, sp;                  // logical grid (co groups, n groups, pixel splits), see the XCD mapping below
 };
 
-constexpr int WU = 8;      // k-steps (of 4 pixels) whose loads are issued before the first use
+constexpr int WUMAX = 8;   // k-steps (of 4 pixels) whose loads are issued before the first use
 constexpr int WNW = 8;     // waves per block (512 threads)
-constexpr int WSP = 68;    // LDS pitch of the merge tile (2-way bank aliasing = the 64-lane minimum)
 
 // ACT: activation applied to the X operand (0 none, 1 ReLU, 2 GELU)
 // TAP: 3x3 convolution (pad 1): the N index is n' = ci*9 + tap (the OIHW memory order, so the block's
@@ -531,6 +530,8 @@ constexpr int WSP = 68;    // LDS pitch of the merge tile (2-way bank aliasing =
 // the correspondingly shifted input pixel (exact zero outside the image).
 template <int MT, int NT, bool BNB, int ACT, bool TAP>
 __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a) {
+  constexpr int WU = MT * NT > 16 ? WUMAX / 2 : WUMAX;       // keep the 5x5-tile variants inside 256 VGPRs
+  constexpr int WSP = NT * 16 + 4;                           // LDS pitch of the merge tile (2-way bank aliasing at most)
   __shared__ float sAcc[2 * MT * 16 * WSP];
   __shared__ float sBias[WNW * MT * 16];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -671,9 +672,9 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a)
     bsm += __shfl_xor(bsm, 16); bsm += __shfl_xor(bsm, 32);
     if (lane < 16) sBias[wave * (MT * 16) + 16 * i + lane] = bsm;
   }
-  for (int e = tid; e < MT * 16 * 64; e += 64 * WNW) {
-    const int row = e >> 6, col = e & 63;
-    if (col < NT * 16 && m0 + row < a.Cout && n0 + col < Np)
+  for (int e = tid; e < MT * 16 * NT * 16; e += 64 * WNW) {
+    const int row = e / (NT * 16), col = e - row * (NT * 16);
+    if (m0 + row < a.Cout && n0 + col < Np)
       hrf_atomic_add(&a.dw[(long)(m0 + row) * Np + n0 + col], sAcc[row * WSP + col] + sAcc[MT * 16 * WSP + row * WSP + col]);
   }
   __syncthreads();
@@ -868,9 +869,21 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     d.tf_rowstat = tf_mode == HRF_TF_LN ? tf_rowstat : nullptr;
     d.dw = dw; d.dbias = dbias; d.Cout = Cout; d.Cin = Cin; d.Mpix = a.Mpix;
     d.H = H; d.W = W; d.Ho = a.Ho; d.Wo = a.Wo; d.stride = stride;
-    const int mt = Cout <= 32 ? 2 : 4, nt = (tap3 ? Cin * 9 : Cin) <= 32 ? 2 : 4;   // 16x16 tiles per wave (masked when ragged)
+    // 16x16 tiles per wave in each dimension: the count in {2..5} with the least padding (+ one unit per
+    // extra group, which re-reads the other operand); the 3x3 path keeps {2, 4} (N' = 9*Cin is large)
+    auto pick_tiles = [](int C, bool wide) {
+      const int T = hrf_cdiv(C, 16);
+      if (!wide) return T <= 2 ? 2 : 4;
+      int best = 2, cost = 1 << 30;
+      for (int t = 2; t <= 5; ++t) {
+        const int g = hrf_cdiv(T, t), c = g * t + g;
+        if (c <= cost) { cost = c; best = t; }
+      }
+      return best;
+    };
+    const int mt = pick_tiles(Cout, !tap3), nt = pick_tiles(tap3 ? Cin * 9 : Cin, !tap3);
     d.gyc = hrf_cdiv(tap3 ? Cin * 9 : Cin, 16 * nt);
-    int sp = hrf_cdiv(a.Mpix, 4 * WNW * WU);
+    int sp = hrf_cdiv(a.Mpix, 4 * WNW * WUMAX);
     const int cap2 = g_knob[3] > 0 ? g_knob[3] : 32;        // atomic fan-in per output element
     if (sp > cap2) sp = cap2;
     if (sp < 1) sp = 1;
@@ -887,18 +900,32 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     const int act = tf_mode == HRF_TF_AFFINE_RELU ? 1 : (tf_mode == HRF_TF_AFFINE_GELU ? 2 : 0);
 #define HRF_WD_LAUNCH(MT_, NT_, BNB_, ACT_, TAP_) \
     HRF_LAUNCH((wgrad_dense_kernel<MT_, NT_, BNB_, ACT_, TAP_>), g2, dim3(64 * WNW), 0, stream, d)
-#define HRF_WD_TAP(MT_, NT_, BNB_, ACT_) \
-    if (tap3) { HRF_WD_LAUNCH(MT_, NT_, BNB_, ACT_, true); } else { HRF_WD_LAUNCH(MT_, NT_, BNB_, ACT_, false); }
-#define HRF_WD_ACT(MT_, NT_, BNB_)                        \
-    if (act == 1) { HRF_WD_TAP(MT_, NT_, BNB_, 1) }       \
-    else if (act == 2) { HRF_WD_TAP(MT_, NT_, BNB_, 2) }  \
-    else { HRF_WD_TAP(MT_, NT_, BNB_, 0) }
-#define HRF_WD_BNB(MT_, NT_) \
-    if (cA != nullptr) { HRF_WD_ACT(MT_, NT_, true) } else { HRF_WD_ACT(MT_, NT_, false) }
-    if (mt == 2 && nt == 2) { HRF_WD_BNB(2, 2) }
-    else if (mt == 2) { HRF_WD_BNB(2, 4) }
-    else if (nt == 2) { HRF_WD_BNB(4, 2) }
-    else { HRF_WD_BNB(4, 4) }
+#define HRF_WD_ACT(MT_, NT_, BNB_, TAP_)                           \
+    if (act == 1) { HRF_WD_LAUNCH(MT_, NT_, BNB_, 1, TAP_); }      \
+    else if (act == 2) { HRF_WD_LAUNCH(MT_, NT_, BNB_, 2, TAP_); } \
+    else { HRF_WD_LAUNCH(MT_, NT_, BNB_, 0, TAP_); }
+#define HRF_WD_BNB(MT_, NT_, TAP_) \
+    if (cA != nullptr) { HRF_WD_ACT(MT_, NT_, true, TAP_) } else { HRF_WD_ACT(MT_, NT_, false, TAP_) }
+#define HRF_WD_NT(MT_)                                    \
+    switch (nt) {                                         \
+      case 2: HRF_WD_BNB(MT_, 2, false) break;            \
+      case 3: HRF_WD_BNB(MT_, 3, false) break;            \
+      case 4: HRF_WD_BNB(MT_, 4, false) break;            \
+      default: HRF_WD_BNB(MT_, 5, false) break;           \
+    }
+    if (tap3) {
+      if (mt == 2 && nt == 2) { HRF_WD_BNB(2, 2, true) }
+      else if (mt == 2) { HRF_WD_BNB(2, 4, true) }
+      else if (nt == 2) { HRF_WD_BNB(4, 2, true) }
+      else { HRF_WD_BNB(4, 4, true) }
+    } else {
+      switch (mt) {
+        case 2: HRF_WD_NT(2) break;
+        case 3: HRF_WD_NT(3) break;
+        case 4: HRF_WD_NT(4) break;
+        default: HRF_WD_NT(5) break;
+      }
+    }
     return hrf_check_launch();
   }
   const dim3 grid(gx, gy, splits);
