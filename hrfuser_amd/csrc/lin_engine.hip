@@ -41,6 +41,15 @@ __device__ __forceinline__ hrf_f4 ld_group(const float* p, long off, int nvalid)
   return r;
 }
 
+// uniform (per slab / per tile) choice between the 16-byte and the dword path: `full` is the same for
+// every lane of the block, so this is a scalar branch; a 16-channel tile or 16-deep slab that lies
+// completely inside the row uses one 16-byte access per lane even when the row length is not a
+// multiple of 4 (18, 54, 78 ... channels: only the last, partial tile / slab takes the dword path)
+__device__ __forceinline__ hrf_f4 ld_sel(bool full, const float* p, long off, int nvalid) {
+  if (full) return ld_group<true>(p, off, nvalid);
+  return ld_group<false>(p, off, nvalid);
+}
+
 template <bool V4>
 __device__ __forceinline__ void st_group(float* p, hrf_f4 v, int nvalid) {
   if (V4) {
@@ -91,9 +100,8 @@ __device__ __forceinline__ void flush_moments(const float* sStat, double* stats,
 }
 
 // --------------------------------------------------------------------------------- forward
-// NT = 16-channel output tiles per wave (compile time: the unrolled code carries no guards);
-// V4 = K and N are multiples of 4 (16-byte fragment loads), else dword loads.
-template <int NT, int TF, bool V4>
+// NT = 16-channel output tiles per wave (compile time: the unrolled code carries no guards)
+template <int NT, int TF>
 __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
   __shared__ float sStat[4 * 2 * NT * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,9 +116,10 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int chb = n0w + 16 * t + 4 * q, nval = a.N - chb;
-    acc[t] = ld_group<V4>(a.bias, chb, a.bias != nullptr ? nval : 0);
-    const hrf_f4 r1 = ld_group<V4>(a.res, pc * a.ldR + chb, a.res != nullptr ? nval : 0);
-    const hrf_f4 r2 = ld_group<V4>(a.res2, pc * a.ldR + chb, a.res2 != nullptr ? nval : 0);
+    const bool nfull = n0w + 16 * (t + 1) <= a.N;
+    acc[t] = ld_sel(nfull, a.bias, chb, a.bias != nullptr ? nval : 0);
+    const hrf_f4 r1 = ld_sel(nfull, a.res, pc * a.ldR + chb, a.res != nullptr ? nval : 0);
+    const hrf_f4 r2 = ld_sel(nfull, a.res2, pc * a.ldR + chb, a.res2 != nullptr ? nval : 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[t][r] += r1[r] + r2[r];
   }
@@ -125,12 +134,13 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
       const int kbase = 16 * (kb + s) + 4 * q, kval = a.K - kbase;
-      xa[s] = ld_group<V4>(a.x, xrow + kbase, kval);
-      if (TF != HRF_TF_NONE) { sc[s] = ld_group<V4>(a.tf_scale, kbase, kval); sh[s] = ld_group<V4>(a.tf_shift, kbase, kval); }
+      const bool kfull = 16 * (kb + s + 1) <= a.K;
+      xa[s] = ld_sel(kfull, a.x, xrow + kbase, kval);
+      if (TF != HRF_TF_NONE) { sc[s] = ld_sel(kfull, a.tf_scale, kbase, kval); sh[s] = ld_sel(kfull, a.tf_shift, kbase, kval); }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int n = n0w + 16 * t + j;
-        wv[s][t] = ld_group<V4>(a.w, (long)n * a.K + kbase, n < a.N ? kval : 0);
+        wv[s][t] = ld_sel(kfull, a.w, (long)n * a.K + kbase, n < a.N ? kval : 0);
       }
     }
 #pragma unroll
@@ -150,7 +160,8 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int chb = n0w + 16 * t + 4 * q;
-    st_group<V4>(a.y + (long)pc * a.ldY + a.yoff + chb, acc[t], pixv ? a.N - chb : 0);
+    if (n0w + 16 * (t + 1) <= a.N) st_group<true>(a.y + (long)pc * a.ldY + a.yoff + chb, acc[t], pixv ? a.N - chb : 0);
+    else st_group<false>(a.y + (long)pc * a.ldY + a.yoff + chb, acc[t], pixv ? a.N - chb : 0);
   }
   if (a.stats != nullptr) {
     wave_moments<NT>(sStat, wave, j, q, pixv, n0w, a.N, acc, acc);
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
 }
 
 // --------------------------------------------------------------------------------- backward data
-template <int NT, bool BNB, bool V4>
+template <int NT, bool BNB>
 __global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataArgs a) {
   __shared__ float sStat[4 * 2 * NT * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,8 +185,9 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataArgs a) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int chb = n0w + 16 * t + 4 * q, nval = a.N - chb;
-    xr[t] = ld_group<V4>(a.xraw, pc * a.ldXr + chb, a.epi == 1 ? nval : 0);
-    acc[t] = ld_group<V4>(a.dx, pc * a.ldDx + chb, (a.epi != 1 && a.accumulate) ? nval : 0);
+    const bool nfull = n0w + 16 * (t + 1) <= a.N;
+    xr[t] = ld_sel(nfull, a.xraw, pc * a.ldXr + chb, a.epi == 1 ? nval : 0);
+    acc[t] = ld_sel(nfull, a.dx, pc * a.ldDx + chb, (a.epi != 1 && a.accumulate) ? nval : 0);
   }
 
   const int nslab = (a.K + 15) >> 4;
@@ -186,10 +198,11 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataArgs a) {
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
       const int kbase = 16 * (kb + s) + 4 * q, kval = a.K - kbase;
-      dv[s] = ld_group<V4>(a.dy, drow + kbase, kval);
+      const bool kfull = 16 * (kb + s + 1) <= a.K;
+      dv[s] = ld_sel(kfull, a.dy, drow + kbase, kval);
       if (BNB) {
-        yv[s] = ld_group<V4>(a.yraw, drow + kbase, kval);
-        ca[s] = ld_group<V4>(a.cA, kbase, kval); cb[s] = ld_group<V4>(a.cB, kbase, kval); cc[s] = ld_group<V4>(a.cC, kbase, kval);
+        yv[s] = ld_sel(kfull, a.yraw, drow + kbase, kval);
+        ca[s] = ld_sel(kfull, a.cA, kbase, kval); cb[s] = ld_sel(kfull, a.cB, kbase, kval); cc[s] = ld_sel(kfull, a.cC, kbase, kval);
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -214,7 +227,8 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int chb = n0w + 16 * t + 4 * q, nval = a.N - chb;
-      const hrf_f4 sc = ld_group<V4>(a.tf_scale, chb, nval), sh = ld_group<V4>(a.tf_shift, chb, nval);
+      const bool nfull = n0w + 16 * (t + 1) <= a.N;
+      const hrf_f4 sc = ld_sel(nfull, a.tf_scale, chb, nval), sh = ld_sel(nfull, a.tf_shift, chb, nval);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] *= hrf_act_grad(a.act, fmaf(xr[t][r], sc[r], sh[r]));
     }
@@ -222,7 +236,8 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataArgs a) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int chb = n0w + 16 * t + 4 * q;
-    st_group<V4>(a.dx + (long)pc * a.ldDx + chb, acc[t], pixv ? a.N - chb : 0);
+    if (n0w + 16 * (t + 1) <= a.N) st_group<true>(a.dx + (long)pc * a.ldDx + chb, acc[t], pixv ? a.N - chb : 0);
+    else st_group<false>(a.dx + (long)pc * a.ldDx + chb, acc[t], pixv ? a.N - chb : 0);
   }
   if (a.epi == 1 && a.stats != nullptr) {
     wave_moments<NT>(sStat, wave, j, q, pixv, n0w, a.N, acc, xr);
@@ -245,7 +260,7 @@ inline int pick_ntw(int M, int T) {
 
 }  // namespace
 
-#define HRF_LF_LAUNCH(NT_, TF_, V4_) HRF_LAUNCH((lin_fwd_kernel<NT_, TF_, V4_>), grid, dim3(256), 0, stream, a)
+#define HRF_LF_LAUNCH(NT_, TF_, V4_) HRF_LAUNCH((lin_fwd_kernel<NT_, TF_>), grid, dim3(256), 0, stream, a)
 #define HRF_LF_NT(TF_, V4_)                          \
   switch (ntw) {                                     \
     case 1: HRF_LF_LAUNCH(1, TF_, V4_); break;       \
@@ -254,13 +269,12 @@ inline int pick_ntw(int M, int T) {
     case 5: HRF_LF_LAUNCH(5, TF_, V4_); break;       \
     default: HRF_LF_LAUNCH(9, TF_, V4_); break;      \
   }
-#define HRF_LF_V4(TF_) if (v4) { HRF_LF_NT(TF_, true) } else { HRF_LF_NT(TF_, false) }
+#define HRF_LF_V4(TF_) { HRF_LF_NT(TF_, true) }
 
 int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return -1;
   const int T = (a.N + 15) / 16;
   const int ntw = pick_ntw(a.M, T);
-  const bool v4 = (a.K % 4 == 0) && (a.N % 4 == 0);
   const dim3 grid(hrf_cdiv(a.M, 64), hrf_cdiv(T, ntw));
   switch (a.tf_mode) {
     case HRF_TF_NONE: HRF_LF_V4(HRF_TF_NONE) break;
@@ -273,7 +287,7 @@ int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
   return hrf_check_launch();
 }
 
-#define HRF_LB_LAUNCH(NT_, BNB_, V4_) HRF_LAUNCH((lin_bwd_data_kernel<NT_, BNB_, V4_>), grid, dim3(256), 0, stream, a)
+#define HRF_LB_LAUNCH(NT_, BNB_, V4_) HRF_LAUNCH((lin_bwd_data_kernel<NT_, BNB_>), grid, dim3(256), 0, stream, a)
 #define HRF_LB_NT(BNB_, V4_)                         \
   switch (ntw) {                                     \
     case 1: HRF_LB_LAUNCH(1, BNB_, V4_); break;      \
@@ -282,13 +296,12 @@ int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
     case 5: HRF_LB_LAUNCH(5, BNB_, V4_); break;      \
     default: HRF_LB_LAUNCH(9, BNB_, V4_); break;     \
   }
-#define HRF_LB_V4(BNB_) if (v4) { HRF_LB_NT(BNB_, true) } else { HRF_LB_NT(BNB_, false) }
+#define HRF_LB_V4(BNB_) { HRF_LB_NT(BNB_, true) }
 
 int hrf_lin_bwd_data_launch(const LinBwdDataArgs& a, void* stream) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return -1;
   const int T = (a.N + 15) / 16;
   const int ntw = pick_ntw(a.M, T);
-  const bool v4 = (a.K % 4 == 0) && (a.N % 4 == 0);
   const dim3 grid(hrf_cdiv(a.M, 64), hrf_cdiv(T, ntw));
   if (a.cA != nullptr) { HRF_LB_V4(true) } else { HRF_LB_V4(false) }
   return hrf_check_launch();

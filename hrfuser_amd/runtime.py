@@ -362,8 +362,14 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
         # weight gradients are leaves of the backward graph: issue them on a side lane so they overlap
         # the latency-bound data-gradient chain (operands are never mutated afterwards)
         bgrad = bias.grad if (bias is not None and bias.requires_grad) else None
+        xw, sw = x, strides
+        if isinstance(src, RawInput) and KH == 3:
+            # NCHW network input: the pixel-major weight-gradient kernel wants channel-contiguous rows;
+            # one 6 MB layout copy (torch, capturable) replaces the 207 us strided LDS kernel by ~40 us
+            xw = _keep(x.permute(0, 2, 3, 1).contiguous())
+            sw = _nhwc_strides(B, H, W, Cin)
         ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
-            dy, ldD, doff, yraw, cA, cB, cC, x, *strides, B, H, W, Cin, KH, stride, Cout,
+            dy, ldD, doff, yraw, cA, cB, cC, xw, *sw, B, H, W, Cin, KH, stride, Cout,
             tf, sc, sh, rowstat, weight.grad, bgrad, ctx.stream))
     if not _needs_grad(src):
         return
