@@ -29,14 +29,13 @@ template <int S>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwFwdArgs a) {
   constexpr int TH = DwTile<S>::TH, IH = DwTile<S>::IH, IW = DwTile<S>::IW;
   __shared__ float sIn[IH * IW * CB];
-  __shared__ float sStat[2 * CB];
+  __shared__ float sStat[8 * 2 * CB];                    // per row-group partial moments (no LDS atomics)
   const int tid = threadIdx.x;
   int t = blockIdx.x;
   const int tx = t % a.tilesX; t /= a.tilesX;
   const int ty = t % a.tilesY; const int b = t / a.tilesY;
   const int c0 = blockIdx.y * CB;
   const int oy0 = ty * TH, ox0 = tx * TW;
-  if (tid < 2 * CB) sStat[tid] = 0.f;
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   {
     const int c = tid & 31, cg = c0 + c;
@@ -92,13 +91,15 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwFwdArgs a) {
     }
   }
   if (a.stats) {
-    hrf_atomic_add(&sStat[c], s1);
-    hrf_atomic_add(&sStat[CB + c], s2);
+    sStat[rg * 2 * CB + c] = s1;
+    sStat[rg * 2 * CB + CB + c] = s2;
     __syncthreads();
-    if (tid < CB && c0 + tid < a.C) {
+    if (tid < 2 * CB && c0 + (tid & (CB - 1)) < a.C) {
+      float tot = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) tot += sStat[g * 2 * CB + tid];
       double* st = a.stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.C;
-      hrf_atomic_add(&st[c0 + tid], (double)sStat[tid]);
-      hrf_atomic_add(&st[a.C + c0 + tid], (double)sStat[CB + tid]);
+      hrf_atomic_add(&st[(tid < CB ? 0 : a.C) + c0 + (tid & (CB - 1))], (double)tot);
     }
   }
 }
@@ -117,14 +118,13 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
   // tile over INPUT pixels 8 x 16; staged dY region: S=1 (10 x 18, origin -1), S=2 (5 x 9, origin y0/2)
   constexpr int TH = 8, RH = S == 1 ? 10 : 5, RW = S == 1 ? 18 : 9;
   __shared__ float sD[RH * RW * CB];
-  __shared__ float sStat[2 * CB];
+  __shared__ float sStat[8 * 2 * CB];
   const int tid = threadIdx.x;
   int t = blockIdx.x;
   const int tx = t % a.tilesX; t /= a.tilesX;
   const int ty = t % a.tilesY; const int b = t / a.tilesY;
   const int c0 = blockIdx.y * CB;
   const int y0 = ty * TH, x0 = tx * TW;
-  if (tid < 2 * CB) sStat[tid] = 0.f;
   const int ry0 = S == 1 ? y0 - 1 : y0 / 2, rx0 = S == 1 ? x0 - 1 : x0 / 2;
   const int c = tid & 31, cg = c0 + c;
   const bool cv = cg < a.C;
@@ -198,13 +198,15 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
     }
   }
   if (a.epi == 1 && a.stats) {
-    hrf_atomic_add(&sStat[c], s1);
-    hrf_atomic_add(&sStat[CB + c], s2);
+    sStat[r * 2 * CB + c] = s1;
+    sStat[r * 2 * CB + CB + c] = s2;
     __syncthreads();
-    if (tid < CB && c0 + tid < a.C) {
+    if (tid < 2 * CB && c0 + (tid & (CB - 1)) < a.C) {
+      float tot = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) tot += sStat[g * 2 * CB + tid];
       double* st = a.stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.C;
-      hrf_atomic_add(&st[c0 + tid], (double)sStat[tid]);
-      hrf_atomic_add(&st[a.C + c0 + tid], (double)sStat[CB + tid]);
+      hrf_atomic_add(&st[(tid < CB ? 0 : a.C) + c0 + (tid & (CB - 1))], (double)tot);
     }
   }
 }
@@ -221,14 +223,13 @@ template <int S>
 __global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) {
   constexpr int TH = DwTile<S>::TH, IH = DwTile<S>::IH, IW = DwTile<S>::IW;
   __shared__ float sIn[IH * IW * CB];
-  __shared__ float sAcc[10 * CB];
+  __shared__ float sAcc[8 * 10 * CB];                    // per row-group partials (plain stores, no LDS atomics)
   const int tid = threadIdx.x;
   int t = blockIdx.x;
   const int tx = t % a.tilesX; t /= a.tilesX;
   const int ty = t % a.tilesY; const int b = t / a.tilesY;
   const int c0 = blockIdx.y * CB;
   const int oy0 = ty * TH, ox0 = tx * TW;
-  for (int i = tid; i < 10 * CB; i += 256) sAcc[i] = 0.f;
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   const int c = tid & 31, cg = c0 + c;
   const bool cv = cg < a.C;
@@ -293,14 +294,17 @@ __global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) {
     acc[9] += g;
   }
 #pragma unroll
-  for (int k = 0; k < 10; ++k) hrf_atomic_add(&sAcc[k * CB + c], acc[k]);
+  for (int k = 0; k < 10; ++k) sAcc[(rg * 10 + k) * CB + c] = acc[k];
   __syncthreads();
   const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride;
   for (int i = tid; i < 10 * CB; i += 256) {
     const int k = i / CB, cc2 = c0 + (i % CB);
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) tot += sAcc[g * 10 * CB + i];
     if (cc2 < a.C) {
-      if (k < 9) hrf_atomic_add(&a.dw[cp + cc2 * 9 + k], sAcc[i]);
-      else if (a.dbias) hrf_atomic_add(&a.dbias[cp + cc2], sAcc[i]);
+      if (k < 9) hrf_atomic_add(&a.dw[cp + cc2 * 9 + k], tot);
+      else if (a.dbias) hrf_atomic_add(&a.dbias[cp + cc2], tot);
     }
   }
 }

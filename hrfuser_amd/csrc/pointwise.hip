@@ -319,46 +319,63 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a) {
 
 // adjoint of the bilinear up-sampling written as a gather over the low-res grid (no atomics on the
 // tensor), plus the (sum, sum*ylow) moments for the BatchNorm that precedes the up-sampling.
+// A thread keeps ONE channel for its whole life (C <= 256: 256/C low-res pixels per pass), so the
+// moments accumulate in registers (the first version paid two LDS atomics per element: 31 us).
 __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const float* g, int B, int H, int W, int C,
                                                               const float* ylow, int Hs, int Ws, float* du,
                                                               double* stats) {
   HRF_DYN_SMEM(float, sacc);                              // [2*C]
   for (int i = threadIdx.x; i < 2 * C; i += 256) sacc[i] = 0.f;
-  __syncthreads();
-  const long total = (long)B * Hs * Ws * C;
+  const int cw = C <= 256 ? C : 256, R = C <= 256 ? 256 / C : 1;
+  const int r = threadIdx.x / cw, c0 = threadIdx.x - r * cw;
+  const bool active = r < R;
+  const long npix = (long)B * Hs * Ws;
   const float ry = (float)H / (float)Hs, rx = (float)W / (float)Ws;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const long q = i / C;
+  float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
+  for (long q0 = (long)blockIdx.x * R; q0 < npix; q0 += (long)gridDim.x * R) {
+    const long q = q0 + r;
+    if (!active || q >= npix) continue;
     const int qx = (int)(q % Ws), qy = (int)((q / Ws) % Hs), b = (int)(q / ((long)Ws * Hs));
     // candidate hi-res rows whose i0 or i1 can equal qy: src in (qy-1, qy+1)
     int ylo = (int)floorf(((float)qy - 1.f + 0.5f) * ry - 0.5f) - 1, yhi = (int)ceilf(((float)qy + 1.f + 0.5f) * ry - 0.5f) + 1;
     int xlo = (int)floorf(((float)qx - 1.f + 0.5f) * rx - 0.5f) - 1, xhi = (int)ceilf(((float)qx + 1.f + 0.5f) * rx - 0.5f) + 1;
     ylo = max(ylo, 0); yhi = min(yhi, H - 1); xlo = max(xlo, 0); xhi = min(xhi, W - 1);
-    float acc = 0.f;
-    for (int y = ylo; y <= yhi; ++y) {
-      int y0, y1; float wy;
-      bil_src(y, Hs, H, y0, y1, wy);
-      const float cy = (y0 == qy ? 1.f - wy : 0.f) + (y1 == qy ? wy : 0.f);
-      if (cy == 0.f) continue;
-      for (int x = xlo; x <= xhi; ++x) {
-        int x0, x1; float wx;
-        bil_src(x, Ws, W, x0, x1, wx);
-        const float cx = (x0 == qx ? 1.f - wx : 0.f) + (x1 == qx ? wx : 0.f);
-        if (cx != 0.f) acc = fmaf(cy * cx, g[(((long)b * H + y) * W + x) * C + c], acc);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c = c0 + 256 * j;
+      if (c >= C) break;
+      float acc = 0.f;
+      for (int y = ylo; y <= yhi; ++y) {
+        int y0, y1; float wy;
+        bil_src(y, Hs, H, y0, y1, wy);
+        const float cy = (y0 == qy ? 1.f - wy : 0.f) + (y1 == qy ? wy : 0.f);
+        if (cy == 0.f) continue;
+        for (int x = xlo; x <= xhi; ++x) {
+          int x0, x1; float wx;
+          bil_src(x, Ws, W, x0, x1, wx);
+          const float cx = (x0 == qx ? 1.f - wx : 0.f) + (x1 == qx ? wx : 0.f);
+          if (cx != 0.f) acc = fmaf(cy * cx, g[(((long)b * H + y) * W + x) * C + c], acc);
+        }
       }
+      const long i = q * C + c;
+      du[i] = acc;
+      a1[j] += acc;
+      a2[j] = fmaf(acc, ylow[i], a2[j]);
     }
-    du[i] = acc;
-    hrf_atomic_add(&sacc[c], acc);
-    hrf_atomic_add(&sacc[C + c], acc * ylow[i]);
+  }
+  if (stats == nullptr) return;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c = c0 + 256 * j;
+    if (active && c < C) { hrf_atomic_add(&sacc[c], a1[j]); hrf_atomic_add(&sacc[C + c], a2[j]); }
   }
   __syncthreads();
-  if (stats)
-    for (int c = threadIdx.x; c < C; c += 256) {
-      const size_t cp = (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
-      hrf_atomic_add(&stats[cp + c], (double)sacc[c]);
-      hrf_atomic_add(&stats[cp + C + c], (double)sacc[C + c]);
-    }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const size_t cp = (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
+    hrf_atomic_add(&stats[cp + c], (double)sacc[c]);
+    hrf_atomic_add(&stats[cp + C + c], (double)sacc[C + c]);
+  }
 }
 
 // dst[map[i]] += sum_k scratch[k*copy_stride + i]: folds the replicated parameter-gradient accumulators
@@ -497,9 +514,13 @@ extern "C" int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const 
 
 extern "C" int hrf_bilinear_up_bwd(const float* g, int B, int H, int W, int C, const float* ylow, int Hs, int Ws,
                                    float* du, double* stats, void* stream) {
-  const long total = (long)B * Hs * Ws * C;
-  if (total <= 0) return HRF_OK;
-  HRF_LAUNCH(bilinear_up_bwd_kernel, dim3(ew_grid(total / 2 + 1)), dim3(256), (size_t)2 * C * sizeof(float), stream, g,
+  const long npix = (long)B * Hs * Ws;
+  if (npix * C <= 0) return HRF_OK;
+  if (C > 768) return HRF_ERR_ARG;
+  const int R = C <= 256 ? 256 / C : 1;
+  int grid = hrf_cdiv(npix, R);
+  if (grid > 1024) grid = 1024;
+  HRF_LAUNCH(bilinear_up_bwd_kernel, dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), stream, g,
              B, H, W, C, ylow, Hs, Ws, du, stats);
   return hrf_check_launch();
 }
