@@ -96,7 +96,10 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: the RCCL watchdog thread polls events of earlier (eager) collectives while we
+        # capture; in the default "global" mode such a call from another thread invalidates the capture
+        # ("capturing stream has unjoined work", seen in ~3 of 4 runs with collectives in the graph)
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             self._graph_outs = self._step_impl(x, mods, cots)
         self.graph = g
         return g
