@@ -14,6 +14,8 @@ configs/hrfuser/*_fusion.py:37-48 - restricted to the backbone hot path:
     (decay_mult=0 for `relative_position_bias_table` and `norm` keys) and a device-side step count;
   * the whole step is captured into a hipGraph when possible (launch-bound regime at batch 2).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -95,6 +97,13 @@ class Trainer:
                 self._step_impl(x, mods, cots)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.world > 1 or self.force:
+            # The RCCL watchdog thread is still polling the end events of the warm-up collectives (one
+            # sweep per 100 ms); an event query that lands on the communicator stream after it joined the
+            # capture invalidates the capture ("capturing stream has unjoined work": 3 of 6 runs).  Give
+            # the watchdog time to retire the eager work first (6 of 6 runs pass with the pause).
+            import time
+            time.sleep(float(os.environ.get('HRF_CAPTURE_SETTLE', '1.0')))
         g = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread polls events of earlier (eager) collectives while we
         # capture; in the default "global" mode such a call from another thread invalidates the capture
