@@ -1,22 +1,26 @@
-// fp32 MFMA implicit-GEMM convolution engine for gfx950 (NHWC activations, OIHW weights).
+// C-ABI entry points of every dense convolution / Linear of the HRFuser backbone (forward, backward
+// data, backward weight) for gfx950, NHWC activations, OIHW weights, and two of the engines behind them:
 //
-// Three kernels cover every dense convolution / Linear of the HRFuser backbone and its backward:
-//   conv_fwd      Y[m][n]  = sum_k tf(X)[m@k] * W[n][k]  (+bias)(+res)  (+ per-channel stats)
-//   conv_bwd_data dX[m][n] = sum_k bnbwd(dY)[m@k] * W^T[k][n]           (+act' , stats | +=)
-//   conv_bwd_wgt  dW[co][n'] += sum_pix bnbwd(dY)[pix][co] * tf(X)[pix@n']  (split-K, atomics)
+//   hrf_conv_fwd / hrf_conv_bwd_data dispatch, by shape, to
+//     lin_engine.hip    stride-1 1x1 on channel-contiguous rows: LDS-free row-GEMM kernels
+//     conv3_engine.hip  3x3 with >= 32 input channels: halo-staged engine (fwd, bwd s1, bwd s2 by parity)
+//     this file         everything else (NCHW stem input, strided 3x3 forward, narrow 3x3):
+//                       conv_fwd_kernel / conv_bwd_data_kernel, LDS implicit GEMM, 64x64 tiles
+//   hrf_conv_bwd_weight dispatches to
+//     wgrad_dense_kernel (this file)  1x1 and NHWC 3x3: pixel-major fragments straight from global
+//     conv_bwd_wgt_kernel (this file) the remaining strided/NCHW cases
+//
 // All contractions run on v_mfma_f32_16x16x4_f32 (exact fp32: parity with the fp32 reference is a
 // hard requirement - SURVEY.md 7 "hard parts": bf16/fp16 inputs fail the 1e-3 gate).
 // BatchNorm / LayerNorm / activation are never materialised: the loaders read the producer's RAW
-// output, apply the per-channel affine while staging into LDS and the (expensive, erf-based)
-// activation when the MFMA fragment is read - off the global-load -> LDS critical path; the
-// epilogues emit the per-channel sums the next BatchNorm needs.
+// output and apply the per-channel affine / activation on the fragment ("transform on load"); the
+// epilogues emit the per-channel sums the next BatchNorm needs into 16 replicated accumulators
+// (same-address global atomics serialise at ~25 ns each on MI355X, see include/hrfuser_hip.h).
 //
 // Shape of the problem (HRFuser-T, 2 images/GPU): M = 480..30720 pixels, K = 18..2304, N = 18..576,
-// ~1200 launches per training step, each far too small to fill 256 CUs.  The kernels are therefore
-// built for LATENCY: 64-row tiles (many blocks), 64-deep K steps (few barrier/latency round trips),
-// all global loads of a step issued unconditionally and back-to-back (clamped addresses - a load
-// under a per-element branch costs one dependent memory round trip each), next step prefetched
-// into registers under the current step's MFMAs.
+// ~1200 launches per training step, each far too small to fill 256 CUs: the kernels are built for
+// LATENCY (all global loads of a batch issued unconditionally and back-to-back, compile-time tile
+// counts instead of guards, small code: the instruction cache is cold at every launch).
 //
 // Reference ops replaced: every nn.Conv2d(k=1|3, groups=1) + nn.Linear reached from
 // mmdet/models/backbones/{hrfuser_hrformer_based,hrformer,hrnet,resnet}.py.

@@ -20,6 +20,7 @@ import torch
 
 from . import _lib
 
+_MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
 _FORCE_COLL = os.environ.get('HRF_FORCE_COLLECTIVES', '0') == '1'
 TF_NONE, TF_AFFINE, TF_RELU, TF_GELU, TF_LN = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -146,19 +147,21 @@ class Ctx:
         # capture on ROCm 7.x, and a flat fork/join schedule expresses all the parallelism we need
         if not self.multi or n <= 1 or self.cur is not self.main:
             return [self.cur] * n
-        while len(self._free) < n:
+        m = n if _MAX_LANES <= 0 else min(n, _MAX_LANES)      # HRF_MAX_LANES: fewer streams than siblings
+        while len(self._free) < m:
             self._free.append(self.owner._lane_pool(grow=True))
-        kids = [self._free.pop() for _ in range(n)]
-        for k in kids:
+        uniq = [self._free.pop() for _ in range(m)]
+        for k in uniq:
             k.stream.wait_stream(self.cur.stream)
         if self.record:
-            self.tape.append(('F', self.cur, kids))
-        return kids
+            self.tape.append(('F', self.cur, uniq))
+        return [uniq[i % m] for i in range(n)]
 
     def join(self, kids):
         """The current lane continues after all sibling lanes have finished."""
         if not self.multi or len(kids) <= 1 or kids[0] is self.cur:
             return
+        kids = list(dict.fromkeys(kids))                    # lanes may repeat under HRF_MAX_LANES
         for k in kids:
             self.cur.stream.wait_stream(k.stream)
         if self.record:
