@@ -161,8 +161,47 @@ class Engine:
             self.ps_scratch.zero_()
         self.ps_dirty = False
 
+    # ---- per-step random pools: ONE Bernoulli launch (per drop probability) and one DropPath draw per step
+    # instead of one torch RNG kernel chain per fusion block (every graph node costs ~5 us of host time)
+    def _rng_begin(self):
+        plan = self.__dict__.setdefault('_rng_plan', {})
+        self._rng_pool = {}
+        for key, need in plan.items():
+            kind, p = key
+            if kind == 'mask':
+                pool = torch.empty(need, device=self.device, dtype=torch.float32).bernoulli_(1.0 - p)
+            else:
+                keep = 1.0 - p
+                pool = (torch.rand(need, device=self.device) + keep).floor_().div_(keep)
+            self._rng_pool[key] = [pool, 0]
+        self._rng_need = {}
+
+    def _rng_take(self, kind, p, n, fresh):
+        key = (kind, float(p))
+        self._rng_need[key] = self._rng_need.get(key, 0) + n
+        ent = self._rng_pool.get(key)
+        if ent is not None and ent[1] + n <= ent[0].numel():
+            out = ent[0][ent[1]:ent[1] + n]
+            ent[1] += n
+        else:
+            out = fresh()                       # first training step (sizes unknown yet)
+        self._rng_plan[key] = max(self._rng_plan.get(key, 0), self._rng_need[key])
+        return out
+
+    def dropout_mask(self, shape, p):
+        n = 1
+        for d in shape:
+            n *= d
+        return self._rng_take('mask', p, n, lambda: R._new((n,), self.device).bernoulli_(1.0 - p)).view(shape)
+
+    def droppath_scale(self, B, p):
+        keep = 1.0 - p
+        return self._rng_take('dp', p, B, lambda: (torch.rand(B, device=self.device) + keep).floor_().div_(keep))
+
     def begin_forward(self, training):
         R.release_step_buffers()
+        if training:
+            self._rng_begin()
         self.arena_d.zero_()
         if training:
             self.nbt_flat.add_(1)
@@ -371,7 +410,7 @@ class MultiWindowCrossAttention(nn.Module):
         if ctx.training and a.proj_drop.training and (p > 0 or drop_path_scale is not None):
             mask = None
             if p > 0:
-                mask = R._new((B, H, W, C), dev).bernoulli_(1.0 - p)
+                mask = ctx.owner._engine().dropout_mask((B, H, W, C), p)
             drop = (mask, 1.0 / (1.0 - p) if p > 0 else 1.0, drop_path_scale)
         return R.linear_residual(ctx, o, a.out_proj, acc, res2=z, drop=drop)
 
@@ -399,8 +438,7 @@ class HRFuserFusionBlock(nn.Module):
         p = self.drop_path_prob
         if not (ctx.training and self.training) or p <= 0.0:
             return None
-        keep = 1.0 - p
-        return (torch.rand(B, device=dev) + keep).floor_().div_(keep)
+        return ctx.owner._engine().droppath_scale(B, p)
 
     def run(self, ctx, x, mods):
         if self.with_cp and ctx.record:
@@ -808,7 +846,7 @@ class HRFuserHRFormerBased(HipModule):
         Cout = w.shape[0]
         strides = (H * W * C, W * C, C, 1)
         L.hrf_conv_fwd(x.t, *strides, B, H, W, C, w, None, 3, 1, Cout, out.t, Cout, 0, None, None, 0,
-                       R.TF_NONE, None, None, None, None, s)
+                       R.TF_NONE, None, None, None, None, None, 0.0, s)
         act = R.Act(out.t.view(B, H, W, Cout))
 
         def bwd():

@@ -722,9 +722,10 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
                             const float* w, const float* bias, int KH, int stride, int Cout,
                             float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
                             int tf_mode, const float* tf_scale, const float* tf_shift,
-                            const float* tf_rowstat, double* stats, void* stream) {
+                            const float* tf_rowstat, double* stats, float* ln_rowstat, float ln_eps, void* stream) {
   if ((KH != 1 && KH != 3) || (stride != 1 && stride != 2)) return HRF_ERR_ARG;
   if (tf_mode < 0 || tf_mode > 4) return HRF_ERR_ARG;
+  if (ln_rowstat != nullptr && (ldY != Cout || yoff != 0)) return HRF_ERR_ARG;   // row statistics of a full output row
   if (tf_mode == HRF_TF_LN && (KH != 1 || stride != 1)) return HRF_ERR_ARG;
   ConvFwdArgs a;
   const int pad = KH / 2;
@@ -740,8 +741,9 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     LinFwdArgs l;
     l.x = x; l.ldX = sX; l.w = w; l.bias = bias; l.y = y; l.ldY = ldY; l.yoff = yoff;
     l.res = res; l.res2 = res2; l.ldR = ldR; l.tf_mode = tf_mode; l.tf_scale = tf_scale; l.tf_shift = tf_shift;
-    l.tf_rowstat = tf_rowstat; l.stats = stats; l.M = a.M; l.K = Cin; l.N = Cout;
+    l.tf_rowstat = tf_rowstat; l.stats = stats; l.M = a.M; l.K = Cin; l.N = Cout; l.ln_out = ln_rowstat; l.ln_eps = ln_eps;
     const int rc = hrf_lin_fwd_launch(l, stream);
+    if (rc == HRF_OK && l.ln_out != nullptr && !hrf_lin_fwd_emits_ln(l)) return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream);
     if (rc >= 0) return rc;
   }
   if (KH == 3 && stride == 1 && Cin >= 32 && sC == 1 && sY == W * sX && sB == H * sY && g_knob[6] == 0) {
@@ -749,7 +751,9 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     c.in = x; c.ldIn = sX; c.t0 = tf_scale; c.t1 = tf_shift; c.tf_mode = tf_mode; c.w = w; c.wCin = Cin; c.bias = bias;
     c.out = y; c.ldOut = ldY; c.ooff = yoff; c.res = res; c.res2 = res2; c.ldR = ldR; c.stats = stats;
     c.B = B; c.H = H; c.W = W; c.Cin = Cin; c.Cout = Cout;
-    return hrf_conv3_fwd_launch(c, stream);
+    const int rc3 = hrf_conv3_fwd_launch(c, stream);
+    if (rc3 == HRF_OK && ln_rowstat != nullptr) return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream);
+    return rc3;
   }
   const int nt = pick_nt(Cout);
   if (KH == 1) {
@@ -757,6 +761,7 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
   } else {
     HRF_CF_TF(3)
   }
+  if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();
 }
 
@@ -821,7 +826,9 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
   return hrf_check_launch();
 }
 
+extern "C" int hrf_pw_knob(int key, int value);
 extern "C" int hrf_debug_knob(int key, int value) {
+  if (key >= 16 && key < 20) return hrf_pw_knob(key - 16, value);      // pointwise.hip tuning aids
   if (key < 0 || key >= 8) return HRF_ERR_ARG;
   g_knob[key] = value;
   return HRF_OK;

@@ -9,6 +9,7 @@ struct LinFwdArgs {
   const float* res; const float* res2; int ldR;  // optional residual rows [M][ldR]
   int tf_mode; const float* tf_scale; const float* tf_shift; const float* tf_rowstat;
   double* stats;                                 // [HRF_STAT_COPIES][2*N] or null
+  float* ln_out; float ln_eps;                   // optional LayerNorm (mean, rstd) of the output rows
   int M, K, N;
 };
 
@@ -25,6 +26,7 @@ struct LinBwdDataArgs {
 // Return HRF_OK after enqueueing the launch, or -1 when the shape is not supported (caller falls
 // back to the LDS-tiled implicit-GEMM kernels).
 int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream);
+bool hrf_lin_fwd_emits_ln(const LinFwdArgs& a);       // true when the launch above covers whole rows per wave
 int hrf_lin_bwd_data_launch(const LinBwdDataArgs& a, void* stream);
 
 // ---- conv3_engine.hip: 3x3 / stride-1 / pad-1 convolution (forward and backward-data) on NHWC rows,

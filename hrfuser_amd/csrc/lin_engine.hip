@@ -163,6 +163,24 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
     if (n0w + 16 * (t + 1) <= a.N) st_group<true>(a.y + (long)pc * a.ldY + a.yoff + chb, acc[t], pixv ? a.N - chb : 0);
     else st_group<false>(a.y + (long)pc * a.ldY + a.yoff + chb, acc[t], pixv ? a.N - chb : 0);
   }
+  if (a.ln_out != nullptr && gridDim.y == 1) {
+    // LayerNorm row statistics of the output row (all N channels of pixel j live in this wave: lanes
+    // j, j+16, j+32, j+48 hold 4*NT channels each) - two-pass like ln_stats_kernel
+    float sm = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sm += (16 * t + 4 * q + r < a.N) ? acc[t][r] : 0.f;
+    sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+    const float mu = sm / (float)a.N;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float dd = (16 * t + 4 * q + r < a.N) ? acc[t][r] - mu : 0.f; sq = fmaf(dd, dd, sq); }
+    sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+    if (q == 0 && pixv) { a.ln_out[2 * (long)pix] = mu; a.ln_out[2 * (long)pix + 1] = 1.0f / sqrtf(sq / (float)a.N + a.ln_eps); }
+  }
   if (a.stats != nullptr) {
     wave_moments<NT>(sStat, wave, j, q, pixv, n0w, a.N, acc, acc);
     __syncthreads();
@@ -270,6 +288,12 @@ inline int pick_ntw(int M, int T) {
     default: HRF_LF_LAUNCH(9, TF_, V4_); break;      \
   }
 #define HRF_LF_V4(TF_) { HRF_LF_NT(TF_, true) }
+
+bool hrf_lin_fwd_emits_ln(const LinFwdArgs& a) {
+  if (a.K < 4 || a.N < 4 || a.M <= 0) return false;
+  const int T = (a.N + 15) / 16;
+  return hrf_cdiv(T, pick_ntw(a.M, T)) == 1;
+}
 
 int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return -1;

@@ -182,6 +182,45 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(const float* y1, co
   }
 }
 
+// out = res + rowscale*act(sc1*y1+sh1) (CrossFFN tail) AND the LayerNorm row statistics of `out` for the
+// next block's norm1: 16 lanes per row, lane `sub` owns channels sub, sub+16, ...
+template <int NCH>
+__global__ __launch_bounds__(256) void ffn_tail_kernel(const float* y1, const float* sc1, const float* sh1, const float* res,
+                                                       const float* rowscale, int rows_per_sample, int act, float* out,
+                                                       int rows, int C, float eps, float* rowstat) {
+  const int sub = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool rv = row < rows;
+  const long base = (long)(rv ? row : 0) * C;
+  const float rs = rowscale ? rowscale[(rv ? row : 0) / rows_per_sample] : 1.f;
+  float yv[NCH], rsd[NCH], v[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = sub + 16 * k;
+    const long idx = (rv && c < C) ? base + c : 0;
+    yv[k] = y1[idx];
+    rsd[k] = res ? res[idx] : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = sub + 16 * k;
+    const bool ok = rv && c < C;
+    const int cc = c < C ? c : 0;
+    const float t = rsd[k] + rs * hrf_act(act, fmaf(yv[k], sc1[cc], sh1[cc]));
+    v[k] = ok ? t : 0.f;
+    if (ok) out[base + c] = t;
+    s += v[k];
+  }
+  s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) { const float d = (rv && sub + 16 * k < C) ? v[k] - mean : 0.f; q = fmaf(d, d, q); }
+  q += __shfl_xor(q, 8); q += __shfl_xor(q, 4); q += __shfl_xor(q, 2); q += __shfl_xor(q, 1);
+  if (rv && sub == 0) { rowstat[2 * (long)row] = mean; rowstat[2 * (long)row + 1] = 1.0f / sqrtf(q / (float)C + eps); }
+}
+
 // g = dout * act'(.)  written once; per-channel (sum g, sum g*y_k) for up to three BatchNorms fed by g.
 //   mode 0: mask = out > 0            (ReLU applied last: uses the saved output)
 //   mode 1: g = dout*rowscale*gelu'(sc*y1+sh)   (GELU applied first)
@@ -417,6 +456,8 @@ __global__ void adamw_tick_kernel(float* state, float b1, float b2) {
   }
 }
 
+static int g_pw_knob[4] = {0, 0, 0, 0};      // tuning aids (hrf_debug_knob keys 16..19)
+
 inline int ew_grid(long total) {
   long g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -451,8 +492,8 @@ extern "C" int hrf_ln_bwd(const float* da, const float* x, const float* rowstat,
                           float* dx, int accumulate, float* dgamma, float* dbeta, long copy_stride, void* stream) {
   if (rows <= 0) return HRF_OK;
   if (C > 640) return HRF_ERR_ARG;
-  int grid = hrf_cdiv(hrf_cdiv(rows, 16), 2);
-  if (grid > 1024) grid = 1024;
+  int grid = hrf_cdiv(hrf_cdiv(rows, 16), g_pw_knob[0] > 0 ? g_pw_knob[0] : 2);
+  if (grid > 2048) grid = 2048;
   const int nch = hrf_cdiv(C, 16);
 #define HRF_LNB(N_) HRF_LAUNCH(ln_bwd_kernel<N_>, dim3(grid), dim3(256), 0, stream, da, x, rowstat, gamma, rows, C, dx, \
                                accumulate, dgamma, dbeta, copy_stride)
@@ -464,11 +505,21 @@ extern "C" int hrf_ln_bwd(const float* da, const float* x, const float* rowstat,
 extern "C" int hrf_affine_act_res(const float* y1, const float* sc1, const float* sh1, const float* y2,
                                   const float* sc2, const float* sh2, const float* res, const float* rowscale,
                                   int rows_per_sample, int act, int act_first, float* out, long rows, int C,
-                                  void* stream) {
+                                  float* ln_rowstat, float ln_eps, void* stream) {
   const long total = rows * C;
   if (total <= 0) return HRF_OK;
+  if (ln_rowstat != nullptr && act_first && y2 == nullptr && C <= 640) {
+    const int nch = hrf_cdiv(C, 16);
+    const dim3 grid(hrf_cdiv(rows, 16));
+#define HRF_FT(N_) HRF_LAUNCH(ffn_tail_kernel<N_>, grid, dim3(256), 0, stream, y1, sc1, sh1, res, rowscale, rows_per_sample, act, \
+                              out, (int)rows, C, ln_eps, ln_rowstat)
+    if (nch <= 2) { HRF_FT(2); } else if (nch <= 3) { HRF_FT(3); } else if (nch <= 5) { HRF_FT(5); }
+    else if (nch <= 10) { HRF_FT(10); } else if (nch <= 20) { HRF_FT(20); } else { HRF_FT(40); }
+    return hrf_check_launch();
+  }
   HRF_LAUNCH(affine_act_res_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, y1, sc1, sh1, y2, sc2, sh2, res,
              rowscale, rows_per_sample, act, act_first, out, total, C);
+  if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(out, (int)rows, C, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();
 }
 
@@ -488,8 +539,8 @@ extern "C" int hrf_act_bwd(const float* dout, const float* out, const float* y1,
   if (rows * C <= 0) return HRF_OK;
   if (C > 768) return HRF_ERR_ARG;
   const int R = C <= 256 ? 256 / C : 1;
-  int grid = hrf_cdiv(hrf_cdiv(rows, R), 4);               // ~4 passes per block
-  if (grid > 1024) grid = 1024;
+  int grid = hrf_cdiv(hrf_cdiv(rows, R), g_pw_knob[1] > 0 ? g_pw_knob[1] : 4);   // passes per block
+  if (grid > 2048) grid = 2048;
   HRF_LAUNCH(act_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), stream, dout, out, y1, sc, sh,
              rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, rows, C);
   return hrf_check_launch();
@@ -524,6 +575,8 @@ extern "C" int hrf_bilinear_up_bwd(const float* g, int B, int H, int W, int C, c
              B, H, W, C, ylow, Hs, Ws, du, stats);
   return hrf_check_launch();
 }
+
+extern "C" int hrf_pw_knob(int key, int value) { if (key < 0 || key >= 4) return HRF_ERR_ARG; g_pw_knob[key] = value; return HRF_OK; }
 
 extern "C" int hrf_fold_copies(const float* scratch, long copy_stride, const int* map, float* dst, long n,
                                void* stream) {

@@ -20,6 +20,7 @@ import torch
 
 from . import _lib
 
+LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
 _MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
 _FORCE_COLL = os.environ.get('HRF_FORCE_COLLECTIVES', '0') == '1'
 TF_NONE, TF_AFFINE, TF_RELU, TF_GELU, TF_LN = 0, 1, 2, 3, 4
@@ -29,12 +30,13 @@ _TF2ACT = {TF_NONE: ACT_NONE, TF_AFFINE: ACT_NONE, TF_RELU: ACT_RELU, TF_GELU: A
 
 class Act:
     """A materialised NHWC activation (B,H,W,C) with an explicit gradient slot."""
-    __slots__ = ('t', 'grad', 'needs_grad')
+    __slots__ = ('t', 'grad', 'needs_grad', 'rowstat')
 
     def __init__(self, t, needs_grad=True):
         self.t = t
         self.grad = None
         self.needs_grad = needs_grad
+        self.rowstat = None          # (eps, [rows, 2] (mean, rstd)) when the producer emitted LayerNorm statistics
 
     @property
     def shape(self):
@@ -417,7 +419,7 @@ def conv_bn(ctx, src, conv, bn, mode):
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None
     L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
-                   tf, sc, sh, rowstat, stats, s)
+                   tf, sc, sh, rowstat, stats, None, 0.0, s)
     st = bn_forward(ctx, bn, y, stats)
     out = Lazy(st, mode)
 
@@ -445,7 +447,7 @@ def linear_into(ctx, src, lin, out, off):
     Cout = w.shape[0]
     ld = out.t.shape[-1]
     L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, 1, 1, Cout, out.t, ld, off, None, None, 0,
-                   tf, sc, sh, rowstat, None, s)
+                   tf, sc, sh, rowstat, None, None, 0.0, s)
 
     def bwd():
         _conv_backward(ctx, src, w, b, 1, 1, Cout, out.grad, ld, off, None, None)
@@ -462,13 +464,16 @@ def linear_residual(ctx, o, lin, res, res2=None, drop=None):
     out = Act(_new_like(res.t))
     strides = _nhwc_strides(B, H, W, C)
     if drop is None:
+        # the new residual stream is what the next LayerNorm reads: its row statistics come for free
+        out.rowstat = (LN_EPS, _new((rows, 2), res.t.device))
         L.hrf_conv_fwd(o.t, *strides, B, H, W, C, w, b, 1, 1, C, out.t, C, 0, res.t,
-                       res2.t if res2 is not None else None, C, TF_NONE, None, None, None, None, s)
+                       res2.t if res2 is not None else None, C, TF_NONE, None, None, None, None,
+                       out.rowstat[1], LN_EPS, s)
     else:
         mask, mscale, rowscale = drop
         y = _new_like(res.t)
         L.hrf_conv_fwd(o.t, *strides, B, H, W, C, w, b, 1, 1, C, y, C, 0, None, None, 0,
-                       TF_NONE, None, None, None, None, s)
+                       TF_NONE, None, None, None, None, None, 0.0, s)
         L.hrf_scale_add(y, mask, mscale, rowscale, H * W, res.t, res2.t if res2 is not None else None,
                         out.t, rows, C, s)
 
@@ -502,7 +507,10 @@ def ln_input(ctx, act, ln, cache=None):
     """LayerNorm as a transform-on-load: only the (mean, rstd) row statistics are computed."""
     B, H, W, C = act.t.shape
     key = (id(act), float(ln.eps))
-    if cache is not None and key in cache:
+    pre = getattr(act, 'rowstat', None)
+    if pre is not None and abs(pre[0] - float(ln.eps)) < 1e-12:
+        rowstat = pre[1]                       # emitted by the producing kernel's epilogue
+    elif cache is not None and key in cache:
         rowstat = cache[key]
     else:
         rowstat = _new((B * H * W, 2), act.t.device)
@@ -590,9 +598,13 @@ def materialize(ctx, lazy, act, res=None, lazy2=None, act_first=False, rowscale=
     rows = B * H * W
     out = Act(_new_like(st.raw))
     st2 = lazy2.st if lazy2 is not None else None
+    rs_out = None
+    if act_first:                              # CrossFFN tail = input of the next block's norm1
+        out.rowstat = (LN_EPS, _new((rows, 2), st.raw.device))
+        rs_out = out.rowstat[1]
     L.hrf_affine_act_res(st.raw, st.scale, st.shift, st2.raw if st2 else None, st2.scale if st2 else None,
                          st2.shift if st2 else None, res.t if res is not None else None, rowscale, H * W,
-                         act, 1 if act_first else 0, out.t, rows, C, s)
+                         act, 1 if act_first else 0, out.t, rows, C, rs_out, LN_EPS, s)
 
     def bwd():
         g = _new_like(out.t)

@@ -45,7 +45,7 @@ int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int B, int H, i
                  const float* w, const float* bias, int KH, int stride, int Cout,
                  float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
                  int tf_mode, const float* tf_scale, const float* tf_shift,
-                 const float* tf_rowstat, double* stats, void* stream);
+                 const float* tf_rowstat, double* stats, float* ln_rowstat, float ln_eps, void* stream);
 /* dX (or, epi=1, dU = dX*act'(scale*xraw+shift) plus (sum dU, sum dU*xraw) for the producer BN).
  * (cA,cB,cC) != NULL applies the BatchNorm backward on load: dy = cA*du + cB*yraw + cC.        */
 int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float* yraw,
@@ -119,13 +119,15 @@ int hrf_ln_stats(const float* x, int rows, int C, float eps, float* rowstat, voi
 int hrf_ln_bwd(const float* da, const float* x, const float* rowstat, const float* gamma, int rows, int C,
                float* dx, int accumulate, float* dgamma, float* dbeta, long copy_stride, void* stream);
 
+/* `ln_rowstat` (hrf_conv_fwd, hrf_affine_act_res; nullable): also emit the LayerNorm row statistics
+ * (mean, rstd with ln_eps) of the OUTPUT rows - the consumer's LayerNorm needs no hrf_ln_stats launch. */
 /* ---- BN-apply + activation + residual materialisation and its adjoint ---------------------
  * act: 0 none, 1 ReLU, 2 GELU.  act_first=1: out = res + rowscale[b]*act(sc1*y1+sh1)
  * (CrossFFN tail hrformer.py:371 / DropPath); act_first=0: out = act(sc1*y1+sh1 + res + sc2*y2+sh2)
  * (Bottleneck tail resnet.py:282-300, transition ReLU hrnet.py:438-440).                        */
 int hrf_affine_act_res(const float* y1, const float* sc1, const float* sh1, const float* y2,
                        const float* sc2, const float* sh2, const float* res, const float* rowscale,
-                       int rows_per_sample, int act, int act_first, float* out, long rows, int C,
+                       int rows_per_sample, int act, int act_first, float* out, long rows, int C, float* ln_rowstat, float ln_eps,
                        void* stream);
 /* out = res + res2 + y*mask*mscale*rowscale[b]: nn.Dropout(proj_drop) hrfuser_hrformer_based.py:97
  * and mmcv DropPath hrfuser_hrformer_based.py:301-315 arithmetic (mask / rowscale nullable).    */

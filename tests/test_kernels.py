@@ -83,8 +83,11 @@ def run_conv(case, backend):
     st = (H * W * Cin, W * Cin, Cin, 1)
     yk = torch.zeros(B, Ho, Wo, Cout, device=dev)
     stats = zstat(Cout, dev)
+    lnrs = torch.zeros(B * Ho * Wo, 2, device=dev)      # fused LayerNorm row statistics of the output
     L.hrf_conv_fwd(D(xr), *st, B, H, W, Cin, D(w), D(bias), KH, stride, Cout, yk, Cout, 0, D(res), None, Cout,
-                   tf, D(sc) if tf else None, D(sh) if tf else None, D(rowstat), stats, _lib.stream_ptr())
+                   tf, D(sc) if tf else None, D(sh) if tf else None, D(rowstat), stats, lnrs, 1e-6, _lib.stream_ptr())
+    yr_ = yref.reshape(-1, Cout)
+    assert r(lnrs[:, 0], yr_.mean(-1)) < TOL and r(lnrs[:, 1], (yr_.var(-1, unbiased=False) + 1e-6).rsqrt()) < 1e-4
     assert r(yk, yref) < TOL
     s1, s2 = yref.reshape(-1, Cout).double().sum(0), (yref.reshape(-1, Cout).double() ** 2).sum(0)
     assert r(fold(stats)[:Cout], s1) < TOL and r(fold(stats)[Cout:], s2) < TOL
@@ -92,7 +95,7 @@ def run_conv(case, backend):
     if tf == 0:
         yk2 = torch.zeros_like(yk)
         L.hrf_conv_fwd(D(xraw.contiguous()), Cin * H * W, W, 1, H * W, B, H, W, Cin, D(w), D(bias), KH, stride, Cout,
-                       yk2, Cout, 0, None, None, 0, 0, None, None, None, None, _lib.stream_ptr())
+                       yk2, Cout, 0, None, None, 0, 0, None, None, None, None, None, 0.0, _lib.stream_ptr())
         assert r(yk2, nhwc(y.detach())) < TOL
     # ---- backward
     du, yraw = rn(B, Ho, Wo, Cout), rn(B, Ho, Wo, Cout)
@@ -258,7 +261,7 @@ def run_pointwise(backend):
     n = float(B * H * W)
     L.hrf_bn_finalize(st, D(bn.weight), D(bn.bias), rm, rv, n, 1e-5, 0.1, 1, sc, sh, mean, inv, C, s)
     o = torch.zeros(B, H, W, C, device=dev)
-    L.hrf_affine_act_res(D(y), sc, sh, None, None, None, None, None, 1, 1, 0, o, B * H * W, C, s)
+    L.hrf_affine_act_res(D(y), sc, sh, None, None, None, None, None, 1, 1, 0, o, B * H * W, C, None, 0.0, s)
     assert r(o, out) < TOL and r(rm, bn.running_mean) < TOL and r(rv, bn.running_var) < TOL
     gk = torch.zeros(B, H, W, C, device=dev)
     gst = zstat(C, dev)
@@ -268,9 +271,12 @@ def run_pointwise(backend):
     assert r(cA * gk + cB * D(y) + cC, yq.grad) < TOL and r(dg, bn.weight.grad) < TOL and r(db, bn.bias.grad) < TOL
     # ---- CrossFFN tail: res + rowscale*gelu(bn(y)) and its adjoint
     res, rs = rn(B, H, W, C), torch.tensor([0.0, 1.25])
-    L.hrf_affine_act_res(D(y), sc, sh, None, None, None, D(res), D(rs), H * W, 2, 1, o, B * H * W, C, s)
+    lnr = torch.zeros(B * H * W, 2, device=dev)
+    L.hrf_affine_act_res(D(y), sc, sh, None, None, None, D(res), D(rs), H * W, 2, 1, o, B * H * W, C, lnr, 1e-6, s)
     ref = res + rs.view(B, 1, 1, 1) * F.gelu(y * sc.cpu() + sh.cpu())
     assert r(o, ref) < TOL
+    rr_ = ref.reshape(-1, C)
+    assert r(lnr[:, 0], rr_.mean(-1)) < TOL and r(lnr[:, 1], (rr_.var(-1, unbiased=False) + 1e-6).rsqrt()) < 1e-4
     uq = (y * sc.cpu() + sh.cpu()).requires_grad_(True)
     (F.gelu(uq) * rs.view(B, 1, 1, 1) * gg).sum().backward()
     L.hrf_act_bwd(D(gg), None, D(y), sc, sh, D(rs), H * W, 1, gk, None, None, gst.zero_(), None, None, B * H * W, C, s)
