@@ -21,6 +21,7 @@ def _header_int(name, default):
 
 STAT_COPIES = _header_int('HRF_STAT_COPIES', 16)   # replication of cross-block accumulators (see header)
 
+_RAW_RETURN = ('hrf_rec_end', 'hrf_replay_info')       # return a value, not a status
 _ERR = {1: 'HRF_ERR_ARG (bad argument)', 2: 'HRF_ERR_LAUNCH (kernel launch failed)'}
 
 
@@ -96,6 +97,8 @@ class Lib:
                 else:
                     conv.append(v)
             rc = fn(*conv)
+            if name in _RAW_RETURN:
+                return rc
             if rc != 0:
                 raise HRFuserHipError(f'{name} failed: {_ERR.get(rc, rc)}')
         call.__name__ = name

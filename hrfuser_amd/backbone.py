@@ -158,22 +158,25 @@ class Engine:
         """Sum the replicated accumulators into the gradient arena (one launch per backward)."""
         if self.ps_dirty and self.ps_n:
             L.hrf_fold_copies(self.ps_scratch, self.ps_n, self.ps_map, self.flat_g, self.ps_n, stream)
-            self.ps_scratch.zero_()
+            R.gpu_zero_(self.ps_scratch)
         self.ps_dirty = False
 
     # ---- per-step random pools: ONE Bernoulli launch (per drop probability) and one DropPath draw per step
     # instead of one torch RNG kernel chain per fusion block (every graph node costs ~5 us of host time)
     def _rng_begin(self):
         plan = self.__dict__.setdefault('_rng_plan', {})
-        self._rng_pool = {}
+        pools = self.__dict__.setdefault('_rng_pool', {})
         for key, need in plan.items():
             kind, p = key
+            ent = pools.get(key)
+            if ent is None or ent[0].numel() != need:          # persistent buffers: refilled in place
+                ent = pools[key] = [torch.empty(need, device=self.device, dtype=torch.float32), 0]
             if kind == 'mask':
-                pool = torch.empty(need, device=self.device, dtype=torch.float32).bernoulli_(1.0 - p)
+                ent[0].bernoulli_(1.0 - p)
             else:
                 keep = 1.0 - p
-                pool = (torch.rand(need, device=self.device) + keep).floor_().div_(keep)
-            self._rng_pool[key] = [pool, 0]
+                ent[0].uniform_().add_(keep).floor_().div_(keep)
+            ent[1] = 0
         self._rng_need = {}
 
     def _rng_take(self, kind, p, n, fresh):
@@ -198,13 +201,22 @@ class Engine:
         keep = 1.0 - p
         return self._rng_take('dp', p, B, lambda: (torch.rand(B, device=self.device) + keep).floor_().div_(keep))
 
-    def begin_forward(self, training):
-        R.release_step_buffers()
+    def pre_step(self, training):
+        """The torch-side work of a step (random pools, num_batches_tracked): everything that is NOT a
+        library launch, so that a recorded replay program can be preceded by exactly this call."""
         if training:
             self._rng_begin()
-        self.arena_d.zero_()
-        if training:
             self.nbt_flat.add_(1)
+
+    def begin_forward(self, training, pre=True):
+        R.release_step_buffers()
+        if pre:
+            self.pre_step(training)
+        else:
+            for ent in self.__dict__.get('_rng_pool', {}).values():
+                ent[1] = 0
+            self._rng_need = {}
+        R.gpu_zero_(self.arena_d)
 
     def bn_eval_affine(self, bn):
         key = id(bn)
@@ -789,8 +801,23 @@ class HRFuserHRFormerBased(HipModule):
                 raise AssertionError('camera and modality inputs must share batch and spatial size')
         return self._call_engine((x,) + tuple(x_mod))
 
+    def refresh_inputs(self, inputs):
+        """Channels-last copies of the NCHW network inputs for the stem weight gradient (torch copies:
+        part of the per-step torch-side work, see Engine.pre_step)."""
+        bufs = self.__dict__.setdefault('_nhwc_in', {})
+        for i, t in enumerate(inputs):
+            Bn, C, H, W = t.shape
+            b = bufs.get(i)
+            if b is None or b.shape != (Bn, H, W, C) or b.device != t.device:
+                b = bufs[i] = torch.empty(Bn, H, W, C, device=t.device, dtype=torch.float32)
+            b.copy_(t.permute(0, 2, 3, 1))
+        return bufs
+
     def _wrap_inputs(self, inputs):
-        return [R.RawInput(t, bool(t.requires_grad)) for t in inputs]
+        bufs = {}
+        if self.training and inputs[0].is_cuda:
+            bufs = self.refresh_inputs(inputs)
+        return [R.RawInput(t, bool(t.requires_grad), bufs.get(i)) for i, t in enumerate(inputs)]
 
     def _stem(self, ctx, src, c1, b1, c2, b2, layer):
         y = R.conv_bn(ctx, src, c1, b1, R.TF_RELU)

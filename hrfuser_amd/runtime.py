@@ -28,6 +28,23 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 _TF2ACT = {TF_NONE: ACT_NONE, TF_AFFINE: ACT_NONE, TF_RELU: ACT_RELU, TF_GELU: ACT_GELU}
 
 
+def gpu_add_(dst, g):
+    """dst += g through the library (a torch add_ would not be part of a recorded replay program)."""
+    _lib.lib().hrf_scale_add(g, None, 1.0, None, 1, dst, None, dst, g.numel(), 1, _lib.stream_ptr())
+    return dst
+
+
+def gpu_clone(g):
+    out = _new_like(g)
+    _lib.lib().hrf_scale_add(g, None, 1.0, None, 1, None, None, out, g.numel(), 1, _lib.stream_ptr())
+    return out
+
+
+def gpu_zero_(t):
+    _lib.lib().hrf_memset(t, 0, t.numel() * t.element_size(), _lib.stream_ptr())
+    return t
+
+
 class Act:
     """A materialised NHWC activation (B,H,W,C) with an explicit gradient slot."""
     __slots__ = ('t', 'grad', 'needs_grad', 'rowstat')
@@ -54,7 +71,7 @@ class Act:
         if self.grad is None:
             self.grad = g
         else:
-            self.grad.add_(g)
+            gpu_add_(self.grad, g)
 
 
 class BNState:
@@ -94,10 +111,11 @@ class LNIn:
 
 class RawInput:
     """A network input in its native NCHW layout (read through element strides by the stem conv)."""
-    __slots__ = ('t', 'grad', 'needs_grad')
+    __slots__ = ('t', 'grad', 'needs_grad', 'nhwc')
 
-    def __init__(self, t, needs_grad):
+    def __init__(self, t, needs_grad, nhwc=None):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
+        self.nhwc = nhwc             # optional channels-last copy made by the owner's pre_step()
 
     @property
     def shape(self):
@@ -136,6 +154,12 @@ class Ctx:
         self._side_i = 0
         self._side_used = {}
         self._deferred = []
+        self.recording = bool(getattr(owner, '_hrf_recording', False))
+
+    def _rec_sync(self, src, dst):
+        """While a replay program is being recorded: dst's next launches come after src's launches so far."""
+        if self.recording:
+            self.L.hrf_rec_sync(src.ptr, dst.ptr)
 
     # ---- tape ----------------------------------------------------------------------------------
     def push(self, fn):
@@ -155,6 +179,7 @@ class Ctx:
         uniq = [self._free.pop() for _ in range(m)]
         for k in uniq:
             k.stream.wait_stream(self.cur.stream)
+            self._rec_sync(self.cur, k)
         if self.record:
             self.tape.append(('F', self.cur, uniq))
         return [uniq[i % m] for i in range(n)]
@@ -166,6 +191,7 @@ class Ctx:
         kids = list(dict.fromkeys(kids))                    # lanes may repeat under HRF_MAX_LANES
         for k in kids:
             self.cur.stream.wait_stream(k.stream)
+            self._rec_sync(k, self.cur)
         if self.record:
             self.tape.append(('J', self.cur, kids))
         self._free.extend(kids)
@@ -203,9 +229,11 @@ class Ctx:
             if e[0] == 'J':                     # reverse of a join = fork
                 for k in e[2]:
                     k.stream.wait_stream(e[1].stream)
+                    self._rec_sync(e[1], k)
             elif e[0] == 'F':                   # reverse of a fork = join
                 for k in e[2]:
                     e[1].stream.wait_stream(k.stream)
+                    self._rec_sync(k, e[1])
             else:
                 fn, lane = e
                 with _LaneScope(self, lane):
@@ -216,9 +244,10 @@ class Ctx:
             fns, self._deferred = self._deferred, []
             k = int(os.environ.get('HRF_WGRAD_LANES', '8'))
             lanes = self.fork(k)
-            for i, fn in enumerate(fns):
-                with _LaneScope(self, lanes[i % k]):
-                    fn()
+            for j in range(k):
+                with _LaneScope(self, lanes[j]):
+                    for fn in fns[j::k]:
+                        fn()
             self.join(lanes)
         if self.multi:
             for lane in self._side_used.values():
@@ -371,7 +400,7 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
         if isinstance(src, RawInput) and KH == 3:
             # NCHW network input: the pixel-major weight-gradient kernel wants channel-contiguous rows;
             # one 6 MB layout copy (torch, capturable) replaces the 207 us strided LDS kernel by ~40 us
-            xw = _keep(x.permute(0, 2, 3, 1).contiguous())
+            xw = src.nhwc if src.nhwc is not None else _keep(x.permute(0, 2, 3, 1).contiguous())
             sw = _nhwc_strides(B, H, W, Cin)
         ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
             dy, ldD, doff, yraw, cA, cB, cC, xw, *sw, B, H, W, Cin, KH, stride, Cout,
@@ -494,7 +523,7 @@ def linear_residual(ctx, o, lin, res, res2=None, drop=None):
         # identity paths: the residual streams receive the output gradient unchanged
         if res2 is not None and res2.needs_grad:
             if res2.grad is None and res.grad is None and res.needs_grad:
-                res2.grad = _keep(g.clone())
+                res2.grad = gpu_clone(g)
             else:
                 res2.add_grad(g)
         if res.needs_grad:
@@ -625,9 +654,9 @@ def materialize(ctx, lazy, act, res=None, lazy2=None, act_first=False, rowscale=
             if res is not None and res.needs_grad:
                 # g stays alive as st.du for the producer conv's backward -> never alias it
                 if res.grad is None:
-                    res.grad = _keep(g.clone())
+                    res.grad = gpu_clone(g)
                 else:
-                    res.grad.add_(g)
+                    gpu_add_(res.grad, g)
     ctx.push(bwd)
     return out
 
@@ -666,10 +695,10 @@ def fuse_sum(ctx, dims, terms):
             if kind == 'id':
                 if t.needs_grad:
                     if t.grad is None:
-                        t.grad = g if can_alias else _keep(g.clone())
+                        t.grad = g if can_alias else gpu_clone(g)
                         can_alias = False
                     else:
-                        t.grad.add_(g)
+                        gpu_add_(t.grad, g)
             elif kind == 'same':
                 t.st.du = g
             else:

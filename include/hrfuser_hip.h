@@ -164,6 +164,19 @@ int hrf_adamw(float* p, const float* g, float* m, float* v, const float* wd_mask
               float beta1, float beta2, float eps, float weight_decay, const float* state,
               float grad_scale, void* stream);
 
+/* ---- launch recorder / replayer (one host thread per stream; replaces multi-stream hipGraph replay,
+ * whose host-side enqueue costs ~4.3 us per node on this ROCm).  hrf_rec_begin .. hrf_rec_end record
+ * every kernel launch of the library (while also executing it) plus the fork/join points given by
+ * hrf_rec_sync(src_stream, dst_stream); hrf_rec_end returns a program id > 0; hrf_replay(id) enqueues
+ * the recorded launches with the recorded argument values on the recorded streams.               */
+int hrf_rec_begin(void);
+int hrf_rec_sync(void* src_stream, void* dst_stream);
+int hrf_rec_end(void);
+int hrf_replay(int program);
+int hrf_replay_free(int program);
+int hrf_replay_info(int program, int what);   /* what: 0 launches, 1 streams, 2 events; -1 on error */
+int hrf_memset(void* ptr, int value, long bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
