@@ -104,9 +104,10 @@ class Engine:
         K = _lib.STAT_COPIES                       # replicated accumulators: see include/hrfuser_hip.h
         self.arena_d = torch.zeros(4 * csum * K, device=device, dtype=torch.float64)
         self.arena_f = torch.zeros(7 * csum, device=device, dtype=torch.float32)
+        self.tickets = torch.zeros(2 * (K + 1) * max(1, len(bns)), device=device, dtype=torch.int32)   # fused finalize
         self.slots = {}
         od = of = 0
-        for m in bns:
+        for bi, m in enumerate(bns):
             C = m.num_features
             d = self.arena_d
             f = self.arena_f
@@ -114,7 +115,9 @@ class Engine:
                 stats=d[od:od + 2 * C * K], gstats=d[od + 2 * C * K:od + 4 * C * K],
                 scale=f[of:of + C], shift=f[of + C:of + 2 * C], mean=f[of + 2 * C:of + 3 * C],
                 invstd=f[of + 3 * C:of + 4 * C], cA=f[of + 4 * C:of + 5 * C], cB=f[of + 5 * C:of + 6 * C],
-                cC=f[of + 6 * C:of + 7 * C])
+                cC=f[of + 6 * C:of + 7 * C],
+                tick_f=self.tickets[2 * (K + 1) * bi:2 * (K + 1) * bi + K + 1],
+                tick_b=self.tickets[2 * (K + 1) * bi + K + 1:2 * (K + 1) * (bi + 1)])
             od += 4 * C * K
             of += 7 * C
         # parameter gradients that MANY blocks add into (LayerNorm gamma/beta, depthwise weights/bias)
@@ -873,7 +876,7 @@ class HRFuserHRFormerBased(HipModule):
         Cout = w.shape[0]
         strides = (H * W * C, W * C, C, 1)
         L.hrf_conv_fwd(x.t, *strides, B, H, W, C, w, None, 3, 1, Cout, out.t, Cout, 0, None, None, 0,
-                       R.TF_NONE, None, None, None, None, None, 0.0, s)
+                       R.TF_NONE, None, None, None, None, None, None, 0.0, s)
         act = R.Act(out.t.view(B, H, W, Cout))
 
         def bwd():

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
         hrf_atomic_add(&st[which * a.Cout + ch], (double)sm);
       }
     }
+    if (MODE == 0 && a.fin.ticket != nullptr) hrf_bn_fin_fused(a.fin, a.stats, 64 * NWV, gridDim.x, gridDim.y);
   }
 }
 

@@ -722,7 +722,8 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
                             const float* w, const float* bias, int KH, int stride, int Cout,
                             float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
                             int tf_mode, const float* tf_scale, const float* tf_shift,
-                            const float* tf_rowstat, double* stats, float* ln_rowstat, float ln_eps, void* stream) {
+                            const float* tf_rowstat, double* stats, const hrf_bn_fin_t* bn_fin, float* ln_rowstat,
+                            float ln_eps, void* stream) {
   if ((KH != 1 && KH != 3) || (stride != 1 && stride != 2)) return HRF_ERR_ARG;
   if (tf_mode < 0 || tf_mode > 4) return HRF_ERR_ARG;
   if (ln_rowstat != nullptr && (ldY != Cout || yoff != 0)) return HRF_ERR_ARG;   // row statistics of a full output row
@@ -742,6 +743,8 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     l.x = x; l.ldX = sX; l.w = w; l.bias = bias; l.y = y; l.ldY = ldY; l.yoff = yoff;
     l.res = res; l.res2 = res2; l.ldR = ldR; l.tf_mode = tf_mode; l.tf_scale = tf_scale; l.tf_shift = tf_shift;
     l.tf_rowstat = tf_rowstat; l.stats = stats; l.M = a.M; l.K = Cin; l.N = Cout; l.ln_out = ln_rowstat; l.ln_eps = ln_eps;
+    l.fin = hrf_bn_fin_t{};
+    if (bn_fin != nullptr && stats != nullptr) l.fin = *bn_fin;
     const int rc = hrf_lin_fwd_launch(l, stream);
     if (rc == HRF_OK && l.ln_out != nullptr && !hrf_lin_fwd_emits_ln(l)) return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream);
     if (rc >= 0) return rc;
@@ -751,6 +754,7 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     c.in = x; c.ldIn = sX; c.t0 = tf_scale; c.t1 = tf_shift; c.tf_mode = tf_mode; c.w = w; c.wCin = Cin; c.bias = bias;
     c.out = y; c.ldOut = ldY; c.ooff = yoff; c.res = res; c.res2 = res2; c.ldR = ldR; c.stats = stats;
     c.B = B; c.H = H; c.W = W; c.Cin = Cin; c.Cout = Cout;
+    if (bn_fin != nullptr && stats != nullptr) c.fin = *bn_fin;
     const int rc3 = hrf_conv3_fwd_launch(c, stream);
     if (rc3 == HRF_OK && ln_rowstat != nullptr) return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream);
     return rc3;
@@ -760,6 +764,13 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     if (tf_mode == HRF_TF_LN) { HRF_CF_NT(1, HRF_TF_LN) } else { HRF_CF_TF(1) }
   } else {
     HRF_CF_TF(3)
+  }
+  if (bn_fin != nullptr && stats != nullptr) {            // generic engine: BatchNorm finalize as its own launch
+    if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH;
+    const int rcf = hrf_bn_finalize(stats, bn_fin->gamma, bn_fin->beta, bn_fin->running_mean, bn_fin->running_var, bn_fin->count,
+                                    bn_fin->eps, bn_fin->momentum, bn_fin->update_running, bn_fin->scale, bn_fin->shift,
+                                    bn_fin->mean, bn_fin->invstd, bn_fin->C, stream);
+    if (rcf != HRF_OK) return rcf;
   }
   if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();

@@ -20,7 +20,7 @@ template <int S> struct DwTile {
 };
 
 struct DwFwdArgs {
-  const float* x; const float* w; const float* bias; float* y; double* stats;
+  const float* x; const float* w; const float* bias; float* y; double* stats; hrf_bn_fin_t fin;
   int tf_mode; const float* tf_scale; const float* tf_shift;
   int B, H, W, C, Ho, Wo, tilesX, tilesY;
 };
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwFwdArgs a) {
       double* st = a.stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.C;
       hrf_atomic_add(&st[(tid < CB ? 0 : a.C) + c0 + (tid & (CB - 1))], (double)tot);
     }
+    if (a.fin.ticket != nullptr) hrf_bn_fin_fused(a.fin, a.stats, 256, gridDim.x, gridDim.y);
   }
 }
 
@@ -313,10 +314,12 @@ __global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) {
 
 extern "C" int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias,
                               int stride, int tf_mode, const float* tf_scale, const float* tf_shift, float* y,
-                              double* stats, void* stream) {
+                              double* stats, const hrf_bn_fin_t* bn_fin, void* stream) {
   if (stride != 1 && stride != 2) return HRF_ERR_ARG;
   DwFwdArgs a;
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.tf_mode = tf_mode; a.tf_scale = tf_scale;
+  a.fin = hrf_bn_fin_t{};
+  if (bn_fin != nullptr && stats != nullptr) a.fin = *bn_fin;
   a.tf_shift = tf_shift; a.B = B; a.H = H; a.W = W; a.C = C;
   a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
   const int th = stride == 1 ? 8 : 4;

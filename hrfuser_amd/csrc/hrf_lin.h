@@ -1,6 +1,7 @@
 // Internal interface between conv_engine.hip (C-ABI entry points) and lin_engine.hip (LDS-free
 // "row GEMM" kernels for stride-1 1x1 convolutions / Linear layers on channel-contiguous rows).
 #pragma once
+#include "../../include/hrfuser_hip.h"
 
 struct LinFwdArgs {
   const float* x; int ldX;                       // [M][ldX], K = Cin valid per row
@@ -10,6 +11,7 @@ struct LinFwdArgs {
   int tf_mode; const float* tf_scale; const float* tf_shift; const float* tf_rowstat;
   double* stats;                                 // [HRF_STAT_COPIES][2*N] or null
   float* ln_out; float ln_eps;                   // optional LayerNorm (mean, rstd) of the output rows
+  hrf_bn_fin_t fin;                              // fin.ticket != null: the last block finalises the BatchNorm
   int M, K, N;
 };
 
@@ -42,6 +44,7 @@ struct Conv3Args {
   const float* res; const float* res2; int ldR;
   int accumulate, epi; const float* xraw; int ldXr; const float* esc; const float* esh; int act;
   double* stats;                             // [HRF_STAT_COPIES][2*Cout] or null
+  hrf_bn_fin_t fin;                          // forward: fused BatchNorm finalize (ticket != null)
   int B, H, W, Cin, Cout;                    // output grid; channels of `in` / of `out`
   int Hs, Ws;                                // stride-2 backward only: grid of `in` (the conv's output)
   int tilesX, tilesY;

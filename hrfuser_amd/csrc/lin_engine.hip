@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
     wave_moments<NT>(sStat, wave, j, q, pixv, n0w, a.N, acc, acc);
     __syncthreads();
     flush_moments<NT>(sStat, a.stats, n0w, a.N);
+    if (a.fin.ticket != nullptr) hrf_bn_fin_fused(a.fin, a.stats, 256, gridDim.x, gridDim.y);
   }
 }
 

@@ -20,6 +20,7 @@ import torch
 
 from . import _lib
 
+_FUSE_BN = os.environ.get('HRF_FUSE_BN', '1') != '0'     # BatchNorm finalize inside the producing kernels
 LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
 _MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
 _FORCE_COLL = os.environ.get('HRF_FORCE_COLLECTIVES', '0') == '1'
@@ -341,8 +342,22 @@ def _needs_grad(src):
 
 
 # ----------------------------------------------------------------------------- BatchNorm plumbing
-def bn_forward(ctx, bn, raw, stats):
-    """Turn (raw conv output, accumulated sums) into a BNState with scale/shift on device."""
+def bn_fin_args(ctx, bn, C, rows):
+    """hrf_bn_fin_t for a producer launch, or None when the finalize must stay a separate launch
+    (eval mode, or SyncBN: the moments are all-reduced between producer and finalize)."""
+    if not (ctx.training and bn.training) or (ctx.group is not None and (ctx.world > 1 or _FORCE_COLL)) or not _FUSE_BN:
+        return None
+    slot = ctx.owner._bn_slot(bn)
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    P = _lib._ptr
+    return _lib.BnFin(P(slot['tick_f']), P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var),
+                      P(slot['scale']), P(slot['shift']), P(slot['mean']), P(slot['invstd']),
+                      float(rows * ctx.world), float(bn.eps), float(mom), 1 if bn.track_running_stats else 0, C)
+
+
+def bn_forward(ctx, bn, raw, stats, fused=False):
+    """Turn (raw conv output, accumulated sums) into a BNState with scale/shift on device.
+    fused=True: the producing kernel already ran the finalize (bn_fin_args)."""
     st = BNState()
     C = raw.shape[-1]
     st.bn, st.C, st.raw, st.du, st.coef = bn, C, raw, None, None
@@ -352,8 +367,10 @@ def bn_forward(ctx, bn, raw, stats):
         st.stats, st.gstats = slot['stats'], slot['gstats']
         st.scale, st.shift, st.mean, st.invstd = slot['scale'], slot['shift'], slot['mean'], slot['invstd']
         rows = raw.numel() // C
-        ctx.all_reduce(st.stats)
         st.count = float(rows * ctx.world)
+        if fused:
+            return st
+        ctx.all_reduce(st.stats)
         mom = bn.momentum if bn.momentum is not None else 0.1
         ctx.L.hrf_bn_finalize(st.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, st.count,
                               float(bn.eps), float(mom), 1 if bn.track_running_stats else 0,
@@ -447,9 +464,10 @@ def conv_bn(ctx, src, conv, bn, mode):
     slot = ctx.owner._bn_slot(bn)
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None
+    fin = bn_fin_args(ctx, bn, Cout, B * Ho * Wo)
     L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
-                   tf, sc, sh, rowstat, stats, None, 0.0, s)
-    st = bn_forward(ctx, bn, y, stats)
+                   tf, sc, sh, rowstat, stats, fin, None, 0.0, s)
+    st = bn_forward(ctx, bn, y, stats, fused=fin is not None)
     out = Lazy(st, mode)
 
     def bwd():
@@ -476,7 +494,7 @@ def linear_into(ctx, src, lin, out, off):
     Cout = w.shape[0]
     ld = out.t.shape[-1]
     L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, 1, 1, Cout, out.t, ld, off, None, None, 0,
-                   tf, sc, sh, rowstat, None, None, 0.0, s)
+                   tf, sc, sh, rowstat, None, None, None, 0.0, s)
 
     def bwd():
         _conv_backward(ctx, src, w, b, 1, 1, Cout, out.grad, ld, off, None, None)
@@ -496,13 +514,13 @@ def linear_residual(ctx, o, lin, res, res2=None, drop=None):
         # the new residual stream is what the next LayerNorm reads: its row statistics come for free
         out.rowstat = (LN_EPS, _new((rows, 2), res.t.device))
         L.hrf_conv_fwd(o.t, *strides, B, H, W, C, w, b, 1, 1, C, out.t, C, 0, res.t,
-                       res2.t if res2 is not None else None, C, TF_NONE, None, None, None, None,
+                       res2.t if res2 is not None else None, C, TF_NONE, None, None, None, None, None,
                        out.rowstat[1], LN_EPS, s)
     else:
         mask, mscale, rowscale = drop
         y = _new_like(res.t)
         L.hrf_conv_fwd(o.t, *strides, B, H, W, C, w, b, 1, 1, C, y, C, 0, None, None, 0,
-                       TF_NONE, None, None, None, None, None, 0.0, s)
+                       TF_NONE, None, None, None, None, None, None, 0.0, s)
         L.hrf_scale_add(y, mask, mscale, rowscale, H * W, res.t, res2.t if res2 is not None else None,
                         out.t, rows, C, s)
 
@@ -587,8 +605,9 @@ def dwconv_bn(ctx, src, conv, bn, mode):
     slot = ctx.owner._bn_slot(bn)
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None
-    L.hrf_dwconv_fwd(x, B, H, W, C, w, b, stride, tf, sc, sh, y, stats, s)
-    st = bn_forward(ctx, bn, y, stats)
+    fin = bn_fin_args(ctx, bn, C, B * Ho * Wo)
+    L.hrf_dwconv_fwd(x, B, H, W, C, w, b, stride, tf, sc, sh, y, stats, fin, s)
+    st = bn_forward(ctx, bn, y, stats, fused=fin is not None)
     out = Lazy(st, mode)
 
     def bwd():

@@ -31,6 +31,24 @@
  *     hrf_fold_copies adds the summed copies into the gradient arena. */
 #define HRF_STAT_COPIES 16
 
+/* BatchNorm bookkeeping fused into the kernel that PRODUCES the moments ("last block finalises"):
+ * a producer given one of these runs the arithmetic of hrf_bn_finalize / hrf_bn_bwd_finalize in the block
+ * that arrives last at a two-level ticket (HRF_STAT_COPIES group tickets + 1 master), so the ~660
+ * separate finalize launches of a step disappear (every launch costs ~5.5 us of serialized host time).
+ * `ticket`: HRF_STAT_COPIES+1 unsigned ints, zeroed once by the caller, left at zero by the kernel. */
+typedef struct hrf_bn_fin {
+  unsigned* ticket;
+  const float* gamma; const float* beta; float* running_mean; float* running_var;
+  float* scale; float* shift; float* mean; float* invstd;
+  double count; float eps; float momentum; int update_running; int C;
+} hrf_bn_fin_t;
+typedef struct hrf_bn_bfin {
+  unsigned* ticket;
+  const float* gamma; const float* mean; const float* invstd;
+  float* dgamma; float* dbeta; float* cA; float* cB; float* cC;
+  double count; int train; int C;
+} hrf_bn_bfin_t;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -45,7 +63,7 @@ int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int B, int H, i
                  const float* w, const float* bias, int KH, int stride, int Cout,
                  float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
                  int tf_mode, const float* tf_scale, const float* tf_shift,
-                 const float* tf_rowstat, double* stats, float* ln_rowstat, float ln_eps, void* stream);
+                 const float* tf_rowstat, double* stats, const hrf_bn_fin_t* bn_fin, float* ln_rowstat, float ln_eps, void* stream);
 /* dX (or, epi=1, dU = dX*act'(scale*xraw+shift) plus (sum dU, sum dU*xraw) for the producer BN).
  * (cA,cB,cC) != NULL applies the BatchNorm backward on load: dy = cA*du + cB*yraw + cC.        */
 int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float* yraw,
@@ -72,7 +90,7 @@ int hrf_debug_knob(int key, int value);
  * fuse-down chains hrformer.py:532-541 (stride 2, no bias).  w is (C,1,3,3).                    */
 int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias,
                    int stride, int tf_mode, const float* tf_scale, const float* tf_shift, float* y,
-                   double* stats, void* stream);
+                   double* stats, const hrf_bn_fin_t* bn_fin, void* stream);
 int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const float* cA, const float* cB,
                         const float* cC, const float* w, int stride, int B, int H, int W, int C,
                         float* dx, int accumulate, int epi, const float* xraw, const float* tf_scale,

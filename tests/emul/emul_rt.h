@@ -124,6 +124,8 @@ inline void hrf_atomic_add(double* p, double v) {
   } while (!__atomic_compare_exchange_n(ip, &old, nw, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
 }
 inline float atomicAdd(float* p, float v) { hrf_atomic_add(p, v); return 0.f; }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 inline bool __any(bool p) {
   int v = p ? 1 : 0;

@@ -12,6 +12,31 @@ TOL = 2e-5
 KC = _lib.STAT_COPIES      # cross-block accumulators are replicated (include/hrfuser_hip.h)
 
 
+def make_fin(C, count, dev, g):
+    """hrf_bn_fin_t + its buffers for the fused-finalize checks: (struct, dict of tensors)."""
+    t = dict(ticket=torch.zeros(KC + 1, dtype=torch.int32, device=dev), gamma=(torch.rand(C, generator=g) + 0.5).to(dev),
+             beta=torch.randn(C, generator=g).to(dev), rm=torch.randn(C, generator=g).to(dev),
+             rv=(torch.rand(C, generator=g) + 0.5).to(dev), scale=torch.zeros(C, device=dev), shift=torch.zeros(C, device=dev),
+             mean=torch.zeros(C, device=dev), invstd=torch.zeros(C, device=dev))
+    P = _lib._ptr
+    fin = _lib.BnFin(P(t['ticket']), P(t['gamma']), P(t['beta']), P(t['rm']), P(t['rv']), P(t['scale']), P(t['shift']),
+                     P(t['mean']), P(t['invstd']), float(count), 1e-5, 0.1, 1, C)
+    return fin, t
+
+
+def check_fin(L, stats, t, C, count):
+    """the fused finalize must equal hrf_bn_finalize run on the same moments (and leave the ticket at zero)"""
+    dev = stats.device
+    ref = {k: torch.zeros(C, device=dev) for k in ('scale', 'shift', 'mean', 'invstd')}
+    rm, rv = t['rm0'].clone(), t['rv0'].clone()
+    L.hrf_bn_finalize(stats, t['gamma'], t['beta'], rm, rv, float(count), 1e-5, 0.1, 1, ref['scale'], ref['shift'],
+                      ref['mean'], ref['invstd'], C, _lib.stream_ptr())
+    for k in ref:
+        assert r(t[k], ref[k]) < 1e-6, k
+    assert r(t['rm'], rm) < 1e-6 and r(t['rv'], rv) < 1e-6
+    assert int(t['ticket'].abs().sum()) == 0
+
+
 def zstat(C, dev):
     return torch.zeros(KC * 2 * C, dtype=torch.float64, device=dev)
 
@@ -84,8 +109,11 @@ def run_conv(case, backend):
     yk = torch.zeros(B, Ho, Wo, Cout, device=dev)
     stats = zstat(Cout, dev)
     lnrs = torch.zeros(B * Ho * Wo, 2, device=dev)      # fused LayerNorm row statistics of the output
+    fin, ft = make_fin(Cout, B * Ho * Wo, dev, g)
+    ft['rm0'], ft['rv0'] = ft['rm'].clone(), ft['rv'].clone()
     L.hrf_conv_fwd(D(xr), *st, B, H, W, Cin, D(w), D(bias), KH, stride, Cout, yk, Cout, 0, D(res), None, Cout,
-                   tf, D(sc) if tf else None, D(sh) if tf else None, D(rowstat), stats, lnrs, 1e-6, _lib.stream_ptr())
+                   tf, D(sc) if tf else None, D(sh) if tf else None, D(rowstat), stats, fin, lnrs, 1e-6, _lib.stream_ptr())
+    check_fin(L, stats, ft, Cout, B * Ho * Wo)
     yr_ = yref.reshape(-1, Cout)
     assert r(lnrs[:, 0], yr_.mean(-1)) < TOL and r(lnrs[:, 1], (yr_.var(-1, unbiased=False) + 1e-6).rsqrt()) < 1e-4
     assert r(yk, yref) < TOL
@@ -95,7 +123,7 @@ def run_conv(case, backend):
     if tf == 0:
         yk2 = torch.zeros_like(yk)
         L.hrf_conv_fwd(D(xraw.contiguous()), Cin * H * W, W, 1, H * W, B, H, W, Cin, D(w), D(bias), KH, stride, Cout,
-                       yk2, Cout, 0, None, None, 0, 0, None, None, None, None, None, 0.0, _lib.stream_ptr())
+                       yk2, Cout, 0, None, None, 0, 0, None, None, None, None, None, None, 0.0, _lib.stream_ptr())
         assert r(yk2, nhwc(y.detach())) < TOL
     # ---- backward
     du, yraw = rn(B, Ho, Wo, Cout), rn(B, Ho, Wo, Cout)
@@ -147,8 +175,11 @@ def run_dw(case, backend):
     yk = torch.zeros(B, Ho, Wo, C, device=dev)
     st = zstat(C, dev)
     xr = nhwc(xraw)
+    fin, ft = make_fin(C, B * Ho * Wo, dev, g)
+    ft['rm0'], ft['rv0'] = ft['rm'].clone(), ft['rv'].clone()
     L.hrf_dwconv_fwd(D(xr), B, H, W, C, D(w), D(b), S, tf, D(sc) if tf else None, D(sh) if tf else None, yk, st,
-                     _lib.stream_ptr())
+                     fin, _lib.stream_ptr())
+    check_fin(L, st, ft, C, B * Ho * Wo)
     yr = nhwc(y.detach())
     assert r(yk, yr) < TOL
     assert r(fold(st)[:C], yr.reshape(-1, C).double().sum(0)) < TOL and r(fold(st)[C:], (yr.reshape(-1, C).double() ** 2).sum(0)) < TOL

@@ -21,7 +21,7 @@ L.hrf_debug_knob(5,0)
 def conv(B,H,W,Cin,Cout,tf,stats,res):
     x=R(B,H,W,Cin); w=R(Cout,Cin,1,1); b=R(Cout); y=R(B,H,W,Cout); st=torch.zeros(32*Cout,dtype=torch.float64,device=dev) if stats else None
     sc=R(Cin); sh=R(Cin); rs=R(B*H*W,2); rr=R(B,H,W,Cout) if res else None
-    return lambda: L.hrf_conv_fwd(x,H*W*Cin,W*Cin,Cin,1,B,H,W,Cin,w,b,1,1,Cout,y,Cout,0,rr,None,Cout,tf,sc if tf else None,sh if tf else None,rs if tf==4 else None,st,None,0.0,sp())
+    return lambda: L.hrf_conv_fwd(x,H*W*Cin,W*Cin,Cin,1,B,H,W,Cin,w,b,1,1,Cout,y,Cout,0,rr,None,Cout,tf,sc if tf else None,sh if tf else None,rs if tf==4 else None,st,None,None,0.0,sp())
 def bwdd(B,H,W,Cin,Cout,bnb,epi):
     dy=R(B,H,W,Cout); yr=R(B,H,W,Cout); w=R(Cout,Cin,1,1); dx=R(B,H,W,Cin); xr=R(B,H,W,Cin); sc=R(Cin); sh=R(Cin)
     cA=R(Cout); cB=R(Cout); cC=R(Cout); st=torch.zeros(32*Cin,dtype=torch.float64,device=dev)
