@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
 // branches, not FLOPs or bytes, set the duration of these ~5 us kernels: the instruction cache
 // is cold at every launch).  The 8 waves of a block are merged through LDS with plain ld/st rounds
 // (LDS float atomics run at ~1 lane/clk: measured 45 us for a 64x64 tile) and the block issues ONE
-// coalesced fp32 atomic per output element; the split count is capped at 32 because same-address
+// coalesced fp32 atomic per output element; the split count is capped at 128 because same-address
 // global atomics serialise at ~25 ns each.
 struct WgradDenseArgs {
   const float* dy; int ldD; int doff; const float* yraw;
@@ -906,7 +906,7 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     const int mt = pick_tiles(Cout, !tap3), nt = pick_tiles(tap3 ? Cin * 9 : Cin, !tap3);
     d.gyc = hrf_cdiv(tap3 ? Cin * 9 : Cin, 16 * nt);
     int sp = hrf_cdiv(a.Mpix, 4 * WNW * WUMAX);
-    const int cap2 = g_knob[3] > 0 ? g_knob[3] : 32;        // atomic fan-in per output element
+    const int cap2 = g_knob[3] > 0 ? g_knob[3] : 128;       // atomic fan-in per output element (128 x 25 ns = 3 us tail)
     if (sp > cap2) sp = cap2;
     if (sp < 1) sp = 1;
     const int gxy = hrf_cdiv(Cout, 16 * mt) * d.gyc;
