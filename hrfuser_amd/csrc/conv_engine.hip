@@ -906,7 +906,8 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     const int mt = pick_tiles(Cout, !tap3), nt = pick_tiles(tap3 ? Cin * 9 : Cin, !tap3);
     d.gyc = hrf_cdiv(tap3 ? Cin * 9 : Cin, 16 * nt);
     int sp = hrf_cdiv(a.Mpix, 4 * WNW * WUMAX);
-    const int cap2 = g_knob[3] > 0 ? g_knob[3] : 128;       // atomic fan-in per output element (128 x 25 ns = 3 us tail)
+    // atomic fan-in per output element (128 x 25 ns = 3 us tail); the 3x3 path already has 9x the blocks
+    const int cap2 = g_knob[3] > 0 ? g_knob[3] : (tap3 ? 32 : 128);
     if (sp > cap2) sp = cap2;
     if (sp < 1) sp = 1;
     const int gxy = hrf_cdiv(Cout, 16 * mt) * d.gyc;
