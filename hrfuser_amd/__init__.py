@@ -9,4 +9,7 @@ from .backbone import (HRFuserHRFormerBased, HRFuserFusionBlock, HRFormerBlock, 
                        Bottleneck, CrossFFN, LocalWindowSelfAttention, MultiWindowCrossAttention,
                        WindowMSA, WindowMCA)
 
-__all__ = ['BACKBONES', 'build_backbone', 'HRFuserHRFormerBased']
+from .registry import NECKS                                # noqa: F401,E402
+from .neck import HRFPN, build_neck                        # noqa: F401,E402
+
+__all__ = ['BACKBONES', 'NECKS', 'build_backbone', 'build_neck', 'HRFuserHRFormerBased', 'HRFPN']

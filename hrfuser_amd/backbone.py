@@ -70,6 +70,7 @@ class Engine:
         self.slots = {}
         self.eval_cache = {}
         self.epoch = 0
+        self.keep = []                 # step-lifetime buffers of THIS engine (runtime.use_keep_list)
 
     def ready(self, device):
         params = [p for p in self.root.parameters()]
@@ -212,6 +213,7 @@ class Engine:
             self.nbt_flat.add_(1)
 
     def begin_forward(self, training, pre=True):
+        R.use_keep_list(self.keep)
         R.release_step_buffers()
         if pre:
             self.pre_step(training)
@@ -219,7 +221,8 @@ class Engine:
             for ent in self.__dict__.get('_rng_pool', {}).values():
                 ent[1] = 0
             self._rng_need = {}
-        R.gpu_zero_(self.arena_d)
+        if self.arena_d.numel():
+            R.gpu_zero_(self.arena_d)
 
     def bn_eval_affine(self, bn):
         key = id(bn)

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a) {
 // tensor), plus the (sum, sum*ylow) moments for the BatchNorm that precedes the up-sampling.
 // A thread keeps ONE channel for its whole life (C <= 256: 256/C low-res pixels per pass), so the
 // moments accumulate in registers (the first version paid two LDS atomics per element: 31 us).
-__global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const float* g, int B, int H, int W, int C,
+__global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const float* g, int ldG, int goff, int B, int H, int W, int C,
                                                               const float* ylow, int Hs, int Ws, float* du,
                                                               double* stats) {
   HRF_DYN_SMEM(float, sacc);                              // [2*C]
@@ -393,13 +393,13 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const float* g, in
           int x0, x1; float wx;
           bil_src(x, Ws, W, x0, x1, wx);
           const float cx = (x0 == qx ? 1.f - wx : 0.f) + (x1 == qx ? wx : 0.f);
-          if (cx != 0.f) acc = fmaf(cy * cx, g[(((long)b * H + y) * W + x) * C + c], acc);
+          if (cx != 0.f) acc = fmaf(cy * cx, g[(((long)b * H + y) * W + x) * ldG + goff + c], acc);
         }
       }
       const long i = q * C + c;
       du[i] = acc;
       a1[j] += acc;
-      a2[j] = fmaf(acc, ylow[i], a2[j]);
+      if (ylow != nullptr) a2[j] = fmaf(acc, ylow[i], a2[j]);
     }
   }
   if (stats == nullptr) return;
@@ -414,6 +414,58 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const float* g, in
     const size_t cp = (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
     hrf_atomic_add(&stats[cp + c], (double)sacc[c]);
     hrf_atomic_add(&stats[cp + C + c], (double)sacc[C + c]);
+  }
+}
+
+// out[pix][off + c] = bilinear_up(x)[pix][c]  (align_corners=False; identity copy when Hs == H): the HRFPN
+// concat (hrfpn.py:80-84) written straight into the channel slice of the concatenated row buffer
+__global__ __launch_bounds__(256) void bilinear_up_into_kernel(const float* x, int Hs, int Ws, int C, float* out, int ldOut,
+                                                               int off, int B, int H, int W) {
+  const long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long pix = i / C;
+    const int xx = (int)(pix % W), yy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    int y0, y1, x0, x1; float wy, wx;
+    bil_src(yy, Hs, H, y0, y1, wy);
+    bil_src(xx, Ws, W, x0, x1, wx);
+    const float* base = x + (long)b * Hs * Ws * C + c;
+    const float v00 = base[((long)y0 * Ws + x0) * C], v01 = base[((long)y0 * Ws + x1) * C];
+    const float v10 = base[((long)y1 * Ws + x0) * C], v11 = base[((long)y1 * Ws + x1) * C];
+    const float top = (1.f - wx) * v00 + wx * v01, bot = (1.f - wx) * v10 + wx * v11;   // ATen association
+    out[pix * ldOut + off + c] = (1.f - wy) * top + wy * bot;
+  }
+}
+
+// avg_pool2d(kernel = stride = k) on NHWC rows and its adjoint (hrfpn.py:90-91)
+__global__ __launch_bounds__(256) void avg_pool_kernel(const float* x, int B, int H, int W, int C, int k, float* out) {
+  const int Ho = H / k, Wo = W / k;
+  const long total = (long)B * Ho * Wo * C;
+  const float inv = 1.0f / (float)(k * k);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long q = i / C;
+    const int xo = (int)(q % Wo), yo = (int)((q / Wo) % Ho), b = (int)(q / ((long)Wo * Ho));
+    float s = 0.f;
+    for (int dy = 0; dy < k; ++dy)
+      for (int dx = 0; dx < k; ++dx) s += x[(((long)b * H + yo * k + dy) * W + xo * k + dx) * C + c];
+    out[i] = s * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void avg_pool_bwd_kernel(const float* g, int B, int H, int W, int C, int k, float* dx,
+                                                           int accumulate) {
+  const int Ho = H / k, Wo = W / k;
+  const long total = (long)B * H * W * C;
+  const float inv = 1.0f / (float)(k * k);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long pix = i / C;
+    const int xx = (int)(pix % W), yy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    const int yo = yy / k, xo = xx / k;
+    float v = 0.f;
+    if (yo < Ho && xo < Wo) v = g[(((long)b * Ho + yo) * Wo + xo) * C + c] * inv;   // rows/cols cut off by floor(H/k)
+    dx[i] = accumulate ? dx[i] + v : v;
   }
 }
 
@@ -563,16 +615,38 @@ extern "C" int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const 
   return hrf_check_launch();
 }
 
-extern "C" int hrf_bilinear_up_bwd(const float* g, int B, int H, int W, int C, const float* ylow, int Hs, int Ws,
-                                   float* du, double* stats, void* stream) {
+extern "C" int hrf_bilinear_up_bwd(const float* g, int ldG, int goff, int B, int H, int W, int C, const float* ylow,
+                                   int Hs, int Ws, float* du, double* stats, void* stream) {
   const long npix = (long)B * Hs * Ws;
   if (npix * C <= 0) return HRF_OK;
   if (C > 768) return HRF_ERR_ARG;
   const int R = C <= 256 ? 256 / C : 1;
   int grid = hrf_cdiv(npix, R);
   if (grid > 1024) grid = 1024;
-  HRF_LAUNCH(bilinear_up_bwd_kernel, dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), stream, g,
+  HRF_LAUNCH(bilinear_up_bwd_kernel, dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), stream, g, ldG, goff,
              B, H, W, C, ylow, Hs, Ws, du, stats);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_bilinear_up_into(const float* x, int Hs, int Ws, int C, float* out, int ldOut, int off, int B, int H,
+                                    int W, void* stream) {
+  const long total = (long)B * H * W * C;
+  if (total <= 0) return HRF_OK;
+  HRF_LAUNCH(bilinear_up_into_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, x, Hs, Ws, C, out, ldOut, off, B, H, W);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_avg_pool(const float* x, int B, int H, int W, int C, int k, float* out, void* stream) {
+  if (k < 1 || H / k < 1 || W / k < 1) return HRF_ERR_ARG;
+  const long total = (long)B * (H / k) * (W / k) * C;
+  HRF_LAUNCH(avg_pool_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, x, B, H, W, C, k, out);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_avg_pool_bwd(const float* g, int B, int H, int W, int C, int k, float* dx, int accumulate, void* stream) {
+  if (k < 1 || H / k < 1 || W / k < 1) return HRF_ERR_ARG;
+  const long total = (long)B * H * W * C;
+  HRF_LAUNCH(avg_pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, g, B, H, W, C, k, dx, accumulate);
   return hrf_check_launch();
 }
 

@@ -1,0 +1,163 @@
+"""HRFPN neck on the HIP engine - the immediate consumer of the backbone's four maps.
+
+Drop-in for mmdet's `HRFPN` (mmdet/models/necks/hrfpn.py:12-100): same registry name, constructor
+keywords, `forward(inputs) -> tuple[num_outs]` contract and state-dict keys (`reduction_conv.conv.*`,
+`fpn_convs.{i}.conv.*`).  Data path on the device:
+
+  up-sample + concat  : hrf_bilinear_up_into  - each branch written straight into its channel slice of ONE
+                        NHWC row buffer [B*H*W][sum(in_channels)] (no separate interpolate outputs, no cat)
+  reduction 1x1 conv  : hrf_conv_fwd          - row GEMM over the concatenated rows, bias in the accumulators
+  average pyramid     : hrf_avg_pool          - k = 2, 4, 8, ... on the reduced rows
+  3x3 output convs    : hrf_conv_fwd          - halo-tiled MFMA kernel, one lane per pyramid level
+
+and the reverse tape mirrors it (weight gradients on the deferred side phase, like the backbone).
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import runtime as R
+from .backbone import HipModule, _BackboneFn
+from .registry import NECKS
+
+
+class _ConvModule(nn.Module):
+    """mmcv ConvModule(norm_cfg=None, act_cfg=None): a biased nn.Conv2d under the attribute `conv`
+    (hrfpn.py:53-70) - parameter container only, the launches are issued by HRFPN._run."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=True)
+
+
+def _conv_bias(ctx, x, conv):
+    """Act -> Act: dense k=1|3 convolution with bias, no normalisation, no activation."""
+    L, s = ctx.L, ctx.stream
+    B, H, W, C = x.t.shape
+    w, b = conv.weight, conv.bias
+    Cout, KH, stride = w.shape[0], w.shape[2], conv.stride[0]
+    Ho, Wo = R._conv_out_hw(H, W, KH, stride)
+    out = R.Act(R._new((B, Ho, Wo, Cout), x.t.device))
+    strides = R._nhwc_strides(B, H, W, C)
+    L.hrf_conv_fwd(x.t, *strides, B, H, W, C, w, b, KH, stride, Cout, out.t, Cout, 0, None, None, 0,
+                   R.TF_NONE, None, None, None, None, None, None, 0.0, s)
+
+    def bwd():
+        if out.grad is not None:
+            R._conv_backward(ctx, x, w, b, KH, stride, Cout, out.grad, Cout, 0, None, None)
+    ctx.push(bwd)
+    return out
+
+
+@NECKS.register_module()
+class HRFPN(HipModule):
+    """HRFPN (hrfpn.py:12-100).  `inputs`: the backbone's list of `num_ins` logical-NCHW maps, branch i at
+    1/2**i of branch 0's resolution; returns a tuple of `num_outs` logical-NCHW maps (channels-last memory)."""
+
+    def __init__(self, in_channels, out_channels, num_outs=5, pooling_type='AVG', conv_cfg=None, norm_cfg=None,
+                 with_cp=False, stride=1, init_cfg=dict(type='Caffe2Xavier', layer='Conv2d')):
+        super().__init__()
+        assert isinstance(in_channels, list)                                  # hrfpn.py:43
+        if conv_cfg is not None or norm_cfg is not None:
+            raise NotImplementedError('HRFPN on the HIP engine: conv_cfg / norm_cfg must be None '
+                                      '(every HRFuser config leaves them unset, hrfpn.py:38-39)')
+        if pooling_type == 'MAX':
+            raise NotImplementedError('HRFPN on the HIP engine implements pooling_type="AVG" (the default and '
+                                      'what every HRFuser config uses); MAX pooling is not built')
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_ins = len(in_channels)
+        self.num_outs = num_outs
+        self.with_cp = with_cp                    # activation checkpointing: accepted, a no-op here
+        self.conv_cfg, self.norm_cfg = conv_cfg, norm_cfg
+        self.init_cfg = init_cfg
+        self.reduction_conv = _ConvModule(sum(in_channels), out_channels, 1)
+        self.fpn_convs = nn.ModuleList(_ConvModule(out_channels, out_channels, 3, stride, 1)
+                                       for _ in range(num_outs))
+
+    def init_weights(self):
+        """mmcv caffe2_xavier_init = kaiming_uniform(a=1, fan_in, leaky_relu), bias 0 (init_cfg, hrfpn.py:41)."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1, mode='fan_in', nonlinearity='leaky_relu')
+                nn.init.constant_(m.bias, 0)
+        self.params_updated()
+
+    # -- execution ----------------------------------------------------------------------------------
+    def forward(self, inputs):
+        assert len(inputs) == self.num_ins                                    # hrfpn.py:79
+        inputs = tuple(t.float() for t in inputs)
+        B, _, H, W = inputs[0].shape
+        for i, t in enumerate(inputs):
+            if t.shape[0] != B or t.shape[1] != self.in_channels[i]:
+                raise RuntimeError(f'HRFPN input {i}: expected ({B}, {self.in_channels[i]}, H, W), got {tuple(t.shape)}')
+            if (t.shape[2] << i, t.shape[3] << i) != (H, W):
+                # torch.cat in the reference raises for the same inputs (hrfpn.py:84)
+                raise RuntimeError(f'Sizes of tensors must match except in dimension 1: input {i} up-sampled by '
+                                   f'{1 << i} is {(t.shape[2] << i, t.shape[3] << i)}, expected {(H, W)}')
+        anchor = None
+        if torch.is_grad_enabled():
+            anchor = self.__dict__.get('_hrf_anchor')
+            if anchor is None or anchor.device != inputs[0].device:
+                anchor = torch.zeros(1, device=inputs[0].device, requires_grad=True)
+                self.__dict__['_hrf_anchor'] = anchor
+        return tuple(_BackboneFn.apply(self, anchor, *inputs))
+
+    def _wrap_inputs(self, inputs):
+        # the backbone hands over channels-last memory: this permute+contiguous is then a view, not a copy
+        return [R.Act(t.permute(0, 2, 3, 1).contiguous(), bool(t.requires_grad)) for t in inputs]
+
+    def _run(self, ctx, srcs):
+        L, s = ctx.L, ctx.stream
+        B, H, W, _ = srcs[0].t.shape
+        dev = srcs[0].t.device
+        Csum = sum(self.in_channels)
+        cat = R.Act(R._new((B, H, W, Csum), dev))
+        off, spans = 0, []
+        for a in srcs:                                                        # hrfpn.py:80-84
+            _, Hs, Ws, C = a.t.shape
+            L.hrf_bilinear_up_into(a.t, Hs, Ws, C, cat.t, Csum, off, B, H, W, s)
+            spans.append((a, off, Hs, Ws, C))
+            off += C
+
+        def bwd_cat():
+            if cat.grad is None:
+                return
+            for a, o, Hs, Ws, C in spans:
+                if not a.needs_grad:
+                    continue
+                du = R._new((B, Hs, Ws, C), dev)
+                ctx.L.hrf_bilinear_up_bwd(cat.grad, Csum, o, B, H, W, C, None, Hs, Ws, du, None, ctx.stream)
+                a.add_grad(du)
+        ctx.push(bwd_cat)
+
+        red = _conv_bias(ctx, cat, self.reduction_conv.conv)                  # hrfpn.py:85-88
+        levels = [red]
+        for i in range(1, self.num_outs):                                     # hrfpn.py:89-91
+            k = 1 << i
+            if H // k < 1 or W // k < 1:
+                raise RuntimeError(f'HRFPN level {i}: avg_pool2d kernel {k} is larger than the {H}x{W} map')
+            p = R.Act(R._new((B, H // k, W // k, self.out_channels), dev))
+            L.hrf_avg_pool(red.t, B, H, W, self.out_channels, k, p.t, s)
+
+            def bwd_pool(p=p, k=k):
+                if p.grad is None:
+                    return
+                g, acc = red.grad_target()
+                ctx.L.hrf_avg_pool_bwd(p.grad, B, H, W, self.out_channels, k, g, acc, ctx.stream)
+            ctx.push(bwd_pool)
+            levels.append(p)
+        # hrfpn.py:92-100 - the pyramid levels are independent: one lane each (level 0 is 3/4 of the work,
+        # the small levels fill the CUs its tail leaves idle)
+        outs = [None] * self.num_outs
+        lanes = ctx.fork(self.num_outs)
+        for i in range(self.num_outs):
+            with ctx.on(lanes[i]):
+                outs[i] = _conv_bias(ctx, levels[i], self.fpn_convs[i].conv)
+        ctx.join(lanes)
+        return outs
+
+
+def build_neck(cfg):
+    """mmdet.models.builder.build_neck (builder.py:23-25)."""
+    return NECKS.build(cfg)

@@ -62,6 +62,7 @@ def _resolve():
 
 BACKBONES, USING_MMDET = _resolve()
 MODELS = BACKBONES
+NECKS = MODELS            # mmdet 2.19: BACKBONES = NECKS = ... = MODELS (mmdet/models/builder.py:7-15)
 
 
 def build_backbone(cfg):

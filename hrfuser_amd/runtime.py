@@ -225,6 +225,7 @@ class Ctx:
     def run_backward(self):
         tape = self.tape
         self.tape = []
+        use_keep_list(self.owner._engine().keep)
         if self.multi:
             self.main.stream.wait_stream(torch.cuda.current_stream())
         while tape:
@@ -291,9 +292,16 @@ class _LaneScope:
         return False
 
 
-# Tensors created inside ops are kept alive until the next forward of ANY engine begins: with
+# Tensors created inside ops are kept alive until the next forward of the SAME engine begins: with
 # several lanes a buffer may still be read on a sibling stream after its Python owner dropped it.
+# Each engine (backbone, neck, a block harness) owns its list; the one in use is switched at the start
+# of its forward / backward so that a neck step never drops the backbone's buffers.
 _KEEP = []
+
+
+def use_keep_list(lst):
+    global _KEEP
+    _KEEP = lst
 
 
 def _keep(t):
@@ -725,6 +733,6 @@ def fuse_sum(ctx, dims, terms):
             else:
                 st = t.st
                 st.du = _new_like(st.raw)
-                L.hrf_bilinear_up_bwd(g, B, H, W, C, st.raw, st.raw.shape[1], st.raw.shape[2], st.du, st.gstats, s)
+                L.hrf_bilinear_up_bwd(g, C, 0, B, H, W, C, st.raw, st.raw.shape[1], st.raw.shape[2], st.du, st.gstats, s)
     ctx.push(bwd)
     return out

@@ -168,8 +168,18 @@ int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const float* sh0,
                  int type3, const float* p3, const float* sc3, const float* sh3, int Hs3, int Ws3,
                  float* out, int B, int H, int W, int C, void* stream);
 /* adjoint of the bilinear up-sampling (gather form) + (sum du, sum du*ylow) moments              */
-int hrf_bilinear_up_bwd(const float* g, int B, int H, int W, int C, const float* ylow, int Hs, int Ws,
+int hrf_bilinear_up_bwd(const float* g, int ldG, int goff, int B, int H, int W, int C, const float* ylow, int Hs, int Ws,
                         float* du, double* stats, void* stream);
+
+/* ---- HRFPN neck pieces (mmdet/models/necks/hrfpn.py:77-100) --------------------
+ * hrf_bilinear_up_into: out[pix][off + c] = F.interpolate(x, size=(H,W), mode='bilinear')[pix][c]
+ *   (align_corners=False; a plain copy when Hs == H): the up-sample + channel concat in one pass;
+ *   its adjoint is hrf_bilinear_up_bwd reading the concat gradient through (ldG, goff).
+ * hrf_avg_pool / hrf_avg_pool_bwd: F.avg_pool2d(kernel_size = stride = k) on NHWC rows.         */
+int hrf_bilinear_up_into(const float* x, int Hs, int Ws, int C, float* out, int ldOut, int off, int B, int H, int W,
+                         void* stream);
+int hrf_avg_pool(const float* x, int B, int H, int W, int C, int k, float* out, void* stream);
+int hrf_avg_pool_bwd(const float* g, int B, int H, int W, int C, int k, float* dx, int accumulate, void* stream);
 
 /* ---- fused flat-buffer AdamW (configs/hrfuser: AdamW lr 3e-4, wd 0.01, decay_mult 0 masks) ---
  * state = float[4] on device: {1-b1^t, 1-b2^t, t, -}; hrf_adamw_tick advances t on device so a

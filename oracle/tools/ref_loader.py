@@ -137,6 +137,21 @@ def _constant_init(module, val, bias=0.):
         nn.init.constant_(module.bias, bias)
 
 
+class _ConvModule(nn.Module):
+    """mmcv.cnn.ConvModule reduced to what the reference HRFPN uses (norm_cfg=None, act_cfg=None):
+    a biased nn.Conv2d under the attribute name `conv` (mmcv: bias='auto' -> True without a norm)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, conv_cfg=None, norm_cfg=None,
+                 act_cfg=dict(type='ReLU'), **kw):
+        super().__init__()
+        assert norm_cfg is None and act_cfg is None and not kw, 'stand-in covers the HRFPN use only'
+        self.conv = _build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
+                                      padding=padding, bias=True)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
 def _mod(name, **attrs):
     m = types.ModuleType(name)
     m.__dict__.update(attrs)
@@ -160,7 +175,7 @@ def install():
     _mod('mmcv.cnn', build_conv_layer=_build_conv_layer, build_norm_layer=_build_norm_layer,
          build_activation_layer=_build_activation_layer, build_plugin_layer=None,
          constant_init=_constant_init, trunc_normal_init=_trunc_normal_init,
-         kaiming_init=None, MODELS=_Registry('model'))
+         kaiming_init=None, MODELS=_Registry('model'), ConvModule=_ConvModule)
     _mod('mmcv.cnn.bricks')
     _mod('mmcv.cnn.bricks.transformer', build_dropout=_build_dropout)
     _mod('mmcv.runner', BaseModule=_BaseModule, Sequential=_Sequential,
@@ -239,3 +254,13 @@ def build_reference(cfg_name_or_dict):
     cfg = backbone_cfg(cfg_name_or_dict) if isinstance(cfg_name_or_dict, str) \
         else copy.deepcopy(cfg_name_or_dict)
     return BACKBONES.build(cfg)
+
+
+def build_reference_hrfpn(**kw):
+    """The unmodified reference neck (mmdet/models/necks/hrfpn.py) on the mmcv stand-in."""
+    install()
+    if 'mmdet.models.necks' not in sys.modules:
+        pkg = _mod('mmdet.models.necks')
+        pkg.__path__ = [os.path.join(REF_ROOT, 'mmdet/models/necks')]
+    mod = importlib.import_module('mmdet.models.necks.hrfpn')
+    return mod.HRFPN(**kw)

@@ -371,17 +371,17 @@ def run_pointwise(backend):
     assert r(gk, x0.grad) < TOL
     assert r(fold(st3)[C:], (x0.grad.reshape(-1, C).double() * ysame.detach().reshape(-1, C).double()).sum(0)) < TOL
     du, stl = torch.zeros(B, 6, 10, C, device=dev), zstat(C, dev)
-    L.hrf_bilinear_up_bwd(gk, B, H, W, C, D(ylo), 6, 10, du, stl, s)
+    L.hrf_bilinear_up_bwd(gk, C, 0, B, H, W, C, D(ylo), 6, 10, du, stl, s)
     assert r(du * D(scs[0]), ylo.grad) < TOL and r(fold(stl)[:C], du.reshape(-1, C).double().sum(0)) < TOL
     du2 = torch.zeros(B, 3, 5, C, device=dev)
-    L.hrf_bilinear_up_bwd(gk, B, H, W, C, D(ylo2), 3, 5, du2, None, s)
+    L.hrf_bilinear_up_bwd(gk, C, 0, B, H, W, C, D(ylo2), 3, 5, du2, None, s)
     assert r(du2 * D(scs[1]), ylo2.grad) < TOL
     ylo3 = rn(1, 8, 4, C).requires_grad_(True)
     ref3 = F.interpolate(ylo3.permute(0, 3, 1, 2), size=(15, 7), mode='bilinear', align_corners=False).permute(0, 2, 3, 1)
     g3 = rn(1, 15, 7, C)
     ref3.backward(g3)
     du3 = torch.zeros(1, 8, 4, C, device=dev)
-    L.hrf_bilinear_up_bwd(D(g3), 1, 15, 7, C, D(ylo3), 8, 4, du3, None, s)
+    L.hrf_bilinear_up_bwd(D(g3), C, 0, 1, 15, 7, C, None, 8, 4, du3, None, s)
     o3 = torch.zeros(1, 15, 7, C, device=dev)
     one, zero = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     L.hrf_fuse_sum(3, D(ylo3), one, zero, 8, 4, 0, None, None, None, 0, 0, 0, None, None, None, 0, 0, 0, None, None,
