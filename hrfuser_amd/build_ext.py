@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, 'libhrfuser_hip.so')
-SOURCES = ['conv_engine.hip', 'lin_engine.hip', 'conv3_engine.hip', 'dwconv.hip', 'attention.hip', 'pointwise.hip', 'replay.hip']
+SOURCES = ['conv_engine.hip', 'lin_engine.hip', 'conv3_engine.hip', 'conv3w_engine.hip', 'dwconv.hip', 'attention.hip', 'pointwise.hip', 'replay.hip']
 HEADERS = ['hrf_rt.h', 'hrf_common.h', 'hrf_lin.h', 'hrf_replay.h', os.path.join(ROOT, 'include', 'hrfuser_hip.h')]
 ARCH = 'gfx950'
 

@@ -437,6 +437,18 @@ __global__ __launch_bounds__(256) void bilinear_up_into_kernel(const float* x, i
   }
 }
 
+// dst[row][c] (+)= src[row][off + c]: a channel slice of wider rows (adjoint of the identity branch of the HRFPN concat)
+__global__ __launch_bounds__(256) void slice_cols_kernel(const float* src, int ld, int off, long rows, int C, float* dst,
+                                                         int accumulate) {
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    const float v = src[row * ld + off + c];
+    dst[i] = accumulate ? dst[i] + v : v;
+  }
+}
+
 // avg_pool2d(kernel = stride = k) on NHWC rows and its adjoint (hrfpn.py:90-91)
 __global__ __launch_bounds__(256) void avg_pool_kernel(const float* x, int B, int H, int W, int C, int k, float* out) {
   const int Ho = H / k, Wo = W / k;
@@ -633,6 +645,13 @@ extern "C" int hrf_bilinear_up_into(const float* x, int Hs, int Ws, int C, float
   const long total = (long)B * H * W * C;
   if (total <= 0) return HRF_OK;
   HRF_LAUNCH(bilinear_up_into_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, x, Hs, Ws, C, out, ldOut, off, B, H, W);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_slice_cols(const float* src, int ld, int off, long rows, int C, float* dst, int accumulate, void* stream) {
+  const long total = rows * C;
+  if (total <= 0) return HRF_OK;
+  HRF_LAUNCH(slice_cols_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, src, ld, off, rows, C, dst, accumulate);
   return hrf_check_launch();
 }
 

@@ -12,6 +12,8 @@ keywords, `forward(inputs) -> tuple[num_outs]` contract and state-dict keys (`re
 
 and the reverse tape mirrors it (weight gradients on the deferred side phase, like the backbone).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -19,6 +21,9 @@ from . import _lib
 from . import runtime as R
 from .backbone import HipModule, _BackboneFn
 from .registry import NECKS
+
+
+_WIDE = os.environ.get('HRF_NECK_WIDE', '1') != '0'       # 0: route the 3x3 convolutions through hrf_conv_fwd instead
 
 
 class _ConvModule(nn.Module):
@@ -30,12 +35,49 @@ class _ConvModule(nn.Module):
         self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=True)
 
 
+def _conv3_wide(ctx, x, conv):
+    """3x3 / stride-1 convolution with Cin % 32 == 0 and Cout % 64 == 0 on the packed-weight MFMA engine
+    (conv3w_engine.hip): forward and backward-data are the same kernel on the two packings of the weights."""
+    L, s = ctx.L, ctx.stream
+    B, H, W, C = x.t.shape
+    w, b = conv.weight, conv.bias
+    Cout = w.shape[0]
+    out = R.Act(R._new((B, H, W, Cout), x.t.device))
+    wp = R._new((9 * Cout * C,), x.t.device)
+    L.hrf_conv3_pack(w, Cout, C, 0, wp, s)
+    L.hrf_conv3_packed(x.t, C, wp, b, out.t, Cout, 0, B, H, W, C, Cout, s)
+
+    def bwd():
+        if out.grad is None:
+            return
+        L, s = ctx.L, ctx.stream
+        if w.requires_grad:
+            strides = R._nhwc_strides(B, H, W, C)
+            bgrad = b.grad if (b is not None and b.requires_grad) else None
+            if Cout % 128 == 0:
+                scr = R._new((L.hrf_conv3_wgrad_wide_scratch(B, H, W, C, Cout),), x.t.device)
+                ctx.side_launch(lambda: L.hrf_conv3_wgrad_wide(out.grad, Cout, x.t, C, B, H, W, C, Cout, w.grad, bgrad,
+                                                               scr, ctx.stream))
+            else:
+                ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
+                    out.grad, Cout, 0, None, None, None, None, x.t, *strides, B, H, W, C, 3, 1, Cout,
+                    R.TF_NONE, None, None, None, w.grad, bgrad, ctx.stream))
+        if x.needs_grad:
+            L.hrf_conv3_pack(w, Cout, C, 1, wp, s)                 # the forward pack is dead by now: reuse its buffer
+            g, acc = x.grad_target()
+            L.hrf_conv3_packed(out.grad, Cout, wp, None, g, C, acc, B, H, W, Cout, C, s)
+    ctx.push(bwd)
+    return out
+
+
 def _conv_bias(ctx, x, conv):
     """Act -> Act: dense k=1|3 convolution with bias, no normalisation, no activation."""
     L, s = ctx.L, ctx.stream
     B, H, W, C = x.t.shape
     w, b = conv.weight, conv.bias
     Cout, KH, stride = w.shape[0], w.shape[2], conv.stride[0]
+    if KH == 3 and stride == 1 and C % 32 == 0 and Cout % 64 == 0 and C % 64 == 0 and _WIDE:
+        return _conv3_wide(ctx, x, conv)
     Ho, Wo = R._conv_out_hw(H, W, KH, stride)
     out = R.Act(R._new((B, Ho, Wo, Cout), x.t.device))
     strides = R._nhwc_strides(B, H, W, C)
@@ -126,25 +168,33 @@ class HRFPN(HipModule):
             for a, o, Hs, Ws, C in spans:
                 if not a.needs_grad:
                     continue
+                if (Hs, Ws) == (H, W):                    # branch 0: the concat only copied it
+                    g, acc = a.grad_target()
+                    ctx.L.hrf_slice_cols(cat.grad, Csum, o, B * H * W, C, g, acc, ctx.stream)
+                    continue
                 du = R._new((B, Hs, Ws, C), dev)
                 ctx.L.hrf_bilinear_up_bwd(cat.grad, Csum, o, B, H, W, C, None, Hs, Ws, du, None, ctx.stream)
                 a.add_grad(du)
         ctx.push(bwd_cat)
 
         red = _conv_bias(ctx, cat, self.reduction_conv.conv)                  # hrfpn.py:85-88
+        # hrfpn.py:89-91 pools `red` with kernel 2**i for every level; floor-mode k x k windows nest exactly
+        # (rows/cols dropped at level i are dropped at every coarser level too), so level i is the 2 x 2 average
+        # of level i-1: the full-resolution map is read once instead of num_outs-1 times, in both directions
         levels = [red]
-        for i in range(1, self.num_outs):                                     # hrfpn.py:89-91
-            k = 1 << i
-            if H // k < 1 or W // k < 1:
-                raise RuntimeError(f'HRFPN level {i}: avg_pool2d kernel {k} is larger than the {H}x{W} map')
-            p = R.Act(R._new((B, H // k, W // k, self.out_channels), dev))
-            L.hrf_avg_pool(red.t, B, H, W, self.out_channels, k, p.t, s)
+        for i in range(1, self.num_outs):
+            par = levels[-1]
+            _, Hp, Wp, _ = par.t.shape
+            if Hp // 2 < 1 or Wp // 2 < 1:
+                raise RuntimeError(f'HRFPN level {i}: avg_pool2d kernel {1 << i} is larger than the {H}x{W} map')
+            p = R.Act(R._new((B, Hp // 2, Wp // 2, self.out_channels), dev))
+            L.hrf_avg_pool(par.t, B, Hp, Wp, self.out_channels, 2, p.t, s)
 
-            def bwd_pool(p=p, k=k):
+            def bwd_pool(p=p, par=par, Hp=Hp, Wp=Wp):
                 if p.grad is None:
                     return
-                g, acc = red.grad_target()
-                ctx.L.hrf_avg_pool_bwd(p.grad, B, H, W, self.out_channels, k, g, acc, ctx.stream)
+                g, acc = par.grad_target()
+                ctx.L.hrf_avg_pool_bwd(p.grad, B, Hp, Wp, self.out_channels, 2, g, acc, ctx.stream)
             ctx.push(bwd_pool)
             levels.append(p)
         # hrfpn.py:92-100 - the pyramid levels are independent: one lane each (level 0 is 3/4 of the work,

@@ -175,11 +175,33 @@ int hrf_bilinear_up_bwd(const float* g, int ldG, int goff, int B, int H, int W, 
  * hrf_bilinear_up_into: out[pix][off + c] = F.interpolate(x, size=(H,W), mode='bilinear')[pix][c]
  *   (align_corners=False; a plain copy when Hs == H): the up-sample + channel concat in one pass;
  *   its adjoint is hrf_bilinear_up_bwd reading the concat gradient through (ldG, goff).
- * hrf_avg_pool / hrf_avg_pool_bwd: F.avg_pool2d(kernel_size = stride = k) on NHWC rows.         */
+ * hrf_avg_pool / hrf_avg_pool_bwd: F.avg_pool2d(kernel_size = stride = k) on NHWC rows.
+ * hrf_slice_cols: dst[row][c] (+)= src[row][off + c] - the concat adjoint of the branch that is not up-sampled. */
 int hrf_bilinear_up_into(const float* x, int Hs, int Ws, int C, float* out, int ldOut, int off, int B, int H, int W,
                          void* stream);
 int hrf_avg_pool(const float* x, int B, int H, int W, int C, int k, float* out, void* stream);
+int hrf_slice_cols(const float* src, int ld, int off, long rows, int C, float* dst, int accumulate, void* stream);
 int hrf_avg_pool_bwd(const float* g, int B, int H, int W, int C, int k, float* dx, int accumulate, void* stream);
+
+/* Wide 3x3 / stride-1 / pad-1 convolution on tap-major packed weights (the HRFPN 256->256 output convolutions,
+ * hrfpn.py:60-70,92-100, and their backward-data): K % 32 == 0 input channels, N % 64 == 0 output channels.
+ *   hrf_conv3_pack   wp[tap][n][k] = w[n][k][tap]        (dir 0: forward operand, N = Cout, K = Cin)
+ *                    wp[tap][n][k] = w[k][n][8 - tap]    (dir 1: backward-data operand, N = Cin, K = Cout)
+ *                    w is the OIHW tensor [Cout][Cin][3][3]; wp holds 9*Cout*Cin floats (caller-owned scratch,
+ *                    refreshed whenever w changes - once per step).
+ *   hrf_conv3_packed y[pix][n] (+)= bias[n] + sum_{tap,k} x[pix + tap][k] * wp[tap][n][k]   (zero padding);
+ *                    forward: x = input rows, wp = pack(dir 0); backward-data (aten convolution_backward's
+ *                    grad_input): x = dY rows, wp = pack(dir 1), bias = null, accumulate = 1 to add into a gradient. */
+int hrf_conv3_pack(const float* w, int Cout, int Cin, int dir, float* wp, void* stream);
+int hrf_conv3_packed(const float* x, int ldX, const float* wp, const float* bias, float* y, int ldY, int accumulate,
+                     int B, int H, int W, int K, int N, void* stream);
+/*   hrf_conv3_wgrad_wide  dW[co][ci][3][3] += sum_pix dY[pix][co] * x[pix + tap][ci],  dbias[co] += sum_pix dY[pix][co]
+ *                    (aten convolution_backward's grad_weight / grad_bias of the same convolution; OIHW dW;
+ *                    Cout % 128 == 0, Cin % 64 == 0; dbias nullable).  The pixel-split partial sums pass through
+ *                    `scratch`: hrf_conv3_wgrad_wide_scratch(...) floats, caller-owned, contents irrelevant. */
+long hrf_conv3_wgrad_wide_scratch(int B, int H, int W, int Cin, int Cout);
+int hrf_conv3_wgrad_wide(const float* dy, int ldD, const float* x, int ldX, int B, int H, int W, int Cin, int Cout,
+                         float* dw, float* dbias, float* scratch, void* stream);
 
 /* ---- fused flat-buffer AdamW (configs/hrfuser: AdamW lr 3e-4, wd 0.01, decay_mult 0 masks) ---
  * state = float[4] on device: {1-b1^t, 1-b2^t, t, -}; hrf_adamw_tick advances t on device so a

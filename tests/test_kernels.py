@@ -401,6 +401,65 @@ def run_pointwise(backend):
     assert r(pk, pp.data) < TOL and float(state[2]) == 3.0
 
 
+# ------------------------------------------------------------------ wide packed-weight 3x3 convolution
+C3W_CASES = [  # B, H, W, Cin, Cout, forced channel groups per block (0 = dispatcher's choice)
+    (1, 8, 16, 32, 64, 0), (2, 11, 21, 64, 128, 0), (1, 9, 17, 64, 256, 4), (1, 5, 7, 96, 64, 1), (1, 3, 40, 64, 320, 0)]
+
+
+def run_conv3w(case, backend):
+    """hrf_conv3_pack + hrf_conv3_packed (forward, and backward-data on the flipped pack) vs F.conv2d / autograd."""
+    B, H, W, Cin, Cout, wn = case
+    dev = use_backend(backend)
+    try:
+        L, s = _lib.lib(), _lib.stream_ptr()
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).requires_grad_(True)
+        bias = torch.randn(Cout, generator=g)
+        y = F.conv2d(x, w, bias, padding=1)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        D = lambda t: t.detach().to(dev).contiguous()
+        L.hrf_debug_knob(24, wn)
+        xk, wk = D(nhwc(x)), D(w)
+        wp = torch.empty(9 * Cout * Cin, device=dev)
+        yk = torch.full((B, H, W, Cout + 4), 7.0, device=dev)          # ldY > N: the pad columns must stay untouched
+        L.hrf_conv3_pack(wk, Cout, Cin, 0, wp, s)
+        assert torch.equal(wp.view(9, Cout, Cin).cpu(), w.detach().permute(2, 3, 0, 1).reshape(9, Cout, Cin))
+        L.hrf_conv3_packed(xk, Cin, wp, D(bias), yk, Cout + 4, 0, B, H, W, Cin, Cout, s)
+        assert r(yk[..., :Cout], nhwc(y)) < TOL
+        assert float((yk[..., Cout:] - 7.0).abs().max()) == 0.0
+        if Cin % 64 == 0 and Cout % 32 == 0:
+            prev = torch.randn(B, H, W, Cin, generator=g)
+            dx = D(prev).clone()
+            L.hrf_conv3_pack(wk, Cout, Cin, 1, wp, s)
+            L.hrf_conv3_packed(D(nhwc(dy)), Cout, wp, None, dx, Cin, 1, B, H, W, Cout, Cin, s)
+            assert r(dx - D(prev), nhwc(x.grad)) < TOL
+        if Cin % 64 == 0 and Cout % 128 == 0:
+            dw0, db0 = torch.randn(w.shape, generator=g), torch.randn(Cout, generator=g)
+            dw, db = D(dw0).clone(), D(db0).clone()
+            scr = torch.empty(L.hrf_conv3_wgrad_wide_scratch(B, H, W, Cin, Cout), device=dev)
+            L.hrf_conv3_wgrad_wide(D(nhwc(dy)), Cout, xk, Cin, B, H, W, Cin, Cout, dw, db, scr, s)
+            assert r(dw - D(dw0), w.grad) < TOL
+            assert r(db - D(db0), dy.sum((0, 2, 3))) < TOL
+        with pytest.raises(_lib.HRFuserHipError):                     # unsupported K: refused, never a silent fallback
+            L.hrf_conv3_packed(xk, Cin, wp, None, yk, Cout + 4, 0, B, H, W, Cin - 1, Cout, s)
+    finally:
+        _lib.lib().hrf_debug_knob(24, 0)
+        use_backend('hip')
+
+
+@pytest.mark.parametrize('case', C3W_CASES[:4], ids=str)
+def test_conv3w_emul(case):
+    run_conv3w(case, 'emul')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', C3W_CASES + [(2, 96, 160, 256, 256, 0)], ids=str)
+def test_conv3w_gpu(case):
+    run_conv3w(case, 'hip')
+
+
 # ------------------------------------------------------------------ emulator (CPU suite)
 @pytest.mark.parametrize('case', CONV_CASES[:8] + CONV_CASES[-3:], ids=str)
 def test_conv_emul(case):

@@ -25,10 +25,14 @@ def timed(fn, n=20, warm=5):
 
 
 def main():
+    only = os.environ.get('NECK_ONLY', '')           # 'hip' | 'eager' | '' ; NECK_TAG = 'T' | 'B' | ''
+    tags = os.environ.get('NECK_TAG', '')
     import hrfpn_oracle as N             # eager comparison leg only (not the product path)
     import hrfuser_oracle as O
     dev = torch.device('cuda:0')
-    for tag, chans in (('T', [18, 36, 72, 144]), ('B', [78, 156, 312, 624])):
+    for tag, chans in (('T', [18, 36, 72, 144]), ('B', [78, 156, 312, 624]), ('T', [18, 36, 72, 144])):
+        if tags and tag != tags:
+            continue
         B, H, W = 2, 96, 160
         g = torch.Generator().manual_seed(0)
         xs = [torch.randn(B, c, H >> i, W >> i, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
@@ -41,6 +45,8 @@ def main():
         orc.to(dev)
         res = {'neck': tag, 'B': B, 'grid': [H, W]}
         for name, m in (('hip', net), ('eager', orc)):
+            if only and name != only:
+                continue
             m.eval()
             with torch.no_grad():
                 res[f'{name}_fwd_ms'] = round(timed(lambda: m(xs)), 3)
@@ -53,7 +59,8 @@ def main():
             res[f'{name}_fwd_bwd_ms'] = round(timed(step), 3)
         flop = 2 * B * H * W * (sum(chans) * 256 + 9 * 256 * 256 * sum(4.0 ** -i for i in range(5)))
         res['fwd_gflop'] = round(flop / 1e9, 2)
-        res['hip_fwd_tflops'] = round(flop / res['hip_fwd_ms'] / 1e9, 1)
+        if 'hip_fwd_ms' in res:
+            res['hip_fwd_tflops'] = round(flop / res['hip_fwd_ms'] / 1e9, 1)
         print(json.dumps(res), flush=True)
 
 
