@@ -11,8 +11,8 @@
 //     for all of them (wave = 4 pixel rows x 64 channels = 16 MFMA tiles, 64 accumulator registers);
 //   * permutes the contraction index inside a 16-channel chunk (MFMA m of 4 takes k = 4q + m) so that a lane's four
 //     K values are contiguous in LDS: every operand fetch is a ds_read_b128 - 8 LDS reads per 64 MFMAs;
-//   * double-buffers both the halo and the weight tile in LDS (125 KB of the 160 KB): global loads of step s+1 are in
-//     flight while step s runs on the matrix cores, one barrier per step.
+//   * keeps a 3-slot ring of weight tiles in LDS (137 KB of the 160 KB with the halo): global loads run two steps
+//     ahead and the operand fragments of the next chunk are fetched while the current one is on the matrix cores.
 // Output fragments are produced transposed (D[row = channel][col = pixel]) so that a lane holds four consecutive
 // channels of one pixel: the epilogue (bias, += for gradient accumulation) is one 16-byte load/store per tile.
 #include "hrf_common.h"
@@ -34,8 +34,15 @@ struct C3wArgs {
   float* y; int ldY; int accumulate;  // [B*H*W][ldY], N channels
   int B, H, W, K, N;
   int tilesX, tilesY;
-  int dbg;                            // timing experiments (hrf_debug_knob 25): 1 no MFMA, 2 no fragment reads, 4 no weight refill
 };
+
+#ifdef HRF_EMUL
+#define HRF_SCHED_FENCE() ((void)0)
+#define HRF_WAIT_LDS() ((void)0)
+#else
+#define HRF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define HRF_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)      // lgkmcnt(0) only
+#endif
 
 __device__ __forceinline__ hrf_f4 lds_ld4(const float* p) {
 #ifdef HRF_EMUL
@@ -54,13 +61,24 @@ __device__ __forceinline__ void lds_st4(float* p, hrf_f4 v) {
 
 // WN = 64-channel groups per block (1, 2 or 4).  8 waves: wave -> (channel group = wave % WN, row group = wave / WN);
 // each wave owns WN consecutive pixel rows x 64 channels.
+//
+// Schedule of a step s (one tap x 32 input channels = two 16-channel chunks), steady state:
+//   top      weights of step s+2 (global loads issued one step ago) -> LDS ring slot (s+2)%3; global loads of step s+3
+//   chunk 0  fragments are ALREADY in registers (fetched during step s-1); half of its 16*WN MFMAs, the chunk 1
+//            fragment reads, the other half
+//   chunk 1  half of its MFMAs, the chunk 0 fragment reads of step s+1 (ring slot (s+1)%3 is complete since the
+//            previous barrier), the other half
+//   barrier
+// so no LDS read is waited on with an idle matrix core except at the 32-channel slab boundaries (every 9th step),
+// where the single halo buffer is replaced.  Measured on MI355X, 256->256 at 2x96x160: weights double-buffered with
+// fragment reads at the head of each chunk 334 us; MFMAs alone 288 us; everything but the MFMAs 121 us.
 template <int WN>
 __global__ __launch_bounds__(NTHR) void conv3w_kernel(C3wArgs a) {
   constexpr int NB = WN * 64;                 // output channels per block
   constexpr int NHV = (NPIX * (KS / 4) + NTHR - 1) / NTHR;     // halo float4 per thread (3)
   HRF_DYN_SMEM(float, smem);
-  float* sIn = smem;                          // [2][NPIX * LP]
-  float* sB = smem + 2 * NPIX * LP;           // [2][NB * LP]
+  float* sIn = smem;                          // [NPIX * LP]
+  float* sB = smem + NPIX * LP;               // [3][NB * LP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int chg = wave % WN, rg = wave / WN;
@@ -78,7 +96,7 @@ __global__ __launch_bounds__(NTHR) void conv3w_kernel(C3wArgs a) {
     for (int tt = 0; tt < 4; ++tt) acc[rr][tt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
 
   // ---- staging maps
-  const float* hsrc[NHV]; int hdst[NHV];
+  const float* hsrc[NHV]; int hstep[NHV], hdst[NHV];   // padding lanes read the zero block with step 0: branch-free
 #pragma unroll
   for (int e = 0; e < NHV; ++e) {
     const int f = tid + e * NTHR;
@@ -86,86 +104,107 @@ __global__ __launch_bounds__(NTHR) void conv3w_kernel(C3wArgs a) {
     const int py = pix / IW, px = pix - py * IW;
     const int gy = y0 - 1 + py, gx = x0 - 1 + px;
     const bool ok = f < NPIX * 8 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-    hsrc[e] = ok ? a.x + ((long)(b * a.H + gy) * a.W + gx) * a.ldX + 4 * j : nullptr;
+    hsrc[e] = ok ? a.x + ((long)(b * a.H + gy) * a.W + gx) * a.ldX + 4 * j : g_zero4w;
+    hstep[e] = ok ? KS : 0;
     hdst[e] = f < NPIX * 8 ? pix * LP + 4 * j : -1;
   }
   const int wn = tid >> 3, wj = tid & 7;      // weight float4 e: row n = wn + 64*e, channels 4*wj..
   hrf_f4 hpre[NHV], wpre[WN];
-  auto load_halo = [&](int c0) {
+  auto load_halo = [&](int slab) {
 #pragma unroll
-    for (int e = 0; e < NHV; ++e) hpre[e] = hrf_ld4(hsrc[e] != nullptr ? hsrc[e] + c0 : g_zero4w);
+    for (int e = 0; e < NHV; ++e) hpre[e] = hrf_ld4(hsrc[e] + slab * hstep[e]);
   };
-  auto store_halo = [&](float* dst) {
+  auto store_halo = [&]() {
 #pragma unroll
     for (int e = 0; e < NHV; ++e)
-      if (hdst[e] >= 0) lds_st4(dst + hdst[e], hpre[e]);
+      if (hdst[e] >= 0) lds_st4(sIn + hdst[e], hpre[e]);
   };
-  auto load_w = [&](int tap, int c0) {
+  // all step bookkeeping is wave-uniform and incremental (no division in the loop): a step is (tap, slab), its
+  // weight tile sits in ring slot `ring`, its halo offset is hoff = (dy * IW + dx) * LP
+  const float* wrow[WN];                      // this thread's weight rows at (tap 0, slab 0)
 #pragma unroll
-    for (int e = 0; e < WN; ++e) {
-      const int n = n0 + wn + 64 * e;
-      wpre[e] = hrf_ld4(n < a.N ? a.wp + ((long)tap * a.N + n) * a.K + c0 + 4 * wj : g_zero4w);
-    }
+  for (int e = 0; e < WN; ++e) wrow[e] = a.wp + (long)min(n0 + wn + 64 * e, a.N - 1) * a.K + 4 * wj;   // rows past N feed switched-off waves
+  const long wtap = (long)a.N * a.K;
+  auto load_w = [&](int tap, int slab) {
+#pragma unroll
+    for (int e = 0; e < WN; ++e) wpre[e] = hrf_ld4(wrow[e] + tap * wtap + slab * KS);
   };
-  auto store_w = [&](float* dst) {
+  auto store_w = [&](int ring) {
+    float* dst = sB + ring * (NB * LP);
 #pragma unroll
     for (int e = 0; e < WN; ++e) lds_st4(dst + (wn + 64 * e) * LP + 4 * wj, wpre[e]);
+  };
+  hrf_f4 fa[2][WN], fb[2][4];
+  const float* abase = sIn + (rg * WN * IW + i) * LP + 4 * q;
+  const float* bbase = sB + (chg * 64 + i) * LP + 4 * q;
+  auto read_frags = [&](int hoff, int ring, int c16, int slot) {
+    const float* ap = abase + hoff + c16 * 16;
+    const float* bp = bbase + ring * (NB * LP) + c16 * 16;
+#pragma unroll
+    for (int rr = 0; rr < WN; ++rr) fa[slot][rr] = lds_ld4(ap + rr * IW * LP);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) fb[slot][tt] = lds_ld4(bp + tt * 16 * LP);
+  };
+  auto mma = [&](int slot, int half) {        // D[row = channel][col = pixel]: the weight fragment is the row operand
+#pragma unroll
+    for (int m = 2 * half; m < 2 * half + 2; ++m)
+#pragma unroll
+      for (int rr = 0; rr < WN; ++rr)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[rr][tt] = hrf_mfma16(fb[slot][tt][m], fa[slot][rr][m], acc[rr][tt]);
   };
 
   const int nslab = a.K / KS, S = nslab * 9;
   load_halo(0);
   load_w(0, 0);
-  store_halo(sIn);
-  store_w(sB);
+  store_halo();
+  store_w(0);
+  load_w(1, 0);                                // S >= 9
+  store_w(1);
+  load_w(2, 0);                                // stays in registers until the top of step 0
   __syncthreads();
+  // (explicit wait: with nothing pending at the loop header on either path, the waitcnt pass does not have to
+  // drain the chunk-1 reads in front of the chunk-0 MFMAs)
+  if (wave_on) { read_frags(0, 0, 0, 0); HRF_WAIT_LDS(); }
 
-  int slab = 0, tap = 0;
+  int tap = 0, slab = 0, hoff = 0;             // step s
+  int dxn = 1, dyn = 0;                        // tap coordinates of step s+1
+  int tap3 = 3, slab3 = 0;                     // step s+3 (the weight tile fetched during step s)
+  int r0 = 0, r1 = 1, r2 = 2;                  // ring slots of steps s, s+1, s+2
   for (int s = 0; s < S; ++s) {
-    const float* sInb = sIn + (slab & 1) * (NPIX * LP);
-    const float* sBb = sB + (s & 1) * (NB * LP);
-    const bool more = s + 1 < S;
-    const int ntap = tap == 8 ? 0 : tap + 1, nslb = tap == 8 ? slab + 1 : slab;
-    if (more && !(a.dbg & 4)) load_w(ntap, nslb * KS);
-    if (tap == 0 && slab + 1 < nslab) load_halo((slab + 1) * KS);
+    if (s + 2 < S) store_w(r2);
+    if (s + 3 < S) load_w(tap3, slab3);
+    if (tap == 0 && slab + 1 < nslab) load_halo(slab + 1);
+    const bool boundary = tap == 8;            // the next step reads a new halo slab
+    const int hoffn = (dyn * IW + dxn) * LP;
     if (wave_on) {
-      const int dy = tap / 3, dx = tap - 3 * dy;
-      const float* ap = sInb + ((rg * WN + dy) * IW + i + dx) * LP + 4 * q;
-      const float* bp = sBb + (chg * 64 + i) * LP + 4 * q;
-#pragma unroll
-      for (int c16 = 0; c16 < KS / 16; ++c16) {
-        hrf_f4 av[WN], bv[4];
-        if (!(a.dbg & 2) || s == 0) {
-#pragma unroll
-          for (int rr = 0; rr < WN; ++rr) av[rr] = lds_ld4(ap + rr * IW * LP + c16 * 16);
-#pragma unroll
-          for (int tt = 0; tt < 4; ++tt) bv[tt] = lds_ld4(bp + tt * 16 * LP + c16 * 16);
-        } else {
-#pragma unroll
-          for (int rr = 0; rr < WN; ++rr) av[rr] = acc[rr][0];
-#pragma unroll
-          for (int tt = 0; tt < 4; ++tt) bv[tt] = acc[0][tt];
-        }
-        if (a.dbg & 1) {
-#pragma unroll
-          for (int rr = 0; rr < WN; ++rr)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[rr][tt][r] += av[rr][r] * bv[tt][r];
-          continue;
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int rr = 0; rr < WN; ++rr)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[rr][tt] = hrf_mfma16(bv[tt][m], av[rr][m], acc[rr][tt]);
-      }
+      // The fragments of the NEXT chunk are fetched in the middle of the current chunk's MFMAs: LLVM's waitcnt
+      // pass drains ALL outstanding LDS reads (lgkmcnt(0)) in front of the first MFMA that needs one of them, so a
+      // read must be half a chunk (>= 1000 cycles) old by then.  The scheduling fences pin the order written here
+      // (the scheduler otherwise sinks the reads behind the MFMAs and waits with an idle matrix core).
+      HRF_SCHED_FENCE();
+      mma(0, 0);
+      HRF_SCHED_FENCE();
+      read_frags(hoff, r0, 1, 1);
+      HRF_SCHED_FENCE();
+      mma(0, 1);
+      mma(1, 0);
+      HRF_SCHED_FENCE();
+      read_frags(hoffn, r1, 0, 0);              // unconditional; re-fetched below at a slab boundary
+      HRF_SCHED_FENCE();
+      mma(1, 1);
+      HRF_SCHED_FENCE();
     }
-    if (more && !(a.dbg & 4)) store_w(sB + ((s + 1) & 1) * (NB * LP));
-    if (tap == 8 && slab + 1 < nslab) store_halo(sIn + ((slab + 1) & 1) * (NPIX * LP));
     __syncthreads();
-    tap = ntap; slab = nslb;
+    if (boundary && s + 1 < S) {
+      store_halo();
+      __syncthreads();
+      if (wave_on) { read_frags(hoffn, r1, 0, 0); HRF_WAIT_LDS(); }
+    }
+    tap = boundary ? 0 : tap + 1; slab += boundary ? 1 : 0; hoff = hoffn;
+    if (++dxn == 3) { dxn = 0; if (++dyn == 3) dyn = 0; }
+    if (++tap3 == 9) { tap3 = 0; ++slab3; }
+    const int rt = r0; r0 = r1; r1 = r2; r2 = rt;
   }
 
   // ---- epilogue: acc[rr][tt][r] = out(pixel (row rg*WN + rr, col i), channel chg*64 + tt*16 + 4q + r)
@@ -360,7 +399,7 @@ __global__ __launch_bounds__(256) void wgrad3w_fold_kernel(const float* part, in
   dw[e * 9 + t] += (s0 + s1) + (s2 + s3);
 }
 
-int g_force_wn = 0, g_dbg = 0, g_wsplit = 0;
+int g_force_wn = 0, g_wsplit = 0;
 
 int wgrad3w_splits(int B, int H, int W, int Cin, int Cout) {
   const long tiles = (long)hrf_cdiv(W, GW) * hrf_cdiv(H, GH) * B;
@@ -371,7 +410,7 @@ int wgrad3w_splits(int B, int H, int W, int Cin, int Cout) {
 
 template <int WN>
 int launch_w(C3wArgs a, void* stream) {
-  constexpr size_t smem = (size_t)(2 * NPIX * LP + 2 * WN * 64 * LP) * sizeof(float);
+  constexpr size_t smem = (size_t)(NPIX * LP + 3 * WN * 64 * LP) * sizeof(float);
 #ifndef HRF_EMUL
   static bool once = false;
   if (!once) {
@@ -399,12 +438,13 @@ extern "C" int hrf_conv3_packed(const float* x, int ldX, const float* wp, const 
                                 int accumulate, int B, int H, int W, int K, int N, void* stream) {
   if (K <= 0 || N <= 0 || K % KS != 0 || N % 64 != 0) return HRF_ERR_ARG;
   if (B <= 0 || H <= 0 || W <= 0) return HRF_OK;
-  C3wArgs a{x, ldX, wp, bias, y, ldY, accumulate, B, H, W, K, N, hrf_cdiv(W, TW), hrf_cdiv(H, TH), g_dbg};
+  C3wArgs a{x, ldX, wp, bias, y, ldY, accumulate, B, H, W, K, N, hrf_cdiv(W, TW), hrf_cdiv(H, TH)};
   const long tiles = (long)a.tilesX * a.tilesY * B;
-  // few tiles: one 64-channel group per block (4x the blocks, 1/4 the serial depth of each)
-  int wn = (N % 256 == 0 && tiles >= 128) ? 4 : 1;
-  if (g_force_wn == 1 || (g_force_wn == 4 && N % 256 == 0)) wn = g_force_wn;
-  return wn == 4 ? launch_w<4>(a, stream) : launch_w<1>(a, stream);
+  // fewer tiles: fewer 64-channel groups per block (more blocks, shorter serial depth of each; a step of the
+  // 1-group variant is bound by the weight-prefetch latency, so the 2-group one is preferred while it fills the CUs)
+  int wn = (N % 256 == 0 && tiles >= 128) ? 4 : ((N % 128 == 0 && tiles >= 32) ? 2 : 1);
+  if (g_force_wn == 1 || (g_force_wn == 4 && N % 256 == 0) || (g_force_wn == 2 && N % 128 == 0)) wn = g_force_wn;
+  return wn == 4 ? launch_w<4>(a, stream) : (wn == 2 ? launch_w<2>(a, stream) : launch_w<1>(a, stream));
 }
 
 extern "C" long hrf_conv3_wgrad_wide_scratch(int B, int H, int W, int Cin, int Cout) {
@@ -437,7 +477,6 @@ extern "C" int hrf_conv3_wgrad_wide(const float* dy, int ldD, const float* x, in
 
 extern "C" int hrf_conv3w_knob(int key, int value) {
   if (key == 0) { g_force_wn = value; return HRF_OK; }
-  if (key == 1) { g_dbg = value; return HRF_OK; }
   if (key == 2) { g_wsplit = value; return HRF_OK; }
   return HRF_ERR_ARG;
 }

@@ -379,22 +379,66 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const float* g, in
     int ylo = (int)floorf(((float)qy - 1.f + 0.5f) * ry - 0.5f) - 1, yhi = (int)ceilf(((float)qy + 1.f + 0.5f) * ry - 0.5f) + 1;
     int xlo = (int)floorf(((float)qx - 1.f + 0.5f) * rx - 0.5f) - 1, xhi = (int)ceilf(((float)qx + 1.f + 0.5f) * rx - 0.5f) + 1;
     ylo = max(ylo, 0); yhi = min(yhi, H - 1); xlo = max(xlo, 0); xhi = min(xhi, W - 1);
+    // column weights of the window once per output pixel (<= 24 columns covers up-sampling factors up to 10):
+    // the inner loops below are loads and fmas only, 8 independent loads in flight
+    const bool narrow = xhi - xlo < 24;
+    float wv[24];
+#pragma unroll
+    for (int u = 0; u < 24; ++u) {
+      const int x = min(xlo + u, xhi);
+      int x0, x1; float wx;
+      bil_src(x, Ws, W, x0, x1, wx);
+      wv[u] = xlo + u <= xhi ? (x0 == qx ? 1.f - wx : 0.f) + (x1 == qx ? wx : 0.f) : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int c = c0 + 256 * j;
       if (c >= C) break;
       float acc = 0.f;
+      if (narrow) {
+        for (int y = ylo; y <= yhi; ++y) {
+          int y0, y1; float wy;
+          bil_src(y, Hs, H, y0, y1, wy);
+          const float cy = (y0 == qy ? 1.f - wy : 0.f) + (y1 == qy ? wy : 0.f);
+          if (cy == 0.f) continue;
+          const float* grow = g + (((long)b * H + y) * W) * ldG + goff + c;
+          float part = 0.f;
+#pragma unroll
+          for (int bq = 0; bq < 3; ++bq) {
+            if (xlo + 8 * bq > xhi) break;
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = grow[(long)min(xlo + 8 * bq + u, xhi) * ldG];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part = fmaf(wv[8 * bq + u], v[u], part);
+          }
+          acc = fmaf(cy, part, acc);
+        }
+      } else
       for (int y = ylo; y <= yhi; ++y) {
         int y0, y1; float wy;
         bil_src(y, Hs, H, y0, y1, wy);
         const float cy = (y0 == qy ? 1.f - wy : 0.f) + (y1 == qy ? wy : 0.f);
         if (cy == 0.f) continue;
-        for (int x = xlo; x <= xhi; ++x) {
-          int x0, x1; float wx;
-          bil_src(x, Ws, W, x0, x1, wx);
-          const float cx = (x0 == qx ? 1.f - wx : 0.f) + (x1 == qx ? wx : 0.f);
-          if (cx != 0.f) acc = fmaf(cy * cx, g[(((long)b * H + y) * W + x) * ldG + goff + c], acc);
+        // fixed batches of 8 window columns with unconditional (clamped) loads: 8 loads in flight per thread instead
+        // of one load per dependent branch (a x8 up-sample gathers 16 x 16 values per output, latency-bound otherwise)
+        const float* grow = g + (((long)b * H + y) * W) * ldG + goff + c;
+        float part = 0.f;
+        for (int xb = xlo; xb <= xhi; xb += 8) {
+          float v[8], wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int x = min(xb + u, xhi);
+            int x0, x1; float wx;
+            bil_src(x, Ws, W, x0, x1, wx);
+            const float cx = (x0 == qx ? 1.f - wx : 0.f) + (x1 == qx ? wx : 0.f);
+            wv[u] = xb + u <= xhi ? cx : 0.f;
+            v[u] = grow[(long)x * ldG];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) part = fmaf(wv[u], v[u], part);
         }
+        acc = fmaf(cy, part, acc);
       }
       const long i = q * C + c;
       du[i] = acc;

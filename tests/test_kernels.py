@@ -403,7 +403,8 @@ def run_pointwise(backend):
 
 # ------------------------------------------------------------------ wide packed-weight 3x3 convolution
 C3W_CASES = [  # B, H, W, Cin, Cout, forced channel groups per block (0 = dispatcher's choice)
-    (1, 8, 16, 32, 64, 0), (2, 11, 21, 64, 128, 0), (1, 9, 17, 64, 256, 4), (1, 5, 7, 96, 64, 1), (1, 3, 40, 64, 320, 0)]
+    (1, 8, 16, 32, 64, 0), (2, 11, 21, 64, 128, 0), (1, 9, 17, 64, 256, 4), (1, 5, 7, 96, 64, 1), (1, 3, 40, 64, 320, 0),
+    (1, 10, 9, 64, 128, 2)]
 
 
 def run_conv3w(case, backend):
@@ -449,7 +450,7 @@ def run_conv3w(case, backend):
         use_backend('hip')
 
 
-@pytest.mark.parametrize('case', C3W_CASES[:4], ids=str)
+@pytest.mark.parametrize('case', C3W_CASES[:4] + C3W_CASES[-1:], ids=str)
 def test_conv3w_emul(case):
     run_conv3w(case, 'emul')
 
