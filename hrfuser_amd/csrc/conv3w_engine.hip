@@ -381,6 +381,165 @@ __global__ __launch_bounds__(NTHR) void wgrad3w_kernel(W3wArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Row GEMM for the wide 1x1 convolutions (the HRFPN reduction convolution sum(in_channels) -> 256, hrfpn.py:53-58,85, and
+// its backward-data): y[m][n] (+)= bias[n] + sum_k x[m][k] * wp[n][k], K % 16 == 0, N % 16 == 0 (the caller pads with
+// zero columns / zero weight rows).  Same machinery as the 3x3 engine with a 16-deep step: block = 128 rows x up to
+// 256 channels, both operand tiles in a 2-slot LDS ring (61 KB: the fragments of step s+1 are fetched in the middle
+// of step s's MFMAs, so slot s%2 is free again when step s starts), global loads three steps ahead.
+constexpr int GK = 16, GLP = GK + 4, GROWS = 128;
+
+struct RgArgs {
+  const float* x; int ldX; const float* wp; const float* bias;
+  float* y; int ldY; int accumulate;
+  long M; int K, N;
+};
+
+template <int WN>
+__global__ __launch_bounds__(NTHR) void rowgemm_kernel(RgArgs a) {
+  constexpr int NB = WN * 64, SLOT = (GROWS + NB) * GLP;
+  constexpr int NWV = (NB * 4 + NTHR - 1) / NTHR;      // weight float4 per thread
+  HRF_DYN_SMEM(float, smem);                            // [2][SLOT]: x tile rows first, then the weight rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int chg = wave % WN, rg = wave / WN;
+  const long m0 = (long)blockIdx.x * GROWS;
+  const int n0 = blockIdx.y * NB;
+  bool tile_on[4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) tile_on[tt] = n0 + chg * 64 + tt * 16 < a.N;
+
+  hrf_f4 acc[WN][4];
+#pragma unroll
+  for (int rr = 0; rr < WN; ++rr)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[rr][tt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: x tile = 128 rows x 4 float4 (one per thread); weight tile = NB rows x 4 float4
+  const long xr = m0 + (tid >> 2) < a.M ? m0 + (tid >> 2) : a.M - 1;          // tail rows re-read the last row, never stored
+  const float* xsrc = a.x + xr * a.ldX + 4 * (tid & 3);
+  const int xdst = (tid >> 2) * GLP + 4 * (tid & 3);
+  const float* wsrc[NWV]; int wdst[NWV];
+#pragma unroll
+  for (int e = 0; e < NWV; ++e) {
+    const int f = tid + e * NTHR, n = min(f >> 2, NB - 1);
+    wsrc[e] = a.wp + (long)min(n0 + n, a.N - 1) * a.K + 4 * (f & 3);
+    wdst[e] = f < NB * 4 ? (GROWS + n) * GLP + 4 * (f & 3) : -1;
+  }
+  hrf_f4 xpre, wpre[NWV];
+  auto load_tile = [&](int s) {
+    xpre = hrf_ld4(xsrc + s * GK);
+#pragma unroll
+    for (int e = 0; e < NWV; ++e) wpre[e] = hrf_ld4(wsrc[e] + s * GK);
+  };
+  auto store_tile = [&](int slot) {
+    float* d = smem + slot * SLOT;
+    lds_st4(d + xdst, xpre);
+#pragma unroll
+    for (int e = 0; e < NWV; ++e)
+      if (wdst[e] >= 0) lds_st4(d + wdst[e], wpre[e]);
+  };
+  hrf_f4 fa[2][WN], fb[2][4];
+  const float* abase = smem + (rg * 16 * WN + i) * GLP + 4 * q;
+  const float* bbase = smem + (GROWS + chg * 64 + i) * GLP + 4 * q;
+  auto read_frags = [&](int slot, int set) {
+#pragma unroll
+    for (int rr = 0; rr < WN; ++rr) fa[set][rr] = lds_ld4(abase + slot * SLOT + rr * 16 * GLP);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) fb[set][tt] = lds_ld4(bbase + slot * SLOT + tt * 16 * GLP);
+  };
+  auto mma = [&](int set, int half) {
+#pragma unroll
+    for (int m = 2 * half; m < 2 * half + 2; ++m)
+#pragma unroll
+      for (int rr = 0; rr < WN; ++rr)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+          if (tile_on[tt]) acc[rr][tt] = hrf_mfma16(fb[set][tt][m], fa[set][rr][m], acc[rr][tt]);
+  };
+
+  const int S = a.K / GK;
+  load_tile(0);
+  store_tile(0);
+  if (S > 1) { load_tile(1); store_tile(1); }
+  if (S > 2) load_tile(2);
+  __syncthreads();
+  read_frags(0, 0);
+  HRF_WAIT_LDS();
+  // one step: MFMAs of step s on fragment set `set`, with the tile of step s+2 written into slot s%2 (its fragments
+  // are in registers already) and the fragments of step s+1 fetched from the other slot half-way
+  auto step = [&](int s, int set) {
+    HRF_SCHED_FENCE();
+    mma(set, 0);
+    HRF_SCHED_FENCE();
+    if (s + 2 < S) store_tile(s & 1);
+    if (s + 3 < S) load_tile(s + 3);
+    read_frags((s + 1) & 1, set ^ 1);          // complete since the previous barrier (stale but valid after the last step)
+    HRF_SCHED_FENCE();
+    mma(set, 1);
+    HRF_SCHED_FENCE();
+    __syncthreads();
+  };
+  for (int s = 0; s < S; s += 2) {
+    step(s, 0);
+    if (s + 1 < S) step(s + 1, 1);
+  }
+
+  // ---- epilogue: acc[rr][tt][r] = y(row m0 + rg*16*WN + rr*16 + i, channel n0 + chg*64 + tt*16 + 4q + r)
+  // an odd S leaves the last accumulators in the same registers either way (acc is shared by both sets)
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    if (!tile_on[tt]) continue;
+    const int ch = n0 + chg * 64 + tt * 16 + 4 * q;
+    hrf_f4 bv = hrf_f4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr) bv = hrf_ld4(a.bias + ch);
+#pragma unroll
+    for (int rr = 0; rr < WN; ++rr) {
+      const long m = m0 + rg * 16 * WN + rr * 16 + i;
+      if (m < a.M) {
+        float* o = a.y + m * a.ldY + ch;
+        hrf_f4 v = acc[rr][tt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+        if (a.accumulate) {
+          const hrf_f4 p = hrf_ld4(o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += p[r];
+        }
+        hrf_st4(o, v);
+      }
+    }
+  }
+}
+
+// wp[n][k], n < Np, k < Kp: dir 0: w[n][k] (n < Cout, k < Cin); dir 1: w[k][n] (n < Cin, k < Cout); zero elsewhere
+__global__ __launch_bounds__(256) void rowgemm_pack_kernel(const float* w, int Cout, int Cin, int dir, int Np, int Kp, float* wp) {
+  const long total = (long)Np * Kp;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int k = (int)(e % Kp), n = (int)(e / Kp);
+    float v = 0.f;
+    if (dir == 0) { if (n < Cout && k < Cin) v = w[(long)n * Cin + k]; }
+    else if (n < Cin && k < Cout) v = w[(long)k * Cin + n];
+    wp[e] = v;
+  }
+}
+
+template <int WN>
+int launch_rg(const RgArgs& a, void* stream) {
+  constexpr size_t smem = (size_t)2 * (GROWS + WN * 64) * GLP * sizeof(float);
+#ifndef HRF_EMUL
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess) return HRF_ERR_LAUNCH;
+    once = true;
+  }
+#endif
+  const dim3 grid(hrf_cdiv(a.M, GROWS), hrf_cdiv(a.N, WN * 64));
+  HRF_LAUNCH((rowgemm_kernel<WN>), grid, dim3(NTHR), smem, stream, a);
+  return hrf_check_launch();
+}
+
 // dw[co][ci][t] += sum_s part[s][t][co][ci]: one thread per (t, co, ci); reads coalesced over ci, the split loop
 // unrolled so that 8 loads are in flight per thread
 __global__ __launch_bounds__(256) void wgrad3w_fold_kernel(const float* part, int splits, int Cout, int Cin, float* dw) {
@@ -445,6 +604,25 @@ extern "C" int hrf_conv3_packed(const float* x, int ldX, const float* wp, const 
   int wn = (N % 256 == 0 && tiles >= 128) ? 4 : ((N % 128 == 0 && tiles >= 32) ? 2 : 1);
   if (g_force_wn == 1 || (g_force_wn == 4 && N % 256 == 0) || (g_force_wn == 2 && N % 128 == 0)) wn = g_force_wn;
   return wn == 4 ? launch_w<4>(a, stream) : (wn == 2 ? launch_w<2>(a, stream) : launch_w<1>(a, stream));
+}
+
+extern "C" int hrf_rowgemm_pack(const float* w, int Cout, int Cin, int dir, int Np, int Kp, float* wp, void* stream) {
+  const long total = (long)Np * Kp;
+  if (total <= 0) return HRF_OK;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  HRF_LAUNCH(rowgemm_pack_kernel, dim3(grid), dim3(256), 0, stream, w, Cout, Cin, dir, Np, Kp, wp);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_rowgemm(const float* x, int ldX, const float* wp, const float* bias, float* y, int ldY, int accumulate,
+                           long M, int K, int N, void* stream) {
+  if (K <= 0 || N <= 0 || K % GK != 0 || N % 16 != 0) return HRF_ERR_ARG;
+  if (M <= 0) return HRF_OK;
+  RgArgs a{x, ldX, wp, bias, y, ldY, accumulate, M, K, N};
+  const long mtiles = (M + GROWS - 1) / GROWS;
+  int wn = (N > 128 && mtiles >= 128) ? 4 : (N > 64 ? 2 : 1);
+  if (g_force_wn == 1 || g_force_wn == 2 || g_force_wn == 4) wn = g_force_wn;
+  return wn == 4 ? launch_rg<4>(a, stream) : (wn == 2 ? launch_rg<2>(a, stream) : launch_rg<1>(a, stream));
 }
 
 extern "C" long hrf_conv3_wgrad_wide_scratch(int B, int H, int W, int Cin, int Cout) {

@@ -149,18 +149,57 @@ class HRFPN(HipModule):
         # the backbone hands over channels-last memory: this permute+contiguous is then a view, not a copy
         return [R.Act(t.permute(0, 2, 3, 1).contiguous(), bool(t.requires_grad)) for t in inputs]
 
+    def _zeros(self, n, B, dev):
+        z = self.__dict__.get('_zero_pad')
+        if z is None or z.numel() < B * n or z.device != dev:
+            z = self.__dict__['_zero_pad'] = torch.zeros(B * 16, device=dev, dtype=torch.float32)
+        return z
+
+    def _reduce_gemm(self, ctx, cat, Csum):
+        """reduction_conv (hrfpn.py:53-58,85) on the row-GEMM engine: `cat` rows are padded to K % 16 == 0."""
+        L, s = ctx.L, ctx.stream
+        conv = self.reduction_conv.conv
+        w, b = conv.weight, conv.bias
+        B, H, W, Kp = cat.t.shape
+        Cout, rows, dev = w.shape[0], B * H * W, cat.t.device
+        red = R.Act(R._new((B, H, W, Cout), dev))
+        wp = R._new((Cout * Kp,), dev)
+        L.hrf_rowgemm_pack(w, Cout, Csum, 0, Cout, Kp, wp, s)
+        L.hrf_rowgemm(cat.t, Kp, wp, b, red.t, Cout, 0, rows, Kp, Cout, s)
+
+        def bwd():
+            if red.grad is None:
+                return
+            L, s = ctx.L, ctx.stream
+            if w.requires_grad:
+                bgrad = b.grad if (b is not None and b.requires_grad) else None
+                strides = (H * W * Kp, W * Kp, Kp, 1)
+                ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
+                    red.grad, Cout, 0, None, None, None, None, cat.t, *strides, B, H, W, Csum, 1, 1, Cout,
+                    R.TF_NONE, None, None, None, w.grad, bgrad, ctx.stream))
+            L.hrf_rowgemm_pack(w, Cout, Csum, 1, Kp, Cout, wp, s)             # [Kp][Cout], zero rows past Csum
+            cat.grad = R._new((B, H, W, Kp), dev)
+            L.hrf_rowgemm(red.grad, Cout, wp, None, cat.grad, Kp, 0, rows, Cout, Kp, s)
+        ctx.push(bwd)
+        return red
+
     def _run(self, ctx, srcs):
         L, s = ctx.L, ctx.stream
         B, H, W, _ = srcs[0].t.shape
         dev = srcs[0].t.device
         Csum = sum(self.in_channels)
-        cat = R.Act(R._new((B, H, W, Csum), dev))
+        gemm = _WIDE and self.out_channels % 16 == 0          # LDS-tiled MFMA row GEMM for the reduction convolution
+        ld = (Csum + 15) // 16 * 16 if gemm else Csum         # its K is padded to 16 with zero columns
+        cat = R.Act(R._new((B, H, W, ld), dev))
         off, spans = 0, []
         for a in srcs:                                                        # hrfpn.py:80-84
             _, Hs, Ws, C = a.t.shape
-            L.hrf_bilinear_up_into(a.t, Hs, Ws, C, cat.t, Csum, off, B, H, W, s)
+            L.hrf_bilinear_up_into(a.t, Hs, Ws, C, cat.t, ld, off, B, H, W, s)
             spans.append((a, off, Hs, Ws, C))
             off += C
+        if ld > Csum:
+            # zero the pad columns: the "up-sampling" of a 1x1 map of zeros into them (the buffer is fresh memory)
+            L.hrf_bilinear_up_into(self._zeros(ld - Csum, B, dev), 1, 1, ld - Csum, cat.t, ld, Csum, B, H, W, s)
 
         def bwd_cat():
             if cat.grad is None:
@@ -170,14 +209,14 @@ class HRFPN(HipModule):
                     continue
                 if (Hs, Ws) == (H, W):                    # branch 0: the concat only copied it
                     g, acc = a.grad_target()
-                    ctx.L.hrf_slice_cols(cat.grad, Csum, o, B * H * W, C, g, acc, ctx.stream)
+                    ctx.L.hrf_slice_cols(cat.grad, ld, o, B * H * W, C, g, acc, ctx.stream)
                     continue
                 du = R._new((B, Hs, Ws, C), dev)
-                ctx.L.hrf_bilinear_up_bwd(cat.grad, Csum, o, B, H, W, C, None, Hs, Ws, du, None, ctx.stream)
+                ctx.L.hrf_bilinear_up_bwd(cat.grad, ld, o, B, H, W, C, None, Hs, Ws, du, None, ctx.stream)
                 a.add_grad(du)
         ctx.push(bwd_cat)
 
-        red = _conv_bias(ctx, cat, self.reduction_conv.conv)                  # hrfpn.py:85-88
+        red = self._reduce_gemm(ctx, cat, Csum) if gemm else _conv_bias(ctx, cat, self.reduction_conv.conv)   # hrfpn.py:85-88
         # hrfpn.py:89-91 pools `red` with kernel 2**i for every level; floor-mode k x k windows nest exactly
         # (rows/cols dropped at level i are dropped at every coarser level too), so level i is the 2 x 2 average
         # of level i-1: the full-resolution map is read once instead of num_outs-1 times, in both directions

@@ -203,6 +203,15 @@ long hrf_conv3_wgrad_wide_scratch(int B, int H, int W, int Cin, int Cout);
 int hrf_conv3_wgrad_wide(const float* dy, int ldD, const float* x, int ldX, int B, int H, int W, int Cin, int Cout,
                          float* dw, float* dbias, float* scratch, void* stream);
 
+/* Wide 1x1 convolution / Linear as an LDS-tiled MFMA row GEMM (the HRFPN reduction convolution, hrfpn.py:53-58,85):
+ *   hrf_rowgemm_pack  wp[n][k] (n < Np, k < Kp) = w[n][k] (dir 0: forward operand, w = [Cout][Cin]) or w[k][n]
+ *                     (dir 1: backward-data operand), zero outside the tensor: Np / Kp are the padded sizes.
+ *   hrf_rowgemm       y[m][n] (+)= bias[n] + sum_k x[m][k] * wp[n][k];  K % 16 == 0, N % 16 == 0 (pad columns of x must
+ *                     hold zeros or finite values matched by zero weights; bias, if given, has N entries). */
+int hrf_rowgemm_pack(const float* w, int Cout, int Cin, int dir, int Np, int Kp, float* wp, void* stream);
+int hrf_rowgemm(const float* x, int ldX, const float* wp, const float* bias, float* y, int ldY, int accumulate,
+                long M, int K, int N, void* stream);
+
 /* ---- fused flat-buffer AdamW (configs/hrfuser: AdamW lr 3e-4, wd 0.01, decay_mult 0 masks) ---
  * state = float[4] on device: {1-b1^t, 1-b2^t, t, -}; hrf_adamw_tick advances t on device so a
  * captured hipGraph replays correct bias corrections.                                           */

@@ -450,6 +450,56 @@ def run_conv3w(case, backend):
         use_backend('hip')
 
 
+RG_CASES = [(200, 270, 256, 0), (131, 48, 64, 0), (300, 1170, 256, 4), (128, 256, 270, 2), (77, 64, 40, 0)]   # M, K, N, groups
+
+
+def run_rowgemm(case, backend):
+    """hrf_rowgemm_pack + hrf_rowgemm: forward y = x W^T + b on zero-padded K, backward dx = dy W on padded N."""
+    M, K, N, wn = case
+    dev = use_backend(backend)
+    try:
+        L, s = _lib.lib(), _lib.stream_ptr()
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        bias = torch.randn(N, generator=g)
+        Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
+        L.hrf_debug_knob(24, wn)
+        xk = torch.zeros(M, Kp, device=dev); xk[:, :K] = x.to(dev)
+        wp = torch.empty(Np * Kp, device=dev)
+        bk = torch.zeros(Np, device=dev); bk[:N] = bias.to(dev)
+        L.hrf_rowgemm_pack(w.to(dev).contiguous(), N, K, 0, Np, Kp, wp, s)
+        y = torch.full((M, Np + 4), 3.0, device=dev)
+        L.hrf_rowgemm(xk, Kp, wp, bk, y, Np + 4, 0, M, Kp, Np, s)
+        ref = x @ w.t() + bias
+        assert r(y[:, :N], ref) < TOL
+        assert float(y[:, N:Np].abs().max()) == 0.0 if Np > N else True        # zero weight rows, zero bias
+        assert float((y[:, Np:] - 3.0).abs().max()) == 0.0
+        # backward-data operand: dx[m][k] = sum_n dy[m][n] w[n][k], accumulated into an existing gradient
+        dy = torch.randn(M, N, generator=g)
+        dyk = torch.zeros(M, Np, device=dev); dyk[:, :N] = dy.to(dev)
+        wq = torch.empty(Kp * Np, device=dev)
+        L.hrf_rowgemm_pack(w.to(dev).contiguous(), N, K, 1, Kp, Np, wq, s)
+        prev = torch.randn(M, Kp, generator=g)
+        dx = prev.to(dev).clone()
+        L.hrf_rowgemm(dyk, Np, wq, None, dx, Kp, 1, M, Np, Kp, s)
+        assert r(dx[:, :K] - prev[:, :K].to(dev), dy @ w) < TOL
+    finally:
+        _lib.lib().hrf_debug_knob(24, 0)
+        use_backend('hip')
+
+
+@pytest.mark.parametrize('case', RG_CASES[:2] + RG_CASES[3:], ids=str)
+def test_rowgemm_emul(case):
+    run_rowgemm(case, 'emul')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', RG_CASES + [(61440, 272, 256, 0)], ids=str)
+def test_rowgemm_gpu(case):
+    run_rowgemm(case, 'hip')
+
+
 @pytest.mark.parametrize('case', C3W_CASES[:4] + C3W_CASES[-1:], ids=str)
 def test_conv3w_emul(case):
     run_conv3w(case, 'emul')
