@@ -50,6 +50,7 @@ def parse():
                     help='replay through the library launch recorder (hrf_replay) instead of hipGraph (1 GPU only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-neck', action='store_true', help='skip the HRFPN neck timing (the consumer of the 4 maps)')
     ap.add_argument('--profile-steps', type=int, default=1)
     ap.add_argument('--dump-kernels', default='', help='write the per-kernel table (JSON) to this path')
     return ap.parse_args()
@@ -198,6 +199,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(tag, B, H, W, mc)
 
+    neck = None
+    if rank == 0 and world == 1 and not args.no_neck:
+        # the HRFPN neck that consumes the four maps, timed on its own (not part of `value`)
+        try:
+            widths = cfg['extra']['stage4']['num_channels']
+            neck = profiling.time_neck(list(widths), B, H // 4, W // 4)
+        except Exception as e:
+            neck = {'error': str(e)[:200]}
+
     if rank == 0:
         line = {
             'metric': 'train images/sec HRFuser-T r640 3-modal @1/2/4/8 MI355X; fwd ms/img',
@@ -210,7 +220,7 @@ def main():
                        'global_batch': B * world, 'parallelism': f'dp{world}',
                        'launch': 'recorded program replay' if use_prog else ('hipGraph replay' if use_graph else 'eager')},
             'fwd_ms_per_img': fwd_ms,
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'cpu_baseline': cpu, 'neck': neck,
         }
         print(json.dumps(line), flush=True)
     sys.stdout.flush()

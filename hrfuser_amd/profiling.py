@@ -299,3 +299,46 @@ def time_eval_forward(net, x, mods, iters=30, use_graph=True):
             run()
         torch.cuda.synchronize()
     return round((time.perf_counter() - t0) / iters / B * 1e3, 4)
+
+
+def time_neck(in_channels, B, H, W, out_channels=256, iters=20, warm=15, seed=0):
+    """HRFPN neck on cuda:0 at the backbone's output shapes, random weights / inputs:
+    -> dict(fwd_ms, fwd_bwd_ms, fwd_gflop).  Inputs are channels-last like the backbone's outputs."""
+    import time
+    from .neck import HRFPN
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn(B, c, H >> i, W >> i, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+          for i, c in enumerate(in_channels)]
+    net = HRFPN(in_channels=list(in_channels), out_channels=out_channels)
+    net.init_weights()
+    net.to(dev)
+
+    def timed(fn):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    net.eval()
+    with torch.no_grad():
+        fwd = timed(lambda: net(xs))
+    net.train()
+    xr = [t.detach().requires_grad_(True) for t in xs]
+    ones = None
+
+    def step():
+        nonlocal ones
+        ys = net(xr)
+        if ones is None:
+            ones = [torch.ones_like(y) for y in ys]
+        torch.autograd.backward(list(ys), ones)
+    both = timed(step)
+    flop = 2.0 * B * H * W * (sum(in_channels) * out_channels + 9 * out_channels * out_channels * sum(4.0 ** -i for i in range(5)))
+    return {'workload': f'HRFPN {list(in_channels)}->{out_channels}, {B}x{H}x{W} finest grid, 5 levels',
+            'fwd_ms': round(fwd, 3), 'fwd_bwd_ms': round(both, 3), 'fwd_gflop': round(flop / 1e9, 2),
+            'fwd_tflops': round(flop / fwd / 1e9, 1)}

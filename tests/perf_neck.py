@@ -7,13 +7,13 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ may use the oracle (eager comparison leg)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 from hrfuser_amd import HRFPN          # noqa: E402
 
 
-def timed(fn, n=20, warm=5):
+def timed(fn, n=20, warm=15):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_neck
 rm -rf $OUT; mkdir -p $OUT
 export NECK_ONLY=${NECK_ONLY:-hip} NECK_TAG=${NECK_TAG:-T}
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o n -- python3 $GRAFT_REPO_ROOT/tools/bench_neck.py > $OUT/bench_neck_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o n -- python3 $GRAFT_REPO_ROOT/tests/perf_neck.py > $OUT/bench_neck_under_rocprof.log 2>&1
 echo trace rc=$?
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
