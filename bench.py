@@ -208,6 +208,33 @@ def main():
         except Exception as e:
             neck = {'error': str(e)[:200]}
 
+    feat = None
+    if rank == 0 and world == 1 and not args.no_neck and use_graph:
+        # extract_feat training step = backbone + neck on both tapes in ONE hipGraph (not part of `value`)
+        try:
+            from hrfuser_amd.detector import FeatureExtractor, ExtractTrainer, make_pyramid_cotangents
+            from hrfuser_amd import HRFPN
+            widths = list(cfg['extra']['stage4']['num_channels'])
+            nk = HRFPN(in_channels=widths, out_channels=256)
+            nk.init_weights()
+            fx = FeatureExtractor(net, nk.to(dev))
+            fx.train()
+            pc = make_pyramid_cotangents(fx, x, mods)
+            et = ExtractTrainer(fx)
+            et.capture(x, mods, pc)
+            for _ in range(5):
+                et.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                et.replay()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 20 * 1e3
+            feat = {'workload': f'extract_feat train step: {tag} backbone + HRFPN {widths}->256, {B} img, one hipGraph',
+                    'ms_per_step': round(ms, 3), 'images_per_sec': round(B / ms * 1e3, 2)}
+        except Exception as e:
+            feat = {'error': str(e)[:200]}
+
     if rank == 0:
         line = {
             'metric': 'train images/sec HRFuser-T r640 3-modal @1/2/4/8 MI355X; fwd ms/img',
@@ -220,7 +247,7 @@ def main():
                        'global_batch': B * world, 'parallelism': f'dp{world}',
                        'launch': 'recorded program replay' if use_prog else ('hipGraph replay' if use_graph else 'eager')},
             'fwd_ms_per_img': fwd_ms,
-            'roofline': roof, 'cpu_baseline': cpu, 'neck': neck,
+            'roofline': roof, 'cpu_baseline': cpu, 'neck': neck, 'extract_feat': feat,
         }
         print(json.dumps(line), flush=True)
     sys.stdout.flush()

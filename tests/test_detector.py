@@ -1,0 +1,88 @@
+"""Detector-level caller: combine_mod_imgs / extract_feat / simple_test list handling
+(mmdet/models/detectors/two_stage.py:9-19,76-84,211-220) and the backbone+neck training step."""
+import copy
+
+import pytest
+import torch
+
+import helpers as T
+import hrfuser_oracle as O
+import hrfpn_oracle as N
+
+
+def test_combine_mod_imgs_matches_reference_semantics():
+    from hrfuser_amd.detector import combine_mod_imgs
+    a, b, c = object(), object(), object()
+    assert combine_mod_imgs() is None                                   # two_stage.py:17-18
+    assert combine_mod_imgs(lidar_img=a) == [a]
+    assert combine_mod_imgs(radar_img=b, lidar_img=a) == [a, b]         # fixed order lidar, radar, gated
+    assert combine_mod_imgs(gated_img=c, lidar_img=a) == [a, c]
+    assert combine_mod_imgs(a, b, c) == [a, b, c]
+
+
+def test_feature_extractor_builds_from_config_and_routes_calls():
+    from hrfuser_amd.detector import FeatureExtractor
+    from hrfuser_amd import HRFuserHRFormerBased, HRFPN
+    cfg = T.load_cfgs()['t_nus']
+    fx = FeatureExtractor(copy.deepcopy(cfg), dict(type='HRFPN', in_channels=[18, 36, 72, 144], out_channels=256))
+    assert isinstance(fx.backbone, HRFuserHRFormerBased) and isinstance(fx.neck, HRFPN) and fx.with_neck
+    assert not FeatureExtractor(copy.deepcopy(cfg)).with_neck
+    seen = {}
+
+    def fake_extract(img, mod_imgs=None):
+        seen['img'], seen['mods'] = img, mod_imgs
+        return 'feats'
+    fx.extract_feat = fake_extract
+    img, li, ra = torch.zeros(1), torch.ones(1), torch.full((1,), 2.0)
+    assert fx(img, lidar_img=li, radar_img=ra) == 'feats' and seen['mods'] == [li, ra]
+    # simple_test: every modality arrives wrapped in a list (one entry per test-time augmentation)
+    assert fx.simple_test_feats(img, lidar_img=[li], radar_img=[ra]) == 'feats'
+    assert seen['mods'][0] is li and seen['mods'][1] is ra
+    with pytest.raises(NotImplementedError):
+        FeatureExtractor.extract_feat(fx, img)                          # camera-only call: plain HRFormer (8f-4)
+
+
+def _pair(dev):
+    from hrfuser_amd.detector import FeatureExtractor
+    from hrfuser_amd import HRFPN
+    net, orc, cfg = T.build_pair('t_nus', dev)
+    norc = N.HRFPNOracle(in_channels=[18, 36, 72, 144], out_channels=256)
+    O.seeded_fill_(norc, 11)
+    neck = HRFPN(in_channels=[18, 36, 72, 144], out_channels=256)
+    neck.load_state_dict(norc.state_dict())
+    neck.to(dev)
+    return FeatureExtractor(net, neck), orc, norc, cfg
+
+
+@pytest.mark.gpu
+def test_extract_trainer_step_gpu():
+    """One ExtractTrainer step (explicit tapes, both engines) leaves the same gradients in the two arenas as the
+    torch.autograd route through the module boundaries, and the captured hipGraph replays the same step."""
+    from hrfuser_amd.detector import ExtractTrainer, make_pyramid_cotangents
+    dev = T.use_backend('hip')
+    fx, orc, norc, cfg = _pair(dev)
+    x, mods = O.seeded_inputs(2, 64, 96, cfg.get('mod_in_channels', [3, 3]), seed=1)
+    x, mods = x.to(dev), [m.to(dev) for m in mods]
+    fx.train()
+    cots = make_pyramid_cotangents(fx, x, mods)
+    eb, en = fx.backbone._engine(), fx.neck._engine()
+    # autograd route
+    eb.ready(dev); en.ready(dev)
+    eb.flat_g.zero_(); en.flat_g.zero_()
+    ys = fx.extract_feat(x, mods)
+    sum((y.permute(0, 2, 3, 1) * c).sum() for y, c in zip(ys, cots)).backward()
+    torch.cuda.synchronize()
+    gb, gn = eb.flat_g.clone(), en.flat_g.clone()
+    # explicit-tape trainer (lr = 0: the parameters stay put, the arenas hold this step's gradients)
+    tr = ExtractTrainer(fx, lr=0.0, weight_decay=0.0)
+    bn_state = {k: v.clone() for k, v in fx.backbone.state_dict().items() if 'running' in k}
+    tr.step(x, mods, cots)
+    torch.cuda.synchronize()
+    assert T.rel_l2(en.flat_g, gn) < 1e-4 and T.rel_l2(eb.flat_g, gb) < 1e-3
+    # captured step == eager step
+    tr.capture(x, mods, cots)
+    tr.replay()
+    torch.cuda.synchronize()
+    assert T.rel_l2(en.flat_g, gn) < 1e-4 and T.rel_l2(eb.flat_g, gb) < 1e-3
+    assert all(torch.isfinite(v).all() for v in fx.state_dict().values())
+    assert any(not torch.equal(v, fx.backbone.state_dict()[k]) for k, v in bn_state.items())   # BN running stats moved
