@@ -353,7 +353,7 @@ class LocalWindowSelfAttention(nn.Module):
         ws = (window_size, window_size) if isinstance(window_size, int) else tuple(window_size)
         self.attn = WindowMSA(embed_dims, num_heads, ws)
 
-    def run(self, ctx, x, ln, cache=None):
+    def run(self, ctx, x, ln, cache=None, drop=None):
         a = self.attn
         B, H, W, C = x.t.shape
         lin = R.ln_input(ctx, x, ln, cache)
@@ -362,11 +362,12 @@ class LocalWindowSelfAttention(nn.Module):
         bq = a.qkv.bias
         o = R.window_attention(ctx, qkv, 0, qkv, C, qkv, 2 * C, bq[C:2 * C], bq[2 * C:], bq, C, bq, 2 * C,
                                a.relative_position_bias_table, a.num_heads, (B, H, W, C))
-        return R.linear_residual(ctx, o, a.out_proj, x)
+        return R.linear_residual(ctx, o, a.out_proj, x, drop=drop)
 
 
 class HRFormerBlock(nn.Module):
-    """hrformer.py:365-373: x += LSA(LN1(x)); x += CrossFFN(LN2(x))  (DropPath is Identity, App. D-2)."""
+    """hrformer.py:365-373: x += DropPath(LSA(LN1(x))); x += DropPath(CrossFFN(LN2(x))).  DropPath is Identity on
+    the HRFuser path (App. D-2: the rate never reaches the stages); the plain HRFormer applies its linspace schedule."""
     expansion = 1
 
     def __init__(self, in_channels, out_channels, num_heads, window_size=WIN, mlp_ratio=4, drop_path=0.0,
@@ -377,13 +378,18 @@ class HRFormerBlock(nn.Module):
                                              with_pad_mask=kw.get('with_pad_mask', False))
         self.norm2 = build_ln(transformer_norm_cfg, out_channels)
         self.ffn = CrossFFN(in_channels, int(in_channels * mlp_ratio), out_channels, norm_cfg)
-        if drop_path > 0.0:
-            raise NotImplementedError('HRFormerBlock drop_path is always 0 on this path (SURVEY App. D-2)')
+        self.drop_path_prob = float(drop_path)
 
     def run(self, ctx, x):
-        x = self.attn.run(ctx, x, self.norm1)
+        p = self.drop_path_prob
+        s1 = s2 = None
+        if p > 0.0 and ctx.training and self.training:
+            # mmcv DropPath: per-sample floor(keep + U[0,1)) / keep, drawn independently for the two residual paths
+            eng = ctx.owner._engine()
+            s1, s2 = eng.droppath_scale(x.t.shape[0], p), eng.droppath_scale(x.t.shape[0], p)
+        x = self.attn.run(ctx, x, self.norm1, drop=None if s1 is None else (None, 1.0, s1))
         tail = self.ffn.run(ctx, R.ln_input(ctx, x, self.norm2))
-        return R.materialize(ctx, tail, R.ACT_GELU, res=x, act_first=True)
+        return R.materialize(ctx, tail, R.ACT_GELU, res=x, act_first=True, rowscale=s2)
 
 
 class WindowMCA(nn.Module):
@@ -497,10 +503,11 @@ class HRFomerModule(nn.Module):
         ch = self.in_channels
         self.branches = nn.ModuleList(
             nn.Sequential(*[block(ch[i], num_channels[i], num_heads=num_heads[i], window_size=num_window_sizes[i],
-                                  mlp_ratio=num_mlp_ratios[i], drop_path=drop_paths[0] if drop_paths else 0.0,
+                                  mlp_ratio=num_mlp_ratios[i],
+                                  drop_path=drop_paths[min(b, len(drop_paths) - 1)] if drop_paths else 0.0,   # hrformer.py:453-497: block b <- drop_paths[b]
                                   norm_cfg=norm_cfg, transformer_norm_cfg=transformer_norm_cfg,
                                   with_pad_mask=with_pad_mask)
-                            for _ in range(num_blocks[i])]) for i in range(nb))
+                            for b in range(num_blocks[i])]) for i in range(nb))
         self.fuse_layers = None
         if nb > 1:
             rows = []
@@ -927,3 +934,95 @@ class HRFuserHRFormerBased(HipModule):
         ys = self._run_stage(ctx, cam_stage, xs)
         ctx.join(lanes)
         return ys, mods
+
+
+@BACKBONES.register_module()
+class HRFormer(HipModule):
+    """Plain camera-only HRFormer on the same kernels: drop-in for mmdet's `HRFormer`
+    (hrformer.py:565-740 over HRNet, hrnet.py:211-596): registry name, constructor keywords, `forward(x) -> list`,
+    state-dict keys.  It is the camera stream of HRFuserHRFormerBased without the fusion blocks, with three
+    differences taken from the reference: block key 'HRFORMERBLOCK', the stochastic-depth schedule IS applied
+    (hrformer.py:666-678) and `transition1[i]` runs whole (hrnet.py:563-566)."""
+
+    blocks_dict = {'BOTTLENECK': Bottleneck, 'HRFORMERBLOCK': HRFormerBlock}
+    _make_stage = HRFuserHRFormerBased._make_stage
+    init_weights = HRFuserHRFormerBased.init_weights
+    refresh_inputs = HRFuserHRFormerBased.refresh_inputs
+    _wrap_inputs = HRFuserHRFormerBased._wrap_inputs
+    _stem = HRFuserHRFormerBased._stem
+    _run_stage = staticmethod(HRFuserHRFormerBased._run_stage)
+
+    def __init__(self, extra, in_channels=3, conv_cfg=None, norm_cfg=dict(type='BN', requires_grad=True),
+                 transformer_norm_cfg=dict(type='LN', eps=1e-6), norm_eval=False, with_cp=False,
+                 multiscale_output=True, drop_path_rate=0., zero_init_residual=False, pretrained=None, init_cfg=None):
+        super().__init__()
+        assert 'stage1' in extra and 'stage2' in extra and 'stage3' in extra and 'stage4' in extra     # hrnet.py:296
+        for i in range(4):
+            cfg = extra[f'stage{i + 1}']
+            assert len(cfg['num_blocks']) == cfg['num_branches'] and len(cfg['num_channels']) == cfg['num_branches']
+        if conv_cfg is not None:
+            raise NotImplementedError('conv_cfg must be None (plain Conv2d), as in every reference config')
+        # stochastic depth (hrformer.py:666-678): linspace over the blocks of stages 2-4; mutates `extra` like the reference
+        depths = [extra[s]['num_blocks'][0] * extra[s]['num_modules'] for s in ('stage2', 'stage3', 'stage4')]
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        extra['stage2']['drop_path_rates'] = dpr[0:depths[0]]
+        extra['stage3']['drop_path_rates'] = dpr[depths[0]:depths[0] + depths[1]]
+        extra['stage4']['drop_path_rates'] = dpr[depths[0] + depths[1]:]
+        self.extra = extra
+        self.norm_cfg, self.transformer_norm_cfg = norm_cfg, transformer_norm_cfg
+        self.norm_eval, self.with_cp = norm_eval, with_cp
+        ncfg = norm_cfg
+        self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)                                   # hrnet.py:337-371
+        self.bn1 = build_bn(ncfg, 64)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = build_bn(ncfg, 64)
+        self.stage1_cfg = extra['stage1']
+        if self.blocks_dict[self.stage1_cfg['block']] is not Bottleneck:
+            raise NotImplementedError('stage1 block must be BOTTLENECK')
+        c1 = self.stage1_cfg['num_channels'][0]
+        self.layer1 = _make_res_layer(64, c1, self.stage1_cfg['num_blocks'][0], ncfg)
+        pre = [c1 * 4]
+        for si in (2, 3, 4):
+            cfg = extra[f'stage{si}']
+            setattr(self, f'stage{si}_cfg', cfg)
+            ch = [c * self.blocks_dict[cfg['block']].expansion for c in cfg['num_channels']]
+            setattr(self, f'transition{si - 1}', _make_transition(pre, ch, ncfg))
+            stage, pre = self._make_stage(cfg, ch, multiscale_output if si == 4 else True)
+            setattr(self, f'stage{si}', stage)
+        self.init_weights()
+
+    def train(self, mode=True):
+        """hrnet.py:588-596 (norm_eval keeps BN frozen).  Unlike the reference this returns self."""
+        super().train(mode)
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+    def forward(self, x):
+        return self._call_engine((x,))
+
+    @staticmethod
+    def _transition(ctx, trans, prev, first):
+        """hrnet.py:562-582: a non-None transition takes the single stage-1 map (first) / the LAST branch of the
+        previous stage; None keeps branch i."""
+        nb = len(trans)
+        xs = [None] * nb
+        lanes = ctx.fork(nb)
+        for i in range(nb):
+            tr = trans[i]
+            if tr is None:
+                xs[i] = prev[i]
+                continue
+            with ctx.on(lanes[i]):
+                src = prev if first else prev[-1]
+                xs[i] = _run_conv_chain(ctx, src, [tr] if isinstance(tr[0], nn.Conv2d) else list(tr))
+        ctx.join(lanes)
+        return xs
+
+    def _run(self, ctx, srcs):
+        x = self._stem(ctx, srcs[0], self.conv1, self.bn1, self.conv2, self.bn2, self.layer1)
+        ys = self._run_stage(ctx, self.stage2, self._transition(ctx, self.transition1, x, True))
+        ys = self._run_stage(ctx, self.stage3, self._transition(ctx, self.transition2, ys, False))
+        return self._run_stage(ctx, self.stage4, self._transition(ctx, self.transition3, ys, False))

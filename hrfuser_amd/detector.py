@@ -37,11 +37,11 @@ class FeatureExtractor(nn.Module):
         return hasattr(self, 'neck') and self.neck is not None                                      # base.py:27-29
 
     def extract_feat(self, img, mod_imgs=None):
-        """two_stage.py:76-84 (the camera-only call `backbone(img)` is the plain HRFormer family)."""
-        if mod_imgs is None:
-            raise NotImplementedError('camera-only extract_feat needs the plain HRFormer backbone (SURVEY 8f-4); '
-                                      'HRFuserHRFormerBased.forward takes (img, mod_imgs)')
-        x = self.backbone(img, mod_imgs)
+        """two_stage.py:76-84."""
+        if mod_imgs is not None:
+            x = self.backbone(img, mod_imgs)
+        else:
+            x = self.backbone(img)             # camera-only backbones (HRFormer); HRFuser raises TypeError like the reference
         if self.with_neck:
             x = self.neck(x)
         return x

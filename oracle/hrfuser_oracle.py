@@ -283,13 +283,15 @@ class HRFormerModule(nn.Module):
     fuse layers hrformer.py:498-561)."""
 
     def __init__(self, channels, num_blocks, heads, mlp_ratios, norm_cfg, ln_cfg,
-                 multiscale_output=True):
+                 multiscale_output=True, drop_paths=None):
         super().__init__()
         nb = len(channels)
         self.nb = nb
+        # hrformer.py:453-497: block b of EVERY branch takes drop_paths[b]
+        dp = (lambda b: drop_paths[b]) if drop_paths is not None else (lambda b: 0.)
         self.branches = nn.ModuleList(
-            nn.Sequential(*[HRFormerBlock(channels[i], heads[i], mlp_ratios[i], norm_cfg, ln_cfg)
-                            for _ in range(num_blocks[i])]) for i in range(nb))
+            nn.Sequential(*[HRFormerBlock(channels[i], heads[i], mlp_ratios[i], norm_cfg, ln_cfg, drop_path=dp(b))
+                            for b in range(num_blocks[i])]) for i in range(nb))
         self.fuse_layers = None
         if nb > 1:
             rows = []
@@ -476,6 +478,62 @@ class HRFuserOracle(nn.Module):
         for mod in stage:
             xs = mod(xs)
         return xs
+
+
+class HRFormerOracle(nn.Module):
+    """Restatement of the plain camera-only HRFormer (hrformer.py:565-740 over HRNet, hrnet.py:211-596): same ctor
+    kwargs and state-dict keys.  Differences from the HRFuser camera stream: block key 'HRFORMERBLOCK', the
+    stochastic-depth schedule IS applied (linspace over the blocks of stages 2-4, hrformer.py:666-678) and
+    transition1[i] is applied whole (hrnet.py:563-566; the `[0]` quirk is HRFuser's)."""
+
+    def __init__(self, extra, in_channels=3, conv_cfg=None, norm_cfg=dict(type='BN', requires_grad=True),
+                 transformer_norm_cfg=dict(type='LN', eps=1e-6), norm_eval=False, with_cp=False,
+                 multiscale_output=True, drop_path_rate=0., zero_init_residual=False, pretrained=None, init_cfg=None):
+        super().__init__()
+        self.norm_eval = norm_eval
+        self.extra = extra
+        ncfg, lcfg = norm_cfg, transformer_norm_cfg
+        depths = [extra[s]['num_blocks'][0] * extra[s]['num_modules'] for s in ('stage2', 'stage3', 'stage4')]
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        cuts = [0, depths[0], depths[0] + depths[1], sum(depths)]
+        self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)
+        self.bn1 = make_bn(ncfg, 64)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = make_bn(ncfg, 64)
+        s1 = extra['stage1']
+        assert s1['block'] == 'BOTTLENECK'
+        self.layer1 = make_bottleneck_layer(64, s1['num_channels'][0], s1['num_blocks'][0], ncfg)
+        pre = [s1['num_channels'][0] * 4]
+        for k, si in enumerate((2, 3, 4)):
+            cfg = extra[f'stage{si}']
+            assert cfg['block'] == 'HRFORMERBLOCK'
+            ch = list(cfg['num_channels'])
+            setattr(self, f'transition{si - 1}', make_transition(pre, ch, ncfg))
+            rates = dpr[cuts[k]:cuts[k + 1]]
+            n, nb0 = cfg['num_modules'], cfg['num_blocks'][0]
+            ms = multiscale_output if si == 4 else True
+            setattr(self, f'stage{si}', nn.Sequential(*[
+                HRFormerModule(ch, cfg['num_blocks'], cfg['num_heads'], cfg['mlp_ratios'], ncfg, lcfg,
+                               ms or m != n - 1, drop_paths=rates[nb0 * m:nb0 * (m + 1)]) for m in range(n)]))
+            pre = ch
+
+    def train(self, mode=True):
+        super().train(mode)
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+    def forward(self, x):                                                   # hrnet.py:552-586
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = self.layer1(F.relu(self.bn2(self.conv2(x))))
+        xs = [t(x) if t is not None else x for t in self.transition1]
+        ys = HRFuserOracle._run(self.stage2, xs)
+        xs = [t(ys[-1]) if t is not None else ys[i] for i, t in enumerate(self.transition2)]
+        ys = HRFuserOracle._run(self.stage3, xs)
+        xs = [t(ys[-1]) if t is not None else ys[i] for i, t in enumerate(self.transition3)]
+        return HRFuserOracle._run(self.stage4, xs)
 
 
 # ----------------------------------------------------------------------------- shared test utils

@@ -38,8 +38,8 @@ def test_feature_extractor_builds_from_config_and_routes_calls():
     # simple_test: every modality arrives wrapped in a list (one entry per test-time augmentation)
     assert fx.simple_test_feats(img, lidar_img=[li], radar_img=[ra]) == 'feats'
     assert seen['mods'][0] is li and seen['mods'][1] is ra
-    with pytest.raises(NotImplementedError):
-        FeatureExtractor.extract_feat(fx, img)                          # camera-only call: plain HRFormer (8f-4)
+    with pytest.raises(TypeError):
+        FeatureExtractor.extract_feat(fx, img)                          # camera-only call on a fusion backbone (as the reference)
 
 
 def _pair(dev):
