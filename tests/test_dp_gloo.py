@@ -38,6 +38,24 @@ def _worker(rank, world, port, ret):
     N = lambda t: t.detach().float().cpu().numpy().copy()
     res = dict(out=[N(o.t) for o in outs], grad=N(eng.flat_g), param=N(eng.flat_p),
                rm=N(net.bn1.running_mean), rv=N(net.bn1.running_var))
+    # ---- the neck's arena goes through the same exchange: rank-sum of local gradients
+    import hrfpn_oracle as NO
+    from hrfuser_amd import HRFPN
+    norc = NO.HRFPNOracle(in_channels=[18, 36], out_channels=32, num_outs=3)
+    O.seeded_fill_(norc, 11)
+    neck = HRFPN(in_channels=[18, 36], out_channels=32, num_outs=3)
+    neck.load_state_dict(norc.state_dict())
+    neck.train()
+    gm = torch.Generator().manual_seed(9)
+    maps = [torch.randn(B, 18, 8, 16, generator=gm), torch.randn(B, 36, 4, 8, generator=gm)]
+    ncots = [torch.randn(B, 8 >> i, 16 >> i, 32, generator=gm) for i in range(3)]
+    ntr = Trainer(neck, lr=0.0, weight_decay=0.0, group=dist.group.WORLD, world_size=world)
+    ntr.step(maps[0][sl], [maps[1][sl]], [c[sl] for c in ncots])
+    res['neck_grad'] = N(neck._engine().flat_g)
+    if rank == 0:
+        ys = norc(maps)
+        sum((y.permute(0, 2, 3, 1) * c).sum() for y, c in zip(ys, ncots)).backward()
+        ret['neck_ref'] = N(torch.cat([p.grad.reshape(-1) for p in norc.parameters()]))
     if rank == 0:
         # single-process reference on the WHOLE batch: oracle fp64 + torch AdamW with the same masks
         o64 = copy.deepcopy(orc).double().train()
@@ -83,3 +101,5 @@ def test_two_rank_syncbn_and_grad_exchange_equal_single_process():
         worst = max(worst, err)
     assert worst < 2e-2, worst
     assert ret['wd_mask_sum'] > 0
+    # neck: all-reduced arena = gradient of the whole-batch loss (no normalisation layers in HRFPN)
+    assert rel(res['neck_grad'], ret['neck_ref']) < 1e-4
