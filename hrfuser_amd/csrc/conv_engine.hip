@@ -24,6 +24,8 @@
 //
 // Reference ops replaced: every nn.Conv2d(k=1|3, groups=1) + nn.Linear reached from
 // mmdet/models/backbones/{hrfuser_hrformer_based,hrformer,hrnet,resnet}.py.
+#include <algorithm>
+#include <vector>
 #include "hrf_common.h"
 #include "hrf_lin.h"
 #include "../../include/hrfuser_hip.h"
@@ -525,6 +527,17 @@ struct WgradDenseArgs {
   int gx, gy, sp;                  // logical grid (co groups, n groups, pixel splits), see the XCD mapping below
 };
 
+// Weight gradients are LEAVES of the backward graph: up to WGMAX independent problems of the same kernel variant are
+// issued as ONE launch (hrf_wgrad_group_begin/_end): a 13 MB problem alone cannot fill 256 CUs for longer than its own
+// ramp-up, 16 of them back to back do.  Block b of the launch belongs to problem p with bstart[p] <= b < bstart[p+1]
+// (every problem's block count is a multiple of 8, so the XCD-aware mapping below is unchanged).
+constexpr int WGMAX = 16;
+struct WgradGroup {
+  int nprob;
+  int bstart[WGMAX + 1];
+  WgradDenseArgs p[WGMAX];
+};
+
 constexpr int WUMAX = 8;   // k-steps (of 4 pixels) whose loads are issued before the first use
 constexpr int WNW = 8;     // waves per block (512 threads)
 
@@ -533,7 +546,11 @@ constexpr int WNW = 8;     // waves per block (512 threads)
 // output atomics stay coalesced); every lane owns its own (ci, tap) and gathers the X operand from
 // the correspondingly shifted input pixel (exact zero outside the image).
 template <int MT, int NT, bool BNB, int ACT, bool TAP>
-__global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a) {
+__global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_args) {
+  int prob = 0;
+  while (prob + 1 < grp_args.nprob && (int)blockIdx.x >= grp_args.bstart[prob + 1]) ++prob;   // (wave-uniform, <= 15 steps)
+  const WgradDenseArgs& a = grp_args.p[prob];
+  const int bid = (int)blockIdx.x - grp_args.bstart[prob];
   constexpr int WU = MT * NT > 16 ? WUMAX / 2 : WUMAX;       // keep the 5x5-tile variants inside 256 VGPRs
   constexpr int WSP = NT * 16 + 4;                           // LDS pitch of the merge tile (2-way bank aliasing at most)
   __shared__ float sAcc[2 * MT * 16 * WSP];
@@ -546,7 +563,7 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradDenseArgs a)
   // back-to-back there, so the chunk's dY / X rows are fetched from the fabric once, not once per
   // block (measured on the 3x3 64->64 weight gradient: 206 MB of fabric reads for 24 MB of data).
   const int G = a.gx * a.gy;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = bid & 7, slot = bid >> 3;
   const int grp = slot % G, bz = (slot / G) * 8 + xcd;
   if (bz >= a.sp) return;                                   // padding blocks (sp rounded up to 8)
   const int bx = grp % a.gx, by = grp / a.gx;
@@ -847,6 +864,11 @@ extern "C" int hrf_debug_knob(int key, int value) {
   return HRF_OK;
 }
 
+struct WgPending { int key; int blocks; WgradDenseArgs d; };
+static bool g_wg_collect = false;
+static std::vector<WgPending> g_wg_pending;
+static int wgrad_dense_launch(int key, const WgradGroup& d, int total_blocks, void* stream);
+
 #define HRF_BW_LAUNCH(D1_, BNB_, TFA_) \
   HRF_LAUNCH((conv_bwd_wgt_kernel<D1_, BNB_, TFA_>), grid, dim3(256), 0, stream, a)
 #define HRF_BW_TFA(D1_, BNB_)                                       \
@@ -921,8 +943,33 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     d.chunk = hrf_cdiv(hrf_cdiv(a.Mpix, sp), 4 * WNW) * 4 * WNW;
     sp = hrf_cdiv(a.Mpix, d.chunk);
     d.gx = hrf_cdiv(Cout, 16 * mt); d.gy = d.gyc; d.sp = sp;
-    const dim3 g2(d.gx * d.gy * hrf_cdiv(sp, 8) * 8);
+    const int nblocks = d.gx * d.gy * hrf_cdiv(sp, 8) * 8;
     const int act = tf_mode == HRF_TF_AFFINE_RELU ? 1 : (tf_mode == HRF_TF_AFFINE_GELU ? 2 : 0);
+    const int key = ((((mt * 8 + nt) * 2 + (cA != nullptr ? 1 : 0)) * 4 + act) * 2) + (tap3 ? 1 : 0);
+    if (g_wg_collect) {                                      // queued: launched by hrf_wgrad_group_end
+      g_wg_pending.push_back(WgPending{key, nblocks, d});
+      return HRF_OK;
+    }
+    WgradGroup one;
+    one.nprob = 1; one.bstart[0] = 0; one.bstart[1] = nblocks; one.p[0] = d;
+    return wgrad_dense_launch(key, one, nblocks, stream);
+  }
+  const dim3 grid(gx, gy, splits);
+  if (dense1) {
+    if (cA != nullptr) { HRF_BW_TFA(true, true) } else { HRF_BW_TFA(true, false) }
+  } else {
+    if (cA != nullptr) { HRF_BW_TFA(false, true) } else { HRF_BW_TFA(false, false) }
+  }
+  return hrf_check_launch();
+}
+
+// one launch of kernel variant `key` = (mt, nt, BatchNorm-backward, activation, 3x3) over a group of problems
+static int wgrad_dense_launch(int key, const WgradGroup& d, int total_blocks, void* stream) {
+    const bool tap3 = key & 1;
+    const int act = (key >> 1) & 3;
+    const bool bnb = (key >> 3) & 1;
+    const int nt = (key >> 4) & 7, mt = key >> 7;
+    const dim3 g2(total_blocks);
 #define HRF_WD_LAUNCH(MT_, NT_, BNB_, ACT_, TAP_) \
     HRF_LAUNCH((wgrad_dense_kernel<MT_, NT_, BNB_, ACT_, TAP_>), g2, dim3(64 * WNW), 0, stream, d)
 #define HRF_WD_ACT(MT_, NT_, BNB_, TAP_)                           \
@@ -930,7 +977,7 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     else if (act == 2) { HRF_WD_LAUNCH(MT_, NT_, BNB_, 2, TAP_); } \
     else { HRF_WD_LAUNCH(MT_, NT_, BNB_, 0, TAP_); }
 #define HRF_WD_BNB(MT_, NT_, TAP_) \
-    if (cA != nullptr) { HRF_WD_ACT(MT_, NT_, true, TAP_) } else { HRF_WD_ACT(MT_, NT_, false, TAP_) }
+    if (bnb) { HRF_WD_ACT(MT_, NT_, true, TAP_) } else { HRF_WD_ACT(MT_, NT_, false, TAP_) }
 #define HRF_WD_NT(MT_)                                    \
     switch (nt) {                                         \
       case 2: HRF_WD_BNB(MT_, 2, false) break;            \
@@ -952,12 +999,35 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
       }
     }
     return hrf_check_launch();
+}
+
+// ---- grouped weight-gradient launches (see WgradGroup): between begin and end every hrf_conv_bwd_weight call that
+// maps to the pixel-major kernel is queued; end issues them, WGMAX problems of one kernel variant per launch.
+extern "C" int hrf_wgrad_group_begin(void) {
+  g_wg_pending.clear();
+  g_wg_collect = true;
+  return HRF_OK;
+}
+
+extern "C" int hrf_wgrad_group_end(void* stream) {
+  g_wg_collect = false;
+  std::stable_sort(g_wg_pending.begin(), g_wg_pending.end(),
+                   [](const WgPending& x, const WgPending& y) { return x.key < y.key; });
+  int rc = HRF_OK;
+  size_t i = 0;
+  while (i < g_wg_pending.size()) {
+    WgradGroup g;
+    g.nprob = 0; g.bstart[0] = 0;
+    const int key = g_wg_pending[i].key;
+    while (i < g_wg_pending.size() && g_wg_pending[i].key == key && g.nprob < WGMAX) {
+      g.p[g.nprob] = g_wg_pending[i].d;
+      g.bstart[g.nprob + 1] = g.bstart[g.nprob] + g_wg_pending[i].blocks;
+      ++g.nprob; ++i;
+    }
+    for (int k = g.nprob + 1; k <= WGMAX; ++k) g.bstart[k] = g.bstart[g.nprob];
+    const int r = wgrad_dense_launch(key, g, g.bstart[g.nprob], stream);
+    if (r != HRF_OK) rc = r;
   }
-  const dim3 grid(gx, gy, splits);
-  if (dense1) {
-    if (cA != nullptr) { HRF_BW_TFA(true, true) } else { HRF_BW_TFA(true, false) }
-  } else {
-    if (cA != nullptr) { HRF_BW_TFA(false, true) } else { HRF_BW_TFA(false, false) }
-  }
-  return hrf_check_launch();
+  g_wg_pending.clear();
+  return rc;
 }

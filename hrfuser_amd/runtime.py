@@ -246,12 +246,21 @@ class Ctx:
             self._deferred = []                 # timing experiments only: drops the weight-gradient phase
         if self._deferred:
             fns, self._deferred = self._deferred, []
-            k = int(os.environ.get('HRF_WGRAD_LANES', '8'))
+            k = int(os.environ.get('HRF_WGRAD_LANES', '4'))
+            group = os.environ.get('HRF_WGRAD_GROUP', '1') != '0'
             lanes = self.fork(k)
             for j in range(k):
                 with _LaneScope(self, lanes[j]):
-                    for fn in fns[j::k]:
-                        fn()
+                    # the dense weight gradients of a lane are queued and issued as a few grouped launches
+                    # (up to 16 same-variant problems each, include/hrfuser_hip.h); everything else launches at once
+                    if group:
+                        self.L.hrf_wgrad_group_begin()
+                    try:
+                        for fn in fns[j::k]:
+                            fn()
+                    finally:
+                        if group:
+                            self.L.hrf_wgrad_group_end(self.stream)
             self.join(lanes)
         if self.multi:
             for lane in self._side_used.values():

@@ -212,6 +212,13 @@ int hrf_rowgemm_pack(const float* w, int Cout, int Cin, int dir, int Np, int Kp,
 int hrf_rowgemm(const float* x, int ldX, const float* wp, const float* bias, float* y, int ldY, int accumulate,
                 long M, int K, int N, void* stream);
 
+/* Grouped weight gradients.  Weight gradients are leaves of the backward graph; between hrf_wgrad_group_begin() and
+ * hrf_wgrad_group_end(stream) every hrf_conv_bwd_weight call that maps to the pixel-major kernel is queued instead of
+ * launched (its `stream` argument is ignored), and _end issues the queue on `stream`, up to 16 problems of one kernel
+ * variant per launch (results identical to separate launches).  Calls that use other kernels launch immediately. */
+int hrf_wgrad_group_begin(void);
+int hrf_wgrad_group_end(void* stream);
+
 /* ---- fused flat-buffer AdamW (configs/hrfuser: AdamW lr 3e-4, wd 0.01, decay_mult 0 masks) ---
  * state = float[4] on device: {1-b1^t, 1-b2^t, t, -}; hrf_adamw_tick advances t on device so a
  * captured hipGraph replays correct bias corrections.                                           */

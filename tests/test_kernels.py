@@ -511,6 +511,52 @@ def test_conv3w_gpu(case):
     run_conv3w(case, 'hip')
 
 
+# ------------------------------------------------------------------ grouped weight-gradient launches
+def run_wgrad_group(backend):
+    """hrf_wgrad_group_begin/_end: queued problems (several shapes / kernel variants, > 16 of one variant so that the
+    group is split) must produce what separate launches produce."""
+    dev = use_backend(backend)
+    try:
+        L, s = _lib.lib(), _lib.stream_ptr()
+        g = torch.Generator().manual_seed(3)
+        probs = []
+        shapes = [(1, 6, 10, 18, 72, 1)] * 18 + [(1, 6, 10, 72, 18, 1)] * 3 + [(2, 5, 7, 64, 64, 3)] * 2 + [(1, 4, 9, 36, 36, 1)]
+        for (B, H, W, Cin, Cout, KH) in shapes:
+            x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+            dy = torch.randn(B, H, W, Cout, generator=g).to(dev)
+            probs.append((B, H, W, Cin, Cout, KH, x, dy))
+
+        def run(grouped):
+            outs = []
+            if grouped:
+                L.hrf_wgrad_group_begin()
+            for (B, H, W, Cin, Cout, KH, x, dy) in probs:
+                dw = torch.zeros(Cout, Cin, KH, KH, device=dev)
+                db = torch.zeros(Cout, device=dev)
+                L.hrf_conv_bwd_weight(dy, Cout, 0, None, None, None, None, x, H * W * Cin, W * Cin, Cin, 1, B, H, W, Cin,
+                                      KH, 1, Cout, 0, None, None, None, dw, db, s)
+                outs.append((dw, db))
+            if grouped:
+                assert all(float(dw.abs().max()) == 0.0 for dw, _ in outs)      # nothing launched yet
+                L.hrf_wgrad_group_end(s)
+            return outs
+        ref, got = run(False), run(True)
+        for (dw0, db0), (dw1, db1) in zip(ref, got):
+            assert float(dw0.abs().max()) > 0
+            assert r(dw1, dw0) < TOL and r(db1, db0) < TOL
+    finally:
+        use_backend('hip')
+
+
+def test_wgrad_group_emul():
+    run_wgrad_group('emul')
+
+
+@pytest.mark.gpu
+def test_wgrad_group_gpu():
+    run_wgrad_group('hip')
+
+
 # ------------------------------------------------------------------ emulator (CPU suite)
 @pytest.mark.parametrize('case', CONV_CASES[:8] + CONV_CASES[-3:], ids=str)
 def test_conv_emul(case):
