@@ -1009,6 +1009,46 @@ extern "C" int hrf_wgrad_group_begin(void) {
   return HRF_OK;
 }
 
+// in-situ timing of the grouped launches (hrf_debug_knob 7 = 1): HIP events on the launching stream around every
+// launch of an eager step; hrf_wgrad_group_report aggregates them per kernel variant (bench.py's roofline leg)
+#ifndef HRF_EMUL
+struct WgTimed { int key, nprob; double bytes, flops; int Cin, Cout, H, W, stride, KH; hipEvent_t e0, e1; };
+static std::vector<WgTimed> g_wg_timed;
+#endif
+
+extern "C" long hrf_wgrad_group_report(double* out, long cap_rows) {
+  // rows of 12 doubles: key, launches, problems, total_us, algorithmic bytes, flops, then the dims of the
+  // heaviest problem of the variant (Cin, Cout, H, W, stride, KH); returns the number of rows; clears the log
+#ifdef HRF_EMUL
+  (void)out; (void)cap_rows;
+  return 0;
+#else
+  std::vector<std::vector<double>> rows;
+  for (auto& t : g_wg_timed) {
+    float ms = 0.f;
+    hipEventSynchronize(t.e1);
+    hipEventElapsedTime(&ms, t.e0, t.e1);
+    hipEventDestroy(t.e0); hipEventDestroy(t.e1);
+    std::vector<double>* r = nullptr;
+    for (auto& q : rows) if ((int)q[0] == t.key) r = &q;
+    if (r == nullptr) { rows.push_back(std::vector<double>(13, 0.0)); r = &rows.back(); (*r)[0] = t.key; }
+    (*r)[1] += 1; (*r)[2] += t.nprob; (*r)[3] += ms * 1e3; (*r)[4] += t.bytes; (*r)[5] += t.flops;
+    if (t.bytes / t.nprob > (*r)[12]) {
+      (*r)[12] = t.bytes / t.nprob;
+      (*r)[6] = t.Cin; (*r)[7] = t.Cout; (*r)[8] = t.H; (*r)[9] = t.W; (*r)[10] = t.stride; (*r)[11] = t.KH;
+    }
+  }
+  g_wg_timed.clear();
+  long n = 0;
+  for (auto& q : rows) {
+    if (n >= cap_rows) break;
+    for (int k = 0; k < 12; ++k) out[n * 12 + k] = q[k];
+    ++n;
+  }
+  return n;
+#endif
+}
+
 extern "C" int hrf_wgrad_group_end(void* stream) {
   g_wg_collect = false;
   std::stable_sort(g_wg_pending.begin(), g_wg_pending.end(),
@@ -1025,7 +1065,28 @@ extern "C" int hrf_wgrad_group_end(void* stream) {
       ++g.nprob; ++i;
     }
     for (int k = g.nprob + 1; k <= WGMAX; ++k) g.bstart[k] = g.bstart[g.nprob];
+#ifndef HRF_EMUL
+    WgTimed tm;
+    if (g_knob[7]) {
+      tm.key = key; tm.nprob = g.nprob; tm.bytes = 0; tm.flops = 0;
+      double best = -1;
+      for (int k = 0; k < g.nprob; ++k) {
+        const WgradDenseArgs& q = g.p[k];
+        const bool tap = key & 1, bnb = (key >> 3) & 1;
+        const double np = (tap ? 9.0 : 1.0) * q.Cin;
+        const double inpix = tap ? (double)q.Mpix / ((double)q.Ho * q.Wo) * q.H * q.W : (double)q.Mpix;
+        const double b = 4.0 * (inpix * q.Cin + (double)q.Mpix * q.Cout * (bnb ? 2 : 1) + (double)q.Cout * np);
+        tm.bytes += b; tm.flops += 2.0 * q.Mpix * q.Cout * np;
+        if (b > best) { best = b; tm.Cin = q.Cin; tm.Cout = q.Cout; tm.H = q.H; tm.W = q.W; tm.stride = q.stride; tm.KH = tap ? 3 : 1; }
+      }
+      hipEventCreate(&tm.e0); hipEventCreate(&tm.e1);
+      hipEventRecord(tm.e0, (hipStream_t)stream);
+    }
+#endif
     const int r = wgrad_dense_launch(key, g, g.bstart[g.nprob], stream);
+#ifndef HRF_EMUL
+    if (g_knob[7]) { hipEventRecord(tm.e1, (hipStream_t)stream); g_wg_timed.push_back(tm); }
+#endif
     if (r != HRF_OK) rc = r;
   }
   g_wg_pending.clear();

@@ -342,3 +342,75 @@ def time_neck(in_channels, B, H, W, out_channels=256, iters=20, warm=15, seed=0)
     return {'workload': f'HRFPN {list(in_channels)}->{out_channels}, {B}x{H}x{W} finest grid, 5 levels',
             'fwd_ms': round(fwd, 3), 'fwd_bwd_ms': round(both, 3), 'fwd_gflop': round(flop / 1e9, 2),
             'fwd_tflops': round(flop / fwd / 1e9, 1)}
+
+
+def grouped_wgrad_report(trainer, x, mods, cots, steps=3):
+    """In-situ durations of the grouped weight-gradient launches (include/hrfuser_hip.h: hrf_wgrad_group_*): `steps`
+    EAGER training steps with HIP events recorded by the library around every grouped launch, on the lane stream it is
+    issued on and with the rest of the step running beside it - the same situation rocprofv3 --kernel-trace sees.
+    -> rows sorted by time: kernel (the rocprof kernel name), launches_per_step, problems_per_launch, avg_launch_us,
+    bytes_per_launch / flops_per_launch (algorithmic, summed over the problems of a launch), heaviest problem."""
+    import ctypes
+    L = _lib.lib()
+    if os.environ.get('HRF_WGRAD_GROUP', '1') == '0' or os.environ.get('HRF_LANES', '1') == '0':
+        return []
+    trainer.step(x, mods, cots)                          # warm (allocator, lanes)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_double * (12 * 64))()
+    L.hrf_wgrad_group_report(ctypes.addressof(buf), 64)  # drop anything logged earlier
+    L.hrf_debug_knob(7, 1)
+    try:
+        for _ in range(steps):
+            trainer.step(x, mods, cots)
+        torch.cuda.synchronize()
+    finally:
+        L.hrf_debug_knob(7, 0)
+    n = L.hrf_wgrad_group_report(ctypes.addressof(buf), 64)
+    rows = []
+    for r in range(n):
+        key, launches, problems, us, nbytes, flops, cin, cout, h, w, stride, kh = [buf[12 * r + k] for k in range(12)]
+        key = int(key)
+        tap, act, bnb, nt, mt = key & 1, (key >> 1) & 3, (key >> 3) & 1, (key >> 4) & 7, key >> 7
+        tf = lambda b: 'true' if b else 'false'
+        rows.append({'kernel': f'wgrad_dense_kernel<{mt}, {nt}, {tf(bnb)}, {act}, {tf(tap)}>',
+                     'launches_per_step': round(launches / steps, 2), 'problems_per_launch': round(problems / launches, 2),
+                     'avg_launch_us': round(us / launches, 2), 'time_per_step_ms': round(us / steps / 1e3, 4),
+                     'bytes_per_launch': nbytes / launches, 'flops_per_launch': flops / launches,
+                     'heaviest_problem': f'conv_bwd_weight[Cin={int(cin)},Cout={int(cout)},H={int(h)},W={int(w)},'
+                                         f'KH={int(kh)},stride={int(stride)}]'})
+    rows.sort(key=lambda r: -r['time_per_step_ms'])
+    return rows
+
+
+def roofline_grouped(rows, peak_f, peak_b, traffic=None):
+    """Roofline object of the dominant kernel when it is the (grouped) weight-gradient family: family-wide aggregate of
+    the in-situ launches + the heaviest variant.  A launch = one grouped kernel launch (what rocprofv3 counts)."""
+    if not rows:
+        return None
+    launches = sum(r['launches_per_step'] for r in rows)
+    t_ms = sum(r['time_per_step_ms'] for r in rows)
+    nbytes = sum(r['bytes_per_launch'] * r['launches_per_step'] for r in rows)
+    flops = sum(r['flops_per_launch'] * r['launches_per_step'] for r in rows)
+
+    def price(b, f, us):
+        bound_b = (f / peak_f) <= (b / peak_b)
+        ach = b / (us * 1e-6) / 1e9 if bound_b else f / (us * 1e-6) / 1e12
+        peak = peak_b / 1e9 if bound_b else peak_f / 1e12
+        return {'bound': 'hbm' if bound_b else 'mfma', 'achieved': round(ach, 1), 'peak': peak,
+                'unit': 'GB/s' if bound_b else 'TFLOP/s', 'frac': round(ach / peak, 4)}
+    avg_us = t_ms * 1e3 / launches
+    row = {'kernel': 'wgrad_dense_kernel (all variants, grouped launches, in situ)'}
+    row.update(price(nbytes / launches, flops / launches, avg_us))
+    row.update({'traffic': None, 'launches_per_step': round(launches, 1), 'avg_launch_us': round(avg_us, 2),
+                'time_per_step_ms': round(t_ms, 4), 'bytes_per_launch': nbytes / launches,
+                'flops_per_launch': flops / launches,
+                'timing': 'HIP events around every grouped launch of 3 eager steps, on the launching stream'})
+    top = dict(rows[0])
+    top.update(price(top['bytes_per_launch'], top['flops_per_launch'], top['avg_launch_us']))
+    top['traffic'] = (traffic or {}).get(top['kernel'])
+    row['dominant_variant'] = top
+    if top['traffic'] is not None:
+        row['traffic'] = top['traffic']
+        row['traffic_note'] = ('PMC (FETCH_SIZE x2 + WRITE_SIZE) bytes of ONE representative grouped launch of dominant_variant '
+                               '(4 problems, 97.1 MB algorithmic: profiles/r01_hbm_traffic.json "grouped", tools/pmc_grouped.py)')
+    return row

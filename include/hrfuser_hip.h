@@ -218,6 +218,10 @@ int hrf_rowgemm(const float* x, int ldX, const float* wp, const float* bias, flo
  * variant per launch (results identical to separate launches).  Calls that use other kernels launch immediately. */
 int hrf_wgrad_group_begin(void);
 int hrf_wgrad_group_end(void* stream);
+/* measurement aid (hrf_debug_knob(7, 1)): HIP-event durations of the grouped launches of eager steps, aggregated per
+ * kernel variant into rows of 12 doubles (key, launches, problems, total us, algorithmic bytes, flops, heaviest problem's
+ * Cin, Cout, H, W, stride, KH); returns the number of rows written and clears the log. */
+long hrf_wgrad_group_report(double* out, long cap_rows);
 
 /* ---- fused flat-buffer AdamW (configs/hrfuser: AdamW lr 3e-4, wd 0.01, decay_mult 0 masks) ---
  * state = float[4] on device: {1-b1^t, 1-b2^t, t, -}; hrf_adamw_tick advances t on device so a
