@@ -399,18 +399,18 @@ def roofline_grouped(rows, peak_f, peak_b, traffic=None):
         return {'bound': 'hbm' if bound_b else 'mfma', 'achieved': round(ach, 1), 'peak': peak,
                 'unit': 'GB/s' if bound_b else 'TFLOP/s', 'frac': round(ach / peak, 4)}
     avg_us = t_ms * 1e3 / launches
-    row = {'kernel': 'wgrad_dense_kernel (all variants, grouped launches, in situ)'}
-    row.update(price(nbytes / launches, flops / launches, avg_us))
-    row.update({'traffic': None, 'launches_per_step': round(launches, 1), 'avg_launch_us': round(avg_us, 2),
+    fam = {'kernel': 'wgrad_dense_kernel (all variants)'}
+    fam.update(price(nbytes / launches, flops / launches, avg_us))
+    fam.update({'launches_per_step': round(launches, 1), 'avg_launch_us': round(avg_us, 2),
                 'time_per_step_ms': round(t_ms, 4), 'bytes_per_launch': nbytes / launches,
-                'flops_per_launch': flops / launches,
-                'timing': 'HIP events around every grouped launch of 3 eager steps, on the launching stream'})
-    top = dict(rows[0])
-    top.update(price(top['bytes_per_launch'], top['flops_per_launch'], top['avg_launch_us']))
-    top['traffic'] = (traffic or {}).get(top['kernel'])
-    row['dominant_variant'] = top
-    if top['traffic'] is not None:
-        row['traffic'] = top['traffic']
-        row['traffic_note'] = ('PMC (FETCH_SIZE x2 + WRITE_SIZE) bytes of ONE representative grouped launch of dominant_variant '
+                'flops_per_launch': flops / launches})
+    # the object itself = the heaviest variant of the family (one rocprofv3 kernel name); the family aggregate beside it
+    row = dict(rows[0])
+    row.update(price(row['bytes_per_launch'], row['flops_per_launch'], row['avg_launch_us']))
+    row['traffic'] = (traffic or {}).get(row['kernel'])
+    row['timing'] = 'HIP events around every grouped launch of 3 eager steps, on the launching stream (in situ)'
+    row['family'] = fam
+    if row['traffic'] is not None:
+        row['traffic_note'] = ('PMC (FETCH_SIZE x2 + WRITE_SIZE) bytes of ONE representative grouped launch of this variant '
                                '(4 problems, 97.1 MB algorithmic: profiles/r01_hbm_traffic.json "grouped", tools/pmc_grouped.py)')
     return row
