@@ -265,7 +265,7 @@ class EngineOwner:
     def _lane_pool(self, grow=False):
         pool = self.__dict__.setdefault('_hrf_lanes', [])
         if grow:
-            lane = R.Lane(torch.cuda.Stream())
+            lane = R.Lane(torch.cuda.Stream(priority=int(os.environ.get('HRF_LANE_PRIORITY', '0'))))
             pool.append(lane)
             return lane
         return pool
@@ -274,7 +274,14 @@ class EngineOwner:
         pool = self.__dict__.get('_hrf_side')
         if pool is None:
             n = int(os.environ.get('HRF_SIDE_LANES', '6') or 6)
-            pool = [R.Lane(torch.cuda.Stream()) for _ in range(max(1, n))]
+            # leaf work (weight gradients) must not delay the latency-bound data-gradient chain: lowest stream priority
+            try:
+                low = max(torch.cuda.Stream.priority_range())
+            except Exception:
+                low = 0
+            if os.environ.get('HRF_SIDE_PRIORITY', '1') == '0':
+                low = 0
+            pool = [R.Lane(torch.cuda.Stream(priority=low)) for _ in range(max(1, n))]
             self.__dict__['_hrf_side'] = pool
         return pool
 

@@ -209,7 +209,7 @@ class Ctx:
         if not self.multi or mode == 'inline':
             fn()
             return
-        if mode == 'defer':
+        if mode in ('defer', 'flush'):
             # weight-gradient launches are leaves of the backward graph: collect them and issue them
             # as one wide, fully parallel phase after the (serial, latency-bound) data-gradient chain
             self._deferred.append(fn)
@@ -222,10 +222,37 @@ class Ctx:
         with _LaneScope(self, lane):
             fn()
 
+    def _flush_deferred(self):
+        """Issue the queued leaf launches on side lanes that start after the main lane's work so far (flat fork from
+        main; joined at the end of run_backward)."""
+        fns, self._deferred = self._deferred, []
+        pool = self.owner._side_pool()
+        k = min(len(pool), int(os.environ.get('HRF_WGRAD_LANES', '4')))
+        group = os.environ.get('HRF_WGRAD_GROUP', '1') != '0'
+        for j in range(k):
+            lane = pool[(self._side_i + j) % len(pool)]
+            lane.stream.wait_stream(self.main.stream)
+            self._rec_sync(self.main, lane)
+            self._side_used[id(lane)] = lane
+            with _LaneScope(self, lane):
+                if group:
+                    self.L.hrf_wgrad_group_begin()
+                try:
+                    for fn in fns[j::k]:
+                        fn()
+                finally:
+                    if group:
+                        self.L.hrf_wgrad_group_end(self.stream)
+        self._side_i += k
+
     def run_backward(self):
         tape = self.tape
         self.tape = []
         use_keep_list(self.owner._engine().keep)
+        # HRF_WGRAD=flush: every time all lanes are joined into the main lane and enough weight gradients are queued,
+        # issue them (grouped) on low-priority side lanes forked from main - they fill the CUs the latency-bound
+        # data-gradient chain leaves idle instead of forming a phase of their own at the end
+        flush_n = int(os.environ.get('HRF_WGRAD_FLUSH', '48')) if (self.multi and os.environ.get('HRF_WGRAD', 'defer') == 'flush') else 0
         if self.multi:
             self.main.stream.wait_stream(torch.cuda.current_stream())
         while tape:
@@ -238,6 +265,8 @@ class Ctx:
                 for k in e[2]:
                     e[1].stream.wait_stream(k.stream)
                     self._rec_sync(k, e[1])
+                if flush_n and e[1] is self.main and len(self._deferred) >= flush_n:
+                    self._flush_deferred()
             else:
                 fn, lane = e
                 with _LaneScope(self, lane):
@@ -265,6 +294,7 @@ class Ctx:
         if self.multi:
             for lane in self._side_used.values():
                 self.main.stream.wait_stream(lane.stream)
+                self._rec_sync(lane, self.main)
             self._side_used = {}
         with _LaneScope(self, self.main):
             self.owner._engine().fold_grads(self.L, self.main.ptr)
