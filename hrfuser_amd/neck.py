@@ -57,7 +57,7 @@ def _conv3_wide(ctx, x, conv):
             if Cout % 128 == 0:
                 scr = R._new((L.hrf_conv3_wgrad_wide_scratch(B, H, W, C, Cout),), x.t.device)
                 ctx.side_launch(lambda: L.hrf_conv3_wgrad_wide(out.grad, Cout, x.t, C, B, H, W, C, Cout, w.grad, bgrad,
-                                                               scr, ctx.stream))
+                                                               scr, ctx.stream), cost=float(B * H * W) * C * Cout)
             else:
                 ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
                     out.grad, Cout, 0, None, None, None, None, x.t, *strides, B, H, W, C, 3, 1, Cout,

@@ -202,7 +202,7 @@ class Ctx:
     def on(self, lane):
         return _LaneScope(self, lane)
 
-    def side_launch(self, fn):
+    def side_launch(self, fn, cost=1.0):
         """Run `fn` (one off-critical-path launch) on a side lane that starts after the current lane's
         work so far and is joined into the main lane at the end of the backward pass."""
         mode = os.environ.get('HRF_WGRAD', 'defer')
@@ -212,7 +212,7 @@ class Ctx:
         if mode in ('defer', 'flush'):
             # weight-gradient launches are leaves of the backward graph: collect them and issue them
             # as one wide, fully parallel phase after the (serial, latency-bound) data-gradient chain
-            self._deferred.append(fn)
+            self._deferred.append((float(cost), fn))
             return
         pool = self.owner._side_pool()
         lane = pool[self._side_i % len(pool)]
@@ -225,7 +225,8 @@ class Ctx:
     def _flush_deferred(self):
         """Issue the queued leaf launches on side lanes that start after the main lane's work so far (flat fork from
         main; joined at the end of run_backward)."""
-        fns, self._deferred = self._deferred, []
+        fns = [fn for _, fn in self._deferred]
+        self._deferred = []
         pool = self.owner._side_pool()
         k = min(len(pool), int(os.environ.get('HRF_WGRAD_LANES', '4')))
         group = os.environ.get('HRF_WGRAD_GROUP', '1') != '0'
@@ -274,10 +275,12 @@ class Ctx:
         if self._deferred and os.environ.get('HRF_DEBUG_SKIP_WGRAD') == '1':
             self._deferred = []                 # timing experiments only: drops the weight-gradient phase
         if self._deferred:
-            fns, self._deferred = self._deferred, []
+            items, self._deferred = self._deferred, []
             k = int(os.environ.get('HRF_WGRAD_LANES', '4'))
             group = os.environ.get('HRF_WGRAD_GROUP', '1') != '0'
             lanes = self.fork(k)
+            parts = _balance(items, k) if os.environ.get('HRF_WGRAD_BALANCE', '1') != '0' else \
+                [[fn for _, fn in items[j::k]] for j in range(k)]
             for j in range(k):
                 with _LaneScope(self, lanes[j]):
                     # the dense weight gradients of a lane are queued and issued as a few grouped launches
@@ -285,7 +288,7 @@ class Ctx:
                     if group:
                         self.L.hrf_wgrad_group_begin()
                     try:
-                        for fn in fns[j::k]:
+                        for fn in parts[j]:
                             fn()
                     finally:
                         if group:
@@ -307,6 +310,18 @@ class Ctx:
         if self.group is not None and (self.world > 1 or _FORCE_COLL):
             import torch.distributed as dist
             dist.all_reduce(t, group=self.group)
+
+
+def _balance(items, k):
+    """Longest-processing-time-first split of (cost, fn) leaf launches over k lanes (the lanes of the deferred
+    weight-gradient phase run concurrently; the phase ends with the slowest one)."""
+    loads = [0.0] * k
+    parts = [[] for _ in range(k)]
+    for cost, fn in sorted(items, key=lambda t: -t[0]):
+        j = loads.index(min(loads))
+        loads[j] += cost
+        parts[j].append(fn)
+    return parts
 
 
 class _LaneScope:
@@ -468,9 +483,12 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
             # one 6 MB layout copy (torch, capturable) replaces the 207 us strided LDS kernel by ~40 us
             xw = src.nhwc if src.nhwc is not None else _keep(x.permute(0, 2, 3, 1).contiguous())
             sw = _nhwc_strides(B, H, W, Cin)
+        Ho, Wo = _conv_out_hw(H, W, KH, stride)
+        # byte-equivalent cost for the lane balancer: operand traffic + flops at ~10 FLOP/B
+        cost = 4.0 * B * (H * W * Cin + Ho * Wo * Cout * (2 if cA is not None else 1)) + 0.2 * B * Ho * Wo * Cout * Cin * KH * KH
         ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
             dy, ldD, doff, yraw, cA, cB, cC, xw, *sw, B, H, W, Cin, KH, stride, Cout,
-            tf, sc, sh, rowstat, weight.grad, bgrad, ctx.stream))
+            tf, sc, sh, rowstat, weight.grad, bgrad, ctx.stream), cost=cost)
     if not _needs_grad(src):
         return
     if isinstance(src, Lazy):
@@ -667,7 +685,8 @@ def dwconv_bn(ctx, src, conv, bn, mode):
             wacc, cs = eng.grad_acc(w)
             bacc = eng.grad_acc(b)[0] if b is not None else None
             ctx.side_launch(lambda: L.hrf_dwconv_bwd_weight(
-                du_, st.raw, cA, cB, cC, x, B, H, W, C, stride, tf, sc, sh, wacc, bacc, cs, ctx.stream))
+                du_, st.raw, cA, cB, cC, x, B, H, W, C, stride, tf, sc, sh, wacc, bacc, cs, ctx.stream),
+                cost=4.0 * B * H * W * C * (1.0 + 2.0 / (stride * stride)))
         if isinstance(src, Lazy):
             ps = src.st
             ps.du = _new_like(ps.raw)
