@@ -131,6 +131,9 @@ def main():
     B = args.batch
     x = torch.randn(B, 3, H, W, generator=g).to(dev)
     mods = [torch.randn(B, c, H, W, generator=g).to(dev) for c in mc]
+    if os.environ.get('HRF_BENCH_CHANNELS_LAST', '0') == '1':     # inputs as hrfuser_amd.pipeline delivers them (experiment)
+        x = x.contiguous(memory_format=torch.channels_last)
+        mods = [m.contiguous(memory_format=torch.channels_last) for m in mods]
     cots = make_cotangents(net, x, mods)
     trainer = Trainer(net, lr=1e-3 if stf else 3e-4, group=group, world_size=world)
 

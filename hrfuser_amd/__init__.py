@@ -11,5 +11,6 @@ from .backbone import (HRFuserHRFormerBased, HRFormer, HRFuserFusionBlock, HRFor
 
 from .registry import NECKS                                # noqa: F401,E402
 from .neck import HRFPN, build_neck                        # noqa: F401,E402
+from .pipeline import DeviceInputPipeline                  # noqa: F401,E402
 
 __all__ = ['BACKBONES', 'NECKS', 'build_backbone', 'build_neck', 'HRFuserHRFormerBased', 'HRFormer', 'HRFPN']

@@ -659,7 +659,10 @@ class HipModule(nn.Module, EngineOwner):
         return ctx, outs, srcs
 
     def _call_engine(self, inputs):
-        inputs = tuple(t.contiguous().float() for t in inputs)
+        # NCHW-contiguous (the reference's layout) or channels-last storage (what hrfuser_amd.pipeline / the HIP modules
+        # produce) are both read in place through element strides; anything else is made contiguous first
+        inputs = tuple((t if (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)) else t.contiguous()).float()
+                       for t in inputs)
         anchor = None
         if torch.is_grad_enabled():
             # parameters are not autograd inputs (their grads are written by the kernels straight
@@ -827,8 +830,11 @@ class HRFuserHRFormerBased(HipModule):
         bufs = self.__dict__.setdefault('_nhwc_in', {})
         for i, t in enumerate(inputs):
             Bn, C, H, W = t.shape
+            if t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous():
+                bufs[i] = t.permute(0, 2, 3, 1)             # already channels-last storage: a view, no copy
+                continue
             b = bufs.get(i)
-            if b is None or b.shape != (Bn, H, W, C) or b.device != t.device:
+            if b is None or b.shape != (Bn, H, W, C) or b.device != t.device or not b.is_contiguous():
                 b = bufs[i] = torch.empty(Bn, H, W, C, device=t.device, dtype=torch.float32)
             b.copy_(t.permute(0, 2, 3, 1))
         return bufs

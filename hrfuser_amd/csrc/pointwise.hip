@@ -481,6 +481,34 @@ __global__ __launch_bounds__(256) void bilinear_up_into_kernel(const float* x, i
   }
 }
 
+// Device-side input pipeline: Normalize (+ BGR->RGB) -> horizontal flip -> zero pad to the padded grid ->
+// sensor drop -> channels-last packing, one pass (transforms.py:706-753,440-466,649-664,487-514; formating.py:212-227).
+// in: [B][H0][W0][C] float32 or uint8 (HWC as the decoders deliver it); out: [B][Hp][Wp][C] float32.
+// out(b, y, x, c) = drop[b] ? 0 : (y < H0 && x < W0 ? (in(b, y, flip[b] ? W0-1-x : x, to_rgb ? C-1-c : c) - mean[c]) * stdinv[c] : 0)
+// with a separate float32 subtract and multiply (cv2.subtract / cv2.multiply; contraction is off for this library).
+__global__ __launch_bounds__(256) void pack_input_kernel(const void* in, int is_u8, int B, int H0, int W0, int C,
+                                                         const float* mean, const float* stdinv, int to_rgb,
+                                                         const unsigned char* flip, const unsigned char* drop,
+                                                         float* out, int Hp, int Wp) {
+  const long total = (long)B * Hp * Wp * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long pix = i / C;
+    const int x = (int)(pix % Wp), y = (int)((pix / Wp) % Hp), b = (int)(pix / ((long)Wp * Hp));
+    float v = 0.f;
+    const bool dropped = drop != nullptr && drop[b] != 0;
+    if (!dropped && y < H0 && x < W0) {
+      const int xs = (flip != nullptr && flip[b] != 0) ? W0 - 1 - x : x;
+      const int cs = to_rgb ? C - 1 - c : c;
+      const long si = (((long)b * H0 + y) * W0 + xs) * C + cs;
+      const float raw = is_u8 ? (float)static_cast<const unsigned char*>(in)[si] : static_cast<const float*>(in)[si];
+      const float d = raw - mean[c];
+      v = d * stdinv[c];
+    }
+    out[i] = v;
+  }
+}
+
 // dst[row][c] (+)= src[row][off + c]: a channel slice of wider rows (adjoint of the identity branch of the HRFPN concat)
 __global__ __launch_bounds__(256) void slice_cols_kernel(const float* src, int ld, int off, long rows, int C, float* dst,
                                                          int accumulate) {
@@ -689,6 +717,17 @@ extern "C" int hrf_bilinear_up_into(const float* x, int Hs, int Ws, int C, float
   const long total = (long)B * H * W * C;
   if (total <= 0) return HRF_OK;
   HRF_LAUNCH(bilinear_up_into_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, x, Hs, Ws, C, out, ldOut, off, B, H, W);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_pack_input(const void* in, int is_u8, int B, int H0, int W0, int C, const float* mean,
+                              const float* stdinv, int to_rgb, const unsigned char* flip, const unsigned char* drop,
+                              float* out, int Hp, int Wp, void* stream) {
+  if (C < 1 || Hp < H0 || Wp < W0) return HRF_ERR_ARG;
+  const long total = (long)B * Hp * Wp * C;
+  if (total <= 0) return HRF_OK;
+  HRF_LAUNCH(pack_input_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, in, is_u8, B, H0, W0, C, mean, stdinv, to_rgb,
+             flip, drop, out, Hp, Wp);
   return hrf_check_launch();
 }
 

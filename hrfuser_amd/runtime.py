@@ -393,7 +393,8 @@ def _src_desc(src):
         return src.act.t, _nhwc_strides(B, H, W, C), (B, H, W, C), TF_LN, src.ln.weight, src.ln.bias, src.rowstat
     if isinstance(src, RawInput):
         B, C, H, W = src.t.shape
-        return src.t, (C * H * W, W, 1, H * W), (B, H, W, C), TF_NONE, None, None, None
+        sB, sC, sY, sX = src.t.stride()          # NCHW-contiguous or channels-last storage, read in place
+        return src.t, (sB, sY, sX, sC), (B, H, W, C), TF_NONE, None, None, None
     raise TypeError(type(src))
 
 

@@ -223,6 +223,17 @@ int hrf_wgrad_group_end(void* stream);
  * Cin, Cout, H, W, stride, KH); returns the number of rows written and clears the log. */
 long hrf_wgrad_group_report(double* out, long cap_rows);
 
+/* Device-side input pipeline: the image side of Normalize -> RandomFlip -> Pad(size_divisor) -> RandomDrop ->
+ * DefaultFormatBundle (mmdet/datasets/pipelines/transforms.py:706-753,440-466,649-664,487-514; formating.py:212-227) for ONE
+ * sensor of a batch in one pass: in = [B][H0][W0][C] HWC images (float32, or uint8 when is_u8), out = [B][Hp][Wp][C]
+ * float32 (channels-last storage of the logical (B,C,Hp,Wp) tensor the backbone takes);
+ *   out = drop[b] ? 0 : inside ? (in(b, y, flip[b] ? W0-1-x : x, to_rgb ? C-1-c : c) - mean[c]) * stdinv[c] : 0.
+ * mean / stdinv: C floats on the device (stdinv = float32(1 / float64(std)), as mmcv.imnormalize computes it);
+ * flip / drop: B bytes each (nullable): the random decisions stay with the host's RNG. */
+int hrf_pack_input(const void* in, int is_u8, int B, int H0, int W0, int C, const float* mean, const float* stdinv,
+                   int to_rgb, const unsigned char* flip, const unsigned char* drop, float* out, int Hp, int Wp,
+                   void* stream);
+
 /* ---- fused flat-buffer AdamW (configs/hrfuser: AdamW lr 3e-4, wd 0.01, decay_mult 0 masks) ---
  * state = float[4] on device: {1-b1^t, 1-b2^t, t, -}; hrf_adamw_tick advances t on device so a
  * captured hipGraph replays correct bias corrections.                                           */
