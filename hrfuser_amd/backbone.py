@@ -10,7 +10,6 @@ Same class names, constructor keywords, error behaviour and state-dict keys as
 but the modules only OWN parameters: all arithmetic is issued through `runtime.py` onto the
 hand-written gfx950 kernels behind `include/hrfuser_hip.h`.  There is no eager/CPU fallback.
 """
-import math
 import os
 
 import torch

@@ -17,7 +17,6 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib
 from . import runtime as R
 from .backbone import HipModule, _BackboneFn
 from .registry import NECKS

@@ -13,7 +13,6 @@ Design (MI355X-first):
 
 Nothing in this file computes on the CPU: every op is a launch on torch's current HIP stream.
 """
-import math
 import os
 
 import torch
