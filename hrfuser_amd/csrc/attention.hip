@@ -15,9 +15,9 @@
 // read as wave-wide ds_read_b128 broadcasts (conflict-free); the whole 49-wide logit row lives in
 // the lane's registers (fully unrolled), so softmax needs no cross-lane traffic and the 49
 // dot-product chains are independent (ILP hides the LDS latency inside a single wave).
-// head_dim is 18 (HRFuser-T) / 39 (HRFuser-B): with 49x49xD contractions padded to 64x64x20 an
-// MFMA tile would waste > 55 % of its lanes, so the contraction runs as per-lane FMA chains at the
-// same fp32 rate the f32 MFMA has ("attention core").
+// The kernels above the MFMA section are the first implementation (per-lane FMA chains; kept as the A/B
+// reference behind hrf_debug_knob(28, 0)); the product path is attn_fwd_mfma_kernel / attn_bwd_mfma_kernel
+// further down: all contractions on v_mfma_f32_16x16x4_f32 with the 49 tokens padded to 64.
 #include "hrf_common.h"
 #include "../../include/hrfuser_hip.h"
 
@@ -311,6 +311,352 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   }
 }
 
+// Staging for the MFMA kernels: [64][P] tiles of Q (scaled), K, V (and dO), zero outside the 49 x D payload.  All global
+// loads of a thread are issued before the first LDS store (one round trip instead of one per loop iteration).
+template <int D, int P, bool BWD>
+__device__ __forceinline__ void stage_tiles(const AttnArgs& a, int b, int wy, int wx, int h, float* sQ, float* sK, float* sV,
+                                            float* sG) {
+  for (int e = threadIdx.x; e < 64 * P; e += 256) {
+    const int j = e / P, d = e - j * P;
+    if (j >= NT || d >= D) { sQ[e] = 0.f; sK[e] = 0.f; sV[e] = 0.f; if (BWD) sG[e] = 0.f; }
+  }
+  constexpr int NE = (NT * D + 255) / 256;
+  float kx[NE], vx[NE], qx[NE], gx[NE];
+  int dst[NE];
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    const int ec = e < NT * D ? e : 0;
+    const int j = ec / D, d = ec - j * D;
+    const int pix = tok_pixel(a, b, wy, wx, j);
+    const long pc = pix >= 0 ? pix : 0;           // unconditional clamped loads, select afterwards
+    const int col = h * D + d;
+    const float k0 = a.k[pc * a.ldk + a.koff + col], kp = a.kpad[col];
+    const float v0 = a.v[pc * a.ldv + a.voff + col], vp = a.vpad[col];
+    const float q0 = a.q[pc * a.ldq + a.qoff + col];
+    const float g0 = BWD ? a.dout[pc * a.lddo + col] : 0.f;
+    kx[u] = pix >= 0 ? k0 : kp;
+    vx[u] = pix >= 0 ? v0 : vp;
+    qx[u] = pix >= 0 ? q0 * a.scale : 0.f;
+    gx[u] = pix >= 0 ? g0 : 0.f;
+    dst[u] = e < NT * D ? j * P + d : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    if (dst[u] >= 0) {
+      sK[dst[u]] = kx[u]; sV[dst[u]] = vx[u]; sQ[dst[u]] = qx[u];
+      if (BWD) sG[dst[u]] = gx[u];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// MFMA forward: both contractions of a (window, head) on v_mfma_f32_16x16x4_f32.  The 49 tokens are padded to 64; wave w
+// owns queries 16w..16w+15.  The score tile is produced TRANSPOSED (row operand = key rows of K, column operand = the
+// wave's query rows of Q): lane (i, q) then holds S[query 16w+i][keys 16t + 4q + r], i.e. one query COLUMN per lane
+// with its 64 keys spread over the four lanes of equal i - the softmax row reduction is 16 in-register values plus two
+// wave shuffles (xor 16, 32), and the probabilities already sit in the A-operand position of the second contraction
+// (contraction slot q of MFMA (t, r) <-> key 16t + 4q + r), so P never moves: O = P V is 16 x ceil(D/16) MFMAs whose B
+// operand is a V row read from LDS.  K/V/Q tiles are staged once per block (pitch 16*ceil(D/16) + 1).
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
+  constexpr int KS = (D + 3) / 4;             // contraction steps of Q K^T
+  constexpr int DT = (D + 15) / 16;           // 16-wide output tiles of P V
+  constexpr int P = DT * 16 + 1;              // LDS pitch (floats)
+  __shared__ float sQ[64 * P];
+  __shared__ float sK[64 * P];
+  __shared__ float sV[64 * P];
+  __shared__ float sT[176];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
+  const int i = lane & 15, q = lane >> 4;
+  const int win = blockIdx.x;
+  const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
+  stage_tiles<D, P, false>(a, b, wy, wx, h, sQ, sK, sV, nullptr);
+  for (int e = threadIdx.x; e < 169; e += 256) sT[e] = a.rpb[e * a.heads + h];
+  __syncthreads();
+
+  // ---- S^T tiles: acc[t][r] = S[query 16w + i][key 16t + 4q + r]
+  hrf_f4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+  const float* qrow = sQ + (16 * wave + i) * P + q;
+  const float* krow = sK + i * P + q;
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const float qv = qrow[4 * kk];              // (columns D .. 16*DT-1 are zero in LDS)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float kv = krow[16 * t * P + 4 * kk];
+      acc[t] = hrf_mfma16(kv, qv, acc[t]);
+    }
+  }
+  // ---- relative position bias, padding of the key axis, softmax over the query's row
+  const int qi = 16 * wave + i;
+  const int qc = qi < NT ? qi : 0;
+  const int yi = qc / 7, xi = qc - 7 * yi;
+  float m = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * t + 4 * q + r;
+      const int jc = j < NT ? j : 0;
+      const int yj = jc / 7, xj = jc - 7 * yj;
+      const float sv = j < NT ? acc[t][r] + sT[(yi - yj + 6) * 13 + (xi - xj + 6)] : -3.0e38f;
+      acc[t][r] = sv;
+      m = fmaxf(m, sv);
+    }
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = __expf(acc[t][r] - m);          // exp(-huge) == 0 for the 15 padding keys
+      acc[t][r] = p;
+      l += p;
+    }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  // ---- O = P V: contraction slot q of MFMA (t, r) is key 16t + 4q + r - the lane's own probability
+  hrf_f4 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* vrow = sV + (16 * t + 4 * q + r) * P + i;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_mfma16(acc[t][r], vrow[16 * dt], o[dt]);
+    }
+  // o[dt][r] = unnormalised O[query 16w + 4q + r][d = 16 dt + i]; the row sums live in the lanes with i = query % 16
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float invr = __shfl(inv, 4 * q + r);
+    const int qo = 16 * wave + 4 * q + r;
+    const int px = qo < NT ? tok_pixel(a, b, wy, wx, qo) : -1;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = 16 * dt + i;
+      if (px >= 0 && d < D) a.o[(long)px * a.ldo + h * D + d] = o[dt][r] * invr;
+    }
+  }
+}
+
+// MFMA backward.  Every 49x49 quantity is produced twice, once per orientation, because an MFMA result can feed the
+// next contraction without moving only as the operand whose contraction index is spread over the lane quartets:
+//   query-column orientation (wave = 16 queries; lane (i, q) holds X[query 16w+i][key 16t+4q+r]): scores -> softmax
+//     statistics (m, 1/l), dP = dO V^T, D = sum_j P dP, dS; contraction over KEYS: dQ = dS K;
+//   key-column orientation (wave = 16 keys; lane holds X[query 16t+4q+r][key 16w+i]): P and dS again from the stored
+//     row statistics; contraction over QUERIES: dV = P^T dO, dK = dS^T Q - complete rows per wave, no cross-wave sums.
+// 176 + MFMAs per wave instead of ~1200 dependent FMAs per lane.  dS also goes to an LDS plane for the relative-
+// position-bias gather; dK / dV rows pass through LDS so that the padded keys of boundary windows are summed in the
+// block before they reach the projection-bias gradients.
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
+  constexpr int KS = (D + 3) / 4, DT = (D + 15) / 16, P = DT * 16 + 1;
+  __shared__ float sQ[64 * P];
+  __shared__ float sK[64 * P];
+  __shared__ float sV[64 * P];
+  __shared__ float sG[64 * P];                                      // dO rows
+  __shared__ float sD[NT * SP];                                     // dS[key][query] plane (relative position bias)
+  __shared__ float sX[NT * DT * 16];                                // dK rows
+  __shared__ float sY[NT * DT * 16];                                // dV rows
+  __shared__ float sT[176];
+  __shared__ float sM[64], sIL[64], sDl[64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
+  const int i = lane & 15, q = lane >> 4;
+  const int win = blockIdx.x;
+  const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
+  stage_tiles<D, P, true>(a, b, wy, wx, h, sQ, sK, sV, sG);
+  for (int e = threadIdx.x; e < 169; e += 256) sT[e] = a.rpb[e * a.heads + h];
+  __syncthreads();
+
+  // ================= query-column orientation: wave = queries 16w .. 16w+15
+  {
+    hrf_f4 s[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+    const float* qrow = sQ + (16 * wave + i) * P + q;
+    const float* grow = sG + (16 * wave + i) * P + q;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const float qv = qrow[4 * kk], gv = grow[4 * kk];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[t] = hrf_mfma16(sK[(16 * t + i) * P + 4 * kk + q], qv, s[t]);
+        dp[t] = hrf_mfma16(sV[(16 * t + i) * P + 4 * kk + q], gv, dp[t]);
+      }
+    }
+    const int qi = 16 * wave + i, qc = qi < NT ? qi : 0;
+    const int yi = qc / 7, xi = qc - 7 * yi;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * t + 4 * q + r, jc = j < NT ? j : 0;
+        const int yj = jc / 7, xj = jc - 7 * yj;
+        const float sv = j < NT ? s[t][r] + sT[(yi - yj + 6) * 13 + (xi - xj + 6)] : -3.0e38f;
+        s[t][r] = sv;
+        m = fmaxf(m, sv);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[t][r] = __expf(s[t][r] - m); l += s[t][r]; }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    float Dl = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[t][r] *= inv; Dl = fmaf(s[t][r], dp[t][r], Dl); }
+    Dl += __shfl_xor(Dl, 16);
+    Dl += __shfl_xor(Dl, 32);
+    if (q == 0) { sM[qi] = m; sIL[qi] = inv; sDl[qi] = Dl; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ds = s[t][r] * (dp[t][r] - Dl);
+        s[t][r] = ds;
+        const int j = 16 * t + 4 * q + r;
+        if (j < NT && qi < NT) sD[j * SP + qi] = ds;
+      }
+    // dQ = dS K (contraction over keys: slot q of MFMA (t, r) is key 16t + 4q + r)
+    hrf_f4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* krow = sK + (16 * t + 4 * q + r) * P + i;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_mfma16(s[t][r], krow[16 * dt], o[dt]);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qo = 16 * wave + 4 * q + r;
+      const int px = qo < NT ? tok_pixel(a, b, wy, wx, qo) : -1;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + i;
+        if (px >= 0 && d < D) a.dq[(long)px * a.lddq + a.dqoff + h * D + d] = o[dt][r] * a.scale;
+      }
+    }
+  }
+  __syncthreads();
+  // ================= key-column orientation: wave = keys 16w .. 16w+15
+  {
+    hrf_f4 s[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+    const float* krow = sK + (16 * wave + i) * P + q;
+    const float* vrow = sV + (16 * wave + i) * P + q;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const float kv = krow[4 * kk], vv = vrow[4 * kk];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[t] = hrf_mfma16(sQ[(16 * t + i) * P + 4 * kk + q], kv, s[t]);       // S[query 16t+4q+r][key 16w+i]
+        dp[t] = hrf_mfma16(sG[(16 * t + i) * P + 4 * kk + q], vv, dp[t]);
+      }
+    }
+    const int kj = 16 * wave + i, kc = kj < NT ? kj : 0;
+    const int yj = kc / 7, xj = kc - 7 * yj;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = 16 * t + 4 * q + r, qc = qi < NT ? qi : 0;
+        const int yi = qc / 7, xi = qc - 7 * yi;
+        const bool ok = kj < NT && qi < NT;
+        const float p = ok ? __expf(s[t][r] + sT[(yi - yj + 6) * 13 + (xi - xj + 6)] - sM[qc]) * sIL[qc] : 0.f;
+        s[t][r] = p;
+        dp[t][r] = ok ? p * (dp[t][r] - sDl[qc]) : 0.f;                         // dS
+      }
+    // dV = P^T dO, dK = dS^T Q (contraction over queries: slot q of MFMA (t, r) is query 16t + 4q + r)
+    hrf_f4 ov[DT], ok_[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { ov[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; ok_[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* gr = sG + (16 * t + 4 * q + r) * P + i;
+        const float* qr = sQ + (16 * t + 4 * q + r) * P + i;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          ov[dt] = hrf_mfma16(s[t][r], gr[16 * dt], ov[dt]);
+          ok_[dt] = hrf_mfma16(dp[t][r], qr[16 * dt], ok_[dt]);
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ko = 16 * wave + 4 * q + r;                                     // result row = key
+      if (ko < NT) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          sX[ko * (DT * 16) + 16 * dt + i] = ok_[dt][r];
+          sY[ko * (DT * 16) + 16 * dt + i] = ov[dt][r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride;
+  for (int e = threadIdx.x; e < NT * D; e += 256) {
+    const int jj = e / D, d = e - jj * D;
+    const int px = tok_pixel(a, b, wy, wx, jj);
+    if (px >= 0) {
+      a.dk[(long)px * a.lddk + a.dkoff + h * D + d] = sX[jj * (DT * 16) + d];
+      a.dv[(long)px * a.lddv + a.dvoff + h * D + d] = sY[jj * (DT * 16) + d];
+    }
+  }
+  // padded keys (boundary windows only): their gradient flows to the projection bias
+  if (wy == 0 || wx == 0 || wy == a.nWh - 1 || wx == a.nWw - 1) {
+    if (threadIdx.x < D) {
+      const int d = threadIdx.x;
+      float pk = 0.f, pv = 0.f;
+      bool anypad = false;
+      for (int jj = 0; jj < NT; ++jj) {
+        if (tok_pixel(a, b, wy, wx, jj) < 0) {
+          pk += sX[jj * (DT * 16) + d];
+          pv += sY[jj * (DT * 16) + d];
+          anypad = true;
+        }
+      }
+      if (anypad) {
+        hrf_atomic_add(&a.dkpad[cp + h * D + d], pk);
+        hrf_atomic_add(&a.dvpad[cp + h * D + d], pv);
+      }
+    }
+  }
+  // dRPB[(yi-yj+6)*13 + (xi-xj+6)] += dS[i][j]: gather over the dS plane, one bin per thread
+  if (threadIdx.x < 169) {
+    const int e = threadIdx.x;
+    const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
+    const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
+    const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
+    float sacc = 0.f;
+    for (int yj = y0; yj <= y1; ++yj)
+      for (int xj = x0; xj <= x1; ++xj)
+        sacc += sD[(yj * 7 + xj) * SP + (yj + dy) * 7 + xj + dx];
+    hrf_atomic_add(&a.drpb[cp + e * a.heads + h], sacc);
+  }
+}
+
+int g_attn_mfma = 1;
+
 inline void window_geom(AttnArgs& a) {
   a.nWh = (a.H + 6) / 7; a.nWw = (a.W + 6) / 7;
   a.pt = (a.nWh * 7 - a.H) / 2; a.pl = (a.nWw * 7 - a.W) / 2;   // centre pad: top/left = pad//2
@@ -341,8 +687,14 @@ extern "C" int hrf_window_attn_fwd(const float* q, int ldq, int qoff, const floa
   window_geom(a);
   const int nwin = B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
-  HRF_ATTN_DISPATCH(attn_fwd_kernel)
+  if (g_attn_mfma) { HRF_ATTN_DISPATCH(attn_fwd_mfma_kernel) }
+  else { HRF_ATTN_DISPATCH(attn_fwd_kernel) }
   return hrf_check_launch();
+}
+
+extern "C" int hrf_attn_knob(int key, int value) {
+  if (key == 0) { g_attn_mfma = value; return HRF_OK; }
+  return HRF_ERR_ARG;
 }
 
 extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const float* k, int ldk, int koff,
@@ -362,6 +714,7 @@ extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const floa
   window_geom(a);
   const int nwin = B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
-  HRF_ATTN_DISPATCH(attn_bwd_kernel)
+  if (g_attn_mfma) { HRF_ATTN_DISPATCH(attn_bwd_mfma_kernel) }
+  else { HRF_ATTN_DISPATCH(attn_bwd_kernel) }
   return hrf_check_launch();
 }

@@ -856,9 +856,11 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
 
 extern "C" int hrf_pw_knob(int key, int value);
 extern "C" int hrf_conv3w_knob(int key, int value);
+extern "C" int hrf_attn_knob(int key, int value);
 extern "C" int hrf_debug_knob(int key, int value) {
   if (key >= 16 && key < 20) return hrf_pw_knob(key - 16, value);      // pointwise.hip tuning aids
   if (key >= 24 && key < 28) return hrf_conv3w_knob(key - 24, value);  // conv3w_engine.hip tuning aids
+  if (key >= 28 && key < 32) return hrf_attn_knob(key - 28, value);    // attention.hip: 28 = MFMA forward on/off
   if (key < 0 || key >= 8) return HRF_ERR_ARG;
   g_knob[key] = value;
   return HRF_OK;
