@@ -43,6 +43,7 @@ struct AttnArgs {
   float* dv; int lddv, dvoff;
   float* dkpad; float* dvpad; float* drpb; long copy_stride;
   int iters;
+  int dbg;                                    // timing experiments only (hrf_debug_knob 29)
 };
 
 __device__ __forceinline__ int tok_pixel(const AttnArgs& a, int b, int wy, int wx, int t) {
@@ -467,16 +468,18 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   __shared__ float sY[NT * DT * 16];                                // dV rows
   __shared__ float sT[176];
   __shared__ float sM[64], sIL[64], sDl[64];
+  __shared__ int sPad[64];                                          // key j is a padded (out-of-image) token
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
   const int i = lane & 15, q = lane >> 4;
   const int win = blockIdx.x;
   const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
   stage_tiles<D, P, true>(a, b, wy, wx, h, sQ, sK, sV, sG);
   for (int e = threadIdx.x; e < 169; e += 256) sT[e] = a.rpb[e * a.heads + h];
+  if (threadIdx.x < 64) sPad[threadIdx.x] = (threadIdx.x < NT && tok_pixel(a, b, wy, wx, threadIdx.x) < 0) ? 1 : 0;
   __syncthreads();
 
   // ================= query-column orientation: wave = queries 16w .. 16w+15
-  {
+  if (!(a.dbg & 16)) {
     hrf_f4 s[4], dp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   }
   __syncthreads();
   // ================= key-column orientation: wave = keys 16w .. 16w+15
-  {
+  if (!(a.dbg & 8)) {
     hrf_f4 s[4], dp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   }
   __syncthreads();
   const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride;
-  for (int e = threadIdx.x; e < NT * D; e += 256) {
+  for (int e = threadIdx.x; e < NT * D && !(a.dbg & 4); e += 256) {
     const int jj = e / D, d = e - jj * D;
     const int px = tok_pixel(a, b, wy, wx, jj);
     if (px >= 0) {
@@ -622,14 +625,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
       a.dv[(long)px * a.lddv + a.dvoff + h * D + d] = sY[jj * (DT * 16) + d];
     }
   }
-  // padded keys (boundary windows only): their gradient flows to the projection bias
-  if (wy == 0 || wx == 0 || wy == a.nWh - 1 || wx == a.nWw - 1) {
-    if (threadIdx.x < D) {
-      const int d = threadIdx.x;
+  // padded keys (boundary windows only): their gradient flows to the projection bias.  Wave w sums keys 13w .. 13w+12
+  // (lane = channel); one atomic per wave and channel into the replicated accumulators
+  if (!(a.dbg & 2) && (wy == 0 || wx == 0 || wy == a.nWh - 1 || wx == a.nWw - 1)) {
+    if (lane < D) {
+      const int d = lane;
       float pk = 0.f, pv = 0.f;
       bool anypad = false;
-      for (int jj = 0; jj < NT; ++jj) {
-        if (tok_pixel(a, b, wy, wx, jj) < 0) {
+      const int j1 = min(NT, 13 * wave + 13);
+      for (int jj = 13 * wave; jj < j1; ++jj) {
+        if (sPad[jj] != 0) {
           pk += sX[jj * (DT * 16) + d];
           pv += sY[jj * (DT * 16) + d];
           anypad = true;
@@ -641,21 +646,32 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
       }
     }
   }
-  // dRPB[(yi-yj+6)*13 + (xi-xj+6)] += dS[i][j]: gather over the dS plane, one bin per thread
-  if (threadIdx.x < 169) {
-    const int e = threadIdx.x;
-    const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
-    const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
-    const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
-    float sacc = 0.f;
-    for (int yj = y0; yj <= y1; ++yj)
-      for (int xj = x0; xj <= x1; ++xj)
-        sacc += sD[(yj * 7 + xj) * SP + (yj + dy) * 7 + xj + dx];
-    hrf_atomic_add(&a.drpb[cp + e * a.heads + h], sacc);
+  // dRPB[(yi-yj+6)*13 + (xi-xj+6)] += dS[i][j]: gather over the dS plane.  169 bins x 4 row groups of the key grid
+  // (wave-sized work items instead of 169 threads walking up to 49 entries each), partial sums merged in LDS,
+  // one atomic per bin and block
+  if (!(a.dbg & 1)) {
+    float* sBin = sX;                                               // (dK rows are stored by now)
+    __syncthreads();
+    for (int it = threadIdx.x; it < 169 * 4; it += 256) {
+      const int e = it % 169, part = it / 169;
+      const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
+      const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
+      const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
+      float sacc = 0.f;
+      for (int yj = y0 + part; yj <= y1; yj += 4)
+        for (int xj = x0; xj <= x1; ++xj)
+          sacc += sD[(yj * 7 + xj) * SP + (yj + dy) * 7 + xj + dx];
+      sBin[part * 176 + e] = sacc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 169) {
+      const int e = threadIdx.x;
+      hrf_atomic_add(&a.drpb[cp + e * a.heads + h], (sBin[e] + sBin[176 + e]) + (sBin[352 + e] + sBin[528 + e]));
+    }
   }
 }
 
-int g_attn_mfma = 1;
+int g_attn_mfma = 1, g_attn_dbg = 0;
 
 inline void window_geom(AttnArgs& a) {
   a.nWh = (a.H + 6) / 7; a.nWw = (a.W + 6) / 7;
@@ -694,6 +710,7 @@ extern "C" int hrf_window_attn_fwd(const float* q, int ldq, int qoff, const floa
 
 extern "C" int hrf_attn_knob(int key, int value) {
   if (key == 0) { g_attn_mfma = value; return HRF_OK; }
+  if (key == 1) { g_attn_dbg = value; return HRF_OK; }
   return HRF_ERR_ARG;
 }
 
@@ -711,6 +728,7 @@ extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const floa
   a.scale = 1.0f / sqrtf((float)D);
   a.dout = dout; a.lddo = lddo; a.dq = dq; a.lddq = lddq; a.dqoff = dqoff; a.dk = dk; a.lddk = lddk; a.dkoff = dkoff;
   a.dv = dv; a.lddv = lddv; a.dvoff = dvoff; a.dkpad = dkpad; a.dvpad = dvpad; a.drpb = drpb; a.copy_stride = copy_stride;
+  a.dbg = g_attn_dbg;
   window_geom(a);
   const int nwin = B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
