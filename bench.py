@@ -218,10 +218,6 @@ def main():
                 json.dump({'kernels': profiling.table_json(table, PEAK_F32_MFMA, PEAK_HBM),
                            'signatures': profiling.profile_step.last_signatures[:60]}, fh, indent=1)
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(tag, B, H, W, mc)
-
     neck = None
     if rank == 0 and world == 1 and not args.no_neck:
         # the HRFPN neck that consumes the four maps, timed on its own (not part of `value`)
@@ -257,6 +253,10 @@ def main():
                     'ms_per_step': round(ms, 3), 'images_per_sec': round(B / ms * 1e3, 2)}
         except Exception as e:
             feat = {'error': str(e)[:200]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(tag, B, H, W, mc)
 
     if rank == 0:
         line = {
