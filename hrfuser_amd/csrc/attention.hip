@@ -464,8 +464,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   __shared__ float sV[64 * P];
   __shared__ float sG[64 * P];                                      // dO rows
   __shared__ float sD[NT * SP];                                     // dS[key][query] plane (relative position bias)
-  __shared__ float sX[NT * DT * 16];                                // dK rows
-  __shared__ float sY[NT * DT * 16];                                // dV rows
+  // dK / dV rows reuse the K / V tiles once the last MFMA has read them: 48 KB of LDS per block at D = 18, i.e. three
+  // resident blocks per CU - the 644 windows of the 96x160 map then run in one round instead of two
+  float* sX = sK;                                                   // dK rows [49][DT*16]
+  float* sY = sV;                                                   // dV rows
   __shared__ float sT[176];
   __shared__ float sM[64], sIL[64], sDl[64];
   __shared__ int sPad[64];                                          // key j is a padded (out-of-image) token
@@ -603,6 +605,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
           ok_[dt] = hrf_mfma16(dp[t][r], qr[16 * dt], ok_[dt]);
         }
       }
+    __syncthreads();                                                            // every wave is done reading sK / sV
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ko = 16 * wave + 4 * q + r;                                     // result row = key
