@@ -43,7 +43,6 @@ struct AttnArgs {
   float* dv; int lddv, dvoff;
   float* dkpad; float* dvpad; float* drpb; long copy_stride;
   int iters;
-  int dbg;                                    // timing experiments only (hrf_debug_knob 29)
 };
 
 __device__ __forceinline__ int tok_pixel(const AttnArgs& a, int b, int wy, int wx, int t) {
@@ -481,7 +480,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   __syncthreads();
 
   // ================= query-column orientation: wave = queries 16w .. 16w+15
-  if (!(a.dbg & 16)) {
+  {
     hrf_f4 s[4], dp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
@@ -561,7 +560,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   }
   __syncthreads();
   // ================= key-column orientation: wave = keys 16w .. 16w+15
-  if (!(a.dbg & 8)) {
+  {
     hrf_f4 s[4], dp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
@@ -620,7 +619,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   }
   __syncthreads();
   const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride;
-  for (int e = threadIdx.x; e < NT * D && !(a.dbg & 4); e += 256) {
+  for (int e = threadIdx.x; e < NT * D; e += 256) {
     const int jj = e / D, d = e - jj * D;
     const int px = tok_pixel(a, b, wy, wx, jj);
     if (px >= 0) {
@@ -630,7 +629,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   }
   // padded keys (boundary windows only): their gradient flows to the projection bias.  Wave w sums keys 13w .. 13w+12
   // (lane = channel); one atomic per wave and channel into the replicated accumulators
-  if (!(a.dbg & 2) && (wy == 0 || wx == 0 || wy == a.nWh - 1 || wx == a.nWw - 1)) {
+  if (wy == 0 || wx == 0 || wy == a.nWh - 1 || wx == a.nWw - 1) {
     if (lane < D) {
       const int d = lane;
       float pk = 0.f, pv = 0.f;
@@ -652,7 +651,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   // dRPB[(yi-yj+6)*13 + (xi-xj+6)] += dS[i][j]: gather over the dS plane.  169 bins x 4 row groups of the key grid
   // (wave-sized work items instead of 169 threads walking up to 49 entries each), partial sums merged in LDS,
   // one atomic per bin and block
-  if (!(a.dbg & 1)) {
+  {
     float* sBin = sX;                                               // (dK rows are stored by now)
     __syncthreads();
     for (int it = threadIdx.x; it < 169 * 4; it += 256) {
@@ -674,7 +673,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   }
 }
 
-int g_attn_mfma = 1, g_attn_dbg = 0;
+int g_attn_mfma = 1;
 
 inline void window_geom(AttnArgs& a) {
   a.nWh = (a.H + 6) / 7; a.nWw = (a.W + 6) / 7;
@@ -713,7 +712,6 @@ extern "C" int hrf_window_attn_fwd(const float* q, int ldq, int qoff, const floa
 
 extern "C" int hrf_attn_knob(int key, int value) {
   if (key == 0) { g_attn_mfma = value; return HRF_OK; }
-  if (key == 1) { g_attn_dbg = value; return HRF_OK; }
   return HRF_ERR_ARG;
 }
 
@@ -731,7 +729,6 @@ extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const floa
   a.scale = 1.0f / sqrtf((float)D);
   a.dout = dout; a.lddo = lddo; a.dq = dq; a.lddq = lddq; a.dqoff = dqoff; a.dk = dk; a.lddk = lddk; a.dkoff = dkoff;
   a.dv = dv; a.lddv = lddv; a.dvoff = dvoff; a.dkpad = dkpad; a.dvpad = dvpad; a.drpb = drpb; a.copy_stride = copy_stride;
-  a.dbg = g_attn_dbg;
   window_geom(a);
   const int nwin = B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
