@@ -108,7 +108,7 @@ class Trainer:
         # thread_local: the RCCL watchdog thread polls events of earlier (eager) collectives while we
         # capture; in the default "global" mode such a call from another thread invalidates the capture
         # ("capturing stream has unjoined work", seen in ~3 of 4 runs with collectives in the graph)
-        with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             self._graph_outs = self._step_impl(x, mods, cots)
         self.graph = g
         return g
