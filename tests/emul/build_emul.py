@@ -14,6 +14,7 @@ SOURCES = ['conv_engine.hip', 'lin_engine.hip', 'conv3_engine.hip', 'conv3w_engi
 
 
 def build(force=False, sanitize=False):
+    sanitize = sanitize or os.environ.get('HRF_EMUL_ASAN') == '1'      # sanitizer runs: HRF_EMUL_ASAN=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 pytest ...
     os.makedirs(OUT, exist_ok=True)
     h = hashlib.sha256()
     files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
