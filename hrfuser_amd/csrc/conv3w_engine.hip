@@ -22,7 +22,8 @@ namespace {
 
 constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2, NPIX = IH * IW;   // 180 halo pixels
 constexpr int KS = 32;        // channels per K slab
-constexpr int LP = KS + 4;    // LDS pitch (floats): 16-byte aligned rows, bank = (4*(row + q)) % 32 for b128 reads
+constexpr int LP = KS + 4;    // LDS pitch of the halo (floats): 16-byte aligned rows
+constexpr int WP = KS;        // weight tile: no padding, the 16-byte chunk index is XOR-swizzled with (row & 7) instead
 constexpr int NTHR = 512;
 
 __device__ float g_zero4w[4] = {0.f, 0.f, 0.f, 0.f};
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(NTHR) void conv3w_kernel(C3wArgs a) {
   constexpr int NHV = (NPIX * (KS / 4) + NTHR - 1) / NTHR;     // halo float4 per thread (3)
   HRF_DYN_SMEM(float, smem);
   float* sIn = smem;                          // [NPIX * LP]
-  float* sB = smem + NPIX * LP;               // [3][NB * LP]
+  float* sB = smem + NPIX * LP;               // [3][NB * WP], chunk c of row n stored at chunk c ^ (n & 7)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int chg = wave % WN, rg = wave / WN;
@@ -130,20 +131,21 @@ __global__ __launch_bounds__(NTHR) void conv3w_kernel(C3wArgs a) {
     for (int e = 0; e < WN; ++e) wpre[e] = hrf_ld4(wrow[e] + tap * wtap + slab * KS);
   };
   auto store_w = [&](int ring) {
-    float* dst = sB + ring * (NB * LP);
+    float* dst = sB + ring * (NB * WP);
 #pragma unroll
-    for (int e = 0; e < WN; ++e) lds_st4(dst + (wn + 64 * e) * LP + 4 * wj, wpre[e]);
+    for (int e = 0; e < WN; ++e) lds_st4(dst + (wn + 64 * e) * WP + 4 * (wj ^ (wn & 7)), wpre[e]);
   };
   hrf_f4 fa[2][WN], fb[2][4];
   const float* abase = sIn + (rg * WN * IW + i) * LP + 4 * q;
-  const float* bbase = sB + (chg * 64 + i) * LP + 4 * q;
+  const float* bbase = sB + (chg * 64 + i) * WP;
+  const int bsw[2] = {4 * (q ^ (i & 7)), 4 * ((q + 4) ^ (i & 7))};        // swizzled chunk of c16 = 0 / 1
   auto read_frags = [&](int hoff, int ring, int c16, int slot) {
     const float* ap = abase + hoff + c16 * 16;
-    const float* bp = bbase + ring * (NB * LP) + c16 * 16;
+    const float* bp = bbase + ring * (NB * WP) + bsw[c16];
 #pragma unroll
     for (int rr = 0; rr < WN; ++rr) fa[slot][rr] = lds_ld4(ap + rr * IW * LP);
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) fb[slot][tt] = lds_ld4(bp + tt * 16 * LP);
+    for (int tt = 0; tt < 4; ++tt) fb[slot][tt] = lds_ld4(bp + tt * 16 * WP);
   };
   auto mma = [&](int slot, int half) {        // D[row = channel][col = pixel]: the weight fragment is the row operand
 #pragma unroll
@@ -569,7 +571,7 @@ int wgrad3w_splits(int B, int H, int W, int Cin, int Cout) {
 
 template <int WN>
 int launch_w(C3wArgs a, void* stream) {
-  constexpr size_t smem = (size_t)(NPIX * LP + 3 * WN * 64 * LP) * sizeof(float);
+  constexpr size_t smem = (size_t)(NPIX * LP + 3 * WN * 64 * WP) * sizeof(float);
 #ifndef HRF_EMUL
   static bool once = false;
   if (!once) {
