@@ -704,10 +704,7 @@ class HRFuserHRFormerBased(HipModule):
         self.norm_cfg, self.transformer_norm_cfg = norm_cfg, transformer_norm_cfg
         self.norm_eval, self.with_cp = norm_eval, with_cp
         self.num_fused_modalities = M = num_fused_modalities
-        self.pre_neck_fusion = True if extra.get('LidarStageD') else False
-        if self.pre_neck_fusion:
-            raise NotImplementedError('LidarStageD / ModFusionD (pre-neck fusion) is disabled in every reference '
-                                      'config (SURVEY 8f-4) and not built yet')
+        self.pre_neck_fusion = True if extra.get('LidarStageD') else False          # :364-366 (off in every config)
         ncfg, lcfg = norm_cfg, transformer_norm_cfg
         # HRFormer.__init__ :666-678 - drop_path_rate is swallowed (always 0 here)
         for s in ('stage2', 'stage3', 'stage4'):
@@ -715,6 +712,8 @@ class HRFuserHRFormerBased(HipModule):
             extra[s]['drop_path_rates'] = [0.0] * n
         extra['LidarStageB']['drop_path_rates'] = extra['stage2']['drop_path_rates']
         extra['LidarStageC']['drop_path_rates'] = extra['stage3']['drop_path_rates']
+        if self.pre_neck_fusion:
+            extra['LidarStageD']['drop_path_rates'] = extra['stage4']['drop_path_rates']
 
         # camera stem + stage 1 (hrnet.py:337-371)
         self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)
@@ -760,6 +759,17 @@ class HRFuserHRFormerBased(HipModule):
                 stages = [self._make_stage(scfg, sch)[0] for _ in range(M)]
                 setattr(self, f'stage_{nxt}', nn.ModuleList(stages))
                 pre_m = [sch for _ in range(M)]
+        if self.pre_neck_fusion:
+            # modality stage D + a fourth fusion AFTER camera stage 4, then ReLU (hrfuser_hrformer_based.py:454-468,609-625)
+            scfg = extra['LidarStageD']
+            self.stage_d_cfg = scfg
+            sch = list(scfg['num_channels'])
+            self.stage_d = nn.ModuleList([self._make_stage(scfg, sch)[0] for _ in range(M)])
+            fcfg = extra['ModFusionD']
+            self.fusion_d_cfg = fcfg
+            ch = list(fcfg['num_channels'])
+            self.transition_d = nn.ModuleList(_make_transition(sch, ch, ncfg) for _ in range(M))
+            self.fusion_d = self._make_multimodal_fusion(fcfg, ch)
         self.init_weights()
 
     # -- construction helpers -------------------------------------------------------------------
@@ -929,9 +939,44 @@ class HRFuserHRFormerBased(HipModule):
         xs, m0 = self._fuse_stage(ctx, ys, self.transition2, self.transition_b, self.fusion_b,
                                   self.stage3_cfg['num_branches'], mods, False)
         ys, mods = self._stages(ctx, self.stage3, xs, self.stage_c, m0)
-        xs, _ = self._fuse_stage(ctx, ys, self.transition3, self.transition_c, self.fusion_c,
-                                 self.stage4_cfg['num_branches'], mods, False)
-        return self._run_stage(ctx, self.stage4, xs)
+        xs, m0 = self._fuse_stage(ctx, ys, self.transition3, self.transition_c, self.fusion_c,
+                                  self.stage4_cfg['num_branches'], mods, False)
+        if not self.pre_neck_fusion:
+            return self._run_stage(ctx, self.stage4, xs)
+        ys, mods = self._stages(ctx, self.stage4, xs, self.stage_d, m0)
+        nb = self.stage4_cfg['num_branches']
+        xs, _ = self._fuse_stage(ctx, ys, [None] * nb, self.transition_d, self.fusion_d, nb, mods, False)
+        lanes = ctx.fork(nb)
+        outs = [None] * nb
+        for i in range(nb):
+            with ctx.on(lanes[i]):
+                outs[i] = self._relu(ctx, xs[i])                                  # :622-623 y_list[i] = self.relu(x_list[i])
+        ctx.join(lanes)
+        return outs
+
+    def _relu(self, ctx, x):
+        """Stand-alone ReLU of a materialised map (only the pre-neck fusion needs one: everywhere else the
+        activation is applied by the consumer on load)."""
+        L, s = ctx.L, ctx.stream
+        Bn, H, W, C = x.t.shape
+        rows = Bn * H * W
+        unit = self.__dict__.setdefault('_unit_vec', {})
+        key = (C, x.t.device)
+        if key not in unit:
+            unit[key] = (torch.ones(C, device=x.t.device), torch.zeros(C, device=x.t.device))
+        one, zero = unit[key]
+        out = R.Act(R._new_like(x.t))
+        L.hrf_affine_act_res(x.t, one, zero, None, None, None, None, None, H * W, R.ACT_RELU, 0, out.t, rows, C, None, 0.0, s)
+
+        def bwd():
+            if out.grad is None:
+                return
+            g = R._new_like(out.t)
+            ctx.L.hrf_act_bwd(out.grad, out.t, x.t, None, None, None, 1, 0, g, None, None, None, None, None, rows, C,
+                              ctx.stream)
+            x.add_grad(g)
+        ctx.push(bwd)
+        return out
 
     def _stages(self, ctx, cam_stage, xs, mod_stages, m0):
         """The camera stage and the M single-branch modality stages are independent.  The modality

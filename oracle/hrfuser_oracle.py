@@ -372,9 +372,7 @@ class HRFuserOracle(nn.Module):
         self.M = M = num_fused_modalities
         self.extra = extra
         ncfg, lcfg = norm_cfg, transformer_norm_cfg
-        if extra.get('LidarStageD'):
-            raise NotImplementedError('pre-neck fusion (LidarStageD) is disabled in every '
-                                      'reference config and not restated')
+        self.pre_neck_fusion = bool(extra.get('LidarStageD'))       # hrfuser_hrformer_based.py:364-366
         # camera stem + stage1 (hrnet.py:337-371)
         self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)
         self.bn1 = make_bn(ncfg, 64)
@@ -416,6 +414,19 @@ class HRFuserOracle(nn.Module):
                 setattr(self, f'stage_{nxt.lower()}', nn.ModuleList(
                     self._make_stage(scfg, ncfg, lcfg, True) for _ in range(M)))
                 pre_m = list(scfg['num_channels'])
+        if self.pre_neck_fusion:                                    # hrfuser_hrformer_based.py:454-468
+            scfg = extra['LidarStageD']
+            self.stage_d = nn.ModuleList(self._make_stage(scfg, ncfg, lcfg, True) for _ in range(M))
+            pre_m = list(scfg['num_channels'])
+            fcfg = extra['ModFusionD']
+            if fcfg['block'] not in ('CA', 'MWCA'):
+                raise Exception('Not valid fusion block')
+            ch = list(fcfg['num_channels'])
+            self.transition_d = nn.ModuleList(make_transition(pre_m, ch, ncfg) for _ in range(M))
+            self.fusion_d = nn.ModuleList(
+                HRFuserFusionBlock(ch[i], fcfg['num_heads'][i], fcfg['mlp_ratios'][i], ncfg, lcfg,
+                                   fcfg['drop_path'], M, fcfg['proj_drop_rate'])
+                for i in range(fcfg['num_branches']))
 
     @staticmethod
     def _make_stage(cfg, ncfg, lcfg, multiscale_output):
@@ -469,9 +480,18 @@ class HRFuserOracle(nn.Module):
                             self.extra['stage3']['num_branches'], False)
         ys = self._run(self.stage3, xs)
         mods = [self._run(self.stage_c[k], [m0[k]])[0] for k in range(self.M)]
-        xs, _ = fuse_stage(ys, self.transition3, self.transition_c, self.fusion_c,
-                           self.extra['stage4']['num_branches'], False)
-        return self._run(self.stage4, xs)
+        xs, m0 = fuse_stage(ys, self.transition3, self.transition_c, self.fusion_c,
+                            self.extra['stage4']['num_branches'], False)
+        ys = self._run(self.stage4, xs)
+        if self.pre_neck_fusion:                                    # hrfuser_hrformer_based.py:609-625
+            mods = [self._run(self.stage_d[k], [m0[k]])[0] for k in range(self.M)]
+            outs = []
+            for i in range(self.extra['stage4']['num_branches']):
+                ms = [self.transition_d[k][i](mods[k]) if self.transition_d[k][i] is not None else mods[k]
+                      for k in range(self.M)]
+                outs.append(F.relu(self.fusion_d[i](ys[i], ms)))
+            ys = outs
+        return ys
 
     @staticmethod
     def _run(stage, xs):

@@ -140,3 +140,57 @@ def test_output_contract_gpu():
         ys = net(x.to(dev), [m.to(dev) for m in mods])
     assert isinstance(ys, list) and [tuple(y.shape) for y in ys] == [(1, 18, 16, 24), (1, 36, 8, 12), (1, 72, 4, 6), (1, 144, 2, 3)]
     assert all(y.is_cuda and y.dtype == torch.float32 for y in ys)
+
+
+def _stage_d_pair(dev):
+    import json
+    from hrfuser_amd import build_backbone
+    from helpers import disable_stochastic
+    with open(os.path.join(GOLD, 'backbone_cfg_stage_d.json')) as fh:
+        cfg = json.load(fh)['t_nus_bn_stage_d']
+    c2 = copy.deepcopy(cfg)
+    c2.pop('type')
+    orc = O.HRFuserOracle(**c2)
+    O.seeded_fill_(orc, 0)
+    net = build_backbone(copy.deepcopy(cfg))
+    net.load_state_dict(orc.state_dict())
+    net.to(dev)
+    disable_stochastic(net, orc)
+    return net, orc
+
+
+def test_pre_neck_fusion_construction():
+    """LidarStageD / ModFusionD (hrfuser_hrformer_based.py:454-468): same parameters as the oracle, which is bit-exact
+    against the reference class with the stage enabled (oracle/tools/make_golden_stage_d.py)."""
+    net, orc = _stage_d_pair(torch.device('cpu'))
+    assert net.pre_neck_fusion
+    assert list(net.state_dict().keys()) == list(orc.state_dict().keys())
+    assert any(k.startswith('fusion_d.') for k in net.state_dict()) and any(k.startswith('stage_d.') for k in net.state_dict())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('train', [False, True])
+def test_pre_neck_fusion_gpu(train):
+    """hrfuser_hrformer_based.py:609-625: modality stage D, a fourth fusion after camera stage 4, ReLU."""
+    from helpers import grad_close
+    dev = use_backend('hip')
+    net, orc = _stage_d_pair(dev)
+    net.train(train)
+    orc.train(train)
+    x, mods = O.seeded_inputs(2, 64, 96, [3, 3], seed=1)
+    o64 = copy.deepcopy(orc).double()
+    xa = x.clone().to(dev).requires_grad_(train)
+    xb = x.double().requires_grad_(train)
+    with torch.set_grad_enabled(train):
+        ya = net(xa, [m.to(dev) for m in mods])
+        yb = o64(xb, [m.double() for m in mods])
+    for i, (p, q) in enumerate(zip(ya, yb)):
+        assert relmax(p, q) < 1e-3, (i, relmax(p, q))
+        assert float(p.detach().min()) >= 0.0                         # the final ReLU
+    if train:
+        g = torch.Generator().manual_seed(5)
+        cots = [torch.randn(t.shape, generator=g) for t in yb]
+        sum((t * c.to(dev)).sum() for t, c in zip(ya, cots)).backward()
+        sum((t * c.double()).sum() for t, c in zip(yb, cots)).backward()
+        assert grad_close(xa.grad, xb.grad, tol=5e-3)
+        grad_check(net.named_parameters(), o64.named_parameters(), tol=5e-3)
