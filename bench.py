@@ -46,8 +46,6 @@ def parse():
     ap.add_argument('--height', type=int, default=0)
     ap.add_argument('--width', type=int, default=0)
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
-    ap.add_argument('--program', action='store_true',
-                    help='replay through the library launch recorder (hrf_replay) instead of hipGraph (1 GPU only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-neck', action='store_true', help='skip the HRFPN neck timing (the consumer of the 4 maps)')
@@ -138,11 +136,7 @@ def main():
     trainer = Trainer(net, lr=1e-3 if stf else 3e-4, group=group, world_size=world)
 
     use_graph = not args.no_graph
-    use_prog = args.program and world == 1 and not force_coll
-    if use_prog:
-        trainer.capture_program(x, mods, cots)
-        use_graph = False
-    elif use_graph:
+    if use_graph:
         try:
             trainer.capture(x, mods, cots)
         except Exception as e:                                    # e.g. collective not capturable
@@ -150,7 +144,7 @@ def main():
                 print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager', file=sys.stderr)
             use_graph = False
             torch.cuda.synchronize()
-    run = trainer.replay_program if use_prog else (trainer.replay if use_graph else (lambda: trainer.step(x, mods, cots)))
+    run = trainer.replay if use_graph else (lambda: trainer.step(x, mods, cots))
 
     def barrier():
         if world > 1:
@@ -268,7 +262,7 @@ def main():
                                    f'{B}x3x{H}x{W} camera + {len(mc)} modalities, '
                                    + ('SyncBN+RCCL all-reduce' if world > 1 else 'BN, single GPU'),
                        'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'launch': 'recorded program replay' if use_prog else ('hipGraph replay' if use_graph else 'eager')},
+                       'launch': 'hipGraph replay' if use_graph else 'eager'},
             'fwd_ms_per_img': fwd_ms,
             'roofline': roof, 'cpu_baseline': cpu, 'neck': neck, 'extract_feat': feat,
         }

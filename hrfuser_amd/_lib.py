@@ -20,29 +20,30 @@ def _header_int(name, default):
 
 
 STAT_COPIES = _header_int('HRF_STAT_COPIES', 16)   # replication of cross-block accumulators (see header)
+FIN_MAXC = _header_int('HRF_FIN_MAXC', 576)        # widest BatchNorm the consumer kernels finalise on load
 
 class BnFin(ctypes.Structure):
-    """hrf_bn_fin_t (include/hrfuser_hip.h): BatchNorm finalize fused into the producing kernel."""
-    _fields_ = [('ticket', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
+    """hrf_bn_fin_t (include/hrfuser_hip.h): BatchNorm of a consumer's input finalised on load."""
+    _fields_ = [('stats', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
                 ('running_mean', ctypes.c_void_p), ('running_var', ctypes.c_void_p), ('scale', ctypes.c_void_p),
                 ('shift', ctypes.c_void_p), ('mean', ctypes.c_void_p), ('invstd', ctypes.c_void_p),
                 ('count', ctypes.c_double), ('eps', ctypes.c_float), ('momentum', ctypes.c_float),
-                ('update_running', ctypes.c_int), ('C', ctypes.c_int)]
+                ('update_running', ctypes.c_int), ('write', ctypes.c_int), ('C', ctypes.c_int)]
 
 
 class BnBFin(ctypes.Structure):
-    """hrf_bn_bfin_t: BatchNorm-backward finalize fused into the kernel that produces (sum du, sum du*x)."""
-    _fields_ = [('ticket', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('mean', ctypes.c_void_p),
+    """hrf_bn_bfin_t: BatchNorm-backward coefficients derived on load by the producing convolution's data gradient."""
+    _fields_ = [('gstats', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('mean', ctypes.c_void_p),
                 ('invstd', ctypes.c_void_p), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p),
                 ('cA', ctypes.c_void_p), ('cB', ctypes.c_void_p), ('cC', ctypes.c_void_p),
-                ('count', ctypes.c_double), ('train', ctypes.c_int), ('C', ctypes.c_int)]
+                ('count', ctypes.c_double), ('train', ctypes.c_int), ('write', ctypes.c_int), ('C', ctypes.c_int)]
 
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_RAW_RETURN = ('hrf_rec_end', 'hrf_replay_info', 'hrf_conv3_wgrad_wide_scratch', 'hrf_wgrad_group_report')       # return a value, not a status
+_RAW_RETURN = ('hrf_conv3_wgrad_wide_scratch', 'hrf_wgrad_group_report')       # return a value, not a status
 _ERR = {1: 'HRF_ERR_ARG (bad argument)', 2: 'HRF_ERR_LAUNCH (kernel launch failed)'}
 
 
@@ -109,7 +110,7 @@ class Lib:
                 if ct is ctypes.c_void_p:
                     if v is None:
                         conv.append(None)
-                    elif isinstance(v, ctypes.Structure):
+                    elif isinstance(v, (ctypes.Structure, ctypes.Array)):
                         conv.append(ctypes.addressof(v))
                     elif isinstance(v, torch.Tensor):
                         if require_cuda and not v.is_cuda:

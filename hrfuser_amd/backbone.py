@@ -11,6 +11,7 @@ but the modules only OWN parameters: all arithmetic is issued through `runtime.p
 hand-written gfx950 kernels behind `include/hrfuser_hip.h`.  There is no eager/CPU fallback.
 """
 import os
+import warnings
 
 import torch
 import torch.nn as nn
@@ -67,13 +68,13 @@ class Engine:
         self.device = None
         self.flat_p = self.flat_g = None
         self.slots = {}
-        self.eval_cache = {}
-        self.epoch = 0
+        self._bns = []
         self.keep = []                 # step-lifetime buffers of THIS engine (runtime.use_keep_list)
 
     def ready(self, device):
         params = [p for p in self.root.parameters()]
-        if self.device != device or self.flat_p is None or (params and params[0].data_ptr() != self._p0):
+        if self.device != device or self.flat_p is None or (params and params[0].data_ptr() != self._p0) or \
+                (self._bns and self._bns[0].running_mean is not None and self._bns[0].running_mean.data_ptr() != self._rs0):
             self._setup(device, params)
         # re-bind gradients dropped by zero_grad(set_to_none=True)
         dirty = False
@@ -100,26 +101,50 @@ class Engine:
                 off += n
         self._p0 = params[0].data_ptr() if params else 0
         bns = [m for m in self.root.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        self._bns = bns
         csum = sum(m.num_features for m in bns)
+        # running statistics become views of ONE flat buffer (like the parameters), so that the eval-mode affine of every
+        # BatchNorm is recomputed on the device by a handful of flat torch ops at the start of each forward that has
+        # frozen BatchNorms - never cached across steps (the kernels update these buffers through raw pointers)
+        self.rstat = torch.zeros(2 * max(1, csum), device=device, dtype=torch.float32)
+        self.eval_f = torch.zeros(4 * max(1, csum), device=device, dtype=torch.float32)    # scale | shift | mean | invstd
+        gidx, bidx, epsv = [], [], []
+        offs0 = {id(p): o for p, (o, _) in zip(params, self._spans)}
         K = _lib.STAT_COPIES                       # replicated accumulators: see include/hrfuser_hip.h
         self.arena_d = torch.zeros(4 * csum * K, device=device, dtype=torch.float64)
         self.arena_f = torch.zeros(7 * csum, device=device, dtype=torch.float32)
-        self.tickets = torch.zeros(2 * (K + 1) * max(1, len(bns)), device=device, dtype=torch.int32)   # fused finalize
         self.slots = {}
-        od = of = 0
+        od = of = oc = 0
         for bi, m in enumerate(bns):
             C = m.num_features
             d = self.arena_d
             f = self.arena_f
+            with torch.no_grad():
+                if m.running_mean is not None:
+                    self.rstat[oc:oc + C].copy_(m.running_mean.to(device))
+                    self.rstat[csum + oc:csum + oc + C].copy_(m.running_var.to(device))
+                    m.running_mean = self.rstat[oc:oc + C]
+                    m.running_var = self.rstat[csum + oc:csum + oc + C]
+            ar = torch.arange(C, dtype=torch.long)
+            gidx.append(ar + offs0[id(m.weight)] if m.weight is not None else torch.full((C,), -1, dtype=torch.long))
+            bidx.append(ar + offs0[id(m.bias)] if m.bias is not None else torch.full((C,), -1, dtype=torch.long))
+            epsv.append(torch.full((C,), float(m.eps)))
+            e = self.eval_f
             self.slots[id(m)] = dict(
                 stats=d[od:od + 2 * C * K], gstats=d[od + 2 * C * K:od + 4 * C * K],
                 scale=f[of:of + C], shift=f[of + C:of + 2 * C], mean=f[of + 2 * C:of + 3 * C],
                 invstd=f[of + 3 * C:of + 4 * C], cA=f[of + 4 * C:of + 5 * C], cB=f[of + 5 * C:of + 6 * C],
                 cC=f[of + 6 * C:of + 7 * C],
-                tick_f=self.tickets[2 * (K + 1) * bi:2 * (K + 1) * bi + K + 1],
-                tick_b=self.tickets[2 * (K + 1) * bi + K + 1:2 * (K + 1) * (bi + 1)])
+                eval=(e[oc:oc + C], e[csum + oc:csum + oc + C], e[2 * csum + oc:2 * csum + oc + C],
+                      e[3 * csum + oc:3 * csum + oc + C]))
             od += 4 * C * K
             of += 7 * C
+            oc += C
+        self._csum = csum
+        self._rs0 = bns[0].running_mean.data_ptr() if (bns and bns[0].running_mean is not None) else 0
+        if bns:
+            self._gidx, self._bidx = torch.cat(gidx).to(device), torch.cat(bidx).to(device)
+            self._epsv = torch.cat(epsv).to(device)
         # parameter gradients that MANY blocks add into (LayerNorm gamma/beta, depthwise weights/bias)
         # accumulate in K replicated fp32 copies and are folded into the arena once per backward
         offs = {id(p): o for p, (o, _) in zip(params, self._spans)}
@@ -147,7 +172,6 @@ class Engine:
                 self.nbt_flat[i] = m.num_batches_tracked.to(device)
                 m.num_batches_tracked = self.nbt_flat[i]          # 0-dim view: one add_ per step updates all
         self.device = device
-        self.eval_cache = {}
 
     def grad_acc(self, p):
         """-> (accumulator tensor, copy_stride) for a parameter gradient written by many blocks."""
@@ -222,20 +246,28 @@ class Engine:
             self._rng_need = {}
         if self.arena_d.numel():
             R.gpu_zero_(self.arena_d)
+        if self._bns and not (training and all(m.training for m in self._bns)):
+            self.refresh_eval_affine()
+
+    def refresh_eval_affine(self):
+        """Frozen-statistics affine of EVERY BatchNorm (eval mode / norm_eval): scale = gamma * rsqrt(running_var + eps),
+        shift = beta - running_mean * scale, as F.batch_norm(training=False) computes it.  Six flat torch launches on the
+        current stream, re-run at the start of every forward that uses them: weights and running statistics are written
+        by the kernels through raw pointers (optimizer, train-mode forwards, hipGraph replays), so nothing here may be
+        cached across steps."""
+        n = self._csum
+        e = self.eval_f
+        with torch.no_grad():
+            torch.add(self.rstat[n:2 * n], self._epsv, out=e[3 * n:4 * n])
+            e[3 * n:4 * n].rsqrt_()
+            torch.mul(self.flat_p[self._gidx.clamp_min(0)], e[3 * n:4 * n], out=e[0:n])
+            torch.where(self._gidx >= 0, e[0:n], e[3 * n:4 * n], out=e[0:n])            # affine=False: gamma == 1
+            e[2 * n:3 * n].copy_(self.rstat[0:n])
+            beta = torch.where(self._bidx >= 0, self.flat_p[self._bidx.clamp_min(0)], torch.zeros((), device=e.device))
+            torch.addcmul(beta, e[2 * n:3 * n], e[0:n], value=-1.0, out=e[n:2 * n])
 
     def bn_eval_affine(self, bn):
-        key = id(bn)
-        ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, self.epoch)
-        hit = self.eval_cache.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
-        with torch.no_grad():
-            invstd = torch.rsqrt(bn.running_var + bn.eps)
-            scale = bn.weight * invstd
-            shift = bn.bias - bn.running_mean * scale
-            val = (scale.contiguous(), shift.contiguous(), bn.running_mean.clone(), invstd.contiguous())
-        self.eval_cache[key] = (ver, val)
-        return val
+        return self.slots[id(bn)]['eval']
 
 
 class EngineOwner:
@@ -289,7 +321,7 @@ class EngineOwner:
         self.sync_group, self.sync_world = group, world
 
     def params_updated(self):
-        self._engine().epoch += 1
+        """Kept for callers that signal a weight update; nothing is cached across steps any more."""
 
 
 # ----------------------------------------------------------------------------- blocks
@@ -603,6 +635,62 @@ def _make_res_layer(inplanes, planes, blocks, norm_cfg):
     return nn.Sequential(*layers)
 
 
+# ----------------------------------------------------------------------------- weight initialisation
+def resolve_init_cfg(pretrained, init_cfg):
+    """hrnet.py:301-318: `pretrained` (deprecated str) becomes an init_cfg of type 'Pretrained'; both at once assert."""
+    assert not (init_cfg and pretrained), 'init_cfg and pretrained cannot be specified at the same time'
+    if isinstance(pretrained, str):
+        warnings.warn('DeprecationWarning: pretrained is deprecated, please use "init_cfg" instead')
+        return dict(type='Pretrained', checkpoint=pretrained)
+    if pretrained is not None:
+        raise TypeError('pretrained must be a str or None')
+    return init_cfg
+
+
+def load_pretrained(module, init_cfg):
+    """mmcv `PretrainedInit` for a local checkpoint file: takes `state_dict` when present, strips `module.` and the
+    optional `prefix` (e.g. 'backbone.'), loads non-strictly and reports missing / unexpected keys as a warning."""
+    path = init_cfg['checkpoint']
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f'init_cfg Pretrained: {path} is not a local file (there is no downloader here)')
+    ckpt = torch.load(path, map_location='cpu')
+    sd = ckpt.get('state_dict', ckpt) if isinstance(ckpt, dict) else ckpt
+    prefix = init_cfg.get('prefix')
+    out = {}
+    for k, v in sd.items():
+        if k.startswith('module.'):
+            k = k[7:]
+        if prefix:
+            p = prefix if prefix.endswith('.') else prefix + '.'
+            if not k.startswith(p):
+                continue
+            k = k[len(p):]
+        out[k] = v
+    res = module.load_state_dict(out, strict=False)
+    if res.missing_keys or res.unexpected_keys:
+        warnings.warn(f'Pretrained init from {path}: {len(res.missing_keys)} missing, '
+                      f'{len(res.unexpected_keys)} unexpected keys')
+    return res
+
+
+def default_or_pretrained_init(module):
+    """Kaiming(conv) / constant-1 (BN) as the reference's default init_cfg (hrnet.py:309-316) - RPB tables stay zero
+    (App. D-4) - or the checkpoint of an init_cfg of type 'Pretrained'.  Any other init_cfg raises."""
+    cfg = getattr(module, 'init_cfg', None)
+    if cfg:
+        if isinstance(cfg, dict) and cfg.get('type') == 'Pretrained':
+            return load_pretrained(module, cfg)
+        raise NotImplementedError(f'init_cfg {cfg!r}: only None (Kaiming / Constant default) and type=Pretrained are built')
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
 # ----------------------------------------------------------------------------- autograd bridge
 class _BackboneFn(torch.autograd.Function):
     """Bridges the explicit tape to torch.autograd at the backbone boundary only."""
@@ -655,6 +743,8 @@ class HipModule(nn.Module, EngineOwner):
         with torch.no_grad():
             srcs = self._wrap_inputs(inputs)
             outs = self._run(ctx, srcs)
+            if ctx.probe is not None:
+                self.__dict__['_relu_masks'] = R.collect_relu_masks(ctx)
         return ctx, outs, srcs
 
     def _call_engine(self, inputs):
@@ -701,6 +791,11 @@ class HRFuserHRFormerBased(HipModule):
             # the reference raises inside the fusion blocks as soon as gradients are needed (:321-322)
             pass
         self.extra = extra
+        self.pretrained = pretrained
+        self.init_cfg = resolve_init_cfg(pretrained, init_cfg)
+        # zero_init_residual is dead code in the reference: hrnet.py:480-481,521-522 require `not hasattr(self, 'init_cfg')`,
+        # and BaseModule.__init__ always sets that attribute - norm3 is never zero-initialised.  Kept as an attribute only.
+        self.zero_init_residual = zero_init_residual
         self.norm_cfg, self.transformer_norm_cfg = norm_cfg, transformer_norm_cfg
         self.norm_eval, self.with_cp = norm_eval, with_cp
         self.num_fused_modalities = M = num_fused_modalities
@@ -805,15 +900,8 @@ class HRFuserHRFormerBased(HipModule):
             for i in range(cfg['num_branches']))
 
     def init_weights(self):
-        """Kaiming(conv) / constant-1 (BN) as hrnet.py:309-316; RPB tables stay zero (App. D-4)."""
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
-            elif isinstance(m, nn.modules.batchnorm._BatchNorm):
-                nn.init.constant_(m.weight, 1)
-                nn.init.constant_(m.bias, 0)
+        """BaseModule.init_weights with the init_cfg resolved in the constructor (hrnet.py:301-318)."""
+        default_or_pretrained_init(self)
 
     def train(self, mode=True):
         """hrnet.py:588-596 (norm_eval keeps BN frozen).  Unlike the reference this returns self."""
@@ -966,7 +1054,9 @@ class HRFuserHRFormerBased(HipModule):
             unit[key] = (torch.ones(C, device=x.t.device), torch.zeros(C, device=x.t.device))
         one, zero = unit[key]
         out = R.Act(R._new_like(x.t))
-        L.hrf_affine_act_res(x.t, one, zero, None, None, None, None, None, H * W, R.ACT_RELU, 0, out.t, rows, C, None, 0.0, s)
+        L.hrf_affine_act_res(x.t, one, zero, None, None, None, None, None, H * W, R.ACT_RELU, 0, out.t, rows, C, None, 0.0, None, None, s)
+        if ctx.probe is not None:
+            ctx.probe.append(('out', out.t))
 
         def bwd():
             if out.grad is None:
@@ -1026,6 +1116,9 @@ class HRFormer(HipModule):
         extra['stage3']['drop_path_rates'] = dpr[depths[0]:depths[0] + depths[1]]
         extra['stage4']['drop_path_rates'] = dpr[depths[0] + depths[1]:]
         self.extra = extra
+        self.pretrained = pretrained
+        self.init_cfg = resolve_init_cfg(pretrained, init_cfg)
+        self.zero_init_residual = zero_init_residual          # dead in the reference (see HRFuserHRFormerBased)
         self.norm_cfg, self.transformer_norm_cfg = norm_cfg, transformer_norm_cfg
         self.norm_eval, self.with_cp = norm_eval, with_cp
         ncfg = norm_cfg

@@ -10,14 +10,8 @@
 // projection bias: padded keys/values are synthesised from (k_bias, v_bias) and - as in the
 // reference (with_pad_mask=False) - are NOT masked.
 //
-// Mapping: one wave64 per (window, head); lane i = query row i (49 of 64 lanes active).  K/V rows
-// of the window are staged once in LDS (rows padded to a multiple of 4 floats, 16 B aligned) and
-// read as wave-wide ds_read_b128 broadcasts (conflict-free); the whole 49-wide logit row lives in
-// the lane's registers (fully unrolled), so softmax needs no cross-lane traffic and the 49
-// dot-product chains are independent (ILP hides the LDS latency inside a single wave).
-// The kernels above the MFMA section are the first implementation (per-lane FMA chains; kept as the A/B
-// reference behind hrf_debug_knob(28, 0)); the product path is attn_fwd_mfma_kernel / attn_bwd_mfma_kernel
-// further down: all contractions on v_mfma_f32_16x16x4_f32 with the 49 tokens padded to 64.
+// Mapping: one 256-thread block per (window, head); all contractions run on v_mfma_f32_16x16x4_f32 with the 49 tokens
+// padded to 64 (attn_fwd_mfma_kernel / attn_bwd_mfma_kernel below).
 #include "hrf_common.h"
 #include "../../include/hrfuser_hip.h"
 
@@ -52,264 +46,7 @@ __device__ __forceinline__ int tok_pixel(const AttnArgs& a, int b, int wy, int w
   return -1;
 }
 
-// dot(q[0..DP), row[0..DP)) + init, row read as DP/4 aligned 16-byte LDS broadcasts
-template <int DP>
-__device__ __forceinline__ float dot_row(const float* q, const float* row, float init) {
-  const V4* r4 = reinterpret_cast<const V4*>(row);
-  float acc = init;
-#pragma unroll
-  for (int c = 0; c < DP / 4; ++c) {
-    const V4 v = r4[c];
-    acc = fmaf(q[4 * c + 0], v.x, acc); acc = fmaf(q[4 * c + 1], v.y, acc);
-    acc = fmaf(q[4 * c + 2], v.z, acc); acc = fmaf(q[4 * c + 3], v.w, acc);
-  }
-  return acc;
-}
-template <int DP>
-__device__ __forceinline__ void axpy_row(float* o, float p, const float* row) {
-  const V4* r4 = reinterpret_cast<const V4*>(row);
-#pragma unroll
-  for (int c = 0; c < DP / 4; ++c) {
-    const V4 v = r4[c];
-    o[4 * c + 0] = fmaf(p, v.x, o[4 * c + 0]); o[4 * c + 1] = fmaf(p, v.y, o[4 * c + 1]);
-    o[4 * c + 2] = fmaf(p, v.z, o[4 * c + 2]); o[4 * c + 3] = fmaf(p, v.w, o[4 * c + 3]);
-  }
-}
-
-constexpr int SP = 65;      // pitch of the [key j][query i] score planes: lane = i or lane = j both <= 2-way
-constexpr int NJ = 13;      // keys (pass A) / queries (pass B) per wave: token 4*jj + wave, jj < 13
-
-// One 256-thread block per (window, head).  The four waves split the 49 KEYS (pass A, lane = query)
-// or the 49 QUERIES (pass B, lane = key): a quarter of the serial FMA/LDS chain per wave and 4x the
-// waves in flight compared with one wave per window (the kernel is latency-bound: 644 windows on
-// 1024 SIMDs left every SIMD with a single, dependency-stalled wave).  Softmax max / sum and the
-// output rows are combined across the waves through small LDS arrays; no atomics anywhere.
-template <int D>
-__device__ __forceinline__ void stage_rows(const AttnArgs& a, int b, int wy, int wx, int h, float* sK, float* sV,
-                                           float* sQ, float* sG) {
-  constexpr int DP = (D + 3) & ~3;
-  for (int e = threadIdx.x; e < NT * DP; e += 256) {
-    const int j = e / DP, d = e - j * DP;
-    const int pix = tok_pixel(a, b, wy, wx, j);
-    const bool dv = d < D;
-    const long pc = pix >= 0 ? pix : 0;           // unconditional clamped loads, select afterwards
-    const int col = h * D + (dv ? d : 0);
-    const float kx = a.k[pc * a.ldk + a.koff + col], kp = a.kpad[col];
-    const float vx = a.v[pc * a.ldv + a.voff + col], vp = a.vpad[col];
-    sK[e] = dv ? (pix >= 0 ? kx : kp) : 0.f;
-    sV[e] = dv ? (pix >= 0 ? vx : vp) : 0.f;
-    if (sQ != nullptr) {
-      const float qx = a.q[pc * a.ldq + a.qoff + col] * a.scale, gx = a.dout[pc * a.lddo + col];
-      sQ[e] = (dv && pix >= 0) ? qx : 0.f;
-      sG[e] = (dv && pix >= 0) ? gx : 0.f;
-    }
-  }
-}
-
-template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-  constexpr int DP = (D + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) float sK[NT * DP];
-  __shared__ __attribute__((aligned(16))) float sV[NT * DP];
-  __shared__ float sO[4][NT * DP];
-  __shared__ float sT[176];
-  __shared__ float sM[4][64], sL[4][64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
-  const int win = blockIdx.x;
-  const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
-  stage_rows<D>(a, b, wy, wx, h, sK, sV, nullptr, nullptr);
-  for (int e = threadIdx.x; e < 169; e += 256) sT[e] = a.rpb[e * a.heads + h];
-  __syncthreads();
-  const int i = lane < NT ? lane : 0;
-  const int pix = lane < NT ? tok_pixel(a, b, wy, wx, i) : -1;
-  const long pc = pix >= 0 ? pix : 0;
-  float q[DP];
-#pragma unroll
-  for (int d = 0; d < DP; ++d) q[d] = (d < D && pix >= 0) ? a.q[pc * a.ldq + a.qoff + h * D + d] * a.scale : 0.f;
-  const int yi = i / 7, xi = i - 7 * yi;
-  const int bias0 = (yi + 6) * 13 + (xi + 6);
-  float sc[NJ];
-  float m = -3.0e38f;
-#pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int j = min(4 * jj + wave, NT - 1);
-    const bool jv = 4 * jj + wave < NT;
-    const float sv = dot_row<DP>(q, sK + j * DP, sT[bias0 - (j / 7) * 13 - (j % 7)]);
-    sc[jj] = jv ? sv : -3.0e38f;
-    m = fmaxf(m, sc[jj]);
-  }
-  sM[wave][lane] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(sM[0][lane], sM[1][lane]), fmaxf(sM[2][lane], sM[3][lane]));
-  float l = 0.f, o[DP];
-#pragma unroll
-  for (int d = 0; d < DP; ++d) o[d] = 0.f;
-#pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int j = min(4 * jj + wave, NT - 1);
-    const float p = __expf(sc[jj] - m);           // exp(-huge) == 0 for the (at most one) padding slot
-    l += p;
-    axpy_row<DP>(o, p, sV + j * DP);
-  }
-  sL[wave][lane] = l;
-  if (lane < NT) {
-#pragma unroll
-    for (int d = 0; d < DP; ++d) sO[wave][lane * DP + d] = o[d];
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < NT * D; e += 256) {
-    const int ii = e / D, d = e - ii * D;
-    const int px = tok_pixel(a, b, wy, wx, ii);
-    const float lt = sL[0][ii] + sL[1][ii] + sL[2][ii] + sL[3][ii];
-    const float ot = sO[0][ii * DP + d] + sO[1][ii * DP + d] + sO[2][ii * DP + d] + sO[3][ii * DP + d];
-    if (px >= 0) a.o[(long)px * a.ldo + h * D + d] = ot / lt;
-  }
-}
-
-template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
-  constexpr int DP = (D + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) float sK[NT * DP];
-  __shared__ __attribute__((aligned(16))) float sV[NT * DP];
-  __shared__ __attribute__((aligned(16))) float sQ[NT * DP];
-  __shared__ __attribute__((aligned(16))) float sG[NT * DP];        // dO rows
-  __shared__ float sP[NT * SP];
-  __shared__ float sD[NT * SP];
-  __shared__ float sX[4][NT * DP];                                  // per-wave partial rows (dQ, then dK)
-  __shared__ float sY[4][NT * DP];                                  // per-wave partial rows (dV)
-  __shared__ float sT[176];
-  __shared__ float sM[4][64], sL[4][64], sA[4][64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = blockIdx.y;
-  const int win = blockIdx.x;
-  const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
-  stage_rows<D>(a, b, wy, wx, h, sK, sV, sQ, sG);
-  for (int e = threadIdx.x; e < 169; e += 256) sT[e] = a.rpb[e * a.heads + h];
-  __syncthreads();
-  const int li = lane < NT ? lane : 0;
-  const int yl = li / 7, xl = li - 7 * yl;
-  // ---- pass A: lane = query row i, wave = key subset
-  {
-    const int i = li;
-    float q[DP], g[DP];
-#pragma unroll
-    for (int d = 0; d < DP; ++d) { q[d] = sQ[i * DP + d]; g[d] = sG[i * DP + d]; }
-    const int bias0 = (yl + 6) * 13 + (xl + 6);
-    // scores / dP of this wave's keys live in the (own-column, conflict-free) LDS planes, not in
-    // registers: the loops stay partially rolled and the kernel fits 128 VGPRs without spills
-    float m = -3.0e38f;
-    const int nj = (NT - wave + 3) >> 2;            // keys 4*jj + wave < 49
-#pragma unroll 2
-    for (int jj = 0; jj < nj; ++jj) {
-      const int j = 4 * jj + wave;
-      const float sv = dot_row<DP>(q, sK + j * DP, sT[bias0 - (j / 7) * 13 - (j % 7)]);
-      sP[j * SP + lane] = sv;
-      sD[j * SP + lane] = dot_row<DP>(g, sV + j * DP, 0.f);
-      m = fmaxf(m, sv);
-    }
-    sM[wave][lane] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(sM[0][lane], sM[1][lane]), fmaxf(sM[2][lane], sM[3][lane]));
-    float l = 0.f, acc = 0.f;
-#pragma unroll 4
-    for (int jj = 0; jj < nj; ++jj) {
-      const int j = 4 * jj + wave;
-      const float p = __expf(sP[j * SP + lane] - m);
-      sP[j * SP + lane] = p;
-      l += p;
-      acc = fmaf(p, sD[j * SP + lane], acc);
-    }
-    sL[wave][lane] = l; sA[wave][lane] = acc;
-    __syncthreads();
-    l = sL[0][lane] + sL[1][lane] + sL[2][lane] + sL[3][lane];
-    acc = sA[0][lane] + sA[1][lane] + sA[2][lane] + sA[3][lane];
-    const float inv = 1.0f / l, Dl = acc * inv;
-    float dq[DP];
-#pragma unroll
-    for (int d = 0; d < DP; ++d) dq[d] = 0.f;
-#pragma unroll 2
-    for (int jj = 0; jj < nj; ++jj) {
-      const int j = 4 * jj + wave;
-      const float p = sP[j * SP + lane] * inv;
-      const float ds = p * (sD[j * SP + lane] - Dl);
-      sP[j * SP + lane] = p;
-      sD[j * SP + lane] = ds;
-      axpy_row<DP>(dq, ds, sK + j * DP);
-    }
-    if (lane < NT) {
-#pragma unroll
-      for (int d = 0; d < DP; ++d) sX[wave][lane * DP + d] = dq[d];
-    }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < NT * D; e += 256) {
-    const int ii = e / D, d = e - ii * D;
-    const int px = tok_pixel(a, b, wy, wx, ii);
-    const float t = sX[0][ii * DP + d] + sX[1][ii * DP + d] + sX[2][ii * DP + d] + sX[3][ii * DP + d];
-    if (px >= 0) a.dq[(long)px * a.lddq + a.dqoff + h * D + d] = t * a.scale;
-  }
-  __syncthreads();
-  // ---- pass B: lane = key column j, wave = query subset
-  {
-    const int j = li;
-    float dk[DP], dv[DP];
-#pragma unroll
-    for (int d = 0; d < DP; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-    const int ni = (NT - wave + 3) >> 2;
-#pragma unroll 2
-    for (int ii = 0; ii < ni; ++ii) {
-      const int i = 4 * ii + wave;
-      axpy_row<DP>(dk, sD[j * SP + i], sQ + i * DP);
-      axpy_row<DP>(dv, sP[j * SP + i], sG + i * DP);
-    }
-    if (lane < NT) {
-#pragma unroll
-      for (int d = 0; d < DP; ++d) { sX[wave][lane * DP + d] = dk[d]; sY[wave][lane * DP + d] = dv[d]; }
-    }
-  }
-  __syncthreads();
-  const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride;
-  bool anypad = false;
-  for (int e = threadIdx.x; e < NT * D; e += 256) {
-    const int jj = e / D, d = e - jj * D;
-    const int px = tok_pixel(a, b, wy, wx, jj);
-    const float tk = sX[0][jj * DP + d] + sX[1][jj * DP + d] + sX[2][jj * DP + d] + sX[3][jj * DP + d];
-    const float tv = sY[0][jj * DP + d] + sY[1][jj * DP + d] + sY[2][jj * DP + d] + sY[3][jj * DP + d];
-    if (px >= 0) {
-      a.dk[(long)px * a.lddk + a.dkoff + h * D + d] = tk;
-      a.dv[(long)px * a.lddv + a.dvoff + h * D + d] = tv;
-    }
-  }
-  // padded keys (boundary windows only): their gradient flows to the projection bias
-  if (wy == 0 || wx == 0 || wy == a.nWh - 1 || wx == a.nWw - 1) {
-    if (threadIdx.x < D) {
-      const int d = threadIdx.x;
-      float pk = 0.f, pv = 0.f;
-      for (int jj = 0; jj < NT; ++jj) {
-        if (tok_pixel(a, b, wy, wx, jj) < 0) {
-          pk += sX[0][jj * DP + d] + sX[1][jj * DP + d] + sX[2][jj * DP + d] + sX[3][jj * DP + d];
-          pv += sY[0][jj * DP + d] + sY[1][jj * DP + d] + sY[2][jj * DP + d] + sY[3][jj * DP + d];
-          anypad = true;
-        }
-      }
-      if (anypad) {
-        hrf_atomic_add(&a.dkpad[cp + h * D + d], pk);
-        hrf_atomic_add(&a.dvpad[cp + h * D + d], pv);
-      }
-    }
-  }
-  // dRPB[(yi-yj+6)*13 + (xi-xj+6)] += dS[i][j]: gather over the dS plane, one bin per thread
-  if (threadIdx.x < 169) {
-    const int e = threadIdx.x;
-    const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
-    const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
-    const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
-    float sacc = 0.f;
-    for (int yj = y0; yj <= y1; ++yj)
-      for (int xj = x0; xj <= x1; ++xj)
-        sacc += sD[(yj * 7 + xj) * SP + (yj + dy) * 7 + xj + dx];
-    hrf_atomic_add(&a.drpb[cp + e * a.heads + h], sacc);
-  }
-}
+constexpr int SP = 65;      // pitch of the [key j][query i] dS plane of the backward kernel
 
 // Staging for the MFMA kernels: [64][P] tiles of Q (scaled), K, V (and dO), zero outside the 49 x D payload.  All global
 // loads of a thread are issued before the first LDS store (one round trip instead of one per loop iteration).
@@ -673,8 +410,6 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   }
 }
 
-int g_attn_mfma = 1;
-
 inline void window_geom(AttnArgs& a) {
   a.nWh = (a.H + 6) / 7; a.nWw = (a.W + 6) / 7;
   a.pt = (a.nWh * 7 - a.H) / 2; a.pl = (a.nWw * 7 - a.W) / 2;   // centre pad: top/left = pad//2
@@ -705,14 +440,8 @@ extern "C" int hrf_window_attn_fwd(const float* q, int ldq, int qoff, const floa
   window_geom(a);
   const int nwin = B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
-  if (g_attn_mfma) { HRF_ATTN_DISPATCH(attn_fwd_mfma_kernel) }
-  else { HRF_ATTN_DISPATCH(attn_fwd_kernel) }
+  HRF_ATTN_DISPATCH(attn_fwd_mfma_kernel)
   return hrf_check_launch();
-}
-
-extern "C" int hrf_attn_knob(int key, int value) {
-  if (key == 0) { g_attn_mfma = value; return HRF_OK; }
-  return HRF_ERR_ARG;
 }
 
 extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const float* k, int ldk, int koff,
@@ -732,7 +461,6 @@ extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const floa
   window_geom(a);
   const int nwin = B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
-  if (g_attn_mfma) { HRF_ATTN_DISPATCH(attn_bwd_mfma_kernel) }
-  else { HRF_ATTN_DISPATCH(attn_bwd_kernel) }
+  HRF_ATTN_DISPATCH(attn_bwd_mfma_kernel)
   return hrf_check_launch();
 }

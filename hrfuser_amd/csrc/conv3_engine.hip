@@ -50,6 +50,22 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
   const int Hs = MODE == 2 ? a.Hs : a.H, Ws = MODE == 2 ? a.Ws : a.W;   // source (staged) grid
   const int y0 = ty * TH, x0 = tx * TW;
   const int n0 = blockIdx.y * (NT * 16);
+  // BatchNorm of the input finalised on load (forward) / BatchNorm-backward coefficients derived on load (backward)
+  __shared__ __attribute__((aligned(16))) float sFin[3 * HRF_FIN_MAXC];
+  const float* t0p = a.t0;
+  const float* t1p = a.t1;
+  const float* t2p = a.t2;
+  if (MODE == 0) {
+    if (a.fin.stats != nullptr) {
+      hrf_bn_fin_onload(a.fin, sFin, sFin + HRF_FIN_MAXC, tid, 64 * NWV, blockIdx.x == 0 && blockIdx.y == 0);
+      __syncthreads();
+      t0p = sFin; t1p = sFin + HRF_FIN_MAXC;
+    }
+  } else if (a.bfin.gstats != nullptr) {
+    hrf_bn_bfin_onload(a.bfin, sFin, sFin + HRF_FIN_MAXC, sFin + 2 * HRF_FIN_MAXC, tid, 64 * NWV, blockIdx.x == 0 && blockIdx.y == 0);
+    __syncthreads();
+    t0p = sFin; t1p = sFin + HRF_FIN_MAXC; t2p = sFin + 2 * HRF_FIN_MAXC;
+  }
 
   hrf_f4 acc[NT];
 #pragma unroll
@@ -68,8 +84,8 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
     float hv[NHL], hv2[NHL];
     const bool cv = hc < csz;
     float p0 = 1.f, p1 = 0.f, p2 = 0.f;
-    if (MODE == 0) { if (a.tf_mode != HRF_TF_NONE) { p0 = a.t0[cv ? c0 + hc : 0]; p1 = a.t1[cv ? c0 + hc : 0]; } }
-    else if (a.t0 != nullptr) { p0 = a.t0[cv ? c0 + hc : 0]; p1 = a.t1[cv ? c0 + hc : 0]; p2 = a.t2[cv ? c0 + hc : 0]; }
+    if (MODE == 0) { if (a.tf_mode != HRF_TF_NONE) { p0 = t0p[cv ? c0 + hc : 0]; p1 = t1p[cv ? c0 + hc : 0]; } }
+    else if (t0p != nullptr) { p0 = t0p[cv ? c0 + hc : 0]; p1 = t1p[cv ? c0 + hc : 0]; p2 = t2p[cv ? c0 + hc : 0]; }
 #pragma unroll
     for (int e = 0; e < NHL; ++e) {
       const int pix = e * NWV + hg;
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
     for (int e = 0; e < NHL; ++e) {
       const int pix = e * NWV + hg;
       float v = hv[e];
-      if (MODE != 0 && a.t0 != nullptr) {
+      if (MODE != 0 && t0p != nullptr) {
         const int py = pix / IWm, px = pix - py * IWm;
         const int gy = y0 + ORG + py, gx = x0 + ORG + px;
         const bool ok = cv && (unsigned)gy < (unsigned)Hs && (unsigned)gx < (unsigned)Ws;
@@ -207,7 +223,6 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
         hrf_atomic_add(&st[which * a.Cout + ch], (double)sm);
       }
     }
-    if (MODE == 0 && a.fin.ticket != nullptr) hrf_bn_fin_fused(a.fin, a.stats, 64 * NWV, gridDim.x, gridDim.y);
   }
 }
 

@@ -49,6 +49,7 @@ struct ConvFwdArgs {
   const float* res; int ldR; const float* res2;
   const float* tf_scale; const float* tf_shift; const float* tf_rowstat;
   double* stats;
+  hrf_bn_fin_t fin;                            // fin.stats != null: BatchNorm of x finalised on load
   int B, H, W, Cin, Ho, Wo, Cout, stride, pad;
   int sB, sY, sX, sC;
   int M, K;
@@ -64,6 +65,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kl = tid & 63, r0 = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  __shared__ float sFin[(TF >= HRF_TF_AFFINE && TF <= HRF_TF_AFFINE_GELU) ? 2 * HRF_FIN_MAXC : 4];
+  const float* scp = a.tf_scale;
+  const float* shp = a.tf_shift;
+  if (TF >= HRF_TF_AFFINE && TF <= HRF_TF_AFFINE_GELU) {
+    if (a.fin.stats != nullptr) {
+      hrf_bn_fin_onload(a.fin, sFin, sFin + HRF_FIN_MAXC, tid, 256, blockIdx.x == 0 && blockIdx.y == 0);
+      __syncthreads();
+      scp = sFin; shp = sFin + HRF_FIN_MAXC;
+    }
+  }
 
   // per-thread row bookkeeping for its 16 staged rows (r0 + 4p)
   int rb[RP];
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     if (KH == 3) { const int tap = ci / a.Cin; ci -= tap * a.Cin; dy = tap / 3; dx = tap - 3 * dy; }
     const int koff = dy * a.sY + dx * a.sX + ci * a.sC;
     float sc = 1.f, sh = 0.f;
-    if (TF != HRF_TF_NONE) { sc = a.tf_scale[ci]; sh = a.tf_shift[ci]; }
+    if (TF != HRF_TF_NONE) { sc = scp[ci]; sh = shp[ci]; }
     float raw[RP];
     bool okv[RP];
 #pragma unroll
@@ -205,6 +216,7 @@ struct ConvBwdDataArgs {
   const float* xraw; int ldXr;                 // epi 1: raw producer output (NHWC, ld)
   const float* tf_scale; const float* tf_shift; int act;
   double* stats;                               // epi 1: (sum du, sum du*xraw) per Cin
+  hrf_bn_bfin_t bfin;                          // bfin.gstats != null: cA/cB/cC derived on load
   int B, H, W, Cin, Ho, Wo, Cout, stride, pad;
   int M, K;                                    // M = B*H*W, K = KH*KH*Cout
 };
@@ -218,6 +230,17 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kl = tid & 63, r0 = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  __shared__ float sFin[BNB ? 3 * HRF_FIN_MAXC : 4];
+  const float* cAp = a.cA;
+  const float* cBp = a.cB;
+  const float* cCp = a.cC;
+  if (BNB) {
+    if (a.bfin.gstats != nullptr) {
+      hrf_bn_bfin_onload(a.bfin, sFin, sFin + HRF_FIN_MAXC, sFin + 2 * HRF_FIN_MAXC, tid, 256, blockIdx.x == 0 && blockIdx.y == 0);
+      __syncthreads();
+      cAp = sFin; cBp = sFin + HRF_FIN_MAXC; cCp = sFin + 2 * HRF_FIN_MAXC;
+    }
+  }
 
   int rbase[RP];
   unsigned ryx[RP];
@@ -239,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
     int dyy = 0, dxx = 0, co = kv ? k : 0;
     if (KH == 3) { const int tap = co / a.Cout; co -= tap * a.Cout; dyy = tap / 3; dxx = tap - 3 * dyy; }
     float ca = 1.f, cb = 0.f, cc = 0.f;
-    if (BNB) { ca = a.cA[co]; cb = a.cB[co]; cc = a.cC[co]; }
+    if (BNB) { ca = cAp[co]; cb = cBp[co]; cc = cCp[co]; }
     float dv[RP], yv[RP];
     bool okv[RP];
 #pragma unroll
@@ -739,16 +762,20 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
                             const float* w, const float* bias, int KH, int stride, int Cout,
                             float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
                             int tf_mode, const float* tf_scale, const float* tf_shift,
-                            const float* tf_rowstat, double* stats, const hrf_bn_fin_t* bn_fin, float* ln_rowstat,
+                            const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat,
                             float ln_eps, void* stream) {
   if ((KH != 1 && KH != 3) || (stride != 1 && stride != 2)) return HRF_ERR_ARG;
   if (tf_mode < 0 || tf_mode > 4) return HRF_ERR_ARG;
   if (ln_rowstat != nullptr && (ldY != Cout || yoff != 0)) return HRF_ERR_ARG;   // row statistics of a full output row
   if (tf_mode == HRF_TF_LN && (KH != 1 || stride != 1)) return HRF_ERR_ARG;
+  if (tf_fin != nullptr && (tf_mode < HRF_TF_AFFINE || tf_mode > HRF_TF_AFFINE_GELU || tf_fin->C != Cin || Cin > HRF_FIN_MAXC ||
+                            tf_fin->stats == nullptr)) return HRF_ERR_ARG;
   ConvFwdArgs a;
   const int pad = KH / 2;
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.ldY = ldY; a.yoff = yoff; a.res = res; a.res2 = res2; a.ldR = ldR;
   a.tf_scale = tf_scale; a.tf_shift = tf_shift; a.tf_rowstat = tf_rowstat;
+  a.fin = hrf_bn_fin_t{};
+  if (tf_fin != nullptr) a.fin = *tf_fin;
   a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin;
   a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KH) / stride + 1;
   a.Cout = Cout; a.stride = stride; a.pad = pad; a.sB = sB; a.sY = sY; a.sX = sX; a.sC = sC;
@@ -760,8 +787,7 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     l.x = x; l.ldX = sX; l.w = w; l.bias = bias; l.y = y; l.ldY = ldY; l.yoff = yoff;
     l.res = res; l.res2 = res2; l.ldR = ldR; l.tf_mode = tf_mode; l.tf_scale = tf_scale; l.tf_shift = tf_shift;
     l.tf_rowstat = tf_rowstat; l.stats = stats; l.M = a.M; l.K = Cin; l.N = Cout; l.ln_out = ln_rowstat; l.ln_eps = ln_eps;
-    l.fin = hrf_bn_fin_t{};
-    if (bn_fin != nullptr && stats != nullptr) l.fin = *bn_fin;
+    l.fin = a.fin;
     const int rc = hrf_lin_fwd_launch(l, stream);
     if (rc == HRF_OK && l.ln_out != nullptr && !hrf_lin_fwd_emits_ln(l)) return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream);
     if (rc >= 0) return rc;
@@ -771,7 +797,7 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     c.in = x; c.ldIn = sX; c.t0 = tf_scale; c.t1 = tf_shift; c.tf_mode = tf_mode; c.w = w; c.wCin = Cin; c.bias = bias;
     c.out = y; c.ldOut = ldY; c.ooff = yoff; c.res = res; c.res2 = res2; c.ldR = ldR; c.stats = stats;
     c.B = B; c.H = H; c.W = W; c.Cin = Cin; c.Cout = Cout;
-    if (bn_fin != nullptr && stats != nullptr) c.fin = *bn_fin;
+    c.fin = a.fin;
     const int rc3 = hrf_conv3_fwd_launch(c, stream);
     if (rc3 == HRF_OK && ln_rowstat != nullptr) return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream);
     return rc3;
@@ -781,13 +807,6 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     if (tf_mode == HRF_TF_LN) { HRF_CF_NT(1, HRF_TF_LN) } else { HRF_CF_TF(1) }
   } else {
     HRF_CF_TF(3)
-  }
-  if (bn_fin != nullptr && stats != nullptr) {            // generic engine: BatchNorm finalize as its own launch
-    if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH;
-    const int rcf = hrf_bn_finalize(stats, bn_fin->gamma, bn_fin->beta, bn_fin->running_mean, bn_fin->running_var, bn_fin->count,
-                                    bn_fin->eps, bn_fin->momentum, bn_fin->update_running, bn_fin->scale, bn_fin->shift,
-                                    bn_fin->mean, bn_fin->invstd, bn_fin->C, stream);
-    if (rcf != HRF_OK) return rcf;
   }
   if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();
@@ -803,15 +822,18 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
   }
 
 extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float* yraw,
-                                 const float* cA, const float* cB, const float* cC,
+                                 const float* cA, const float* cB, const float* cC, const hrf_bn_bfin_t* bfin,
                                  const float* w, int KH, int stride, int Cout,
                                  int B, int H, int W, int Cin,
                                  float* dx, int sB, int sY, int sX, int sC, int accumulate,
                                  int epi, const float* xraw, int ldXr, const float* tf_scale,
                                  const float* tf_shift, int act, double* stats, void* stream) {
   if ((KH != 1 && KH != 3) || (stride != 1 && stride != 2)) return HRF_ERR_ARG;
+  if (bfin != nullptr && (cA == nullptr || bfin->C != Cout || Cout > HRF_FIN_MAXC || bfin->gstats == nullptr)) return HRF_ERR_ARG;
   ConvBwdDataArgs a;
   const int pad = KH / 2;
+  a.bfin = hrf_bn_bfin_t{};
+  if (bfin != nullptr) a.bfin = *bfin;
   a.dy = dy; a.ldD = ldD; a.doff = doff; a.yraw = yraw; a.cA = cA; a.cB = cB; a.cC = cC; a.w = w;
   a.dx = dx; a.sB = sB; a.sY = sY; a.sX = sX; a.sC = sC; a.accumulate = accumulate; a.epi = epi;
   a.xraw = xraw; a.ldXr = ldXr; a.tf_scale = tf_scale; a.tf_shift = tf_shift; a.act = act; a.stats = stats;
@@ -824,7 +846,7 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
     LinBwdDataArgs l;
     l.dy = dy; l.ldD = ldD; l.doff = doff; l.yraw = yraw; l.cA = cA; l.cB = cB; l.cC = cC; l.w = w;
     l.dx = dx; l.ldDx = sX; l.accumulate = accumulate; l.epi = epi; l.xraw = xraw; l.ldXr = ldXr;
-    l.tf_scale = tf_scale; l.tf_shift = tf_shift; l.act = act; l.stats = stats;
+    l.tf_scale = tf_scale; l.tf_shift = tf_shift; l.act = act; l.stats = stats; l.bfin = a.bfin;
     l.M = a.M; l.K = Cout; l.N = Cin;
     const int rc = hrf_lin_bwd_data_launch(l, stream);
     if (rc >= 0) return rc;
@@ -833,7 +855,7 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
     Conv3Args c{};
     c.in = dy + doff; c.ldIn = ldD; c.in2 = cA != nullptr ? yraw + doff : nullptr; c.t0 = cA; c.t1 = cB; c.t2 = cC;
     c.w = w; c.wCin = Cin; c.out = dx; c.ldOut = sX; c.accumulate = accumulate; c.epi = epi; c.xraw = xraw; c.ldXr = ldXr;
-    c.esc = tf_scale; c.esh = tf_shift; c.act = act; c.stats = stats;
+    c.esc = tf_scale; c.esh = tf_shift; c.act = act; c.stats = stats; c.bfin = a.bfin;
     c.B = B; c.H = H; c.W = W; c.Cin = Cout; c.Cout = Cin;
     return hrf_conv3_bwd_data_launch(c, stream);
   }
@@ -841,7 +863,7 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
     Conv3Args c{};
     c.in = dy + doff; c.ldIn = ldD; c.in2 = cA != nullptr ? yraw + doff : nullptr; c.t0 = cA; c.t1 = cB; c.t2 = cC;
     c.w = w; c.wCin = Cin; c.out = dx; c.ldOut = sX; c.accumulate = accumulate; c.epi = epi; c.xraw = xraw; c.ldXr = ldXr;
-    c.esc = tf_scale; c.esh = tf_shift; c.act = act; c.stats = stats;
+    c.esc = tf_scale; c.esh = tf_shift; c.act = act; c.stats = stats; c.bfin = a.bfin;
     c.B = B; c.H = H; c.W = W; c.Cin = Cout; c.Cout = Cin; c.Hs = a.Ho; c.Ws = a.Wo;
     return hrf_conv3s2_bwd_data_launch(c, stream);
   }
@@ -856,11 +878,9 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
 
 extern "C" int hrf_pw_knob(int key, int value);
 extern "C" int hrf_conv3w_knob(int key, int value);
-extern "C" int hrf_attn_knob(int key, int value);
 extern "C" int hrf_debug_knob(int key, int value) {
   if (key >= 16 && key < 20) return hrf_pw_knob(key - 16, value);      // pointwise.hip tuning aids
   if (key >= 24 && key < 28) return hrf_conv3w_knob(key - 24, value);  // conv3w_engine.hip tuning aids
-  if (key >= 28 && key < 32) return hrf_attn_knob(key - 28, value);    // attention.hip: 28 = MFMA forward on/off
   if (key < 0 || key >= 8) return HRF_ERR_ARG;
   g_knob[key] = value;
   return HRF_OK;

@@ -37,11 +37,20 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwFwdArgs a) {
   const int c0 = blockIdx.y * CB;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  // BatchNorm of the input finalised on load: this block's CB channels only (hrf_bn_fin_t)
+  __shared__ float sFin[2 * CB];
+  const float* scp = a.tf_scale;
+  const float* shp = a.tf_shift;
+  if (a.fin.stats != nullptr) {
+    hrf_bn_fin_onload(a.fin, sFin, sFin + CB, tid, 256, blockIdx.x == 0, c0, CB);
+    __syncthreads();
+    scp = sFin - c0; shp = sFin + CB - c0;
+  }
   {
     const int c = tid & 31, cg = c0 + c;
     const bool cv = cg < a.C;
     float sc = 1.f, sh = 0.f;
-    if (a.tf_mode != HRF_TF_NONE) { sc = a.tf_scale[cv ? cg : 0]; sh = a.tf_shift[cv ? cg : 0]; }
+    if (a.tf_mode != HRF_TF_NONE) { sc = scp[cv ? cg : c0]; sh = shp[cv ? cg : c0]; }
     // unconditional clamped loads (no load under a per-element branch), value selected afterwards
     constexpr int NIT = (IH * IW + 7) / 8;
     float raw[NIT];
@@ -101,7 +110,6 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwFwdArgs a) {
       double* st = a.stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.C;
       hrf_atomic_add(&st[(tid < CB ? 0 : a.C) + c0 + (tid & (CB - 1))], (double)tot);
     }
-    if (a.fin.ticket != nullptr) hrf_bn_fin_fused(a.fin, a.stats, 256, gridDim.x, gridDim.y);
   }
 }
 
@@ -111,6 +119,7 @@ struct DwBwdDataArgs {
   const float* w;
   float* dx; int accumulate;
   int epi; const float* xraw; const float* tf_scale; const float* tf_shift; int act; double* stats;
+  hrf_bn_bfin_t bfin;
   int B, H, W, C, Ho, Wo, tilesX, tilesY;
 };
 
@@ -129,10 +138,20 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
   const int ry0 = S == 1 ? y0 - 1 : y0 / 2, rx0 = S == 1 ? x0 - 1 : x0 / 2;
   const int c = tid & 31, cg = c0 + c;
   const bool cv = cg < a.C;
+  // BatchNorm-backward coefficients derived on load: this block's CB channels only (hrf_bn_bfin_t)
+  __shared__ float sFin[3 * CB];
+  const float* cAp = a.cA;
+  const float* cBp = a.cB;
+  const float* cCp = a.cC;
+  if (a.bfin.gstats != nullptr) {
+    hrf_bn_bfin_onload(a.bfin, sFin, sFin + CB, sFin + 2 * CB, tid, 256, blockIdx.x == 0, c0, CB);
+    __syncthreads();
+    cAp = sFin - c0; cBp = sFin + CB - c0; cCp = sFin + 2 * CB - c0;
+  }
   {
     const bool bnb = a.cA != nullptr;
     float ca = 1.f, cb = 0.f, cc = 0.f;
-    if (bnb) { const int cs = cv ? cg : 0; ca = a.cA[cs]; cb = a.cB[cs]; cc = a.cC[cs]; }
+    if (bnb) { const int cs = cv ? cg : c0; ca = cAp[cs]; cb = cBp[cs]; cc = cCp[cs]; }
     constexpr int NIT = (RH * RW + 7) / 8;
     float rd[NIT], ry[NIT];
 #pragma unroll
@@ -314,12 +333,13 @@ __global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) {
 
 extern "C" int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias,
                               int stride, int tf_mode, const float* tf_scale, const float* tf_shift, float* y,
-                              double* stats, const hrf_bn_fin_t* bn_fin, void* stream) {
+                              double* stats, const hrf_bn_fin_t* tf_fin, void* stream) {
   if (stride != 1 && stride != 2) return HRF_ERR_ARG;
+  if (tf_fin != nullptr && (tf_mode < HRF_TF_AFFINE || tf_mode > HRF_TF_AFFINE_GELU || tf_fin->C != C || tf_fin->stats == nullptr)) return HRF_ERR_ARG;
   DwFwdArgs a;
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.tf_mode = tf_mode; a.tf_scale = tf_scale;
   a.fin = hrf_bn_fin_t{};
-  if (bn_fin != nullptr && stats != nullptr) a.fin = *bn_fin;
+  if (tf_fin != nullptr) a.fin = *tf_fin;
   a.tf_shift = tf_shift; a.B = B; a.H = H; a.W = W; a.C = C;
   a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
   const int th = stride == 1 ? 8 : 4;
@@ -332,11 +352,14 @@ extern "C" int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const 
 }
 
 extern "C" int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const float* cA, const float* cB,
-                                   const float* cC, const float* w, int stride, int B, int H, int W, int C,
+                                   const float* cC, const hrf_bn_bfin_t* bfin, const float* w, int stride, int B, int H, int W, int C,
                                    float* dx, int accumulate, int epi, const float* xraw, const float* tf_scale,
                                    const float* tf_shift, int act, double* stats, void* stream) {
   if (stride != 1 && stride != 2) return HRF_ERR_ARG;
+  if (bfin != nullptr && (cA == nullptr || bfin->C != C || bfin->gstats == nullptr)) return HRF_ERR_ARG;
   DwBwdDataArgs a;
+  a.bfin = hrf_bn_bfin_t{};
+  if (bfin != nullptr) a.bfin = *bfin;
   a.dy = dy; a.yraw = yraw; a.cA = cA; a.cB = cB; a.cC = cC; a.w = w; a.dx = dx; a.accumulate = accumulate;
   a.epi = epi; a.xraw = xraw; a.tf_scale = tf_scale; a.tf_shift = tf_shift; a.act = act; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;

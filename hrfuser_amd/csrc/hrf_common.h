@@ -79,102 +79,74 @@ __device__ __forceinline__ int hrf_tf_act(int mode) {
   return mode == HRF_TF_AFFINE_RELU ? HRF_ACT_RELU : (mode == HRF_TF_AFFINE_GELU ? HRF_ACT_GELU : HRF_ACT_NONE);
 }
 
-// ------------------------------------------------------------------ fused BatchNorm finalize
-// Ordering without device-scope fences: a `__threadfence()` (agent-scope release) writes back the whole
-// XCD L2 on gfx950 - measured +30 us per producer launch.  Device-scope ATOMICS execute at the memory side,
-// so it is enough that (1) every thread waits for the completion of its own moment atomics (workgroup
-// fence = s_waitcnt) before the block's ticket increment and (2) the finalising block reads the moments
-// with agent-scope (cache-bypassing) loads.
-#ifdef HRF_EMUL
-#define HRF_LOAD_COHERENT(p) (*(p))
-#define HRF_FENCE_WG() __atomic_thread_fence(__ATOMIC_SEQ_CST)
-#else
-#define HRF_LOAD_COHERENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define HRF_FENCE_WG() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
-#endif
-
-// one channel of hrf_bn_finalize (sums the replicated moment copies)
-__device__ __forceinline__ void hrf_bn_fin_channel(const double* stats, const hrf_bn_fin_t& f, int c) {
+// ------------------------------------------------------------------ BatchNorm finalize on load (consumer side)
+// See hrf_bn_fin_t in include/hrfuser_hip.h.  Every thread of the block calls these in the kernel prologue, followed by
+// a __syncthreads(); the per-channel results land in LDS (sSc/sSh resp. sA/sB/sC, >= f.C floats each) and the kernel then
+// reads its transform coefficients from there instead of from the global scale/shift arrays.  `writer` selects the one
+// block of the grid that also publishes the results (and the running statistics / parameter gradients) to memory.
+// (c_begin, c_count): the channel slice this block needs (results at sSc[c - c_begin]); default = all channels.
+__device__ __forceinline__ void hrf_bn_fin_onload(const hrf_bn_fin_t& f, float* sSc, float* sSh, int tid, int nthreads,
+                                                  bool writer, int c_begin = 0, int c_count = 1 << 30) {
   const int C = f.C;
-  double s1 = 0.0, s2 = 0.0;
+  const int c_end = min(C, c_begin + c_count);
+  sSc -= c_begin; sSh -= c_begin;
+  for (int c = c_begin + tid; c < c_end; c += nthreads) {
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-  for (int k = 0; k < HRF_STAT_COPIES; ++k) {
-    s1 += HRF_LOAD_COHERENT(&stats[(size_t)k * 2 * C + c]);
-    s2 += HRF_LOAD_COHERENT(&stats[(size_t)k * 2 * C + C + c]);
-  }
-  const double mean = s1 / f.count;
-  double var = s2 / f.count - mean * mean;               // biased variance (train-mode normalisation)
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
-  const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
-  const float sc = g * invstd;
-  f.scale[c] = sc;
-  f.shift[c] = b - (float)mean * sc;
-  f.mean[c] = (float)mean;
-  f.invstd[c] = invstd;
-  if (f.update_running) {                                // torch: running_var uses the UNBIASED var
-    const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
-    f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
-    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
-  }
-}
-
-// one channel of hrf_bn_bwd_finalize (single-rank form: local == global moments)
-__device__ __forceinline__ void hrf_bn_bfin_channel(const double* gstats, const hrf_bn_bfin_t& f, int c) {
-  const int C = f.C;
-  double sdu = 0.0, sdux = 0.0;
-#pragma unroll
-  for (int k = 0; k < HRF_STAT_COPIES; ++k) {
-    sdu += HRF_LOAD_COHERENT(&gstats[(size_t)k * 2 * C + c]);
-    sdux += HRF_LOAD_COHERENT(&gstats[(size_t)k * 2 * C + C + c]);
-  }
-  const double mu = f.mean[c], is = f.invstd[c], g = f.gamma ? f.gamma[c] : 1.f;
-  const double sduy = (sdux - mu * sdu) * is;            // sum du * yhat
-  if (f.dgamma) f.dgamma[c] += (float)sduy;
-  if (f.dbeta) f.dbeta[c] += (float)sdu;
-  if (f.train) {
-    const double a = sdu / f.count, b = sduy / f.count;
-    f.cA[c] = (float)(g * is);
-    f.cB[c] = (float)(-g * is * is * b);
-    f.cC[c] = (float)(-g * is * a + g * is * is * b * mu);
-  } else {
-    f.cA[c] = (float)(g * is); f.cB[c] = 0.f; f.cC[c] = 0.f;
-  }
-}
-
-// Two-level ticket: returns true in exactly one block of the grid - the one that arrives last, after every
-// other block's moment atomics are visible.  `copy_blocks` = gridDim.x (the dimension that selects the
-// moment copy), `per_copy_mult` = number of blocks sharing one blockIdx.x (gridDim.y * gridDim.z).
-// Must be called by ALL threads of ALL blocks after the block's own moment atomics.
-__device__ __forceinline__ bool hrf_last_block(unsigned* ticket, unsigned copy_blocks, unsigned per_copy_mult) {
-  __shared__ int s_last;
-  HRF_FENCE_WG();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned c = blockIdx.x % HRF_STAT_COPIES;
-    const unsigned ngrp = copy_blocks < HRF_STAT_COPIES ? copy_blocks : HRF_STAT_COPIES;
-    const unsigned gsz = ((copy_blocks - c + HRF_STAT_COPIES - 1) / HRF_STAT_COPIES) * per_copy_mult;
-    int last = 0;
-    if (atomicAdd(&ticket[c], 1u) == gsz - 1) {
-      ticket[c] = 0;                                       // nobody else touches this group ticket any more
-      if (atomicAdd(&ticket[HRF_STAT_COPIES], 1u) == ngrp - 1) { ticket[HRF_STAT_COPIES] = 0; last = 1; }
+    for (int k = 0; k < HRF_STAT_COPIES; ++k) {
+      s1 += f.stats[(size_t)k * 2 * C + c];
+      s2 += f.stats[(size_t)k * 2 * C + C + c];
     }
-    s_last = last;
+    const double mean = s1 / f.count;
+    double var = s2 / f.count - mean * mean;               // biased variance (train-mode normalisation)
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    const float sc = g * invstd;
+    const float sh = b - (float)mean * sc;
+    sSc[c] = sc;
+    sSh[c] = sh;
+    if (writer && f.write) {
+      f.scale[c] = sc; f.shift[c] = sh; f.mean[c] = (float)mean; f.invstd[c] = invstd;
+      if (f.update_running) {                              // torch: running_var uses the UNBIASED var
+        const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+      }
+    }
   }
-  __syncthreads();
-  return s_last != 0;
 }
 
-__device__ __forceinline__ void hrf_bn_fin_fused(const hrf_bn_fin_t& f, const double* stats, unsigned nthreads,
-                                                 unsigned copy_blocks, unsigned per_copy_mult) {
-  if (!hrf_last_block(f.ticket, copy_blocks, per_copy_mult)) return;
-  for (int c = threadIdx.x; c < f.C; c += nthreads) hrf_bn_fin_channel(stats, f, c);
-}
-
-__device__ __forceinline__ void hrf_bn_bfin_fused(const hrf_bn_bfin_t& f, const double* gstats, unsigned nthreads,
-                                                  unsigned copy_blocks, unsigned per_copy_mult) {
-  if (!hrf_last_block(f.ticket, copy_blocks, per_copy_mult)) return;
-  for (int c = threadIdx.x; c < f.C; c += nthreads) hrf_bn_bfin_channel(gstats, f, c);
+__device__ __forceinline__ void hrf_bn_bfin_onload(const hrf_bn_bfin_t& f, float* sA, float* sB, float* sC, int tid,
+                                                   int nthreads, bool writer, int c_begin = 0, int c_count = 1 << 30) {
+  const int C = f.C;
+  const int c_end = min(C, c_begin + c_count);
+  sA -= c_begin; sB -= c_begin; sC -= c_begin;
+  for (int c = c_begin + tid; c < c_end; c += nthreads) {
+    double sdu = 0.0, sdux = 0.0;
+#pragma unroll
+    for (int k = 0; k < HRF_STAT_COPIES; ++k) {
+      sdu += f.gstats[(size_t)k * 2 * C + c];
+      sdux += f.gstats[(size_t)k * 2 * C + C + c];
+    }
+    const double mu = f.mean[c], is = f.invstd[c], g = f.gamma ? f.gamma[c] : 1.f;
+    const double sduy = (sdux - mu * sdu) * is;            // sum du * yhat
+    float a, b2, c2;
+    if (f.train) {
+      const double am = sdu / f.count, bm = sduy / f.count;
+      a = (float)(g * is);
+      b2 = (float)(-g * is * is * bm);
+      c2 = (float)(-g * is * am + g * is * is * bm * mu);
+    } else {                                               // frozen statistics: dy = gamma*invstd*du
+      a = (float)(g * is); b2 = 0.f; c2 = 0.f;
+    }
+    sA[c] = a; sB[c] = b2; sC[c] = c2;
+    if (writer && f.write) {
+      f.cA[c] = a; f.cB[c] = b2; f.cC[c] = c2;
+      if (f.dgamma) f.dgamma[c] += (float)sduy;
+      if (f.dbeta) f.dbeta[c] += (float)sdu;
+    }
+  }
 }
 
 __device__ __forceinline__ float hrf_wave_sum(float v) {

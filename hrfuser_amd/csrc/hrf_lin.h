@@ -11,7 +11,7 @@ struct LinFwdArgs {
   int tf_mode; const float* tf_scale; const float* tf_shift; const float* tf_rowstat;
   double* stats;                                 // [HRF_STAT_COPIES][2*N] or null
   float* ln_out; float ln_eps;                   // optional LayerNorm (mean, rstd) of the output rows
-  hrf_bn_fin_t fin;                              // fin.ticket != null: the last block finalises the BatchNorm
+  hrf_bn_fin_t fin;                              // fin.stats != null: BatchNorm of X finalised on load (tf_mode 1..3)
   int M, K, N;
 };
 
@@ -22,6 +22,7 @@ struct LinBwdDataArgs {
   float* dx; int ldDx; int accumulate;                       // [M][ldDx]
   int epi; const float* xraw; int ldXr; const float* tf_scale; const float* tf_shift; int act;
   double* stats;                                             // [HRF_STAT_COPIES][2*N] or null
+  hrf_bn_bfin_t bfin;                                        // bfin.gstats != null: cA/cB/cC derived on load
   int M, K, N;
 };
 
@@ -44,7 +45,8 @@ struct Conv3Args {
   const float* res; const float* res2; int ldR;
   int accumulate, epi; const float* xraw; int ldXr; const float* esc; const float* esh; int act;
   double* stats;                             // [HRF_STAT_COPIES][2*Cout] or null
-  hrf_bn_fin_t fin;                          // forward: fused BatchNorm finalize (ticket != null)
+  hrf_bn_fin_t fin;                          // forward: BatchNorm of the input finalised on load (stats != null)
+  hrf_bn_bfin_t bfin;                        // backward: BatchNorm-backward coefficients derived on load (gstats != null)
   int B, H, W, Cin, Cout;                    // output grid; channels of `in` / of `out`
   int Hs, Ws;                                // stride-2 backward only: grid of `in` (the conv's output)
   int tilesX, tilesY;

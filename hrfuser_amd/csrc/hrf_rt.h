@@ -14,14 +14,9 @@
 #define HRF_DYN_SMEM(T, name)                                                   \
   extern __shared__ __attribute__((aligned(16))) unsigned char hrf_dyn_smem_[]; \
   T* name = reinterpret_cast<T*>(hrf_dyn_smem_)
-#include "hrf_replay.h"
-// every launch of the library goes through here: eager launch + (while recording) an entry in the
-// replay program of the stream (hrf_replay.h)
-#define HRF_LAUNCH(kern, grid, block, smem, stream, ...)                                            \
-  do {                                                                                              \
-    if (hrf_rp::recording()) hrf_rp::record_launch(kern, grid, block, smem, (void*)(stream), __VA_ARGS__); \
-    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__);                \
-  } while (0)
+// every launch of the library goes through here
+#define HRF_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
 typedef float hrf_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ hrf_f4 hrf_mfma16(float a, float b, hrf_f4 c) {
   // v_mfma_f32_16x16x4_f32: exact fp32 (fmaf chain), A[l&15][l>>4], B[l>>4][l&15],

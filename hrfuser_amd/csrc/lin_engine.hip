@@ -104,12 +104,23 @@ __device__ __forceinline__ void flush_moments(const float* sStat, double* stats,
 template <int NT, int TF>
 __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
   __shared__ float sStat[4 * 2 * NT * 16];
+  __shared__ __attribute__((aligned(16))) float sFin[(TF >= HRF_TF_AFFINE && TF <= HRF_TF_AFFINE_GELU) ? 2 * HRF_FIN_MAXC : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int n0w = blockIdx.y * (NT * 16);
   const int pix = blockIdx.x * 64 + wave * 16 + j;
   const bool pixv = pix < a.M;
   const long pc = pixv ? pix : a.M - 1;
+  // BatchNorm of the input finalised on load (hrf_bn_fin_t): scale / shift come from LDS instead of memory
+  const float* scp = a.tf_scale;
+  const float* shp = a.tf_shift;
+  if (TF >= HRF_TF_AFFINE && TF <= HRF_TF_AFFINE_GELU) {
+    if (a.fin.stats != nullptr) {
+      hrf_bn_fin_onload(a.fin, sFin, sFin + HRF_FIN_MAXC, tid, 256, blockIdx.x == 0 && blockIdx.y == 0);
+      __syncthreads();
+      scp = sFin; shp = sFin + HRF_FIN_MAXC;
+    }
+  }
 
   // accumulators start as bias + residual rows (D = A*B + C): no separate epilogue loads
   hrf_f4 acc[NT];
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
       const int kbase = 16 * (kb + s) + 4 * q, kval = a.K - kbase;
       const bool kfull = 16 * (kb + s + 1) <= a.K;
       xa[s] = ld_sel(kfull, a.x, xrow + kbase, kval);
-      if (TF != HRF_TF_NONE) { sc[s] = ld_sel(kfull, a.tf_scale, kbase, kval); sh[s] = ld_sel(kfull, a.tf_shift, kbase, kval); }
+      if (TF != HRF_TF_NONE) { sc[s] = ld_sel(kfull, scp, kbase, kval); sh[s] = ld_sel(kfull, shp, kbase, kval); }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int n = n0w + 16 * t + j;
@@ -185,7 +196,6 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
     wave_moments<NT>(sStat, wave, j, q, pixv, n0w, a.N, acc, acc);
     __syncthreads();
     flush_moments<NT>(sStat, a.stats, n0w, a.N);
-    if (a.fin.ticket != nullptr) hrf_bn_fin_fused(a.fin, a.stats, 256, gridDim.x, gridDim.y);
   }
 }
 
@@ -193,12 +203,24 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
 template <int NT, bool BNB>
 __global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataArgs a) {
   __shared__ float sStat[4 * 2 * NT * 16];
+  __shared__ __attribute__((aligned(16))) float sFin[BNB ? 3 * HRF_FIN_MAXC : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int n0w = blockIdx.y * (NT * 16);
   const int pix = blockIdx.x * 64 + wave * 16 + j;
   const bool pixv = pix < a.M;
   const long pc = pixv ? pix : a.M - 1;
+  // BatchNorm-backward coefficients of dY derived on load (hrf_bn_bfin_t)
+  const float* cAp = a.cA;
+  const float* cBp = a.cB;
+  const float* cCp = a.cC;
+  if (BNB) {
+    if (a.bfin.gstats != nullptr) {
+      hrf_bn_bfin_onload(a.bfin, sFin, sFin + HRF_FIN_MAXC, sFin + 2 * HRF_FIN_MAXC, tid, 256, blockIdx.x == 0 && blockIdx.y == 0);
+      __syncthreads();
+      cAp = sFin; cBp = sFin + HRF_FIN_MAXC; cCp = sFin + 2 * HRF_FIN_MAXC;
+    }
+  }
 
   hrf_f4 acc[NT], xr[NT];
 #pragma unroll
@@ -221,7 +243,7 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataArgs a) {
       dv[s] = ld_sel(kfull, a.dy, drow + kbase, kval);
       if (BNB) {
         yv[s] = ld_sel(kfull, a.yraw, drow + kbase, kval);
-        ca[s] = ld_sel(kfull, a.cA, kbase, kval); cb[s] = ld_sel(kfull, a.cB, kbase, kval); cc[s] = ld_sel(kfull, a.cC, kbase, kval);
+        ca[s] = ld_sel(kfull, cAp, kbase, kval); cb[s] = ld_sel(kfull, cBp, kbase, kval); cc[s] = ld_sel(kfull, cCp, kbase, kval);
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {

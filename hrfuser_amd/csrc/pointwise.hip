@@ -165,7 +165,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* da, const floa
 __global__ __launch_bounds__(256) void affine_act_res_kernel(const float* y1, const float* sc1, const float* sh1,
                                                              const float* y2, const float* sc2, const float* sh2,
                                                              const float* res, const float* rowscale, int rows_per_sample,
-                                                             int act, int act_first, float* out, long total, int C) {
+                                                             int act, int act_first, float* out, long total, int C,
+                                                             hrf_bn_fin_t fin1, hrf_bn_fin_t fin2) {
+  // BatchNorm(s) of the inputs finalised on load (hrf_bn_fin_t)
+  __shared__ float sFin[4 * HRF_FIN_MAXC];
+  if (fin1.stats != nullptr) { hrf_bn_fin_onload(fin1, sFin, sFin + HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0); sc1 = sFin; sh1 = sFin + HRF_FIN_MAXC; }
+  if (fin2.stats != nullptr) { hrf_bn_fin_onload(fin2, sFin + 2 * HRF_FIN_MAXC, sFin + 3 * HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0); sc2 = sFin + 2 * HRF_FIN_MAXC; sh2 = sFin + 3 * HRF_FIN_MAXC; }
+  if (fin1.stats != nullptr || fin2.stats != nullptr) __syncthreads();
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     float v = fmaf(y1[i], sc1[c], sh1[c]);
@@ -187,7 +193,13 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(const float* y1, co
 template <int NCH>
 __global__ __launch_bounds__(256) void ffn_tail_kernel(const float* y1, const float* sc1, const float* sh1, const float* res,
                                                        const float* rowscale, int rows_per_sample, int act, float* out,
-                                                       int rows, int C, float eps, float* rowstat) {
+                                                       int rows, int C, float eps, float* rowstat, hrf_bn_fin_t fin1) {
+  __shared__ float sFin[2 * HRF_FIN_MAXC];
+  if (fin1.stats != nullptr) {                             // BatchNorm of y1 finalised on load (hrf_bn_fin_t)
+    hrf_bn_fin_onload(fin1, sFin, sFin + HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0);
+    __syncthreads();
+    sc1 = sFin; sh1 = sFin + HRF_FIN_MAXC;
+  }
   const int sub = threadIdx.x & 15;
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   const bool rv = row < rows;
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(256) void scale_add_kernel(const float* y, const fl
 
 // ------------------------------------------------------------------------------- cross-resolution exchange
 struct FuseTerm { int type; const float* p; const float* sc; const float* sh; int Hs, Ws; };
-struct FuseArgs { FuseTerm t[4]; float* out; int B, H, W, C; };
+struct FuseArgs { FuseTerm t[4]; float* out; int B, H, W, C; hrf_bn_fin_t fin[4]; };
 
 __device__ __forceinline__ void bil_src(int dst, int in, int out, int& i0, int& i1, float& w1) {
   // F.interpolate(mode='bilinear', align_corners=False): src = (dst+0.5)*in/out - 0.5, clamped at 0
@@ -329,6 +341,19 @@ __device__ __forceinline__ void bil_src(int dst, int in, int out, int& i0, int& 
 
 __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a) {
   const long total = (long)a.B * a.H * a.W * a.C;
+  // BatchNorms of the conv-produced terms finalised on load (hrf_bn_fin_t; C <= HRF_FIN_MAXC / 2 per term)
+  __shared__ float sFin[4 * HRF_FIN_MAXC];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (a.fin[k].stats != nullptr) {
+      float* base = sFin + k * HRF_FIN_MAXC;
+      hrf_bn_fin_onload(a.fin[k], base, base + HRF_FIN_MAXC / 2, threadIdx.x, 256, blockIdx.x == 0);
+      a.t[k].sc = base; a.t[k].sh = base + HRF_FIN_MAXC / 2;
+      any = true;
+    }
+  }
+  if (any) __syncthreads();
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % a.C);
     const long pix = i / a.C;
@@ -641,20 +666,24 @@ extern "C" int hrf_ln_bwd(const float* da, const float* x, const float* rowstat,
 extern "C" int hrf_affine_act_res(const float* y1, const float* sc1, const float* sh1, const float* y2,
                                   const float* sc2, const float* sh2, const float* res, const float* rowscale,
                                   int rows_per_sample, int act, int act_first, float* out, long rows, int C,
-                                  float* ln_rowstat, float ln_eps, void* stream) {
+                                  float* ln_rowstat, float ln_eps, const hrf_bn_fin_t* fin1, const hrf_bn_fin_t* fin2,
+                                  void* stream) {
   const long total = rows * C;
   if (total <= 0) return HRF_OK;
+  if ((fin1 != nullptr && (fin1->C != C || C > HRF_FIN_MAXC || fin1->stats == nullptr)) ||
+      (fin2 != nullptr && (fin2->C != C || C > HRF_FIN_MAXC || fin2->stats == nullptr || y2 == nullptr))) return HRF_ERR_ARG;
+  const hrf_bn_fin_t f1 = fin1 != nullptr ? *fin1 : hrf_bn_fin_t{}, f2 = fin2 != nullptr ? *fin2 : hrf_bn_fin_t{};
   if (ln_rowstat != nullptr && act_first && y2 == nullptr && C <= 640) {
     const int nch = hrf_cdiv(C, 16);
     const dim3 grid(hrf_cdiv(rows, 16));
 #define HRF_FT(N_) HRF_LAUNCH(ffn_tail_kernel<N_>, grid, dim3(256), 0, stream, y1, sc1, sh1, res, rowscale, rows_per_sample, act, \
-                              out, (int)rows, C, ln_eps, ln_rowstat)
+                              out, (int)rows, C, ln_eps, ln_rowstat, f1)
     if (nch <= 2) { HRF_FT(2); } else if (nch <= 3) { HRF_FT(3); } else if (nch <= 5) { HRF_FT(5); }
     else if (nch <= 10) { HRF_FT(10); } else if (nch <= 20) { HRF_FT(20); } else { HRF_FT(40); }
     return hrf_check_launch();
   }
   HRF_LAUNCH(affine_act_res_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, y1, sc1, sh1, y2, sc2, sh2, res,
-             rowscale, rows_per_sample, act, act_first, out, total, C);
+             rowscale, rows_per_sample, act, act_first, out, total, C, f1, f2);
   if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(out, (int)rows, C, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();
 }
@@ -686,8 +715,15 @@ extern "C" int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const 
                             int type1, const float* p1, const float* sc1, const float* sh1, int Hs1, int Ws1,
                             int type2, const float* p2, const float* sc2, const float* sh2, int Hs2, int Ws2,
                             int type3, const float* p3, const float* sc3, const float* sh3, int Hs3, int Ws3,
-                            float* out, int B, int H, int W, int C, void* stream) {
+                            float* out, int B, int H, int W, int C, const hrf_bn_fin_t* fins, void* stream) {
   FuseArgs a;
+  for (int k = 0; k < 4; ++k) {
+    a.fin[k] = hrf_bn_fin_t{};
+    if (fins != nullptr && fins[k].stats != nullptr) {
+      if (fins[k].C != C || C > HRF_FIN_MAXC / 2) return HRF_ERR_ARG;
+      a.fin[k] = fins[k];
+    }
+  }
   a.t[0] = FuseTerm{type0, p0, sc0, sh0, Hs0, Ws0};
   a.t[1] = FuseTerm{type1, p1, sc1, sh1, Hs1, Ws1};
   a.t[2] = FuseTerm{type2, p2, sc2, sh2, Hs2, Ws2};
@@ -773,4 +809,14 @@ extern "C" int hrf_adamw(float* p, const float* g, float* m, float* v, const flo
   HRF_LAUNCH(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, p, g, m, v, wd_mask, n, lr, beta1, beta2, eps,
              weight_decay, state, grad_scale);
   return hrf_check_launch();
+}
+
+extern "C" int hrf_memset(void* ptr, int value, long bytes, void* stream) {
+  if (bytes <= 0) return HRF_OK;
+#ifdef HRF_EMUL
+  memset(ptr, value, (size_t)bytes);
+  return HRF_OK;
+#else
+  return hipMemsetAsync(ptr, value, (size_t)bytes, (hipStream_t)stream) == hipSuccess ? HRF_OK : HRF_ERR_LAUNCH;
+#endif
 }

@@ -19,9 +19,13 @@ import torch
 
 from . import _lib
 
-# BatchNorm finalize inside the producing kernels (two-level ticket): -329 launches, but the ticket round
-# trips add 3-6 us to each producer and the step time is unchanged (19.19 vs 19.28 ms) -> opt-in
-_FUSE_BN = os.environ.get('HRF_FUSE_BN', '0') == '1'
+# BatchNorm finalize ON LOAD: the consumer of a train-mode BatchNorm derives scale/shift in its own prologue from the
+# producer's replicated moments (hrf_bn_fin_t), the data-gradient kernel of the producing convolution does the same
+# for the backward coefficients (hrf_bn_bfin_t): no hrf_bn_finalize / hrf_bn_bwd_finalize launches on the chain.
+# HRF_FIN_ONLOAD=0 restores the separate launches (A/B measurements; SyncBN always uses them: the moments are
+# exchanged between producer and finalize).
+_FIN_ONLOAD = os.environ.get('HRF_FIN_ONLOAD', '1') != '0'
+FIN_MAXC = _lib.FIN_MAXC
 LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
 _MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
 _FORCE_COLL = os.environ.get('HRF_FORCE_COLLECTIVES', '0') == '1'
@@ -31,7 +35,7 @@ _TF2ACT = {TF_NONE: ACT_NONE, TF_AFFINE: ACT_NONE, TF_RELU: ACT_RELU, TF_GELU: A
 
 
 def gpu_add_(dst, g):
-    """dst += g through the library (a torch add_ would not be part of a recorded replay program)."""
+    """dst += g through the library (one launch on the current lane)."""
     _lib.lib().hrf_scale_add(g, None, 1.0, None, 1, dst, None, dst, g.numel(), 1, _lib.stream_ptr())
     return dst
 
@@ -79,7 +83,7 @@ class Act:
 class BNState:
     """One BatchNorm application: raw conv output + the per-channel vectors around it."""
     __slots__ = ('bn', 'C', 'raw', 'count', 'scale', 'shift', 'mean', 'invstd', 'stats', 'gstats',
-                 'coef', 'du', 'train')
+                 'coef', 'du', 'train', 'pending')
 
 
 class Lazy:
@@ -156,12 +160,8 @@ class Ctx:
         self._side_i = 0
         self._side_used = {}
         self._deferred = []
-        self.recording = bool(getattr(owner, '_hrf_recording', False))
-
-    def _rec_sync(self, src, dst):
-        """While a replay program is being recorded: dst's next launches come after src's launches so far."""
-        if self.recording:
-            self.L.hrf_rec_sync(src.ptr, dst.ptr)
+        # test instrumentation (tests/helpers.py: ReLU-mask pinning): a list that receives every ReLU site of the forward
+        self.probe = [] if owner.__dict__.get('_relu_probe') else None
 
     # ---- tape ----------------------------------------------------------------------------------
     def push(self, fn):
@@ -181,7 +181,6 @@ class Ctx:
         uniq = [self._free.pop() for _ in range(m)]
         for k in uniq:
             k.stream.wait_stream(self.cur.stream)
-            self._rec_sync(self.cur, k)
         if self.record:
             self.tape.append(('F', self.cur, uniq))
         return [uniq[i % m] for i in range(n)]
@@ -193,7 +192,6 @@ class Ctx:
         kids = list(dict.fromkeys(kids))                    # lanes may repeat under HRF_MAX_LANES
         for k in kids:
             self.cur.stream.wait_stream(k.stream)
-            self._rec_sync(k, self.cur)
         if self.record:
             self.tape.append(('J', self.cur, kids))
         self._free.extend(kids)
@@ -232,7 +230,6 @@ class Ctx:
         for j in range(k):
             lane = pool[(self._side_i + j) % len(pool)]
             lane.stream.wait_stream(self.main.stream)
-            self._rec_sync(self.main, lane)
             self._side_used[id(lane)] = lane
             with _LaneScope(self, lane):
                 if group:
@@ -260,11 +257,9 @@ class Ctx:
             if e[0] == 'J':                     # reverse of a join = fork
                 for k in e[2]:
                     k.stream.wait_stream(e[1].stream)
-                    self._rec_sync(e[1], k)
             elif e[0] == 'F':                   # reverse of a fork = join
                 for k in e[2]:
                     e[1].stream.wait_stream(k.stream)
-                    self._rec_sync(k, e[1])
                 if flush_n and e[1] is self.main and len(self._deferred) >= flush_n:
                     self._flush_deferred()
             else:
@@ -296,7 +291,6 @@ class Ctx:
         if self.multi:
             for lane in self._side_used.values():
                 self.main.stream.wait_stream(lane.stream)
-                self._rec_sync(lane, self.main)
             self._side_used = {}
         with _LaneScope(self, self.main):
             self.owner._engine().fold_grads(self.L, self.main.ptr)
@@ -406,25 +400,16 @@ def _needs_grad(src):
 
 
 # ----------------------------------------------------------------------------- BatchNorm plumbing
-def bn_fin_args(ctx, bn, C, rows):
-    """hrf_bn_fin_t for a producer launch, or None when the finalize must stay a separate launch
-    (eval mode, or SyncBN: the moments are all-reduced between producer and finalize)."""
-    if not (ctx.training and bn.training) or (ctx.group is not None and (ctx.world > 1 or _FORCE_COLL)) or not _FUSE_BN:
-        return None
-    slot = ctx.owner._bn_slot(bn)
-    mom = bn.momentum if bn.momentum is not None else 0.1
-    P = _lib._ptr
-    return _lib.BnFin(P(slot['tick_f']), P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var),
-                      P(slot['scale']), P(slot['shift']), P(slot['mean']), P(slot['invstd']),
-                      float(rows * ctx.world), float(bn.eps), float(mom), 1 if bn.track_running_stats else 0, C)
+def _collectives(ctx):
+    return ctx.group is not None and (ctx.world > 1 or _FORCE_COLL)
 
 
-def bn_forward(ctx, bn, raw, stats, fused=False):
-    """Turn (raw conv output, accumulated sums) into a BNState with scale/shift on device.
-    fused=True: the producing kernel already ran the finalize (bn_fin_args)."""
+def bn_forward(ctx, bn, raw, stats):
+    """Turn (raw conv output, accumulated sums) into a BNState.  Train mode without SyncBN: nothing is launched - the
+    finalize is left to the consumer's prologue (st.pending, take_fin)."""
     st = BNState()
     C = raw.shape[-1]
-    st.bn, st.C, st.raw, st.du, st.coef = bn, C, raw, None, None
+    st.bn, st.C, st.raw, st.du, st.coef, st.pending = bn, C, raw, None, None, None
     slot = ctx.owner._bn_slot(bn)
     st.train = bool(ctx.training and bn.training)
     if st.train:
@@ -432,13 +417,13 @@ def bn_forward(ctx, bn, raw, stats, fused=False):
         st.scale, st.shift, st.mean, st.invstd = slot['scale'], slot['shift'], slot['mean'], slot['invstd']
         rows = raw.numel() // C
         st.count = float(rows * ctx.world)
-        if fused:
-            return st
-        ctx.all_reduce(st.stats)
-        mom = bn.momentum if bn.momentum is not None else 0.1
-        ctx.L.hrf_bn_finalize(st.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, st.count,
-                              float(bn.eps), float(mom), 1 if bn.track_running_stats else 0,
-                              st.scale, st.shift, st.mean, st.invstd, C, ctx.stream)
+        if _collectives(ctx):
+            ctx.all_reduce(st.stats)
+            _finalize_now(ctx, st)
+        elif _FIN_ONLOAD:
+            st.pending = 'fwd'
+        else:
+            _finalize_now(ctx, st)
     else:
         st.stats, st.gstats = None, slot['gstats']
         st.scale, st.shift, st.mean, st.invstd = ctx.owner._bn_eval_affine(bn)
@@ -446,20 +431,60 @@ def bn_forward(ctx, bn, raw, stats, fused=False):
     return st
 
 
-def bn_backward_coef(ctx, st):
-    """After a consumer wrote st.du / st.gstats: dgamma/dbeta += and the on-load dy coefficients."""
+def _finalize_now(ctx, st):
+    bn = st.bn
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    ctx.L.hrf_bn_finalize(st.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, st.count,
+                          float(bn.eps), float(mom), 1 if bn.track_running_stats else 0,
+                          st.scale, st.shift, st.mean, st.invstd, st.C, ctx.stream)
+    st.pending = None
+
+
+def take_fin(ctx, st, limit=FIN_MAXC):
+    """hrf_bn_fin_t for a launch that consumes BN(st.raw), or None when scale/shift are already in memory.  The first
+    taker is the designated writer (scale/shift/mean/invstd, running statistics); a BatchNorm wider than `limit` is
+    finalised by its own launch instead."""
+    if st is None or st.pending is None:
+        return None
+    if st.C > limit:
+        _finalize_now(ctx, st)
+        return None
+    bn = st.bn
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    P = _lib._ptr
+    fin = _lib.BnFin(P(st.stats), P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var),
+                     P(st.scale), P(st.shift), P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom),
+                     1 if bn.track_running_stats else 0, 1 if st.pending == 'fwd' else 0, st.C)
+    st.pending = 'written'
+    return fin
+
+
+def _src_fin(ctx, src, limit=FIN_MAXC):
+    return take_fin(ctx, src.st, limit) if isinstance(src, Lazy) else None
+
+
+def bn_backward_coef(ctx, st, consumer_follows=True, limit=FIN_MAXC):
+    """After a consumer wrote st.du / st.gstats: -> ((cA, cB, cC), bfin).  bfin (hrf_bn_bfin_t) is handed to the
+    data-gradient launch of the producing convolution, which derives the coefficients on load, publishes them for
+    the weight-gradient kernel and adds dgamma / dbeta; bfin is None when the separate finalize launch ran instead
+    (SyncBN, no data-gradient launch to come, BatchNorm wider than `limit`)."""
     slot = ctx.owner._bn_slot(st.bn)
     cA, cB, cC = slot['cA'], slot['cB'], slot['cC']
-    local = None
-    if st.train and ctx.group is not None and (ctx.world > 1 or _FORCE_COLL):
-        local = _keep(st.gstats.clone())
-        ctx.all_reduce(st.gstats)
+    st.coef = (cA, cB, cC)
     wg = st.bn.weight.grad if st.bn.weight.requires_grad else None
     bg = st.bn.bias.grad if st.bn.bias.requires_grad else None
+    coll = st.train and _collectives(ctx)
+    if _FIN_ONLOAD and consumer_follows and not coll and st.C <= limit:
+        P = _lib._ptr
+        return st.coef, _lib.BnBFin(P(st.gstats), P(st.bn.weight), P(st.mean), P(st.invstd), P(wg), P(bg), P(cA), P(cB),
+                                    P(cC), st.count, 1 if st.train else 0, 1, st.C)
+    local = None
+    if coll:
+        local = _keep(st.gstats.clone())
+        ctx.all_reduce(st.gstats)
     ctx.L.hrf_bn_bwd_finalize(st.gstats, local, st.bn.weight, st.mean, st.invstd, st.count, 1 if st.train else 0,
                               wg, bg, cA, cB, cC, st.C, ctx.stream)
-    st.coef = (cA, cB, cC)
-    return st.coef
+    return st.coef, None
 
 
 # ----------------------------------------------------------------------------- conv / linear ops
@@ -468,11 +493,46 @@ def _conv_out_hw(H, W, KH, stride):
     return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KH) // stride + 1
 
 
-def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw, coef):
-    """Shared backward of every dense conv / linear: dW (+db), then dX routed by the source kind."""
+def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw, st=None):
+    """Shared backward of every dense conv / linear: dX routed by the source kind, then dW (+db).
+    `st`: BNState of the BatchNorm that follows the convolution (dy = st.du, BatchNorm backward applied on load)."""
     L, s = ctx.L, ctx.stream
     x, strides, (B, H, W, Cin), tf, sc, sh, rowstat = _src_desc(src)
-    cA, cB, cC = coef if coef is not None else (None, None, None)
+    needs = _needs_grad(src)
+    bfin = None
+    cA = cB = cC = None
+    if st is not None:
+        (cA, cB, cC), bfin = bn_backward_coef(ctx, st, consumer_follows=needs)
+    # the data gradient goes first: with `bfin` it is the launch that publishes cA/cB/cC for the weight gradient
+    if not needs:
+        pass
+    elif isinstance(src, Lazy):
+        ps = src.st
+        ps.du = _new_like(ps.raw)
+        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
+                            ps.du, *strides, 0, 1, ps.raw, Cin, ps.scale, ps.shift, _TF2ACT[src.mode],
+                            ps.gstats, s)
+    elif isinstance(src, LNIn):
+        da = _new_like(src.act.t)
+        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
+                            da, *strides, 0, 0, None, 0, None, None, 0, None, s)
+        g, acc = src.act.grad_target()
+        eng = ctx.owner._engine()
+        gacc, cs = eng.grad_acc(src.ln.weight)
+        bacc, _ = eng.grad_acc(src.ln.bias)
+        L.hrf_ln_bwd(da, src.act.t, src.rowstat, src.ln.weight, B * H * W, Cin, g, acc, gacc, bacc, cs, s)
+    elif isinstance(src, Act):
+        g, acc = src.grad_target()
+        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
+                            g, *strides, acc, 0, None, 0, None, None, 0, None, s)
+    else:                                   # RawInput (NCHW gradient written through strides)
+        if src.grad is None:
+            src.grad = _new_like(src.t)
+            acc = 0
+        else:
+            acc = 1
+        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
+                            src.grad, *strides, acc, 0, None, 0, None, None, 0, None, s)
     if weight.requires_grad:
         # weight gradients are leaves of the backward graph: issue them on a side lane so they overlap
         # the latency-bound data-gradient chain (operands are never mutated afterwards, see DESIGN.md)
@@ -489,35 +549,6 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
         ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
             dy, ldD, doff, yraw, cA, cB, cC, xw, *sw, B, H, W, Cin, KH, stride, Cout,
             tf, sc, sh, rowstat, weight.grad, bgrad, ctx.stream), cost=cost)
-    if not _needs_grad(src):
-        return
-    if isinstance(src, Lazy):
-        st = src.st
-        st.du = _new_like(st.raw)
-        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
-                            st.du, *strides, 0, 1, st.raw, Cin, st.scale, st.shift, _TF2ACT[src.mode],
-                            st.gstats, s)
-    elif isinstance(src, LNIn):
-        da = _new_like(src.act.t)
-        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
-                            da, *strides, 0, 0, None, 0, None, None, 0, None, s)
-        g, acc = src.act.grad_target()
-        eng = ctx.owner._engine()
-        gacc, cs = eng.grad_acc(src.ln.weight)
-        bacc, _ = eng.grad_acc(src.ln.bias)
-        L.hrf_ln_bwd(da, src.act.t, src.rowstat, src.ln.weight, B * H * W, Cin, g, acc, gacc, bacc, cs, s)
-    elif isinstance(src, Act):
-        g, acc = src.grad_target()
-        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
-                            g, *strides, acc, 0, None, 0, None, None, 0, None, s)
-    else:                                   # RawInput (NCHW gradient written through strides)
-        if src.grad is None:
-            src.grad = _new_like(src.t)
-            acc = 0
-        else:
-            acc = 1
-        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, weight, KH, stride, Cout, B, H, W, Cin,
-                            src.grad, *strides, acc, 0, None, 0, None, None, 0, None, s)
 
 
 def conv_bn(ctx, src, conv, bn, mode):
@@ -531,15 +562,15 @@ def conv_bn(ctx, src, conv, bn, mode):
     slot = ctx.owner._bn_slot(bn)
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None
-    fin = bn_fin_args(ctx, bn, Cout, B * Ho * Wo)
     L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
-                   tf, sc, sh, rowstat, stats, fin, None, 0.0, s)
-    st = bn_forward(ctx, bn, y, stats, fused=fin is not None)
+                   tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, s)
+    st = bn_forward(ctx, bn, y, stats)
     out = Lazy(st, mode)
+    if ctx.probe is not None and mode == TF_RELU:
+        ctx.probe.append(('lazy', st))
 
     def bwd():
-        coef = bn_backward_coef(ctx, st)
-        _conv_backward(ctx, src, w, b, KH, stride, Cout, st.du, Cout, 0, st.raw, coef)
+        _conv_backward(ctx, src, w, b, KH, stride, Cout, st.du, Cout, 0, st.raw, st)
         st.du = None
     ctx.push(bwd)
     return out
@@ -561,7 +592,7 @@ def linear_into(ctx, src, lin, out, off):
     Cout = w.shape[0]
     ld = out.t.shape[-1]
     L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, 1, 1, Cout, out.t, ld, off, None, None, 0,
-                   tf, sc, sh, rowstat, None, None, None, 0.0, s)
+                   tf, sc, sh, rowstat, None, _src_fin(ctx, src), None, 0.0, s)
 
     def bwd():
         _conv_backward(ctx, src, w, b, 1, 1, Cout, out.grad, ld, off, None, None)
@@ -603,7 +634,7 @@ def linear_residual(ctx, o, lin, res, res2=None, drop=None):
             L.hrf_conv_bwd_weight(dy, C, 0, None, None, None, None, o.t, *strides, B, H, W, C, 1, 1, C,
                                   TF_NONE, None, None, None, w.grad, b.grad if b is not None else None, s)
         og, acc = o.grad_target()
-        L.hrf_conv_bwd_data(dy, C, 0, None, None, None, None, w, 1, 1, C, B, H, W, C, og, *strides, acc,
+        L.hrf_conv_bwd_data(dy, C, 0, None, None, None, None, None, w, 1, 1, C, B, H, W, C, og, *strides, acc,
                             0, None, 0, None, None, 0, None, s)
         # identity paths: the residual streams receive the output gradient unchanged
         if res2 is not None and res2.needs_grad:
@@ -672,13 +703,25 @@ def dwconv_bn(ctx, src, conv, bn, mode):
     slot = ctx.owner._bn_slot(bn)
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None
-    fin = bn_fin_args(ctx, bn, C, B * Ho * Wo)
-    L.hrf_dwconv_fwd(x, B, H, W, C, w, b, stride, tf, sc, sh, y, stats, fin, s)
-    st = bn_forward(ctx, bn, y, stats, fused=fin is not None)
+    L.hrf_dwconv_fwd(x, B, H, W, C, w, b, stride, tf, sc, sh, y, stats, _src_fin(ctx, src, 1 << 30), s)
+    st = bn_forward(ctx, bn, y, stats)
     out = Lazy(st, mode)
+    if ctx.probe is not None and mode == TF_RELU:
+        ctx.probe.append(('lazy', st))
 
     def bwd():
-        cA, cB, cC = bn_backward_coef(ctx, st)
+        needs = isinstance(src, Lazy) or src.needs_grad
+        (cA, cB, cC), bfin = bn_backward_coef(ctx, st, consumer_follows=needs, limit=1 << 30)
+        # data gradient first: with `bfin` it publishes cA/cB/cC for the weight-gradient launch below
+        if isinstance(src, Lazy):
+            ps = src.st
+            ps.du = _new_like(ps.raw)
+            L.hrf_dwconv_bwd_data(st.du, st.raw, cA, cB, cC, bfin, w, stride, B, H, W, C, ps.du, 0, 1, ps.raw,
+                                  ps.scale, ps.shift, _TF2ACT[src.mode], ps.gstats, s)
+        elif src.needs_grad:
+            g, acc = src.grad_target()
+            L.hrf_dwconv_bwd_data(st.du, st.raw, cA, cB, cC, bfin, w, stride, B, H, W, C, g, acc, 0, None, None,
+                                  None, 0, None, s)
         if w.requires_grad:
             du_ = st.du
             eng = ctx.owner._engine()
@@ -687,15 +730,6 @@ def dwconv_bn(ctx, src, conv, bn, mode):
             ctx.side_launch(lambda: L.hrf_dwconv_bwd_weight(
                 du_, st.raw, cA, cB, cC, x, B, H, W, C, stride, tf, sc, sh, wacc, bacc, cs, ctx.stream),
                 cost=4.0 * B * H * W * C * (1.0 + 2.0 / (stride * stride)))
-        if isinstance(src, Lazy):
-            ps = src.st
-            ps.du = _new_like(ps.raw)
-            L.hrf_dwconv_bwd_data(st.du, st.raw, cA, cB, cC, w, stride, B, H, W, C, ps.du, 0, 1, ps.raw,
-                                  ps.scale, ps.shift, _TF2ACT[src.mode], ps.gstats, s)
-        elif src.needs_grad:
-            g, acc = src.grad_target()
-            L.hrf_dwconv_bwd_data(st.du, st.raw, cA, cB, cC, w, stride, B, H, W, C, g, acc, 0, None, None,
-                                  None, 0, None, s)
         st.du = None
     ctx.push(bwd)
     return out
@@ -720,7 +754,9 @@ def materialize(ctx, lazy, act, res=None, lazy2=None, act_first=False, rowscale=
         rs_out = out.rowstat[1]
     L.hrf_affine_act_res(st.raw, st.scale, st.shift, st2.raw if st2 else None, st2.scale if st2 else None,
                          st2.shift if st2 else None, res.t if res is not None else None, rowscale, H * W,
-                         act, 1 if act_first else 0, out.t, rows, C, rs_out, LN_EPS, s)
+                         act, 1 if act_first else 0, out.t, rows, C, rs_out, LN_EPS, take_fin(ctx, st), take_fin(ctx, st2), s)
+    if ctx.probe is not None and act == ACT_RELU and not act_first:
+        ctx.probe.append(('out', out.t))
 
     def bwd():
         g = _new_like(out.t)
@@ -756,16 +792,25 @@ def fuse_sum(ctx, dims, terms):
     dev = terms[0][1].t.device if isinstance(terms[0][1], Act) else terms[0][1].raw.device
     out = Act(_new((B, H, W, C), dev))
     args = []
-    for kind, t in terms:
+    fins = (_lib.BnFin * 4)()
+    any_fin = False
+    for k, (kind, t) in enumerate(terms):
         if kind == 'id':
             args += [1, t.t, None, None, 0, 0]
-        elif kind == 'same':
+            continue
+        fin = take_fin(ctx, t.st, FIN_MAXC // 2)
+        if fin is not None:
+            fins[k] = fin
+            any_fin = True
+        if kind == 'same':
             args += [2, t.raw, t.st.scale, t.st.shift, 0, 0]
         else:
             args += [3, t.raw, t.st.scale, t.st.shift, t.raw.shape[1], t.raw.shape[2]]
     for _ in range(4 - len(terms)):
         args += [0, None, None, None, 0, 0]
-    L.hrf_fuse_sum(*args, out.t, B, H, W, C, s)
+    L.hrf_fuse_sum(*args, out.t, B, H, W, C, fins if any_fin else None, s)
+    if ctx.probe is not None:
+        ctx.probe.append(('out', out.t))
 
     def bwd():
         g = _new_like(out.t)
@@ -794,3 +839,20 @@ def fuse_sum(ctx, dims, terms):
                 L.hrf_bilinear_up_bwd(g, C, 0, B, H, W, C, st.raw, st.raw.shape[1], st.raw.shape[2], st.du, st.gstats, s)
     ctx.push(bwd)
     return out
+
+
+def collect_relu_masks(ctx):
+    """Test instrumentation: the sign mask (logical NCHW, bool) of every ReLU the forward applied, in issue order.
+    On-load ReLUs are re-evaluated with the library's own affine + ReLU kernel so the mask is the one the kernels used."""
+    masks = []
+    for kind, obj in ctx.probe:
+        if kind == 'out':
+            t = obj
+        else:
+            st = obj
+            B, H, W, C = st.raw.shape
+            t = torch.empty_like(st.raw)
+            ctx.L.hrf_affine_act_res(st.raw, st.scale, st.shift, None, None, None, None, None, H * W, ACT_RELU, 0, t,
+                                     B * H * W, C, None, 0.0, None, None, ctx.stream)
+        masks.append((t > 0).permute(0, 3, 1, 2))
+    return masks

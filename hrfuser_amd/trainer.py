@@ -116,48 +116,6 @@ class Trainer:
     def replay(self):
         self.graph.replay()
 
-    # -------------------------------------------------------------------------------------------
-    def capture_program(self, x, mods, cots, warmup=2):
-        """Record the full step as a replay program of the HIP library (hrf_rec_* / hrf_replay): the
-        launches of one eager step and the fork/join points of the lane schedule, replayed from one host
-        thread per stream.  Replaces the multi-stream hipGraph, whose replay costs 13-16 ms of host time
-        per step on this ROCm.  Not used with collectives in the step (RCCL calls cannot be recorded)."""
-        if self.world > 1 or self.force:
-            raise RuntimeError('replay programs do not cover collectives; use capture() (hipGraph)')
-        if not self._ready:
-            self._setup(x.device)
-        L = self.net._lib_handle()
-        self.pstream = torch.cuda.Stream()
-        self.pstream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.pstream):
-            for _ in range(warmup):
-                self._step_impl(x, mods, cots)
-        torch.cuda.synchronize()
-        L.hrf_rec_begin()
-        self.net.__dict__['_hrf_recording'] = True
-        try:
-            with torch.cuda.stream(self.pstream):
-                self._prog_outs = self._step_impl(x, mods, cots)
-        finally:
-            self.net.__dict__['_hrf_recording'] = False
-            prog = L.hrf_rec_end()
-        torch.cuda.synchronize()
-        if prog is None or prog <= 0:
-            raise RuntimeError('recording the replay program failed')
-        self._prog_keep = list(R._KEEP)          # every buffer the recorded launches point to
-        self._prog_inputs = (x,) + tuple(mods)
-        self.prog = prog
-        self.prog_info = tuple(L.hrf_replay_info(prog, k) for k in range(3))   # launches, streams, events
-        return prog
-
-    def replay_program(self):
-        L = self.net._lib_handle()
-        eng = self.net._engine()
-        with torch.cuda.stream(self.pstream):
-            eng.pre_step(True)                    # torch-side work of the step: RNG pools, num_batches_tracked
-            self.net.refresh_inputs(self._prog_inputs)
-            L.hrf_replay(self.prog)
-
 
 def make_cotangents(net, x, mods, seed=5):
     """Fixed random output cotangents (NHWC) for the synthetic loss, shaped by a dry eval forward."""

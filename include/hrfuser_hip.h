@@ -31,22 +31,29 @@
  *     hrf_fold_copies adds the summed copies into the gradient arena. */
 #define HRF_STAT_COPIES 16
 
-/* BatchNorm bookkeeping fused into the kernel that PRODUCES the moments ("last block finalises"):
- * a producer given one of these runs the arithmetic of hrf_bn_finalize / hrf_bn_bwd_finalize in the block
- * that arrives last at a two-level ticket (HRF_STAT_COPIES group tickets + 1 master), so the ~660
- * separate finalize launches of a step disappear (every launch costs ~5.5 us of serialized host time).
- * `ticket`: HRF_STAT_COPIES+1 unsigned ints, zeroed once by the caller, left at zero by the kernel. */
+/* BatchNorm finalize ON LOAD (consumer side).  A train-mode BatchNorm needs its batch moments complete before anything
+ * can be normalised, i.e. a grid-wide dependency between the producing convolution and its consumer; the kernel boundary
+ * between the two already is that dependency.  A consumer kernel that is handed one of these for an input tensor derives
+ * the scale/shift of that BatchNorm itself, in its prologue, from the producer's replicated moments `stats`
+ * ([HRF_STAT_COPIES][2*C] doubles) - the arithmetic of hrf_bn_finalize, evaluated redundantly by every block (C <=
+ * HRF_FIN_MAXC) - so the ~330 separate hrf_bn_finalize launches of a training step (and their launch boundaries on the
+ * dependency chain) disappear.  `write` != 0: block 0 of the launch also stores scale/shift/mean/invstd (read by the
+ * backward kernels) and updates the running statistics; exactly one consumer launch per BatchNorm and step sets it.
+ * hrf_bn_bfin_t is the backward counterpart: the data-gradient kernel of the PRODUCING convolution derives the
+ * BatchNorm-backward coefficients (dy = cA*du + cB*y + cC) from `gstats` = replicated (sum du, sum du*y); `write` != 0:
+ * block 0 stores cA/cB/cC (read by the weight-gradient kernel) and adds dgamma / dbeta. */
+#define HRF_FIN_MAXC 576
 typedef struct hrf_bn_fin {
-  unsigned* ticket;
+  const double* stats;
   const float* gamma; const float* beta; float* running_mean; float* running_var;
   float* scale; float* shift; float* mean; float* invstd;
-  double count; float eps; float momentum; int update_running; int C;
+  double count; float eps; float momentum; int update_running; int write; int C;
 } hrf_bn_fin_t;
 typedef struct hrf_bn_bfin {
-  unsigned* ticket;
+  const double* gstats;
   const float* gamma; const float* mean; const float* invstd;
   float* dgamma; float* dbeta; float* cA; float* cB; float* cC;
-  double count; int train; int C;
+  double count; int train; int write; int C;
 } hrf_bn_bfin_t;
 
 #ifdef __cplusplus
@@ -63,11 +70,13 @@ int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int B, int H, i
                  const float* w, const float* bias, int KH, int stride, int Cout,
                  float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
                  int tf_mode, const float* tf_scale, const float* tf_shift,
-                 const float* tf_rowstat, double* stats, const hrf_bn_fin_t* bn_fin, float* ln_rowstat, float ln_eps, void* stream);
+                 const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat, float ln_eps, void* stream);
 /* dX (or, epi=1, dU = dX*act'(scale*xraw+shift) plus (sum dU, sum dU*xraw) for the producer BN).
- * (cA,cB,cC) != NULL applies the BatchNorm backward on load: dy = cA*du + cB*yraw + cC.        */
+ * (cA,cB,cC) != NULL applies the BatchNorm backward on load: dy = cA*du + cB*yraw + cC; with `bfin` (nullable, Cout <=
+ * HRF_FIN_MAXC) the coefficients are derived in the kernel prologue from bfin->gstats instead of being read (see
+ * hrf_bn_bfin_t).  `tf_fin` of hrf_conv_fwd (nullable, tf_mode 1..3, Cin <= HRF_FIN_MAXC) is the forward analogue.    */
 int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float* yraw,
-                      const float* cA, const float* cB, const float* cC,
+                      const float* cA, const float* cB, const float* cC, const hrf_bn_bfin_t* bfin,
                       const float* w, int KH, int stride, int Cout,
                       int B, int H, int W, int Cin,
                       float* dx, int sB, int sY, int sX, int sC, int accumulate,
@@ -90,9 +99,9 @@ int hrf_debug_knob(int key, int value);
  * fuse-down chains hrformer.py:532-541 (stride 2, no bias).  w is (C,1,3,3).                    */
 int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias,
                    int stride, int tf_mode, const float* tf_scale, const float* tf_shift, float* y,
-                   double* stats, const hrf_bn_fin_t* bn_fin, void* stream);
+                   double* stats, const hrf_bn_fin_t* tf_fin, void* stream);
 int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const float* cA, const float* cB,
-                        const float* cC, const float* w, int stride, int B, int H, int W, int C,
+                        const float* cC, const hrf_bn_bfin_t* bfin, const float* w, int stride, int B, int H, int W, int C,
                         float* dx, int accumulate, int epi, const float* xraw, const float* tf_scale,
                         const float* tf_shift, int act, double* stats, void* stream);
 int hrf_dwconv_bwd_weight(const float* dy, const float* yraw, const float* cA, const float* cB,
@@ -146,7 +155,7 @@ int hrf_ln_bwd(const float* da, const float* x, const float* rowstat, const floa
 int hrf_affine_act_res(const float* y1, const float* sc1, const float* sh1, const float* y2,
                        const float* sc2, const float* sh2, const float* res, const float* rowscale,
                        int rows_per_sample, int act, int act_first, float* out, long rows, int C, float* ln_rowstat, float ln_eps,
-                       void* stream);
+                       const hrf_bn_fin_t* fin1, const hrf_bn_fin_t* fin2, void* stream);
 /* out = res + res2 + y*mask*mscale*rowscale[b]: nn.Dropout(proj_drop) hrfuser_hrformer_based.py:97
  * and mmcv DropPath hrfuser_hrformer_based.py:301-315 arithmetic (mask / rowscale nullable).    */
 int hrf_scale_add(const float* y, const float* mask, float mscale, const float* rowscale,
@@ -166,7 +175,9 @@ int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const float* sh0,
                  int type1, const float* p1, const float* sc1, const float* sh1, int Hs1, int Ws1,
                  int type2, const float* p2, const float* sc2, const float* sh2, int Hs2, int Ws2,
                  int type3, const float* p3, const float* sc3, const float* sh3, int Hs3, int Ws3,
-                 float* out, int B, int H, int W, int C, void* stream);
+                 float* out, int B, int H, int W, int C, const hrf_bn_fin_t* fins, void* stream);
+/* `fin1` / `fin2` of hrf_affine_act_res and `fins` of hrf_fuse_sum (an array of FOUR hrf_bn_fin_t, one per term; entries
+ * with stats == NULL are unused; C <= HRF_FIN_MAXC / 2) finalise the BatchNorm of the respective operand on load.  */
 /* adjoint of the bilinear up-sampling (gather form) + (sum du, sum du*ylow) moments              */
 int hrf_bilinear_up_bwd(const float* g, int ldG, int goff, int B, int H, int W, int C, const float* ylow, int Hs, int Ws,
                         float* du, double* stats, void* stream);
@@ -245,17 +256,7 @@ int hrf_adamw(float* p, const float* g, float* m, float* v, const float* wd_mask
               float beta1, float beta2, float eps, float weight_decay, const float* state,
               float grad_scale, void* stream);
 
-/* ---- launch recorder / replayer (one host thread per stream; replaces multi-stream hipGraph replay,
- * whose host-side enqueue costs ~4.3 us per node on this ROCm).  hrf_rec_begin .. hrf_rec_end record
- * every kernel launch of the library (while also executing it) plus the fork/join points given by
- * hrf_rec_sync(src_stream, dst_stream); hrf_rec_end returns a program id > 0; hrf_replay(id) enqueues
- * the recorded launches with the recorded argument values on the recorded streams.               */
-int hrf_rec_begin(void);
-int hrf_rec_sync(void* src_stream, void* dst_stream);
-int hrf_rec_end(void);
-int hrf_replay(int program);
-int hrf_replay_free(int program);
-int hrf_replay_info(int program, int what);   /* what: 0 launches, 1 streams, 2 events; -1 on error */
+/* hipMemsetAsync on `stream` (the per-step zeroing of the replicated accumulators). */
 int hrf_memset(void* ptr, int value, long bytes, void* stream);
 
 #ifdef __cplusplus

@@ -91,6 +91,90 @@ def build_pair(tag, device, seed=0):
     return net, orc, cfg
 
 
+class PinnedReLU:
+    """Context manager that makes every ReLU of the ORACLE follow the product's sign decisions.
+
+    An fp32 pre-activation within rounding noise of 0 lands on either side of the ReLU in two correct fp32
+    implementations; each such "mask flip" changes the gradient inside one receptive field, which is why an un-pinned
+    fp32-vs-fp64 gradient comparison has outliers.  Instead of excusing outliers, the comparison is made
+    flip-free: the product records the sign mask of every ReLU it applied (runtime.collect_relu_masks), and while this
+    context is active `torch.nn.functional.relu` (reached by F.relu and nn.ReLU alike) returns `u * mask_product`.
+    The mask of a call is found by content: the recorded mask of the same shape that agrees best with (u > 0); the
+    agreement must be essentially total (<= max(4, 2e-3 * numel) differing elements), so a wrong pairing or a
+    genuinely different activation pattern fails the test instead of being pinned over.  `flips` counts the imposed
+    differences."""
+
+    def __init__(self, masks):
+        self.by_shape = {}
+        for m in masks:
+            self.by_shape.setdefault(tuple(m.shape), []).append(m.detach().cpu())
+        self.flips = 0
+        self.sites = 0
+
+    def _relu(self, u, inplace=False):
+        cands = self.by_shape.get(tuple(u.shape))
+        assert cands, f'no product ReLU site of shape {tuple(u.shape)}'
+        tgt = u.detach() > 0
+        best, bad = None, None
+        for m in cands:
+            d = int((m != tgt).sum())
+            if bad is None or d < bad:
+                best, bad = m, d
+        assert bad <= max(4, 2e-3 * tgt.numel()), f'ReLU site {tuple(u.shape)}: best product mask differs in {bad} elements'
+        self.flips += bad
+        self.sites += 1
+        return u * best.to(u.dtype)
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._orig = F.relu
+        F.relu = self._relu
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        F.relu = self._orig
+        return False
+
+
+def enable_relu_probe(net):
+    net.__dict__['_relu_probe'] = True
+
+
+def relu_masks(net):
+    return net.__dict__['_relu_masks']
+
+
+def tight_grad_gate(named_prod, named_ref64, named_ref32, tol=1e-3, tag=''):
+    """SURVEY 8c gate, per tensor: rel-L2 err(build, fp64) <= max(tol, 3 * e_ref[k]) with e_ref[k] = the oracle's own
+    fp32-vs-fp64 error on the same tensor (same pinned ReLU masks, so e_ref is rounding noise only).  No global
+    relaxation and no denominator padding.  Analytically-zero gradients (biases in front of a train-mode BatchNorm,
+    the key bias under the softmax: SURVEY App. E) are recognised by their fp64 norm (< 1e-9 of the largest gradient
+    norm) and gated absolutely: max|g| <= 1e-4 * max|g| over the whole net.  Returns (worst, n_above_tol)."""
+    pa, pb, pc = dict(named_prod), dict(named_ref64), dict(named_ref32)
+    ref = {k: v.grad.double() for k, v in pb.items() if v.grad is not None}
+    gmax = max(float(g.abs().max()) for g in ref.values())
+    nmax = max(float(g.norm()) for g in ref.values())
+    worst, above, zeros = (0.0, ''), 0, 0
+    for k, q in ref.items():
+        g = pa[k].grad
+        assert g is not None, k
+        g = g.detach().double().cpu()
+        if float(q.norm()) < 1e-9 * nmax:
+            zeros += 1
+            assert float(g.abs().max()) <= 1e-4 * gmax, (tag, k, 'analytically zero', float(g.abs().max()), gmax)
+            continue
+        den = float(q.norm())
+        e = float((g - q).norm()) / den
+        e_ref = float((pc[k].grad.double() - q).norm()) / den
+        above += e > tol
+        assert e <= max(tol, 3 * e_ref), (tag, k, e, e_ref)
+        worst = max(worst, (e, k))
+    print(f'[grad gate {tag}] {len(ref)} tensors, {zeros} analytically zero, worst rel-L2 {worst[0]:.2e} ({worst[1]}), '
+          f'{above} above {tol:g} (all within 3x the oracle\'s own fp32 error)')
+    return worst, above
+
+
 def grad_check(prod_named, orc_named, tol=1e-3, abs_frac=2e-3):
     """Per-tensor gradient gate: rel-L2 <= tol, with an absolute floor for analytically-zero
     gradients (k-bias, biases in front of a train-mode BN: SURVEY App. E)."""

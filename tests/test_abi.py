@@ -69,3 +69,41 @@ def test_state_dict_manifest(tag):
         assert list(sd[k].shape) == shape and str(sd[k].dtype) == 'torch.' + dt, k
     # optimizer paramwise rules of the reference key on these substrings
     assert any('relative_position_bias_table' in k for k in sd) and any('norm' in k for k in sd)
+
+
+def test_pretrained_and_init_cfg(tmp_path):
+    """hrnet.py:301-318: pretrained (str) == init_cfg Pretrained; both at once assert; non-str raises TypeError;
+    zero_init_residual is dead code in the reference (hrnet.py:480-481) and must not change the initialisation."""
+    from hrfuser_amd import build_backbone
+    cfg = load_cfgs()['t_nus']
+    torch.manual_seed(3)
+    src = build_backbone(copy.deepcopy(cfg))
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(torch.randn_like(p) * 0.01)
+    path = str(tmp_path / 'ckpt.pth')
+    torch.save({'state_dict': {'backbone.' + k: v for k, v in src.state_dict().items()}, 'meta': {}}, path)
+    c2 = copy.deepcopy(cfg)
+    c2['init_cfg'] = dict(type='Pretrained', checkpoint=path, prefix='backbone.')
+    a = build_backbone(c2)
+    for (k, p), (_, q) in zip(a.state_dict().items(), src.state_dict().items()):
+        assert torch.equal(p, q), k
+    plain = str(tmp_path / 'plain.pth')
+    torch.save(src.state_dict(), plain)
+    c3 = copy.deepcopy(cfg)
+    c3['pretrained'] = plain
+    with pytest.warns(UserWarning, match='pretrained is deprecated'):
+        b = build_backbone(c3)
+    assert all(torch.equal(p, q) for p, q in zip(b.state_dict().values(), src.state_dict().values()))
+    c4 = copy.deepcopy(c3)
+    c4['init_cfg'] = dict(type='Pretrained', checkpoint=plain)
+    with pytest.raises(AssertionError):
+        build_backbone(c4)
+    c5 = copy.deepcopy(cfg)
+    c5['pretrained'] = 5
+    with pytest.raises(TypeError):
+        build_backbone(c5)
+    c6 = copy.deepcopy(cfg)
+    c6['zero_init_residual'] = True
+    z = build_backbone(c6)
+    assert float(z.layer1[0].bn3.weight.min()) == 1.0          # norm3 NOT zeroed, as in the reference

@@ -12,29 +12,59 @@ TOL = 2e-5
 KC = _lib.STAT_COPIES      # cross-block accumulators are replicated (include/hrfuser_hip.h)
 
 
-def make_fin(C, count, dev, g):
-    """hrf_bn_fin_t + its buffers for the fused-finalize checks: (struct, dict of tensors)."""
-    t = dict(ticket=torch.zeros(KC + 1, dtype=torch.int32, device=dev), gamma=(torch.rand(C, generator=g) + 0.5).to(dev),
-             beta=torch.randn(C, generator=g).to(dev), rm=torch.randn(C, generator=g).to(dev),
-             rv=(torch.rand(C, generator=g) + 0.5).to(dev), scale=torch.zeros(C, device=dev), shift=torch.zeros(C, device=dev),
-             mean=torch.zeros(C, device=dev), invstd=torch.zeros(C, device=dev))
+def _rep_moments(rows, count, g, dev):
+    """[KC][2*C] doubles whose copies sum to `rows` * count (rows: [2, C] per-sample moments)."""
+    wts = torch.rand(KC, 1, 1, generator=g).double()
+    wts /= wts.sum()
+    return (wts * (rows.double() * count)[None]).reshape(-1).contiguous().to(dev)
+
+
+def make_fin(L, C, count, dev, g, write=1):
+    """hrf_bn_fin_t over synthetic replicated moments, its buffers, and the reference results of hrf_bn_finalize."""
+    mean = torch.randn(C, generator=g) * 0.3
+    var = torch.rand(C, generator=g) * 0.8 + 0.4
+    t = dict(stats=_rep_moments(torch.stack([mean, var + mean ** 2]), count, g, dev),
+             gamma=(torch.rand(C, generator=g) + 0.5).to(dev), beta=(torch.randn(C, generator=g) * 0.3).to(dev),
+             rm=torch.randn(C, generator=g).to(dev), rv=(torch.rand(C, generator=g) + 0.5).to(dev))
+    for k in ('scale', 'shift', 'mean', 'invstd'):
+        t[k] = torch.zeros(C, device=dev)
+        t['ref_' + k] = torch.zeros(C, device=dev)
+    t['ref_rm'], t['ref_rv'] = t['rm'].clone(), t['rv'].clone()
+    L.hrf_bn_finalize(t['stats'], t['gamma'], t['beta'], t['ref_rm'], t['ref_rv'], float(count), 1e-5, 0.1, 1,
+                      t['ref_scale'], t['ref_shift'], t['ref_mean'], t['ref_invstd'], C, _lib.stream_ptr())
     P = _lib._ptr
-    fin = _lib.BnFin(P(t['ticket']), P(t['gamma']), P(t['beta']), P(t['rm']), P(t['rv']), P(t['scale']), P(t['shift']),
-                     P(t['mean']), P(t['invstd']), float(count), 1e-5, 0.1, 1, C)
+    fin = _lib.BnFin(P(t['stats']), P(t['gamma']), P(t['beta']), P(t['rm']), P(t['rv']), P(t['scale']), P(t['shift']),
+                     P(t['mean']), P(t['invstd']), float(count), 1e-5, 0.1, 1, write, C)
     return fin, t
 
 
-def check_fin(L, stats, t, C, count):
-    """the fused finalize must equal hrf_bn_finalize run on the same moments (and leave the ticket at zero)"""
-    dev = stats.device
-    ref = {k: torch.zeros(C, device=dev) for k in ('scale', 'shift', 'mean', 'invstd')}
-    rm, rv = t['rm0'].clone(), t['rv0'].clone()
-    L.hrf_bn_finalize(stats, t['gamma'], t['beta'], rm, rv, float(count), 1e-5, 0.1, 1, ref['scale'], ref['shift'],
-                      ref['mean'], ref['invstd'], C, _lib.stream_ptr())
-    for k in ref:
-        assert r(t[k], ref[k]) < 1e-6, k
-    assert r(t['rm'], rm) < 1e-6 and r(t['rv'], rv) < 1e-6
-    assert int(t['ticket'].abs().sum()) == 0
+def check_fin(t):
+    """the designated writer block of an on-load finalize publishes exactly what hrf_bn_finalize computes"""
+    for k in ('scale', 'shift', 'mean', 'invstd', 'rm', 'rv'):
+        assert r(t[k], t['ref_' + k]) < 1e-6, k
+
+
+def make_bfin(L, C, count, dev, g, train=1):
+    """hrf_bn_bfin_t over synthetic replicated (sum du, sum du*y), and the reference results of hrf_bn_bwd_finalize."""
+    t = dict(gstats=_rep_moments(torch.randn(2, C, generator=g) * 0.2, count, g, dev),
+             gamma=(torch.rand(C, generator=g) + 0.5).to(dev), mean=(torch.randn(C, generator=g) * 0.3).to(dev),
+             invstd=(torch.rand(C, generator=g) + 0.7).to(dev),
+             dgamma=torch.randn(C, generator=g).to(dev), dbeta=torch.randn(C, generator=g).to(dev))
+    for k in ('cA', 'cB', 'cC'):
+        t[k] = torch.zeros(C, device=dev)
+        t['ref_' + k] = torch.zeros(C, device=dev)
+    t['ref_dgamma'], t['ref_dbeta'] = t['dgamma'].clone(), t['dbeta'].clone()
+    L.hrf_bn_bwd_finalize(t['gstats'], None, t['gamma'], t['mean'], t['invstd'], float(count), train, t['ref_dgamma'],
+                          t['ref_dbeta'], t['ref_cA'], t['ref_cB'], t['ref_cC'], C, _lib.stream_ptr())
+    P = _lib._ptr
+    bfin = _lib.BnBFin(P(t['gstats']), P(t['gamma']), P(t['mean']), P(t['invstd']), P(t['dgamma']), P(t['dbeta']),
+                       P(t['cA']), P(t['cB']), P(t['cC']), float(count), train, 1, C)
+    return bfin, t
+
+
+def check_bfin(t):
+    for k in ('cA', 'cB', 'cC', 'dgamma', 'dbeta'):
+        assert r(t[k], t['ref_' + k]) < 1e-6, k
 
 
 def zstat(C, dev):
@@ -96,7 +126,13 @@ def run_conv(case, backend):
     g = torch.Generator().manual_seed(sum(case[:7]))
     rn = lambda *s: torch.randn(*s, generator=g)
     xraw, w, bias = rn(B, Cin, H, W), rn(Cout, Cin, KH, KH) * 0.2, rn(Cout)
+    fin = ft = None
     sc, sh = torch.rand(Cin, generator=g) + 0.5, rn(Cin) * 0.3
+    if tf in (1, 2, 3):
+        # the input's BatchNorm is finalised ON LOAD from replicated moments (hrf_bn_fin_t): scale / shift are what
+        # hrf_bn_finalize derives from the same moments; the kernel gets no scale/shift arrays at all
+        fin, ft = make_fin(L, Cin, 977.0, dev, g)
+        sc, sh = ft['ref_scale'].cpu(), ft['ref_shift'].cpu()
     u, xt, rowstat = _tf_apply(xraw, tf, sc, sh)
     wq, bq = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
     y = F.conv2d(xt, wq, bq, stride, KH // 2)
@@ -109,11 +145,11 @@ def run_conv(case, backend):
     yk = torch.zeros(B, Ho, Wo, Cout, device=dev)
     stats = zstat(Cout, dev)
     lnrs = torch.zeros(B * Ho * Wo, 2, device=dev)      # fused LayerNorm row statistics of the output
-    fin, ft = make_fin(Cout, B * Ho * Wo, dev, g)
-    ft['rm0'], ft['rv0'] = ft['rm'].clone(), ft['rv'].clone()
     L.hrf_conv_fwd(D(xr), *st, B, H, W, Cin, D(w), D(bias), KH, stride, Cout, yk, Cout, 0, D(res), None, Cout,
-                   tf, D(sc) if tf else None, D(sh) if tf else None, D(rowstat), stats, fin, lnrs, 1e-6, _lib.stream_ptr())
-    check_fin(L, stats, ft, Cout, B * Ho * Wo)
+                   tf, D(sc) if (tf and fin is None) else None, D(sh) if (tf and fin is None) else None, D(rowstat), stats,
+                   fin, lnrs, 1e-6, _lib.stream_ptr())
+    if fin is not None:
+        check_fin(ft)
     yr_ = yref.reshape(-1, Cout)
     assert r(lnrs[:, 0], yr_.mean(-1)) < TOL and r(lnrs[:, 1], (yr_.var(-1, unbiased=False) + 1e-6).rsqrt()) < 1e-4
     assert r(yk, yref) < TOL
@@ -136,7 +172,7 @@ def run_conv(case, backend):
     dx = torch.zeros(B, H, W, Cin, device=dev)
     if epi:
         gst = zstat(Cin, dev)
-        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), *co, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 0, 1,
+        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), *co, None, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 0, 1,
                             D(xr), Cin, D(sc), D(sh), act, gst, _lib.stream_ptr())
         assert r(dx, gu) < TOL
         assert r(fold(gst)[:Cin], gu.reshape(-1, Cin).double().sum(0)) < TOL
@@ -144,9 +180,22 @@ def run_conv(case, backend):
     else:
         base = rn(B, H, W, Cin)
         dx.copy_(base)
-        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), *co, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 1, 0,
+        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), *co, None, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 1, 0,
                             None, 0, None, None, 0, None, _lib.stream_ptr())
         assert r(dx, gu + base) < TOL
+    if bnb:
+        # BatchNorm-backward coefficients derived ON LOAD (hrf_bn_bfin_t): same data gradient as with the coefficients
+        # hrf_bn_bwd_finalize computes from the same moments; block 0 publishes cA/cB/cC and adds dgamma / dbeta
+        bfin, bt = make_bfin(L, Cout, 811.0, dev, g)
+        dxa, dxb = torch.zeros(B, H, W, Cin, device=dev), torch.zeros(B, H, W, Cin, device=dev)
+        tail = (1, D(xr), Cin, D(sc), D(sh), act, zstat(Cin, dev)) if epi else (0, None, 0, None, None, 0, None)
+        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), bt['ref_cA'], bt['ref_cB'], bt['ref_cC'], None, D(w), KH, stride, Cout,
+                            B, H, W, Cin, dxa, *st, 0, *tail, _lib.stream_ptr())
+        tail = (1, D(xr), Cin, D(sc), D(sh), act, zstat(Cin, dev)) if epi else (0, None, 0, None, None, 0, None)
+        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), bt['cA'], bt['cB'], bt['cC'], bfin, D(w), KH, stride, Cout,
+                            B, H, W, Cin, dxb, *st, 0, *tail, _lib.stream_ptr())
+        check_bfin(bt)
+        assert r(dxb, dxa) < 1e-6
     dw, db = torch.zeros_like(w, device=dev), torch.zeros(Cout, device=dev)
     L.hrf_conv_bwd_weight(D(du), Cout, 0, D(yraw), *co, D(xr), *st, B, H, W, Cin, KH, stride, Cout, tf,
                           D(sc) if tf else None, D(sh) if tf else None, D(rowstat), dw, db, _lib.stream_ptr())
@@ -168,6 +217,10 @@ def run_dw(case, backend):
     xraw, w = rn(B, C, H, W), rn(C, 1, 3, 3) * 0.3
     b = rn(C) if has_bias else None
     sc, sh = torch.rand(C, generator=g) + 0.5, rn(C) * 0.3
+    fin = ft = None
+    if tf in (1, 2, 3):                      # input BatchNorm finalised on load, as in run_conv
+        fin, ft = make_fin(L, C, 977.0, dev, g)
+        sc, sh = ft['ref_scale'].cpu(), ft['ref_shift'].cpu()
     u, xt, _ = _tf_apply(xraw, tf, sc, sh)
     wq, bq = w.clone().requires_grad_(True), torch.zeros(C, requires_grad=True)
     y = F.conv2d(xt, wq, (b + bq) if has_bias else bq, S, 1, groups=C)
@@ -175,11 +228,10 @@ def run_dw(case, backend):
     yk = torch.zeros(B, Ho, Wo, C, device=dev)
     st = zstat(C, dev)
     xr = nhwc(xraw)
-    fin, ft = make_fin(C, B * Ho * Wo, dev, g)
-    ft['rm0'], ft['rv0'] = ft['rm'].clone(), ft['rv'].clone()
-    L.hrf_dwconv_fwd(D(xr), B, H, W, C, D(w), D(b), S, tf, D(sc) if tf else None, D(sh) if tf else None, yk, st,
-                     fin, _lib.stream_ptr())
-    check_fin(L, st, ft, C, B * Ho * Wo)
+    L.hrf_dwconv_fwd(D(xr), B, H, W, C, D(w), D(b), S, tf, D(sc) if (tf and fin is None) else None,
+                     D(sh) if (tf and fin is None) else None, yk, st, fin, _lib.stream_ptr())
+    if fin is not None:
+        check_fin(ft)
     yr = nhwc(y.detach())
     assert r(yk, yr) < TOL
     assert r(fold(st)[:C], yr.reshape(-1, C).double().sum(0)) < TOL and r(fold(st)[C:], (yr.reshape(-1, C).double() ** 2).sum(0)) < TOL
@@ -192,16 +244,25 @@ def run_dw(case, backend):
     dx = torch.zeros(B, H, W, C, device=dev)
     if epi:
         gst = zstat(C, dev)
-        L.hrf_dwconv_bwd_data(D(du), D(yraw), *co, D(w), S, B, H, W, C, dx, 0, 1, D(xr), D(sc), D(sh), act, gst,
+        L.hrf_dwconv_bwd_data(D(du), D(yraw), *co, None, D(w), S, B, H, W, C, dx, 0, 1, D(xr), D(sc), D(sh), act, gst,
                               _lib.stream_ptr())
         assert r(dx, gu) < TOL
         assert r(fold(gst)[C:], (gu.reshape(-1, C).double() * xr.reshape(-1, C).double()).sum(0)) < TOL
     else:
         base = rn(B, H, W, C)
         dx.copy_(base)
-        L.hrf_dwconv_bwd_data(D(du), D(yraw), *co, D(w), S, B, H, W, C, dx, 1, 0, None, None, None, 0, None,
+        L.hrf_dwconv_bwd_data(D(du), D(yraw), *co, None, D(w), S, B, H, W, C, dx, 1, 0, None, None, None, 0, None,
                               _lib.stream_ptr())
         assert r(dx, gu + base) < TOL
+    if bnb:                                  # coefficients derived on load (hrf_bn_bfin_t), as in run_conv
+        bfin, bt = make_bfin(L, C, 811.0, dev, g)
+        dxa, dxb = torch.zeros(B, H, W, C, device=dev), torch.zeros(B, H, W, C, device=dev)
+        L.hrf_dwconv_bwd_data(D(du), D(yraw), bt['ref_cA'], bt['ref_cB'], bt['ref_cC'], None, D(w), S, B, H, W, C, dxa, 0, 0,
+                              None, None, None, 0, None, _lib.stream_ptr())
+        L.hrf_dwconv_bwd_data(D(du), D(yraw), bt['cA'], bt['cB'], bt['cC'], bfin, D(w), S, B, H, W, C, dxb, 0, 0,
+                              None, None, None, 0, None, _lib.stream_ptr())
+        check_bfin(bt)
+        assert r(dxb, dxa) < 1e-6
     dw, db = torch.zeros_like(w, device=dev), torch.zeros(C, device=dev)
     L.hrf_dwconv_bwd_weight(D(du), D(yraw), *co, D(xr), B, H, W, C, S, tf, D(sc) if tf else None,
                             D(sh) if tf else None, dw, db, 0, _lib.stream_ptr())
@@ -292,8 +353,17 @@ def run_pointwise(backend):
     n = float(B * H * W)
     L.hrf_bn_finalize(st, D(bn.weight), D(bn.bias), rm, rv, n, 1e-5, 0.1, 1, sc, sh, mean, inv, C, s)
     o = torch.zeros(B, H, W, C, device=dev)
-    L.hrf_affine_act_res(D(y), sc, sh, None, None, None, None, None, 1, 1, 0, o, B * H * W, C, None, 0.0, s)
+    L.hrf_affine_act_res(D(y), sc, sh, None, None, None, None, None, 1, 1, 0, o, B * H * W, C, None, 0.0, None, None, s)
     assert r(o, out) < TOL and r(rm, bn.running_mean) < TOL and r(rv, bn.running_var) < TOL
+    # the same materialisation with BOTH BatchNorms finalised on load (Bottleneck tail: relu(bn3(y) + bn_ds(y2)))
+    f1, t1 = make_fin(L, C, 733.0, dev, g)
+    f2, t2 = make_fin(L, C, 733.0, dev, g)
+    y2 = rn(B, H, W, C)
+    o2 = torch.zeros(B, H, W, C, device=dev)
+    L.hrf_affine_act_res(D(y), None, None, D(y2), None, None, None, None, 1, 1, 0, o2, B * H * W, C, None, 0.0, f1, f2, s)
+    check_fin(t1)
+    check_fin(t2)
+    assert r(o2, F.relu(y * t1['ref_scale'].cpu() + t1['ref_shift'].cpu() + y2 * t2['ref_scale'].cpu() + t2['ref_shift'].cpu())) < TOL
     gk = torch.zeros(B, H, W, C, device=dev)
     gst = zstat(C, dev)
     L.hrf_act_bwd(D(gg), o, D(y), None, None, None, 1, 0, gk, None, None, gst, None, None, B * H * W, C, s)
@@ -303,9 +373,15 @@ def run_pointwise(backend):
     # ---- CrossFFN tail: res + rowscale*gelu(bn(y)) and its adjoint
     res, rs = rn(B, H, W, C), torch.tensor([0.0, 1.25])
     lnr = torch.zeros(B * H * W, 2, device=dev)
-    L.hrf_affine_act_res(D(y), sc, sh, None, None, None, D(res), D(rs), H * W, 2, 1, o, B * H * W, C, lnr, 1e-6, s)
+    L.hrf_affine_act_res(D(y), sc, sh, None, None, None, D(res), D(rs), H * W, 2, 1, o, B * H * W, C, lnr, 1e-6, None, None, s)
     ref = res + rs.view(B, 1, 1, 1) * F.gelu(y * sc.cpu() + sh.cpu())
     assert r(o, ref) < TOL
+    f3, t3 = make_fin(L, C, 733.0, dev, g)           # CrossFFN tail with BN3 finalised on load
+    o3_, lnr3 = torch.zeros(B, H, W, C, device=dev), torch.zeros(B * H * W, 2, device=dev)
+    L.hrf_affine_act_res(D(y), None, None, None, None, None, D(res), D(rs), H * W, 2, 1, o3_, B * H * W, C, lnr3, 1e-6, f3, None, s)
+    check_fin(t3)
+    ref3_ = res + rs.view(B, 1, 1, 1) * F.gelu(y * t3['ref_scale'].cpu() + t3['ref_shift'].cpu())
+    assert r(o3_, ref3_) < TOL and r(lnr3[:, 0], ref3_.reshape(-1, C).mean(-1)) < TOL
     rr_ = ref.reshape(-1, C)
     assert r(lnr[:, 0], rr_.mean(-1)) < TOL and r(lnr[:, 1], (rr_.var(-1, unbiased=False) + 1e-6).rsqrt()) < 1e-4
     uq = (y * sc.cpu() + sh.cpu()).requires_grad_(True)
@@ -363,8 +439,21 @@ def run_pointwise(backend):
     ref.backward(gg)
     o = torch.zeros(B, H, W, C, device=dev)
     L.hrf_fuse_sum(1, D(x0), None, None, 0, 0, 3, D(ylo), D(scs[0]), D(shs[0]), 6, 10, 3, D(ylo2), D(scs[1]),
-                   D(shs[1]), 3, 5, 2, D(ysame), D(scs[2]), D(shs[2]), 0, 0, o, B, H, W, C, s)
+                   D(shs[1]), 3, 5, 2, D(ysame), D(scs[2]), D(shs[2]), 0, 0, o, B, H, W, C, None, s)
     assert r(o, ref) < TOL
+    # terms 1 and 3 with their BatchNorms finalised on load (an array of four hrf_bn_fin_t)
+    fa, ta = make_fin(L, C, 611.0, dev, g)
+    fb, tb = make_fin(L, C, 611.0, dev, g)
+    fins = (_lib.BnFin * 4)()
+    fins[1], fins[3] = fa, fb
+    of = torch.zeros(B, H, W, C, device=dev)
+    L.hrf_fuse_sum(1, D(x0), None, None, 0, 0, 3, D(ylo), None, None, 6, 10, 3, D(ylo2), D(scs[1]),
+                   D(shs[1]), 3, 5, 2, D(ysame), None, None, 0, 0, of, B, H, W, C, fins, s)
+    check_fin(ta)
+    check_fin(tb)
+    reff = F.relu(x0 + up(ylo, ta['ref_scale'].cpu(), ta['ref_shift'].cpu()) + up(ylo2, scs[1], shs[1])
+                  + (ysame * tb['ref_scale'].cpu() + tb['ref_shift'].cpu()))
+    assert r(of, reff) < TOL
     gk = torch.zeros(B, H, W, C, device=dev)
     st3 = zstat(C, dev)
     L.hrf_act_bwd(D(gg), o, D(ysame), None, None, None, 1, 0, gk, None, None, st3, None, None, B * H * W, C, s)
@@ -385,7 +474,7 @@ def run_pointwise(backend):
     o3 = torch.zeros(1, 15, 7, C, device=dev)
     one, zero = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     L.hrf_fuse_sum(3, D(ylo3), one, zero, 8, 4, 0, None, None, None, 0, 0, 0, None, None, None, 0, 0, 0, None, None,
-                   None, 0, 0, o3, 1, 15, 7, C, s)
+                   None, 0, 0, o3, 1, 15, 7, C, None, s)
     assert r(o3, F.relu(ref3)) < TOL and r(du3, ylo3.grad) < TOL
     # ---- AdamW vs torch.optim.AdamW (3 steps, device-side step counter)
     n = 1000

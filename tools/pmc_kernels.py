@@ -27,7 +27,7 @@ for it in range(4):
     L.hrf_conv_bwd_weight(dy18,18,0,yr18,*c18,x72,H*W*72,W*72,72,1,B,H,W,72,1,1,18,3,s72,s72,None,dw3,None,sp())
     L.hrf_conv_bwd_weight(dy,Cout,0,yr,cA,cB,cC,x,H*W*Cin,W*Cin,Cin,1,B,H,W,Cin,3,1,Cout,2,sc,sh,None,dw,None,sp())
     L.hrf_conv_fwd(x,H*W*Cin,W*Cin,Cin,1,B,H,W,Cin,w,None,3,1,Cout,y,Cout,0,None,None,0,2,sc,sh,None,st,None,None,0.0,sp())
-    L.hrf_conv_bwd_data(dy,Cout,0,yr,cA,cB,cC,w,3,1,Cout,B,H,W,Cin,dx,H*W*Cin,W*Cin,Cin,1,0,1,x,Cin,sc,sh,1,st,sp())
+    L.hrf_conv_bwd_data(dy,Cout,0,yr,cA,cB,cC,None,w,3,1,Cout,B,H,W,Cin,dx,H*W*Cin,W*Cin,Cin,1,0,1,x,Cin,sc,sh,1,st,sp())
     L.hrf_window_attn_fwd(qkv,3*C,0,qkv,3*C,C,qkv,3*C,2*C,bq[C:2*C],bq[2*C:],Tt,o,C,B,H,W,C,1,sp())
     L.hrf_window_attn_bwd(qkv,3*C,0,qkv,3*C,C,qkv,3*C,2*C,bq[C:2*C],bq[2*C:],Tt,o,C,dqkv,3*C,0,dqkv,3*C,C,dqkv,3*C,2*C,dbq[C:2*C],dbq[2*C:],dT,0,B,H,W,C,1,sp())
     L.hrf_conv_bwd_weight(dy72,72,0,yr72,*c72,x18,H*W*18,W*18,18,1,B,H,W,18,1,1,72,4,s18,s18,rs,dw2,None,sp())
