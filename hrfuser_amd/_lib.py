@@ -22,28 +22,38 @@ def _header_int(name, default):
 STAT_COPIES = _header_int('HRF_STAT_COPIES', 16)   # replication of cross-block accumulators (see header)
 FIN_MAXC = _header_int('HRF_FIN_MAXC', 576)        # widest BatchNorm the consumer kernels finalise on load
 
-class BnFin(ctypes.Structure):
-    """hrf_bn_fin_t (include/hrfuser_hip.h): BatchNorm of a consumer's input finalised on load."""
-    _fields_ = [('stats', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
-                ('running_mean', ctypes.c_void_p), ('running_var', ctypes.c_void_p), ('scale', ctypes.c_void_p),
-                ('shift', ctypes.c_void_p), ('mean', ctypes.c_void_p), ('invstd', ctypes.c_void_p),
-                ('count', ctypes.c_double), ('eps', ctypes.c_float), ('momentum', ctypes.c_float),
-                ('update_running', ctypes.c_int), ('write', ctypes.c_int), ('C', ctypes.c_int)]
+def struct_from_header(tag, path=HEADER):
+    """ctypes mirror of `typedef struct <tag> {...} <tag>_t;` in the public header (the header is the single source of
+    truth for field order and types: pointers -> c_void_p, int / long / float / double by value)."""
+    src = re.sub(r'/\*.*?\*/', '', open(path).read(), flags=re.S)
+    m = re.search(r'typedef\s+struct\s+' + tag + r'\s*\{(.*?)\}\s*' + tag + r'_t\s*;', src, flags=re.S)
+    if not m:
+        raise KeyError(tag)
+    fields = []
+    for decl in m.group(1).split(';'):
+        decl = ' '.join(decl.split())
+        if not decl:
+            continue
+        if '*' in decl:
+            ct, names = ctypes.c_void_p, [re.findall(r'(\w+)$', decl)[0]]
+        else:
+            base, rest = decl.split(' ', 1)
+            ct = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'double': ctypes.c_double}[base]
+            names = [n.strip() for n in rest.split(',')]
+        fields += [(n, ct) for n in names]
+    return type(tag, (ctypes.Structure,), {'_fields_': fields})
 
 
-class BnBFin(ctypes.Structure):
-    """hrf_bn_bfin_t: BatchNorm-backward coefficients derived on load by the producing convolution's data gradient."""
-    _fields_ = [('gstats', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('mean', ctypes.c_void_p),
-                ('invstd', ctypes.c_void_p), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p),
-                ('cA', ctypes.c_void_p), ('cB', ctypes.c_void_p), ('cC', ctypes.c_void_p),
-                ('count', ctypes.c_double), ('train', ctypes.c_int), ('write', ctypes.c_int), ('C', ctypes.c_int)]
+BnFin = struct_from_header('hrf_bn_fin')            # BatchNorm of a consumer's input finalised on load
+BnBFin = struct_from_header('hrf_bn_bfin')          # BatchNorm-backward coefficients derived on load
+AttnBlock = struct_from_header('hrf_attn_block')    # fused window-attention block (csrc/attn_block.hip)
 
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_RAW_RETURN = ('hrf_conv3_wgrad_wide_scratch', 'hrf_wgrad_group_report')       # return a value, not a status
+_RAW_RETURN = ('hrf_conv3_wgrad_wide_scratch', 'hrf_wgrad_group_report', 'hrf_attn_block_supported', 'hrf_attn_block_bwd_supported')       # return a value, not a status
 _ERR = {1: 'HRF_ERR_ARG (bad argument)', 2: 'HRF_ERR_LAUNCH (kernel launch failed)'}
 
 

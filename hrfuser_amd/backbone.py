@@ -70,6 +70,7 @@ class Engine:
         self.slots = {}
         self._bns = []
         self.keep = []                 # step-lifetime buffers of THIS engine (runtime.use_keep_list)
+        self.fs_layers, self.fs_step, self.fs_used, self.fs_sig, self.fs_arena = {}, [], [], None, None
 
     def ready(self, device):
         params = [p for p in self.root.parameters()]
@@ -148,6 +149,8 @@ class Engine:
         # parameter gradients that MANY blocks add into (LayerNorm gamma/beta, depthwise weights/bias)
         # accumulate in K replicated fp32 copies and are folded into the arena once per backward
         offs = {id(p): o for p, (o, _) in zip(params, self._spans)}
+        self._poffs = offs
+        self.fs_layers, self.fs_sig = {}, None
         self.pslot, cols, ps = {}, [], 0
         for m in self.root.modules():
             hit = isinstance(m, nn.LayerNorm) or (isinstance(m, nn.Conv2d) and m.groups == m.in_channels and m.groups > 1)
@@ -182,11 +185,62 @@ class Engine:
         return self.ps_scratch[o:o + p.numel()], self.ps_n
 
     def fold_grads(self, L, stream):
-        """Sum the replicated accumulators into the gradient arena (one launch per backward)."""
+        """Sum the replicated accumulators and the per-window slots of the fused attention blocks into the gradient
+        arena (one launch each per backward)."""
         if self.ps_dirty and self.ps_n:
             L.hrf_fold_copies(self.ps_scratch, self.ps_n, self.ps_map, self.flat_g, self.ps_n, stream)
             R.gpu_zero_(self.ps_scratch)
         self.ps_dirty = False
+        if self.fs_used:
+            L.hrf_fold_slots(self.fs_arena, self.fs_seg, len(self.fs_used), self.fs_map, self.flat_g, self.fs_maxn, stream)
+            self.fs_used = []
+
+    # ---- parameter-gradient slots of the fused attention blocks (runtime.attn_block): every window's workgroup writes
+    # the complete partial sums of its window with plain stores (no atomics, deterministic), hrf_fold_slots adds them up
+    def fs_register(self, key, nslots, entries):
+        """Called by the forward of a fused layer: slot layout {name: offset, '_n': slot size} of layer `key`;
+        entries = [(name, parameter, first element, count)]."""
+        lay = self.fs_layers.get(key)
+        if lay is None or lay['nslots'] != nslots:
+            offs, idx, o = {}, [], 0
+            for name, p, first, cnt in entries:
+                offs[name] = o
+                base = self._poffs.get(id(p))
+                idx.append(torch.arange(base + first, base + first + cnt, dtype=torch.int32) if (base is not None and p.requires_grad)
+                           else torch.full((cnt,), -1, dtype=torch.int32))
+                o += cnt
+            offs['_n'] = o
+            lay = self.fs_layers[key] = dict(nslots=nslots, offs=offs, map=torch.cat(idx), n=o)
+            self.fs_sig = None
+        self.fs_step.append(key)
+        return lay['offs']
+
+    def fs_prepare(self):
+        """Start of a backward pass: place the slots of every fused layer of this step in one arena and build the
+        segment table of hrf_fold_slots (cached while the set of layers does not change)."""
+        keys = tuple(self.fs_step)
+        self.fs_step = []
+        self.fs_used = list(keys)
+        if not keys or keys == self.fs_sig:
+            return
+        seg, maps, off, moff = [], [], 0, 0
+        self.fs_off = {}
+        for k in keys:
+            lay = self.fs_layers[k]
+            self.fs_off[k] = off
+            seg.append([off, lay['nslots'], lay['n'], lay['n'], moff])
+            maps.append(lay['map'])
+            off += lay['nslots'] * lay['n']
+            moff += lay['n']
+        if self.fs_arena is None or self.fs_arena.numel() < off:
+            self.fs_arena = torch.empty(off, device=self.device, dtype=torch.float32)
+        self.fs_seg = torch.tensor(seg, dtype=torch.long).to(self.device)
+        self.fs_map = torch.cat(maps).to(self.device)
+        self.fs_maxn = max(self.fs_layers[k]['n'] for k in keys)
+        self.fs_sig = keys
+
+    def fs_buffer(self, key):
+        return self.fs_arena.data_ptr() + 4 * self.fs_off[key]
 
     # ---- per-step random pools: ONE Bernoulli launch (per drop probability) and one DropPath draw per step
     # instead of one torch RNG kernel chain per fusion block (every graph node costs ~5 us of host time)
@@ -238,6 +292,7 @@ class Engine:
     def begin_forward(self, training, pre=True):
         R.use_keep_list(self.keep)
         R.release_step_buffers()
+        self.fs_step = []
         if pre:
             self.pre_step(training)
         else:
@@ -364,8 +419,12 @@ class CrossFFN(nn.Module):
 
     def run(self, ctx, ln_in):
         l = self.layers
-        h = R.conv_bn(ctx, ln_in, l[0], l[1], R.TF_GELU)
-        h = R.dwconv_bn(ctx, h, l[3], l[4], R.TF_GELU)
+        return self.run_tail(ctx, R.conv_bn(ctx, ln_in, l[0], l[1], R.TF_GELU))
+
+    def run_tail(self, ctx, h1):
+        """Everything after the 1x1 expansion (+BN+GELU, `h1`): the fused attention block produces h1 itself."""
+        l = self.layers
+        h = R.dwconv_bn(ctx, h1, l[3], l[4], R.TF_GELU)
         return R.conv_bn(ctx, h, l[6], l[7], R.TF_GELU)
 
 
@@ -425,6 +484,16 @@ class HRFormerBlock(nn.Module):
             # mmcv DropPath: per-sample floor(keep + U[0,1)) / keep, drawn independently for the two residual paths
             eng = ctx.owner._engine()
             s1, s2 = eng.droppath_scale(x.t.shape[0], p), eng.droppath_scale(x.t.shape[0], p)
+        msa = self.attn.attn
+        C = x.t.shape[-1]
+        if R.attn_block_ok(ctx, C, msa.num_heads) and self.ffn.layers[0].weight.shape[0] == 4 * C:
+            # one launch: norm1 -> qkv -> window attention -> out_proj -> residual -> norm2 -> CrossFFN 1x1 expansion
+            x, h1 = R.attn_block(ctx, id(self), msa.num_heads, x, x, self.norm1, self.norm1, (msa.qkv, 0), (msa.qkv, C),
+                                 (msa.qkv, 2 * C), msa.relative_position_bias_table, msa.out_proj, x,
+                                 drop=None if s1 is None else (None, 1.0, s1),
+                                 ffn=(self.norm2, self.ffn.layers[0], self.ffn.layers[1]))
+            tail = self.ffn.run_tail(ctx, h1)
+            return R.materialize(ctx, tail, R.ACT_GELU, res=x, act_first=True, rowscale=s2)
         x = self.attn.run(ctx, x, self.norm1, drop=None if s1 is None else (None, 1.0, s1))
         tail = self.ffn.run(ctx, R.ln_input(ctx, x, self.norm2))
         return R.materialize(ctx, tail, R.ACT_GELU, res=x, act_first=True, rowscale=s2)
@@ -509,7 +578,30 @@ class HRFuserFusionBlock(nn.Module):
         dev = x.t.device
         cache = {}
         acc = x
-        for k in range(self.num_fused_modalities):
+        M = self.num_fused_modalities
+        C = x.t.shape[-1]
+        heads = self.attn[0].attn.num_heads
+        if R.attn_block_ok(ctx, C, heads) and self.ffn.layers[0].weight.shape[0] == 4 * C:
+            # one launch per modality: norm1[k] / norm2[k] -> q / k / v -> window cross-attention -> out_proj -> Dropout ->
+            # DropPath -> + z_k + running sum; the last one also runs norm3 and the CrossFFN 1x1 expansion
+            h1 = None
+            for k in range(M):
+                a = self.attn[k].attn
+                z = mods[k]
+                dps = self._droppath_scale(ctx, B, dev)
+                p = a.proj_drop.p
+                drop = None
+                if ctx.training and a.proj_drop.training and (p > 0 or dps is not None):
+                    mask = ctx.owner._engine().dropout_mask(tuple(x.t.shape), p) if p > 0 else None
+                    drop = (mask, 1.0 / (1.0 - p) if p > 0 else 1.0, dps)
+                acc, h1 = R.attn_block(ctx, (id(self), k), heads, x, z, self.norm1[k], self.norm2[k], (a.q_proj, 0),
+                                       (a.k_proj, 0), (a.v_proj, 0), a.relative_position_bias_table, a.out_proj, acc,
+                                       res2=z, drop=drop,
+                                       ffn=(self.norm3, self.ffn.layers[0], self.ffn.layers[1]) if k == M - 1 else None)
+            tail = self.ffn.run_tail(ctx, h1)
+            return R.materialize(ctx, tail, R.ACT_GELU, res=acc, act_first=True,
+                                 rowscale=self._droppath_scale(ctx, B, dev))
+        for k in range(M):
             z = mods[k]
             q_in = R.ln_input(ctx, x, self.norm1[k], cache)      # every modality queries the PRE-fusion camera
             kv_in = R.ln_input(ctx, z, self.norm2[k])

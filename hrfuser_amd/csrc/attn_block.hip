@@ -1,0 +1,1030 @@
+// Fused window-attention block (gfx950, fp32): the WHOLE token-local half of an HRFormerBlock / fusion block in ONE
+// launch per direction, one 256-thread workgroup per 7x7 window:
+//
+//   forward   x' = res (+ res2) + drop( out_proj( softmax(q k^T d^-1/2 + RPB) v ) ),   q = LN_q(xq) Wq^T + bq,
+//                                                                                      k,v = LN_kv(xkv) W{k,v}^T + b{k,v}
+//             and, optionally, the head of the CrossFFN that follows:  h1 = LN_2(x') W1^T + b1  (+ BatchNorm moments of h1)
+//
+// Replaces, for one HRFormerBlock (hrformer.py:365-373): norm1 (:343) -> LocalWindowSelfAttention.forward (:184-236:
+// centre zero-pad, window partition) -> WindowMSA.forward (:96-131: qkv Linear, q k^T + relative position bias, softmax,
+// attn v, out_proj) -> window merge / de-pad -> residual add (:369) -> norm2 (:351) -> CrossFFN.layers[0] (:268, the 1x1
+// expansion convolution);  for one modality of a fusion block (hrfuser_hrformer_based.py:305-317): norm1[k] / norm2[k]
+// (:279-280) -> MultiWindowCrossAttention.forward (:189-248) -> WindowMCA.forward (:106-151: q/k/v Linear, attention,
+// out_proj, Dropout) -> DropPath + the two residual adds (:311-313) and, after the last modality, norm3 (:291) + the
+// CrossFFN head.  Everything is local to a window except the CrossFFN's BatchNorm, so nothing but x' (and h1) ever
+// leaves the chip: q / k / v / the attention output live in LDS, LayerNorm rows and softmax rows in registers.
+//
+// Layout: four token-major LDS tiles [64][C+1] (49 tokens padded to 64): X (source rows -> LayerNorm'd rows -> x' -> LN_2
+// rows), Q (scaled q -> attention output), K, V.  Every GEMM is "rows of W x this wave's 16 tokens" on
+// v_mfma_f32_16x16x4_f32: the A fragment comes straight from the (L2-resident) weight matrix with one 16-byte load per
+// four MFMAs (k permuted identically on both operands, as in lin_engine.hip), the B fragment from the LDS tile; wave w
+// owns tokens 16w..16w+15 for the projections and queries 16w..16w+15 for the attention core (which is the MFMA core of
+// attention.hip reading head h at column offset h*D).  Tokens outside the image are exact zeros AFTER LayerNorm in the
+// reference, i.e. their q/k/v equal the projection biases: the LDS rows are zeroed, the GEMM does the rest.
+#include "hrf_common.h"
+#include "../../include/hrfuser_hip.h"
+
+namespace {
+
+constexpr int NTOK = 49;
+
+__device__ float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+
+// 4 consecutive elements p[off..off+3], `nvalid` of them exist (<= 0: none); full = the whole 16-wide group row is valid
+__device__ __forceinline__ hrf_f4 ld_sel(bool full, const float* p, long off, int nvalid) {
+  if (full) return hrf_ld4(nvalid > 0 ? p + off : g_zero4);
+  hrf_f4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = *(e < nvalid ? p + off + e : g_zero4);
+  return r;
+}
+
+__device__ __forceinline__ int ab_tok_pixel(const hrf_attn_block_t& a, int b, int wy, int wx, int t) {
+  const int ty = t / 7, tx = t - 7 * ty;
+  const int py = wy * 7 + ty - a.pt, px = wx * 7 + tx - a.pl;
+  if ((unsigned)py < (unsigned)a.H && (unsigned)px < (unsigned)a.W) return (b * a.H + py) * a.W + px;
+  return -1;
+}
+
+// acc[t] (t < NT) += W[n0 + 16t + i][.] . rows[tok0 + j][.] over K: D[n][token], lane (j, q) ends up holding the four
+// output channels n0 + 16t + 4q + r of token tok0 + j.  W is [N][K] row-major in global memory, rows an LDS tile.
+template <int K, int NT>
+__device__ __forceinline__ void wave_gemm(const float* W, int n0, int N, const float* rows, int pitch, int tok0, int lane,
+                                          hrf_f4* acc) {
+  const int i = lane & 15, q = lane >> 4;
+  constexpr int NS = (K + 15) / 16;
+  const float* brow = rows + (tok0 + i) * pitch;
+#pragma unroll 2
+  for (int s = 0; s < NS; ++s) {
+    const int kbase = 16 * s + 4 * q, kval = K - kbase;
+    const bool kfull = 16 * (s + 1) <= K;
+    hrf_f4 wv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + 16 * t + i;
+      wv[t] = ld_sel(kfull, W, (long)n * K + kbase, n < N ? kval : 0);
+    }
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = r < kval ? brow[kbase + r] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = hrf_mfma16(wv[t][r], bv[r], acc[t]);
+  }
+}
+
+// bias rows into the accumulators (D = A*B + C): acc[t][r] = bias[n0 + 16t + 4q + r]
+template <int NT>
+__device__ __forceinline__ void acc_bias(const float* bias, int n0, int N, int lane, hrf_f4* acc) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int nb = n0 + 16 * t + 4 * q;
+    acc[t] = ld_sel(n0 + 16 * (t + 1) <= N, bias, nb, bias != nullptr ? N - nb : 0);
+  }
+}
+
+// Stage the 49 rows of a window (zeros for tokens outside the image and for rows 49..63) and LayerNorm them in place.
+// Four lanes cooperate on one token; all global loads of a thread are issued before its first LDS store.
+template <int C>
+__device__ __forceinline__ void stage_ln_rows(const hrf_attn_block_t& a, const float* x, const float* gam, const float* bet,
+                                              int b, int wy, int wx, float* sX, const int* sPix) {
+  constexpr int PC = C + 1;
+  constexpr int NE = (NTOK * C + 255) / 256;
+  float v[NE];
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    const int ec = e < NTOK * C ? e : 0;
+    const int j = ec / C, c = ec - j * C;
+    const int pix = sPix[j];
+    const float x0 = x[(long)(pix >= 0 ? pix : 0) * C + c];
+    v[u] = pix >= 0 ? x0 : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    if (e < NTOK * C) { const int j = e / C; sX[j * PC + (e - j * C)] = v[u]; }
+  }
+  __syncthreads();
+  const int t = threadIdx.x >> 2, part = threadIdx.x & 3;           // token, quarter of its channels
+  const float* row = sX + t * PC;
+  float s = 0.f;
+  for (int c = part; c < C; c += 4) s += row[c];
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+  const float mean = s / (float)C;
+  float q = 0.f;
+  for (int c = part; c < C; c += 4) { const float d = row[c] - mean; q = fmaf(d, d, q); }
+  q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
+  const float rstd = 1.0f / sqrtf(q / (float)C + a.ln_eps);
+  const bool real = sPix[t] >= 0;                                   // (rows 49..63 and out-of-image tokens stay zero)
+  float* wrow = sX + t * PC;
+  for (int c = part; c < C; c += 4) wrow[c] = real ? fmaf((row[c] - mean) * rstd, gam[c], bet[c]) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------- forward
+template <int C, int HEADS>
+__global__ __launch_bounds__(256) void attn_block_fwd_kernel(hrf_attn_block_t a) {
+  constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16;
+  constexpr int KSD = (D + 3) / 4, DT = (D + 15) / 16;
+  constexpr int TILE = 64 * PC;
+  HRF_DYN_SMEM(float, smem);
+  float* sX = smem;                       // source rows -> LayerNorm'd rows -> x' -> LN_2(x')
+  float* sQ = sX + TILE;                  // scaled q -> attention output o
+  float* sK = sQ + TILE;
+  float* sV = sK + TILE;                  // (+32 floats of slack behind it: V fragments are read 16 columns wide)
+  float* sT = sV + TILE + 32;             // [HEADS][176] relative position bias of every head
+  float* sStat = sK;                      // [4][2][4C] BatchNorm moments of h1 per wave: aliases K / V once attention is done
+  __shared__ int sPix[64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int win = blockIdx.x;
+  const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
+  if (tid < 64) sPix[tid] = tid < NTOK ? ab_tok_pixel(a, b, wy, wx, tid) : -1;
+  for (int e = tid; e < 64 * PC; e += 256) sX[e] = 0.f;
+  for (int e = tid; e < HEADS * 176; e += 256) {
+    const int h = e / 176, k = e - h * 176;
+    sT[e] = k < 169 ? a.rpb[k * HEADS + h] : 0.f;
+  }
+  if (tid < 32) sV[TILE + tid] = 0.f;
+  if (tid < 64) { sQ[tid * PC + C] = 0.f; sK[tid * PC + C] = 0.f; sV[tid * PC + C] = 0.f; }   // pitch column: read (masked) by the last k-step
+  __syncthreads();
+  const int tok0 = 16 * wave;
+
+  // ---- projections: q from the query source, k / v from the key-value source (the same rows for self-attention)
+  stage_ln_rows<C>(a, a.xq, a.lnq_g, a.lnq_b, b, wy, wx, sX, sPix);
+  __syncthreads();
+  {
+    hrf_f4 acc[CT];
+    acc_bias<CT>(a.bq, 0, C, lane, acc);
+    wave_gemm<C, CT>(a.wq, 0, C, sX, PC, tok0, lane, acc);
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) sQ[(tok0 + i) * PC + n] = acc[t][r] * a.scale; }
+  }
+  if (a.xkv != a.xq) {                                               // (uniform) cross-attention: re-stage the tile
+    __syncthreads();
+    stage_ln_rows<C>(a, a.xkv, a.lnkv_g, a.lnkv_b, b, wy, wx, sX, sPix);
+    __syncthreads();
+  }
+  {
+    hrf_f4 acc[CT];
+    acc_bias<CT>(a.bk, 0, C, lane, acc);
+    wave_gemm<C, CT>(a.wk, 0, C, sX, PC, tok0, lane, acc);
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) sK[(tok0 + i) * PC + n] = acc[t][r]; }
+    acc_bias<CT>(a.bv, 0, C, lane, acc);
+    wave_gemm<C, CT>(a.wv, 0, C, sX, PC, tok0, lane, acc);
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) sV[(tok0 + i) * PC + n] = acc[t][r]; }
+  }
+  __syncthreads();
+
+  // ---- attention core per head (attention.hip's MFMA formulation on the packed tiles): S^T tiles, softmax over the
+  // query's 49 keys in registers, O = P V with P already in A-operand position; o overwrites the wave's own q rows
+  {
+    const int qi = tok0 + i, qc = qi < NTOK ? qi : 0;
+    const int yi = qc / 7, xi = qc - 7 * yi;
+#pragma unroll 1
+    for (int h = 0; h < HEADS; ++h) {
+      hrf_f4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+      const float* qrow = sQ + (tok0 + i) * PC + h * D + q;
+      const float* krow = sK + i * PC + h * D + q;
+#pragma unroll
+      for (int kk = 0; kk < KSD; ++kk) {
+        const float qv = (4 * kk + q < D) ? qrow[4 * kk] : 0.f;      // columns >= D belong to the next head
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = hrf_mfma16(krow[16 * t * PC + 4 * kk], qv, acc[t]);
+      }
+      const float* bias = sT + h * 176;
+      float m = -3.0e38f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * t + 4 * q + r, jc = j < NTOK ? j : 0;
+          const int yj = jc / 7, xj = jc - 7 * yj;
+          const float sv = j < NTOK ? acc[t][r] + bias[(yi - yj + 6) * 13 + (xi - xj + 6)] : -3.0e38f;
+          acc[t][r] = sv;
+          m = fmaxf(m, sv);
+        }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float p = __expf(acc[t][r] - m); acc[t][r] = p; l += p; }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      hrf_f4 o[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* vrow = sV + (16 * t + 4 * q + r) * PC + h * D + i;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_mfma16(acc[t][r], vrow[16 * dt], o[dt]);
+        }
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float invr = __shfl(inv, 4 * q + r);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = 16 * dt + i;
+          if (d < D) sQ[(tok0 + 4 * q + r) * PC + h * D + d] = o[dt][r] * invr;
+        }
+      }
+    }
+  }
+
+  // ---- out_proj + dropout / droppath + residual(s): x' leaves as 16-byte stores, and stays in the accumulators
+  HRF_WAVE_SYNC();                                                  // o rows were stored by other lanes of this wave
+  const int tok = tok0 + i;
+  const int pix = sPix[tok];
+  const long pc = pix >= 0 ? pix : 0;
+  hrf_f4 xo[CT];
+  acc_bias<CT>(a.bo, 0, C, lane, xo);
+  wave_gemm<C, CT>(a.wo, 0, C, sQ, PC, tok0, lane, xo);
+  {
+    const float rs = (a.rowscale != nullptr ? a.rowscale[pc / a.rows_per_sample] : 1.f) * a.mscale;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int nb = 16 * t + 4 * q, nval = C - nb;
+      const bool nfull = 16 * (t + 1) <= C;
+      const hrf_f4 r1 = ld_sel(nfull, a.res, pc * C + nb, nval);
+      const hrf_f4 r2 = ld_sel(nfull, a.res2, pc * C + nb, a.res2 != nullptr ? nval : 0);
+      const hrf_f4 mk = ld_sel(nfull, a.mask, pc * C + nb, a.mask != nullptr ? nval : 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float y = xo[t][r] * rs;
+        if (a.mask != nullptr) y *= mk[r];
+        xo[t][r] = (r1[r] + r2[r]) + y;
+      }
+      if (pix >= 0) {
+        float* dst = a.out + pc * C + nb;
+        if (nfull) hrf_st4(dst, xo[t]);
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (r < nval) dst[r] = xo[t][r];
+        }
+      }
+    }
+  }
+  if (a.w1 == nullptr && a.out_rowstat == nullptr) return;          // (uniform)
+
+  // ---- LayerNorm statistics of the x' row (its C channels live in lanes j, j+16, j+32, j+48), two-pass as ln_stats
+  float sm = 0.f;
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sm += (16 * t + 4 * q + r < C) ? xo[t][r] : 0.f;
+  sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+  const float mu = sm / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float dd = (16 * t + 4 * q + r < C) ? xo[t][r] - mu : 0.f; sq = fmaf(dd, dd, sq); }
+  sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + a.out_eps);
+  if (a.out_rowstat != nullptr && q == 0 && pix >= 0) { a.out_rowstat[2 * pc] = mu; a.out_rowstat[2 * pc + 1] = rstd; }
+  if (a.w1 == nullptr) return;                                      // (uniform)
+
+  // ---- CrossFFN head: h1 = LN_2(x') W1^T + b1 over the wave's own rows of the X tile, BatchNorm moments of h1
+  __syncthreads();                                                  // every wave is done with K / V (sStat aliases them)
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int nb = 16 * t + 4 * q;
+    const hrf_f4 g2 = ld_sel(16 * (t + 1) <= C, a.ln2_g, nb, C - nb), b2 = ld_sel(16 * (t + 1) <= C, a.ln2_b, nb, C - nb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (nb + r < C) sX[tok * PC + nb + r] = fmaf((xo[t][r] - mu) * rstd, g2[r], b2[r]);
+  }
+  HRF_WAVE_SYNC();                                                  // a token's row was stored by four lanes of this wave
+  constexpr int N1 = 4 * C, FT = (N1 / 16 >= 9) ? 9 : (N1 + 15) / 16;  // hidden width; 16-channel tiles per pass
+  const bool tokv = pix >= 0;
+#pragma unroll 1
+  for (int n0 = 0; n0 < N1; n0 += 16 * FT) {
+    hrf_f4 acc[FT];
+    acc_bias<FT>(a.b1, n0, N1, lane, acc);
+    wave_gemm<C, FT>(a.w1, n0, N1, sX, PC, tok0, lane, acc);
+#pragma unroll
+    for (int t = 0; t < FT; ++t) {
+      const int nb = n0 + 16 * t + 4 * q;
+      if (tokv && nb < N1) hrf_st4(a.h1 + pc * N1 + nb, acc[t]);     // (4C is a multiple of 4: whole groups)
+      if (a.stats1 != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = tokv ? acc[t][r] : 0.f;
+          const float s1 = hrf_row16_sum(v), s2 = hrf_row16_sum(v * v);
+          if (i == 0 && nb + r < N1) { sStat[(wave * 2 + 0) * N1 + nb + r] = s1; sStat[(wave * 2 + 1) * N1 + nb + r] = s2; }
+        }
+      }
+    }
+  }
+  if (a.stats1 != nullptr) {
+    __syncthreads();
+    double* st = a.stats1 + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * N1;
+    for (int e = tid; e < 2 * N1; e += 256) {
+      const int which = e / N1, ch = e - which * N1;
+      const float s = (sStat[(0 * 2 + which) * N1 + ch] + sStat[(1 * 2 + which) * N1 + ch]) +
+                      (sStat[(2 * 2 + which) * N1 + ch] + sStat[(3 * 2 + which) * N1 + ch]);
+      hrf_atomic_add(&st[which * N1 + ch], (double)s);
+    }
+  }
+}
+
+template <int C, int HEADS>
+int launch_fwd(const hrf_attn_block_t& a, int nwin, void* stream) {
+  constexpr size_t smem = ((size_t)4 * 64 * (C + 1) + 32 + HEADS * 176) * sizeof(float);
+#ifndef HRF_EMUL
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_fwd_kernel<C, HEADS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return HRF_ERR_LAUNCH;
+    once = true;
+  }
+#endif
+  HRF_LAUNCH((attn_block_fwd_kernel<C, HEADS>), dim3(nwin), dim3(256), smem, stream, a);
+  return hrf_check_launch();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------- backward
+// acc[t] (t < NT) += sum_n rows[tok0 + j][n] * W[n][k0 + 16t + i]: D[k][token] = the adjoint of wave_gemm (contraction over
+// the OUTPUT channels n < N of the Linear, W [N][K] row-major); lane (j, q) ends up with input channels k0+16t+4q+r.
+template <int N, int NT>
+__device__ __forceinline__ void wave_gemm_t(const float* W, int K, int k0, const float* rows, int pitch, int tok0, int lane,
+                                            hrf_f4* acc) {
+  const int i = lane & 15, q = lane >> 4;
+  constexpr int NS = (N + 15) / 16;
+  const float* brow = rows + (tok0 + i) * pitch;
+#pragma unroll 2
+  for (int s = 0; s < NS; ++s) {
+    const int nbase = 16 * s + 4 * q;
+    float bv[4], wv[NT][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool nv = nbase + r < N;
+      bv[r] = nv ? brow[nbase + r] : 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int k = k0 + 16 * t + i;
+        wv[t][r] = *((nv && k < K) ? W + (long)(nbase + r) * K + k : g_zero4);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = hrf_mfma16(wv[t][r], bv[r], acc[t]);
+  }
+}
+
+// Weight-gradient tile sums over the 49 tokens of the window: acc[tk] += sum_tok A[tok][n0 + i] * B(tok)[k0 + 16 tk + j],
+// D[n][k]; A / B are LDS tiles, B optionally mapped through a LayerNorm affine (gam / bet in LDS; rows flagged by realf[tok]
+// == 0 give 0: tokens outside the image).  Lane (j, q) ends up with dW[n0 + 4q + r][k0 + 16 tk + j].
+template <int NTK, bool AFF>
+__device__ __forceinline__ void wave_tgemm(const float* sA, int pitchA, int n0, int N, const float* sB, int pitchB, int k0,
+                                           int K, const float* gam, const float* bet, const float* realf, int lane, hrf_f4* acc) {
+  const int i = lane & 15, q = lane >> 4;
+  const bool nv = n0 + i < N;
+#pragma unroll 1
+  for (int tt = 0; tt < 13; ++tt) {
+    const int tok = 4 * tt + q;
+    const bool tv = tok < NTOK;
+    const int tc = tv ? tok : 0;
+    const float av = (tv && nv) ? sA[tc * pitchA + n0 + i] : 0.f;
+#pragma unroll
+    for (int tk = 0; tk < NTK; ++tk) {
+      const int k = k0 + 16 * tk + i;
+      const int kc = k < K ? k : 0;
+      float bvv = sB[tc * pitchB + kc];
+      if (AFF) bvv = realf[tc] != 0.f ? fmaf(bvv, gam[kc], bet[kc]) : 0.f;
+      acc[tk] = hrf_mfma16(av, (tv && k < K) ? bvv : 0.f, acc[tk]);
+    }
+  }
+}
+
+// store a finished dW tile: slot[(n0 + 4q + r) * K + k0 + 16 tk + j]
+template <int NTK>
+__device__ __forceinline__ void store_wtile(float* dst, int n0, int N, int k0, int K, int lane, const hrf_f4* acc) {
+  const int j = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int tk = 0; tk < NTK; ++tk) {
+    const int k = k0 + 16 * tk + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * q + r;
+      if (n < N && k < K) dst[(long)n * K + k] = acc[tk][r];
+    }
+  }
+}
+
+// stage raw rows of a window, replace them by xhat = (x - mean) * rstd (zeros for tokens outside the image), keep rstd
+template <int C>
+__device__ __forceinline__ void stage_xhat_rows(const hrf_attn_block_t& a, const float* x, float eps, float* sX, float* sRs,
+                                                const int* sPix) {
+  constexpr int PC = C + 1;
+  constexpr int NE = (NTOK * C + 255) / 256;
+  float v[NE];
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    const int ec = e < NTOK * C ? e : 0;
+    const int j = ec / C, c = ec - j * C;
+    const int pix = sPix[j];
+    const float x0 = x[(long)(pix >= 0 ? pix : 0) * C + c];
+    v[u] = pix >= 0 ? x0 : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    if (e < NTOK * C) { const int j = e / C; sX[j * PC + (e - j * C)] = v[u]; }
+  }
+  __syncthreads();
+  const int t = threadIdx.x >> 2, part = threadIdx.x & 3;
+  float* row = sX + t * PC;
+  float s = 0.f;
+  for (int c = part; c < C; c += 4) s += row[c];
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+  const float mean = s / (float)C;
+  float qq = 0.f;
+  for (int c = part; c < C; c += 4) { const float d = row[c] - mean; qq = fmaf(d, d, qq); }
+  qq += __shfl_xor(qq, 1); qq += __shfl_xor(qq, 2);
+  const float rstd = 1.0f / sqrtf(qq / (float)C + eps);
+  const bool real = sPix[t] >= 0;
+  for (int c = part; c < C; c += 4) row[c] = real ? (row[c] - mean) * rstd : 0.f;
+  if (part == 0) sRs[t] = real ? rstd : 0.f;
+}
+
+// LayerNorm backward of one token row held in registers (dn[t][r] = d/d(LN output channel 16t+4q+r) of token tok0 + j):
+// returns dx in place, stores (sum dn*xhat, sum dn) over the wave's tokens into sPar[0..C) / sPar[C..2C).  Tokens outside
+// the image (real == false) carry a constant 0 instead of a LayerNorm output: no gradient, no parameter contribution.
+template <int C, int CT>
+__device__ __forceinline__ void ln_bwd_rows(hrf_f4* dn, const float* sXh, int pitch, int tok, bool real, float rstd,
+                                            const float* gam, float* sPar, int lane) {
+  const int i = lane & 15, q = lane >> 4;
+  float xh[CT][4], g[CT][4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * t + 4 * q + r;
+      const bool kv = k < C && real;
+      if (!kv) dn[t][r] = 0.f;
+      xh[t][r] = kv ? sXh[tok * pitch + k] : 0.f;
+      g[t][r] = kv ? dn[t][r] * gam[k] : 0.f;
+      s1 += g[t][r]; s2 = fmaf(g[t][r], xh[t][r], s2);
+    }
+  s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+  const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * t + 4 * q + r;
+      const float d = dn[t][r];
+      const float pg = hrf_row16_sum(d * xh[t][r]), pb = hrf_row16_sum(d);
+      if (i == 0 && k < C) { sPar[k] = pg; sPar[C + k] = pb; }
+      dn[t][r] = rstd * (g[t][r] - m1 - xh[t][r] * m2);
+    }
+}
+
+template <int C, int HEADS>
+__global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a, hrf_bn_bfin_t bf) {
+  constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16;
+  constexpr int KSD = (D + 3) / 4, DT = (D + 15) / 16;
+  constexpr int TILE = 64 * PC, N1 = 4 * C, PH = N1 + 1, SP = 65;
+  HRF_DYN_SMEM(float, smem);
+  float* sX = smem;                       // xhat of x' (LN_2), later xhat of the query source (LN_q)
+  float* sXkv = sX + TILE;                // xhat of the key/value source (cross-attention only)
+  float* sDY = sXkv + TILE;               // dy = d/d(out_proj output) rows
+  float* sG = sDY + TILE;                 // dO rows (gradient of the attention output)
+  float* sQ = sG + TILE;                  // scaled q
+  float* sK = sQ + TILE;                  // k, later dk
+  float* sV = sK + TILE;                  // v, later dv
+  float* sDQ = sV + TILE + 32;            // dq rows (already multiplied by the q scale)
+  float* sO = sDQ + TILE;                 // recomputed attention output (for d out_proj.weight)
+  float* sD = sO + TILE;                  // [49][SP] dS plane of the current head (relative position bias gradient)
+  float* sH = sD + NTOK * SP + 15;        // [64][PH] dy1 = BatchNorm-backward(du1) rows of the CrossFFN head
+  __shared__ int sPix[64];
+  __shared__ float sReal[64], sRs2[64], sRsQ[64], sRsKV[64], sM[64], sIL[64], sDl[64];
+  __shared__ float sT[HEADS * 176];
+  __shared__ float sGam[3][C], sBet[3][C];                 // LN_2, LN_q, LN_kv affine parameters
+  __shared__ float sPar[4][3][2 * C];                      // per wave: (sum dn*xhat | sum dn) of LN_2, LN_q, LN_kv
+  __shared__ float sBin[4 * 176];
+  __shared__ float sCo[3 * (4 * C)];                       // BatchNorm-backward coefficients of h1 (cA | cB | cC)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int win = blockIdx.x;
+  const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
+  const bool cross = a.xkv != a.xq, ffn = a.w1 != nullptr;
+  float* slot = a.pslot + (long)blockIdx.x * a.slot_stride;
+  if (tid < 64) {
+    const int px = tid < NTOK ? ab_tok_pixel(a, b, wy, wx, tid) : -1;
+    sPix[tid] = px; sReal[tid] = px >= 0 ? 1.f : 0.f;
+  }
+  for (int e = tid; e < 10 * TILE + 32 + NTOK * SP + 15 + (ffn ? 64 * PH : 0); e += 256) smem[e] = 0.f;
+  for (int e = tid; e < HEADS * 176; e += 256) { const int h = e / 176, k = e - h * 176; sT[e] = k < 169 ? a.rpb[k * HEADS + h] : 0.f; }
+  for (int e = tid; e < C; e += 256) {
+    sGam[0][e] = ffn ? a.ln2_g[e] : 0.f; sBet[0][e] = ffn ? a.ln2_b[e] : 0.f;
+    sGam[1][e] = a.lnq_g[e]; sBet[1][e] = a.lnq_b[e];
+    sGam[2][e] = a.lnkv_g[e]; sBet[2][e] = a.lnkv_b[e];
+  }
+  for (int e = tid; e < 4 * 3 * 2 * C; e += 256) (&sPar[0][0][0])[e] = 0.f;
+  if (ffn) {
+    if (bf.gstats != nullptr) hrf_bn_bfin_onload(bf, sCo, sCo + N1, sCo + 2 * N1, tid, 256, blockIdx.x == 0);
+    else for (int e = tid; e < N1; e += 256) { sCo[e] = a.cA1[e]; sCo[N1 + e] = a.cB1[e]; sCo[2 * N1 + e] = a.cC1[e]; }
+  }
+  __syncthreads();
+  const int tok0 = 16 * wave, tok = tok0 + i;
+  const int pix = sPix[tok];
+  const long pc = pix >= 0 ? pix : 0;
+  const bool tokv = pix >= 0;
+
+  // gx = d/d(out row): the incoming gradient, plus (CrossFFN head) the gradient through w1 and LN_2
+  hrf_f4 gx[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int nb = 16 * t + 4 * q;
+    gx[t] = ld_sel(16 * (t + 1) <= C, a.gout, pc * C + nb, tokv ? C - nb : 0);
+  }
+  if (ffn) {
+    // dy1 rows (BatchNorm backward applied while staging) and xhat_2
+    for (int e = tid; e < NTOK * (N1 / 4); e += 256) {
+      const int j = e / (N1 / 4), n = 4 * (e - j * (N1 / 4));
+      const int px = sPix[j];
+      const long pp = px >= 0 ? px : 0;
+      const hrf_f4 du = hrf_ld4(a.du1 + pp * N1 + n), hr = hrf_ld4(a.h1 + pp * N1 + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sH[j * PH + n + r] = px >= 0 ? fmaf(sCo[n + r], du[r], fmaf(sCo[N1 + n + r], hr[r], sCo[2 * N1 + n + r])) : 0.f;
+    }
+    stage_xhat_rows<C>(a, a.out, a.out_eps, sX, sRs2, sPix);
+    __syncthreads();
+    // d LN_2 output = dy1 W1  (this wave's tokens), LayerNorm backward, added to gx
+    hrf_f4 dn[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+    wave_gemm_t<N1, CT>(a.w1, C, 0, sH, PH, tok0, lane, dn);
+    ln_bwd_rows<C, CT>(dn, sX, PC, tok, tokv, sRs2[tok], sGam[0], sPar[wave][0], lane);
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gx[t][r] += tokv ? dn[t][r] : 0.f;
+    // d w1 [4C][C] = dy1^T LN_2(x'), d b1 = column sums of dy1: n tiles round-robin over the waves
+    for (int nt = wave; nt < (N1 + 15) / 16; nt += 4) {
+      hrf_f4 acc[CT];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+      wave_tgemm<CT, true>(sH, PH, 16 * nt, N1, sX, PC, 0, C, sGam[0], sBet[0], sReal, lane, acc);
+      store_wtile<CT>(slot + a.off_w1, 16 * nt, N1, 0, C, lane, acc);
+    }
+    for (int n = tid; n < N1; n += 256) {
+      float sacc = 0.f;
+      for (int j = 0; j < NTOK; ++j) sacc += sH[j * PH + n];
+      slot[a.off_b1 + n] = sacc;
+    }
+  }
+  // dy rows = gx * dropout mask * scales  (the out_proj output enters the residual through Dropout / DropPath)
+  {
+    const float rs = (a.rowscale != nullptr ? a.rowscale[pc / a.rows_per_sample] : 1.f) * a.mscale;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int nb = 16 * t + 4 * q;
+      const hrf_f4 mk = ld_sel(16 * (t + 1) <= C, a.mask, pc * C + nb, a.mask != nullptr ? C - nb : 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float y = tokv ? gx[t][r] * rs : 0.f;
+        if (a.mask != nullptr) y *= mk[r];
+        if (nb + r < C) sDY[tok * PC + nb + r] = y;
+      }
+    }
+  }
+  // dO rows = dy Wo  (own tokens)
+  HRF_WAVE_SYNC();                                                  // a token's dy row was stored by four lanes of this wave
+  {
+    hrf_f4 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+    wave_gemm_t<C, CT>(a.wo, C, 0, sDY, PC, tok0, lane, acc);
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int k = 16 * t + 4 * q + r; if (k < C) sG[tok * PC + k] = acc[t][r]; }
+  }
+  __syncthreads();                                                  // sX (xhat_2) / sH are dead from here on
+
+  // ---- recompute the projections: xhat rows of both sources, q / k / v with the LayerNorm affine applied on read
+  stage_xhat_rows<C>(a, a.xq, a.ln_eps, sX, sRsQ, sPix);
+  if (cross) stage_xhat_rows<C>(a, a.xkv, a.ln_eps, sXkv, sRsKV, sPix);
+  __syncthreads();
+  const float* sXk = cross ? sXkv : sX;
+  const int lkv = cross ? 2 : 1;
+  {
+    // n rows = xhat * gamma + beta (0 for tokens outside the image) are materialised per k-slab inside the GEMM
+    hrf_f4 acc[CT];
+    auto proj = [&](const float* W, const float* bias, const float* xh, int ln, float* dstT, float mul) {
+      acc_bias<CT>(bias, 0, C, lane, acc);
+      const float* brow = xh + tok * PC;
+      const bool real = sReal[tok] != 0.f;
+      constexpr int NS = (C + 15) / 16;
+#pragma unroll 2
+      for (int s = 0; s < NS; ++s) {
+        const int kbase = 16 * s + 4 * q, kval = C - kbase;
+        const bool kfull = 16 * (s + 1) <= C;
+        hrf_f4 wv[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) { const int n = 16 * t + i; wv[t] = ld_sel(kfull, W, (long)n * C + kbase, n < C ? kval : 0); }
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = r < kval ? kbase + r : 0;
+          bv[r] = (r < kval && real) ? fmaf(brow[k], sGam[ln][k], sBet[ln][k]) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc[t] = hrf_mfma16(wv[t][r], bv[r], acc[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) dstT[tok * PC + n] = acc[t][r] * mul; }
+    };
+    proj(a.wq, a.bq, sX, 1, sQ, a.scale);
+    proj(a.wk, a.bk, sXk, lkv, sK, 1.f);
+    proj(a.wv, a.bv, sXk, lkv, sV, 1.f);
+  }
+  __syncthreads();
+
+  // ---- attention backward per head (attention.hip's MFMA formulation on the packed tiles)
+#pragma unroll 1
+  for (int h = 0; h < HEADS; ++h) {
+    const float* bias = sT + h * 176;
+    {  // query-column orientation: wave = queries tok0 .. tok0+15
+      hrf_f4 s[4], dp[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+      const float* qrow = sQ + (tok0 + i) * PC + h * D + q;
+      const float* grow = sG + (tok0 + i) * PC + h * D + q;
+#pragma unroll
+      for (int kk = 0; kk < KSD; ++kk) {
+        const bool kv = 4 * kk + q < D;
+        const float qv = kv ? qrow[4 * kk] : 0.f, gv = kv ? grow[4 * kk] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          s[t] = hrf_mfma16(sK[(16 * t + i) * PC + h * D + 4 * kk + q], qv, s[t]);
+          dp[t] = hrf_mfma16(sV[(16 * t + i) * PC + h * D + 4 * kk + q], gv, dp[t]);
+        }
+      }
+      const int qi = tok0 + i, qc = qi < NTOK ? qi : 0;
+      const int yi = qc / 7, xi = qc - 7 * yi;
+      float m = -3.0e38f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * t + 4 * q + r, jc = j < NTOK ? j : 0;
+          const int yj = jc / 7, xj = jc - 7 * yj;
+          const float sv = j < NTOK ? s[t][r] + bias[(yi - yj + 6) * 13 + (xi - xj + 6)] : -3.0e38f;
+          s[t][r] = sv;
+          m = fmaxf(m, sv);
+        }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[t][r] = __expf(s[t][r] - m); l += s[t][r]; }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      float Dl = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[t][r] *= inv; Dl = fmaf(s[t][r], dp[t][r], Dl); }
+      Dl += __shfl_xor(Dl, 16);
+      Dl += __shfl_xor(Dl, 32);
+      if (q == 0) { sM[qi] = m; sIL[qi] = inv; sDl[qi] = Dl; }
+      // attention output rows again (O = P V) for the out_proj weight gradient
+      hrf_f4 o[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* vrow = sV + (16 * t + 4 * q + r) * PC + h * D + i;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_mfma16(s[t][r], vrow[16 * dt], o[dt]);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { const int d = 16 * dt + i; if (d < D) sO[(tok0 + 4 * q + r) * PC + h * D + d] = o[dt][r]; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ds = s[t][r] * (dp[t][r] - Dl);
+          s[t][r] = ds;
+          const int j = 16 * t + 4 * q + r;
+          if (j < NTOK && qi < NTOK) sD[j * SP + qi] = ds;
+        }
+      // dQ = dS K (contraction over keys)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* krow = sK + (16 * t + 4 * q + r) * PC + h * D + i;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_mfma16(s[t][r], krow[16 * dt], o[dt]);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qo = tok0 + 4 * q + r;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { const int d = 16 * dt + i; if (d < D) sDQ[qo * PC + h * D + d] = qo < NTOK ? o[dt][r] * a.scale : 0.f; }
+      }
+    }
+    __syncthreads();
+    {  // key-column orientation: wave = keys tok0 .. tok0+15
+      hrf_f4 s[4], dp[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+      const float* krow = sK + (tok0 + i) * PC + h * D + q;
+      const float* vrow = sV + (tok0 + i) * PC + h * D + q;
+#pragma unroll
+      for (int kk = 0; kk < KSD; ++kk) {
+        const bool kv = 4 * kk + q < D;
+        const float kvv = kv ? krow[4 * kk] : 0.f, vv = kv ? vrow[4 * kk] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          s[t] = hrf_mfma16(sQ[(16 * t + i) * PC + h * D + 4 * kk + q], kvv, s[t]);       // S[query 16t+4q+r][key tok0+i]
+          dp[t] = hrf_mfma16(sG[(16 * t + i) * PC + h * D + 4 * kk + q], vv, dp[t]);
+        }
+      }
+      const int kj = tok0 + i, kc = kj < NTOK ? kj : 0;
+      const int yj = kc / 7, xj = kc - 7 * yj;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = 16 * t + 4 * q + r, qc = qi < NTOK ? qi : 0;
+          const int yi = qc / 7, xi = qc - 7 * yi;
+          const bool ok = kj < NTOK && qi < NTOK;
+          const float p = ok ? __expf(s[t][r] + bias[(yi - yj + 6) * 13 + (xi - xj + 6)] - sM[qc]) * sIL[qc] : 0.f;
+          s[t][r] = p;
+          dp[t][r] = ok ? p * (dp[t][r] - sDl[qc]) : 0.f;
+        }
+      hrf_f4 ov[DT], okk[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { ov[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; okk[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* gr = sG + (16 * t + 4 * q + r) * PC + h * D + i;
+          const float* qr = sQ + (16 * t + 4 * q + r) * PC + h * D + i;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            ov[dt] = hrf_mfma16(s[t][r], gr[16 * dt], ov[dt]);
+            okk[dt] = hrf_mfma16(dp[t][r], qr[16 * dt], okk[dt]);
+          }
+        }
+      __syncthreads();                                              // every wave is done reading head h of sK / sV
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ko = tok0 + 4 * q + r;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = 16 * dt + i;
+          if (d < D) { sK[ko * PC + h * D + d] = okk[dt][r]; sV[ko * PC + h * D + d] = ov[dt][r]; }
+        }
+      }
+    }
+    // relative position bias gradient of head h: gather over the dS plane (169 bins x 4 row groups)
+    for (int it = tid; it < 169 * 4; it += 256) {
+      const int e = it % 169, part = it / 169;
+      const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
+      const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
+      const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
+      float sacc = 0.f;
+      for (int yj = y0 + part; yj <= y1; yj += 4)
+        for (int xj = x0; xj <= x1; ++xj) sacc += sD[(yj * 7 + xj) * SP + (yj + dy) * 7 + xj + dx];
+      sBin[part * 176 + e] = sacc;
+    }
+    __syncthreads();
+    if (tid < 169) slot[a.off_rpb + tid * HEADS + h] = (sBin[tid] + sBin[176 + tid]) + (sBin[352 + tid] + sBin[528 + tid]);
+    __syncthreads();                                                // sD / sBin are rewritten by the next head
+  }
+
+  // ---- d LN outputs = dq Wq (+ dk Wk + dv Wv), LayerNorm backward, output gradients
+  {
+    hrf_f4 dn[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+    wave_gemm_t<C, CT>(a.wq, C, 0, sDQ, PC, tok0, lane, dn);
+    if (!cross) {
+      wave_gemm_t<C, CT>(a.wk, C, 0, sK, PC, tok0, lane, dn);
+      wave_gemm_t<C, CT>(a.wv, C, 0, sV, PC, tok0, lane, dn);
+    }
+    ln_bwd_rows<C, CT>(dn, sX, PC, tok, tokv, sRsQ[tok], sGam[1], sPar[wave][1], lane);
+    if (a.dq != nullptr && tokv) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int nb = 16 * t + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (nb + r < C) {
+            float v = dn[t][r] + (a.dq_add_res ? gx[t][r] : 0.f);
+            if (a.dq_acc) v += a.dq[pc * C + nb + r];
+            a.dq[pc * C + nb + r] = v;
+          }
+        }
+      }
+    }
+    if (cross) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+      wave_gemm_t<C, CT>(a.wk, C, 0, sK, PC, tok0, lane, dn);
+      wave_gemm_t<C, CT>(a.wv, C, 0, sV, PC, tok0, lane, dn);
+      ln_bwd_rows<C, CT>(dn, sXkv, PC, tok, tokv, sRsKV[tok], sGam[2], sPar[wave][2], lane);
+      if (a.dkv != nullptr && tokv) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+          const int nb = 16 * t + 4 * q;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (nb + r < C) {
+              float v = dn[t][r] + (a.dkv_add_res ? gx[t][r] : 0.f);
+              if (a.dkv_acc) v += a.dkv[pc * C + nb + r];
+              a.dkv[pc * C + nb + r] = v;
+            }
+          }
+        }
+      }
+    }
+    if (a.dres != nullptr && tokv) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int nb = 16 * t + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (nb + r < C) {
+            float v = gx[t][r];
+            if (a.dres_acc) v += a.dres[pc * C + nb + r];
+            a.dres[pc * C + nb + r] = v;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- weight gradients of the four Linear layers: [out tile of 16][all input channels] per wave, round-robin
+  {
+    constexpr int NTC = C / 16 + (C % 16 ? 1 : 0);
+    const int ntiles = 4 * NTC;                                     // wo, wq, wk, wv
+    for (int wt = wave; wt < ntiles; wt += 4) {
+      const int which = wt / NTC, nt = wt - which * NTC;
+      hrf_f4 acc[CT];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+      if (which == 0) {
+        wave_tgemm<CT, false>(sDY, PC, 16 * nt, C, sO, PC, 0, C, nullptr, nullptr, nullptr, lane, acc);
+        store_wtile<CT>(slot + a.off_wo, 16 * nt, C, 0, C, lane, acc);
+      } else if (which == 1) {
+        wave_tgemm<CT, true>(sDQ, PC, 16 * nt, C, sX, PC, 0, C, sGam[1], sBet[1], sReal, lane, acc);
+        store_wtile<CT>(slot + a.off_wq, 16 * nt, C, 0, C, lane, acc);
+      } else {
+        wave_tgemm<CT, true>(which == 2 ? sK : sV, PC, 16 * nt, C, sXk, PC, 0, C, sGam[lkv], sBet[lkv], sReal, lane, acc);
+        store_wtile<CT>(slot + (which == 2 ? a.off_wk : a.off_wv), 16 * nt, C, 0, C, lane, acc);
+      }
+    }
+    // bias gradients = column sums over the 49 tokens (tokens outside the image included: their k / v ARE the biases)
+    for (int e = tid; e < 4 * C; e += 256) {
+      const int which = e / C, n = e - which * C;
+      const float* T = which == 0 ? sDY : (which == 1 ? sDQ : (which == 2 ? sK : sV));
+      float sacc = 0.f;
+      for (int j = 0; j < NTOK; ++j) sacc += T[j * PC + n];
+      slot[(which == 0 ? a.off_bo : (which == 1 ? a.off_bq : (which == 2 ? a.off_bk : a.off_bv))) + n] = sacc;
+    }
+  }
+  __syncthreads();
+  // LayerNorm parameter gradients: sum of the four waves' partials
+  for (int e = tid; e < 3 * 2 * C; e += 256) {
+    const int ln = e / (2 * C), k = e - ln * 2 * C;
+    const float v = (sPar[0][ln][k] + sPar[1][ln][k]) + (sPar[2][ln][k] + sPar[3][ln][k]);
+    const int off = ln == 0 ? (k < C ? a.off_g2 : a.off_bt2) : (ln == 1 ? (k < C ? a.off_gq : a.off_btq) : (k < C ? a.off_gkv : a.off_btkv));
+    if (off >= 0) slot[off + (k < C ? k : k - C)] = v;
+  }
+}
+
+template <int C, int HEADS>
+int launch_bwd(const hrf_attn_block_t& a, const hrf_bn_bfin_t& bf, int nwin, void* stream) {
+  constexpr int TILE = 64 * (C + 1);
+  const size_t smem = ((size_t)10 * TILE + 32 + NTOK * 65 + 15 + (a.w1 != nullptr ? 64 * (4 * C + 1) : 0)) * sizeof(float);
+#ifndef HRF_EMUL
+  static bool once = false;
+  if (!once) {
+    constexpr size_t smax = ((size_t)10 * TILE + 32 + NTOK * 65 + 15 + 64 * (4 * C + 1)) * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_bwd_kernel<C, HEADS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smax) != hipSuccess) return HRF_ERR_LAUNCH;
+    once = true;
+  }
+#endif
+  HRF_LAUNCH((attn_block_bwd_kernel<C, HEADS>), dim3(nwin), dim3(256), smem, stream, a, bf);
+  return hrf_check_launch();
+}
+
+// dst[map[i]] += sum over the slots of one fused layer (blockIdx.y = segment)
+__global__ __launch_bounds__(256) void fold_slots_kernel(const float* slots, const long* seg, const int* map, float* dst) {
+  const long* sg = seg + 5 * blockIdx.y;
+  const long base = sg[0], nslots = sg[1], stride = sg[2], n = sg[3], moff = sg[4];
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int m = map[moff + e];
+    if (m < 0) continue;
+    const float* p = slots + base + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long k = 0;
+    for (; k + 4 <= nslots; k += 4) { s0 += p[k * stride]; s1 += p[(k + 1) * stride]; s2 += p[(k + 2) * stride]; s3 += p[(k + 3) * stride]; }
+    for (; k < nslots; ++k) s0 += p[k * stride];
+    dst[m] += (s0 + s1) + (s2 + s3);
+  }
+}
+
+}  // namespace
+
+extern "C" int hrf_attn_block_supported(int C, int heads) {
+  return (heads > 0 && C == 18 * heads && (heads == 1 || heads == 2 || heads == 4 || heads == 8)) ? 1 : 0;
+}
+
+extern "C" int hrf_attn_block_bwd_supported(int C, int heads) {
+  return (heads > 0 && C == 18 * heads && (heads == 1 || heads == 2)) ? 1 : 0;
+}
+
+static void ab_geometry(hrf_attn_block_t& a) {
+  a.nWh = (a.H + 6) / 7; a.nWw = (a.W + 6) / 7;
+  a.pt = (a.nWh * 7 - a.H) / 2; a.pl = (a.nWw * 7 - a.W) / 2;       // centre pad: top/left = pad//2
+  a.scale = 1.0f / sqrtf((float)(a.C / a.heads));
+  if (a.rows_per_sample <= 0) a.rows_per_sample = a.H * a.W;
+}
+
+extern "C" int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream) {
+  if (p == nullptr || !hrf_attn_block_bwd_supported(p->C, p->heads)) return HRF_ERR_ARG;
+  hrf_attn_block_t a = *p;
+  if (a.xq == nullptr || a.xkv == nullptr || a.gout == nullptr || a.pslot == nullptr) return HRF_ERR_ARG;
+  if (a.w1 != nullptr && (a.hidden != 4 * a.C || a.h1 == nullptr || a.du1 == nullptr || a.out == nullptr ||
+                          (a.bfin1 == nullptr && a.cA1 == nullptr))) return HRF_ERR_ARG;
+  hrf_bn_bfin_t bf{};
+  if (a.w1 != nullptr && a.bfin1 != nullptr) {
+    bf = *a.bfin1;
+    if (bf.C != 4 * a.C || bf.gstats == nullptr) return HRF_ERR_ARG;
+  }
+  a.bfin1 = nullptr;
+  ab_geometry(a);
+  const int nwin = a.B * a.nWh * a.nWw;
+  if (nwin <= 0) return HRF_OK;
+  if (a.heads == 1) return launch_bwd<18, 1>(a, bf, nwin, stream);
+  return launch_bwd<36, 2>(a, bf, nwin, stream);
+}
+
+extern "C" int hrf_fold_slots(const float* slots, const long* seg, int nseg, const int* map, float* dst, long max_n, void* stream) {
+  if (nseg <= 0 || max_n <= 0) return HRF_OK;
+  HRF_LAUNCH(fold_slots_kernel, dim3(hrf_cdiv(max_n, 256), nseg), dim3(256), 0, stream, slots, seg, map, dst);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_attn_block_fwd(const hrf_attn_block_t* p, void* stream) {
+  if (p == nullptr || !hrf_attn_block_supported(p->C, p->heads)) return HRF_ERR_ARG;
+  hrf_attn_block_t a = *p;
+  if (a.xq == nullptr || a.xkv == nullptr || a.res == nullptr || a.out == nullptr) return HRF_ERR_ARG;
+  if (a.w1 != nullptr && (a.hidden != 4 * a.C || a.h1 == nullptr)) return HRF_ERR_ARG;
+  ab_geometry(a);
+  const int nwin = a.B * a.nWh * a.nWw;
+  if (nwin <= 0) return HRF_OK;
+  switch (a.heads) {
+    case 1: return launch_fwd<18, 1>(a, nwin, stream);
+    case 2: return launch_fwd<36, 2>(a, nwin, stream);
+    case 4: return launch_fwd<72, 4>(a, nwin, stream);
+    default: return launch_fwd<144, 8>(a, nwin, stream);
+  }
+}

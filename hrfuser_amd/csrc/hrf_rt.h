@@ -17,6 +17,9 @@
 // every launch of the library goes through here
 #define HRF_LAUNCH(kern, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+// LDS hand-off between lanes of ONE wave (a lane reads what another lane of its wave stored): the hardware executes a
+// wave's LDS operations in program order, so only the compiler must be kept from moving code across the point
+#define HRF_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 typedef float hrf_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ hrf_f4 hrf_mfma16(float a, float b, hrf_f4 c) {
   // v_mfma_f32_16x16x4_f32: exact fp32 (fmaf chain), A[l&15][l>>4], B[l>>4][l&15],

@@ -13,6 +13,7 @@ Design (MI355X-first):
 
 Nothing in this file computes on the CPU: every op is a launch on torch's current HIP stream.
 """
+import ctypes
 import os
 
 import torch
@@ -246,6 +247,7 @@ class Ctx:
         tape = self.tape
         self.tape = []
         use_keep_list(self.owner._engine().keep)
+        self.owner._engine().fs_prepare()
         # HRF_WGRAD=flush: every time all lanes are joined into the main lane and enough weight gradients are queued,
         # issue them (grouped) on low-priority side lanes forked from main - they fill the CUs the latency-bound
         # data-gradient chain leaves idle instead of forming a phase of their own at the end
@@ -690,6 +692,117 @@ def window_attention(ctx, q, qoff, k, koff, v, voff, kpad, vpad, kbias, kboff, v
                               racc, cs, B, H, W, C, heads, s)
     ctx.push(bwd)
     return o
+
+
+# ----------------------------------------------------------------------------- fused window-attention block
+_ATTN_FUSED = os.environ.get('HRF_ATTN_FUSED', '1') != '0'
+
+
+def attn_block_ok(ctx, C, heads):
+    """Is the one-launch attention block (csrc/attn_block.hip) available for this width, in this mode?"""
+    if not _ATTN_FUSED or not ctx.L.hrf_attn_block_supported(C, heads):
+        return False
+    return (not ctx.record) or bool(ctx.L.hrf_attn_block_bwd_supported(C, heads))
+
+
+def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, res, res2=None, drop=None, ffn=None):
+    """out = res (+ res2) + drop(out_proj(window_attention(LN_q(xq), LN_kv(xkv)))) and, with ffn = (LayerNorm, 1x1 conv,
+    BatchNorm), the CrossFFN head h1 = conv(LN(out)) as a Lazy GELU(BN(.)) - ONE launch per direction.
+    wq / wk / wv: (Linear module, first output row): the three projections, possibly rows of one packed qkv Linear.
+    key: hashable identity of the layer instance (its parameter-gradient slots live in the engine).  xkv is xq:
+    self-attention.  The residual conventions are the reference's: self-attention res is xq; cross-attention res is
+    the running sum and res2 the modality map that is also the key/value source."""
+    L, s = ctx.L, ctx.stream
+    B, H, W, C = xq.t.shape
+    cross = xkv is not xq
+    assert res2 is None or res2 is xkv
+    dev = xq.t.device
+    out = Act(_new((B, H, W, C), dev))
+    N1 = 4 * C
+    st = None
+    h1raw = stats = None
+    if ffn is not None:
+        ln2, conv1, bn1 = ffn
+        assert conv1.weight.shape[0] == N1
+        h1raw = _new((B, H, W, N1), dev)
+        slot = ctx.owner._bn_slot(bn1)
+        stats = slot['stats'] if (ctx.training and bn1.training) else None
+    mask, mscale, rowscale = drop if drop is not None else (None, 1.0, None)
+    P = _lib._ptr
+
+    def wrow(spec):
+        lin, r0 = spec
+        return lin.weight.data_ptr() + 4 * r0 * C, (lin.bias.data_ptr() + 4 * r0) if lin.bias is not None else None
+
+    def fill():
+        a = _lib.AttnBlock()
+        a.B, a.H, a.W, a.C, a.heads = B, H, W, C, heads
+        a.xq, a.xkv = P(xq.t), P(xkv.t)
+        a.lnq_g, a.lnq_b, a.lnkv_g, a.lnkv_b, a.ln_eps = P(lnq.weight), P(lnq.bias), P(lnkv.weight), P(lnkv.bias), float(lnq.eps)
+        (a.wq, a.bq), (a.wk, a.bk), (a.wv, a.bv) = wrow(wq), wrow(wk), wrow(wv)
+        a.rpb, a.wo, a.bo = P(rpb), P(out_proj.weight), P(out_proj.bias)
+        a.res, a.res2 = P(res.t), P(res2.t) if res2 is not None else None
+        a.mask, a.mscale, a.rowscale, a.rows_per_sample = P(mask), float(mscale), P(rowscale), H * W
+        a.out = P(out.t)
+        if ffn is not None:
+            a.ln2_g, a.ln2_b, a.out_eps = P(ln2.weight), P(ln2.bias), float(ln2.eps)
+            a.w1, a.b1, a.h1, a.stats1, a.hidden = P(conv1.weight), P(conv1.bias), P(h1raw), P(stats), N1
+        return a
+
+    L.hrf_attn_block_fwd(fill(), s)
+    h1 = None
+    if ffn is not None:
+        st = bn_forward(ctx, bn1, h1raw, stats)
+        h1 = Lazy(st, TF_GELU)
+    if not ctx.record:
+        return out, h1
+    eng = ctx.owner._engine()
+    nwin = B * ((H + 6) // 7) * ((W + 6) // 7)
+    entries = []
+    if ffn is not None:
+        entries += [('w1', conv1.weight, 0, N1 * C), ('b1', conv1.bias, 0, N1), ('g2', ln2.weight, 0, C), ('bt2', ln2.bias, 0, C)]
+    entries += [('wo', out_proj.weight, 0, C * C), ('bo', out_proj.bias, 0, C)]
+    for nm, (lin, r0) in (('q', wq), ('k', wk), ('v', wv)):
+        entries += [('w' + nm, lin.weight, r0 * C, C * C), ('b' + nm, lin.bias, r0, C)]
+    entries += [('gq', lnq.weight, 0, C), ('btq', lnq.bias, 0, C)]
+    if cross:
+        entries += [('gkv', lnkv.weight, 0, C), ('btkv', lnkv.bias, 0, C)]
+    entries += [('rpb', rpb, 0, 169 * heads)]
+    offs = eng.fs_register(key, nwin, entries)
+
+    def bwd():
+        a = fill()
+        a.gout = P(out.grad)
+        keepalive = None
+        if ffn is not None:
+            (cA, cB, cC), bfin = bn_backward_coef(ctx, st, consumer_follows=True)
+            a.du1, a.cA1, a.cB1, a.cC1 = P(st.du), P(cA), P(cB), P(cC)
+            if bfin is not None:
+                keepalive = bfin
+                a.bfin1 = ctypes.addressof(bfin)
+        if cross:
+            if res.needs_grad:
+                g, acc = res.grad_target()
+                a.dres, a.dres_acc = P(g), acc
+            if xkv.needs_grad:
+                g, acc = xkv.grad_target()
+                a.dkv, a.dkv_acc, a.dkv_add_res = P(g), acc, 1 if res2 is not None else 0
+            if xq.needs_grad:
+                g, acc = xq.grad_target()
+                a.dq, a.dq_acc, a.dq_add_res = P(g), acc, 0
+        elif xq.needs_grad:
+            assert res is xq
+            g, acc = xq.grad_target()
+            a.dq, a.dq_acc, a.dq_add_res = P(g), acc, 1
+        a.pslot, a.slot_stride = eng.fs_buffer(key), offs['_n']
+        for nm in ('w1', 'b1', 'g2', 'bt2', 'wo', 'bo', 'wq', 'bq', 'wk', 'bk', 'wv', 'bv', 'gq', 'btq', 'gkv', 'btkv', 'rpb'):
+            setattr(a, 'off_' + nm, offs.get(nm, -1))
+        L.hrf_attn_block_bwd(a, s)
+        del keepalive
+        if st is not None:
+            st.du = None
+    ctx.push(bwd)
+    return out, h1
 
 
 # ----------------------------------------------------------------------------- depthwise conv

@@ -127,6 +127,55 @@ int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const float* k, int l
                         float* dv, int lddv, int dvoff, float* dkpad, float* dvpad, float* drpb, long copy_stride,
                         int B, int H, int W, int C, int heads, void* stream);
 
+/* ---- fused window-attention block (csrc/attn_block.hip): the whole token-local half of an HRFormerBlock
+ * (hrformer.py:365-373: norm1 -> LocalWindowSelfAttention :184-236 / WindowMSA :96-131 -> residual -> norm2 -> CrossFFN
+ * layers[0] :268) or of one modality of a fusion block (hrfuser_hrformer_based.py:305-317: norm1[k] / norm2[k] ->
+ * MultiWindowCrossAttention :189-248 / WindowMCA :106-151 incl. Dropout -> DropPath + residuals; after the last modality
+ * norm3 + the CrossFFN head) in ONE launch per direction, one workgroup per 7x7 window; head_dim 18 (HRFuser-T / STF
+ * widths 18 / 36 / 72 / 144: hrf_attn_block_supported).  Rows are NHWC (B*H*W, C); weights keep the reference layouts
+ * (Linear (out, in); for the packed qkv Linear pass three pointers into the same tensor).
+ *   forward : out = res (+ res2) + mask*mscale*rowscale[b] * out_proj(attn(LN_q(xq), LN_kv(xkv)));  xkv == xq: self-
+ *             attention (LN_kv unused).  mask / rowscale / res2 nullable; mscale = 1 when unused.
+ *             out_rowstat (nullable): LayerNorm (mean, rstd) of the out rows with out_eps.
+ *             w1 != NULL: h1 = LN_2(out) w1^T + b1 (hidden = 4*C rows, pre-BatchNorm) and, stats1 != NULL, its
+ *             replicated moments [HRF_STAT_COPIES][2*hidden] (+=).
+ *   backward: gout = dL/d out rows; du1 (+ cA1/cB1/cC1, or bfin1 to derive them on load like hrf_conv_bwd_data) = the
+ *             gradient reaching h1 through its BatchNorm (dy1 = cA*du1 + cB*h1 + cC).  With gx = gout + (gradient through
+ *             LN_2 / w1):  dres (+)= gx;  dq (+)= gradient through LN_q (+ gx when dq_add_res: self-attention, where the
+ *             residual row IS the query row);  dkv (+)= gradient through LN_kv (+ gx when dkv_add_res: the modality row
+ *             is both residual and key/value source).  Each *_acc flag selects += over =; NULL outputs are skipped.
+ *             Parameter gradients are NOT accumulated with atomics: every workgroup writes the complete partial sums of
+ *             its window to its own slot pslot[blockIdx * slot_stride + off_*] (plain stores, deterministic);
+ *             hrf_fold_slots adds the slots into the gradient arena.  Slot layout (floats; off_* < 0: not produced):
+ *             w1 [4C][C], b1 [4C], ln2 gamma / beta [C]; wo [C][C], bo [C]; wq / wk / wv [C][C], bq / bk / bv [C];
+ *             LN_q gamma / beta, LN_kv gamma / beta [C]; rpb [169][heads].  hrf_attn_block_bwd_supported: widths 18 / 36.
+ * The last five fields are derived by the library.                                                                     */
+typedef struct hrf_attn_block {
+  int B, H, W, C, heads;
+  const float* xq; const float* xkv;
+  const float* lnq_g; const float* lnq_b; const float* lnkv_g; const float* lnkv_b; float ln_eps;
+  const float* wq; const float* bq; const float* wk; const float* bk; const float* wv; const float* bv;
+  const float* rpb; const float* wo; const float* bo;
+  const float* res; const float* res2;
+  const float* mask; float mscale; const float* rowscale; int rows_per_sample;
+  float* out; float* out_rowstat; float out_eps;
+  const float* ln2_g; const float* ln2_b; const float* w1; const float* b1; float* h1; double* stats1; int hidden;
+  const float* gout; const float* du1; const float* cA1; const float* cB1; const float* cC1; const hrf_bn_bfin_t* bfin1;
+  float* dres; int dres_acc; float* dq; int dq_acc; int dq_add_res; float* dkv; int dkv_acc; int dkv_add_res;
+  float* pslot; long slot_stride;
+  int off_w1, off_b1, off_g2, off_bt2, off_wo, off_bo, off_wq, off_bq, off_wk, off_bk, off_wv, off_bv;
+  int off_gq, off_btq, off_gkv, off_btkv, off_rpb;
+  int nWh, nWw, pt, pl; float scale;
+} hrf_attn_block_t;
+int hrf_attn_block_supported(int C, int heads);
+int hrf_attn_block_bwd_supported(int C, int heads);
+int hrf_attn_block_fwd(const hrf_attn_block_t* p, void* stream);
+int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream);
+/* dst[map[i]] += sum_{s < nslots} slots[s*slot_stride + i]  (i < n; map[i] < 0: skipped).  One launch folds the slots of
+ * every fused layer of a step: seg = nseg rows of 5 longs {slot offset (floats) into `slots`, nslots, slot_stride, n,
+ * offset into `map`} on the device.                                                                                  */
+int hrf_fold_slots(const float* slots, const long* seg, int nseg, const int* map, float* dst, long max_n, void* stream);
+
 /* ---- BatchNorm bookkeeping (F.batch_norm, 329 call sites: every build_norm_layer(norm_cfg)) ---
  * stats = (sum y, sum y^2) from the producing conv -> scale/shift used by consumers' loaders,
  * saved mean/invstd, running-stat update (momentum, unbiased var).  With SyncBN the host

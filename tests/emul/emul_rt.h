@@ -54,6 +54,8 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
   hrf_emul::launch(grid, block, smem, [&]() { kern(__VA_ARGS__); })
 
 inline void __syncthreads() { hrf_emul::sync_block(); }
+// lanes of a wave run as separate fibers between rendezvous points: an intra-wave LDS hand-off needs one here
+#define HRF_WAVE_SYNC() hrf_emul::sync_wave()
 
 template <class T>
 inline T hrf_emul_exchange(T v, int src_lane) {

@@ -27,6 +27,10 @@ def _cases():
     c['block_c78_h2'] = (lambda: B.HRFormerBlock(78, 78, 2, norm_cfg=NORM, transformer_norm_cfg=LN),
                          lambda k, b, x: b.run(k, x[0]), lambda: O.HRFormerBlock(78, 2, 4, NORM, LN),
                          lambda m, i: m(i[0]), [(1, 78, 9, 16)])
+    for (ch, h, H, W) in ((18, 1, 10, 13), (72, 4, 8, 9), (144, 8, 7, 10)):       # the other widths of the fused attention block
+        c[f'block_c{ch}_h{h}'] = (lambda ch=ch, h=h: B.HRFormerBlock(ch, ch, h, norm_cfg=NORM, transformer_norm_cfg=LN),
+                                  lambda k, b, x: b.run(k, x[0]), lambda ch=ch, h=h: O.HRFormerBlock(ch, h, 4, NORM, LN),
+                                  lambda m, i: m(i[0]), [(2, ch, H, W)])
     for (ch, h, M, H, W) in ((18, 1, 2, 10, 13), (36, 2, 3, 8, 15)):
         c[f'fusion_c{ch}_M{M}'] = (
             lambda ch=ch, h=h, M=M: B.HRFuserFusionBlock(ch, ch, h, norm_cfg=NORM, transformer_norm_cfg=LN,
