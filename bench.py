@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py — HRFuser-T backbone training step on MI355X (BASELINE.json metric).
+"""bench.py — HRFuser backbone training step on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = forward (train-mode BN) + backward + gradient exchange + fused AdamW of the
-HRFuser-T nuScenes backbone on a synthetic batch of 2 images per GPU (2x3x384x640 camera + lidar +
-radar; BASELINE.json configs[1]; SyncBN + RCCL all-reduce when N > 1; weak scaling).  Everything in
-the timed region runs on the hand-written HIP kernels (no oracle, no CPU fallback).
+One "step" = forward (train-mode BN) + backward + gradient exchange + fused AdamW of the HRFuser-T nuScenes backbone
+on a synthetic batch of 2 images per GPU (2x3x384x640 camera + lidar + radar; BASELINE.json configs[1]; SyncBN + RCCL
+all-reduce when N > 1; weak scaling).  Everything in the timed region runs on the hand-written HIP kernels (no oracle,
+no CPU fallback).  `value` = images of all ranks / wall time of exactly K steps between two barriers (max over ranks).
 
 The JSON line also carries
-  roofline      dominant kernel (largest share of GPU time per step): algorithmic FLOPs (or bytes)
-                per launch / average launch duration.  Durations are measured in-process with HIP
-                events on the launch stream: every distinct (entry point, shape) of one training step
-                is re-issued 20x back-to-back inside a captured hipGraph right after the timed region
-                (events cannot bracket single kernels inside the step's own graph, and an event pair
-                around one eager launch measures the ~10 us host gap, not the kernel);
-                cross-checked by profiles/*.csv (rocprofv3 --kernel-trace --stats)
-  cpu_baseline  the PyTorch-CPU oracle (kind "port": bit-exact restatement of the reference
-                backbone) timed on the host cores on a bounded sample of the same workload.
+  step_ms         per-step GPU durations of the same K steps from HIP events on the launch stream: median / p10 / p90
+  finite          outputs and parameters checked for NaN / Inf after the timed steps (a non-finite run is not a result)
+  eager_autograd  the route an mmdet user gets: `backbone(img, mods)` + `loss.backward()` through torch.autograd + the
+                  fused AdamW, eager (no hipGraph), ms per step
+  roofline        the kernel family with the LARGEST time per step (isolated per-launch durations: every distinct
+                  (entry point, shape) of a step re-issued 20x back-to-back in a captured hipGraph, HIP events on the launch
+                  stream): algorithmic bytes (or flops) per launch / average launch duration, against 8 TB/s resp. the
+                  dense fp32 MFMA peak; `traffic` = PMC-measured fabric bytes per launch with its source stated (a
+                  separate `rocprofv3 --pmc` run kept under profiles/), or null
+  step_roofline   the whole step against its bound: eager-equivalent fp32 bytes and flops of the reference graph
+                  (SURVEY 8d / BASELINE.md section 4) over the measured step time
+  cpu_baseline    the PyTorch-CPU oracle (kind "port": bit-exact restatement of the reference backbone) timed on the host
+                  cores, same workload, train forward+backward, at 8 threads and at all physical cores
 """
 import argparse
 import copy
@@ -34,6 +38,8 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA = 157.3e12     # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
 PEAK_HBM = 8.0e12            # HBM3E spec peak
+# algorithmic work per image of the reference graph (train = 3 x forward): GFLOP, eager-equivalent fp32 GB
+WORK = {'t_nus': (106.2, 3 * 5.58), 'b_nus': (750.2, 3 * 20.04), 't_stf': (265.4, 3 * 13.58)}
 
 
 def parse():
@@ -48,7 +54,8 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--no-neck', action='store_true', help='skip the HRFPN neck timing (the consumer of the 4 maps)')
+    ap.add_argument('--no-neck', action='store_true', help='skip the HRFPN neck / extract_feat timings (consumers of the 4 maps)')
+    ap.add_argument('--no-eager', action='store_true', help='skip the eager torch.autograd route timing')
     ap.add_argument('--profile-steps', type=int, default=1)
     ap.add_argument('--dump-kernels', default='', help='write the per-kernel table (JSON) to this path')
     return ap.parse_args()
@@ -59,9 +66,10 @@ def load_cfg(tag):
         return json.load(fh)[tag]
 
 
-def cpu_baseline(tag, B, H, W, mc, iters=2):
-    """Oracle (PyTorch-CPU restatement of the reference backbone, oracle/hrfuser_oracle.py) timed on
-    the host cores: train-mode forward+backward of the same workload.  Bounded sample."""
+def cpu_baseline(tag, B, H, W, mc, iters=3):
+    """Oracle (PyTorch-CPU restatement of the reference backbone, oracle/hrfuser_oracle.py) timed on the host cores:
+    train-mode forward+backward of the same workload, at 8 threads (the setting of SURVEY section 6) and at all physical
+    cores.  Bounded sample: 1 warm-up + `iters` timed iterations per setting."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import hrfuser_oracle as O
     cfg = copy.deepcopy(load_cfg(tag))
@@ -69,22 +77,34 @@ def cpu_baseline(tag, B, H, W, mc, iters=2):
     orc = O.HRFuserOracle(**cfg)
     O.seeded_fill_(orc, 0)
     orc.train()
-    cores = torch.get_num_threads()
     x, mods = O.seeded_inputs(B, H, W, mc, seed=1)
 
     def step():
         orc.zero_grad(set_to_none=True)
         ys = orc(x, [m.clone() for m in mods])
         sum(y.mean() for y in ys).backward()
-    step()                                                        # warm-up (primitive creation)
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    dt = (time.perf_counter() - t0) / iters
-    return {'value': round(B / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{iters} timed train fwd+bwd iterations (after 1 warm-up) of the same {B}x3x{H}x{W} '
-                      f'+ {len(mc)} modality batch, torch CPU fp32, {cores} threads, no optimizer step',
-            'ms_per_step': round(dt * 1e3, 1)}
+
+    phys = max(1, (os.cpu_count() or 2) // 2)
+    runs = []
+    prev = torch.get_num_threads()
+    for n in sorted({min(8, phys), phys}):
+        torch.set_num_threads(n)
+        step()                                                        # warm-up (primitive creation)
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        runs.append({'value': round(B / med, 4), 'cores': n, 'ms_per_step': round(med * 1e3, 1)})
+    torch.set_num_threads(prev)
+    best = max(runs, key=lambda r: r['value'])
+    return {'value': best['value'], 'unit': 'images/sec', 'cores': best['cores'], 'kind': 'port',
+            'sample': f'median of {iters} timed train fwd+bwd iterations (after 1 warm-up) of the same {B}x3x{H}x{W} + '
+                      f'{len(mc)} modality batch, torch CPU fp32, no optimizer step; run at 8 threads and at all '
+                      f'{phys} physical cores, the faster one is `value`',
+            'ms_per_step': best['ms_per_step'], 'runs': runs}
 
 
 def main():
@@ -108,7 +128,7 @@ def main():
         group = dist.group.WORLD
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    from hrfuser_amd import build_backbone, _lib
+    from hrfuser_amd import build_backbone
     from hrfuser_amd.trainer import Trainer, make_cotangents
     from hrfuser_amd import profiling
 
@@ -136,12 +156,14 @@ def main():
     trainer = Trainer(net, lr=1e-3 if stf else 3e-4, group=group, world_size=world)
 
     use_graph = not args.no_graph
+    capture_note = None
     if use_graph:
         try:
             trainer.capture(x, mods, cots)
         except Exception as e:                                    # e.g. collective not capturable
+            capture_note = f'hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); timed EAGER'
             if rank == 0:
-                print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager', file=sys.stderr)
+                print(f'[bench] {capture_note}', file=sys.stderr)
             use_graph = False
             torch.cuda.synchronize()
     run = trainer.replay if use_graph else (lambda: trainer.step(x, mods, cots))
@@ -155,9 +177,12 @@ def main():
     for _ in range(args.warmup):
         run()
     barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for k in range(args.steps):
         run()
+        evs[k + 1].record()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -167,6 +192,17 @@ def main():
         dt = float(tt)
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
+    per = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps))
+    pick = lambda f: round(per[min(len(per) - 1, int(f * len(per)))], 4)
+    step_ms = {'median': pick(0.5), 'p10': pick(0.1), 'p90': pick(0.9),
+               'timer': 'HIP events on the launch stream around each of the timed steps'}
+
+    # a run that went non-finite is not a result
+    eng = net._engine()
+    outs = trainer._graph_outs if use_graph else trainer.step(x, mods, cots)
+    finite = bool(torch.isfinite(eng.flat_p).all()) and all(bool(torch.isfinite(o.t).all()) for o in outs)
+    if not finite:
+        raise SystemExit('[bench] non-finite parameters / outputs after the timed steps: no result')
 
     # secondary metric: eval forward ms/img (BN running stats), hipGraph replay
     fwd_ms = None
@@ -177,42 +213,52 @@ def main():
             print(f'[bench] eval-forward timing failed: {e}', file=sys.stderr)
         net.train()
 
+    eager = None
+    if rank == 0 and world == 1 and not force_coll and not args.no_eager:
+        # what `backbone(img, mods)` + `loss.backward()` costs through torch.autograd (the drop-in route), eager launches
+        try:
+            for it in range(3 + 10):
+                if it == 3:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                ys = net(x, list(mods))
+                loss = sum((y * c.permute(0, 3, 1, 2)).sum() for y, c in zip(ys, cots))
+                eng.flat_g.zero_()
+                loss.backward()
+                trainer.optimizer_step()
+            torch.cuda.synchronize()
+            eager = {'ms_per_step': round((time.perf_counter() - t1) / 10 * 1e3, 3),
+                     'route': 'backbone(img, mods) -> synthetic loss -> loss.backward() (torch.autograd.Function bridge) -> '
+                              'fused AdamW; eager launches, no hipGraph'}
+        except Exception as e:
+            eager = {'error': f'{type(e).__name__}: {str(e)[:160]}'}
+            torch.cuda.synchronize()
+
     roof = None
     if not args.no_roofline:          # every rank runs it (the step contains collectives when N > 1)
         table = profiling.profile_step(trainer, x, mods, cots, steps=args.profile_steps)
-        traffic = {}
-        tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')     # PMC-measured bytes per launch by shape
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = {k: v['bytes_per_launch'] for k, v in json.load(fh).get('shapes', {}).items()}
-        roof = profiling.roofline_of_dominant(table, PEAK_F32_MFMA, PEAK_HBM, traffic)
-        if roof is not None and roof.get('kernel') == 'wgrad_dense_kernel' and world == 1:
-            # the product issues this family as grouped launches (several problems per launch): price the launches
-            # that actually run - in situ, HIP events on the launching stream - and keep the isolated per-problem
-            # figures (graph-batched single launches) beside them
-            try:
-                grows = profiling.grouped_wgrad_report(trainer, x, mods, cots)
-                gtraffic = {}
-                if os.path.exists(tpath):
-                    with open(tpath) as fh:
-                        gtraffic = {k: v['bytes_per_launch'] for k, v in json.load(fh).get('grouped', {}).items()}
-                groof = profiling.roofline_grouped(grows, PEAK_F32_MFMA, PEAK_HBM, gtraffic)
-                if groof is not None:
-                    groof['isolated_per_problem'] = {k: roof[k] for k in ('achieved', 'frac', 'launches_per_step', 'avg_launch_us',
-                                                                          'time_per_step_ms', 'dominant_shape') if k in roof}
-                    roof = groof
-                    if args.dump_kernels and rank == 0:
-                        with open(args.dump_kernels.replace('.json', '_grouped_wgrad.json'), 'w') as fh:
-                            json.dump(grows, fh, indent=1)
-            except Exception as e:
-                print(f'[bench] grouped weight-gradient timing failed: {e}', file=sys.stderr)
+        roof = profiling.roofline_of_dominant(table, PEAK_F32_MFMA, PEAK_HBM, os.path.join(ROOT, 'profiles'))
+        nl = sum(t[0] // t[4] for t in table.values())
         if args.dump_kernels and rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(args.dump_kernels)), exist_ok=True)
             with open(args.dump_kernels, 'w') as fh:
                 json.dump({'kernels': profiling.table_json(table, PEAK_F32_MFMA, PEAK_HBM),
-                           'signatures': profiling.profile_step.last_signatures[:60]}, fh, indent=1)
+                           'signatures': profiling.profile_step.last_signatures[:80], 'launches_per_step': nl}, fh, indent=1)
+        if roof is not None:
+            roof['library_launches_per_step'] = nl
+
+    gfl, gby = WORK.get(tag.replace('_bn', ''), (None, None))
+    step_roof = None
+    if gfl is not None and (H, W) == (384, 1248 if stf else 640):
+        sec = ms_per_step * 1e-3
+        step_roof = {'eager_bytes_per_step_GB': round(gby * B, 2), 'flops_per_step_G': round(gfl * B, 1),
+                     'bytes_frac': round(gby * 1e9 * B / sec / PEAK_HBM, 4), 'flops_frac': round(gfl * 1e9 * B / sec / PEAK_F32_MFMA, 4),
+                     'bound_img_s': round(1.0 / max(gby * 1e9 / PEAK_HBM, gfl * 1e9 / PEAK_F32_MFMA), 1),
+                     'note': 'eager-equivalent fp32 bytes / flops of the reference graph per step (SURVEY 8d, train = 3 x forward) over '
+                             'the measured step time, against 8 TB/s and 157.3 TFLOP/s; bound_img_s = per-GPU ceiling of that model'}
 
     neck = None
+    feat = None
     if rank == 0 and world == 1 and not args.no_neck:
         # the HRFPN neck that consumes the four maps, timed on its own (not part of `value`)
         try:
@@ -220,33 +266,31 @@ def main():
             neck = profiling.time_neck(list(widths), B, H // 4, W // 4)
         except Exception as e:
             neck = {'error': str(e)[:200]}
-
-    feat = None
-    if rank == 0 and world == 1 and not args.no_neck and use_graph:
-        # extract_feat training step = backbone + neck on both tapes in ONE hipGraph (not part of `value`)
-        try:
-            from hrfuser_amd.detector import FeatureExtractor, ExtractTrainer, make_pyramid_cotangents
-            from hrfuser_amd import HRFPN
-            widths = list(cfg['extra']['stage4']['num_channels'])
-            nk = HRFPN(in_channels=widths, out_channels=256)
-            nk.init_weights()
-            fx = FeatureExtractor(net, nk.to(dev))
-            fx.train()
-            pc = make_pyramid_cotangents(fx, x, mods)
-            et = ExtractTrainer(fx)
-            et.capture(x, mods, pc)
-            for _ in range(5):
-                et.replay()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(20):
-                et.replay()
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 20 * 1e3
-            feat = {'workload': f'extract_feat train step: {tag} backbone + HRFPN {widths}->256, {B} img, one hipGraph',
-                    'ms_per_step': round(ms, 3), 'images_per_sec': round(B / ms * 1e3, 2)}
-        except Exception as e:
-            feat = {'error': str(e)[:200]}
+        if use_graph:
+            # extract_feat training step = backbone + neck on both tapes in ONE hipGraph (not part of `value`)
+            try:
+                from hrfuser_amd.detector import FeatureExtractor, ExtractTrainer, make_pyramid_cotangents
+                from hrfuser_amd import HRFPN
+                widths = list(cfg['extra']['stage4']['num_channels'])
+                nk = HRFPN(in_channels=widths, out_channels=256)
+                nk.init_weights()
+                fx = FeatureExtractor(net, nk.to(dev))
+                fx.train()
+                pc = make_pyramid_cotangents(fx, x, mods)
+                et = ExtractTrainer(fx)
+                et.capture(x, mods, pc)
+                for _ in range(5):
+                    et.replay()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    et.replay()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t1) / 20 * 1e3
+                feat = {'workload': f'extract_feat train step: {tag} backbone + HRFPN {widths}->256, {B} img, one hipGraph',
+                        'ms_per_step': round(ms, 3), 'images_per_sec': round(B / ms * 1e3, 2)}
+            except Exception as e:
+                feat = {'error': str(e)[:200]}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -262,10 +306,13 @@ def main():
                                    f'{B}x3x{H}x{W} camera + {len(mc)} modalities, '
                                    + ('SyncBN+RCCL all-reduce' if world > 1 else 'BN, single GPU'),
                        'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'launch': 'hipGraph replay' if use_graph else 'eager'},
-            'fwd_ms_per_img': fwd_ms,
-            'roofline': roof, 'cpu_baseline': cpu, 'neck': neck, 'extract_feat': feat,
+                       'launch': 'hipGraph replay' if use_graph else 'eager',
+                       'collectives_per_step': trainer.collectives_per_step},
+            'step_ms': step_ms, 'finite': finite, 'fwd_ms_per_img': fwd_ms, 'eager_autograd': eager,
+            'roofline': roof, 'step_roofline': step_roof, 'cpu_baseline': cpu, 'neck': neck, 'extract_feat': feat,
         }
+        if capture_note:
+            line['config']['capture_note'] = capture_note
         print(json.dumps(line), flush=True)
     sys.stdout.flush()
     sys.stderr.flush()

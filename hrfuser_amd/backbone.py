@@ -666,10 +666,11 @@ class HRFomerModule(nn.Module):
         nb = self.num_branches
         xs = list(xs)
         lanes = ctx.fork(nb)                       # parallel branches (hrnet.py:189-190)
-        for i in range(nb):
-            with ctx.on(lanes[i]):
-                for blk in self.branches[i]:
-                    xs[i] = blk.run(ctx, xs[i])
+
+        def branch(i):
+            for blk in self.branches[i]:
+                xs[i] = blk.run(ctx, xs[i])
+        ctx.parallel(lanes, [lambda i=i: branch(i) for i in range(nb)])
         ctx.join(lanes)
         if nb == 1:
             return [xs[0]]
@@ -678,19 +679,20 @@ class HRFomerModule(nn.Module):
         nrows = len(self.fuse_layers)
         terms = [[None] * nb for _ in range(nrows)]
         lanes = ctx.fork(nb)
-        for j in range(nb):
-            with ctx.on(lanes[j]):
-                for i, row in enumerate(self.fuse_layers):
-                    if j == i:
-                        terms[i][j] = ('id', xs[j])
-                    elif j > i:
-                        terms[i][j] = ('up', R.conv_bn(ctx, xs[j], row[j][0], row[j][1], R.TF_AFFINE))
-                    else:
-                        cur = xs[j]
-                        for step in row[j]:
-                            cur = R.dwconv_bn(ctx, cur, step[0], step[1], R.TF_AFFINE)
-                            cur = R.conv_bn(ctx, cur, step[2], step[3], R.TF_RELU if len(step) == 5 else R.TF_AFFINE)
-                        terms[i][j] = ('same', cur)
+
+        def source(j):
+            for i, row in enumerate(self.fuse_layers):
+                if j == i:
+                    terms[i][j] = ('id', xs[j])
+                elif j > i:
+                    terms[i][j] = ('up', R.conv_bn(ctx, xs[j], row[j][0], row[j][1], R.TF_AFFINE))
+                else:
+                    cur = xs[j]
+                    for step in row[j]:
+                        cur = R.dwconv_bn(ctx, cur, step[0], step[1], R.TF_AFFINE)
+                        cur = R.conv_bn(ctx, cur, step[2], step[3], R.TF_RELU if len(step) == 5 else R.TF_AFFINE)
+                    terms[i][j] = ('same', cur)
+        ctx.parallel(lanes, [lambda j=j: source(j) for j in range(nb)])
         ctx.join(lanes)
         return [R.fuse_sum(ctx, tuple(xs[i].t.shape), terms[i]) for i in range(nrows)]
 
@@ -1004,6 +1006,12 @@ class HRFuserHRFormerBased(HipModule):
                     m.eval()
         return self
 
+    def unused_parameter_names(self):
+        """Parameters that never receive a gradient: the camera stream takes only the FIRST child of
+        transition1[0] (hrfuser_hrformer_based.py:550-551), so its BatchNorm is dead; the reference trains with
+        find_unused_parameters=True (mmdet/apis/train.py:114) and torch.optim skips parameters without a gradient."""
+        return ('transition1.0.1.weight', 'transition1.0.1.bias')
+
     # -- execution ------------------------------------------------------------------------------
     def forward(self, x, x_mod):
         if not self.num_fused_modalities == len(x_mod):
@@ -1049,7 +1057,8 @@ class HRFuserHRFormerBased(HipModule):
         # phase 1 - transitions: lane 0 = camera, lane 1+k = modality k (each lane only ever
         # back-propagates into its own source tensor)
         lanes = ctx.fork(1 + M)
-        with ctx.on(lanes[0]):
+
+        def cam_trans():
             for i in range(nb):
                 if first:
                     # reference quirk (:550-551): transition1[i][0] takes only the FIRST child:
@@ -1063,19 +1072,21 @@ class HRFuserHRFormerBased(HipModule):
                     cams[i] = _run_conv_chain(ctx, cam_in[i] if same else cam_in[-1], [tr] if same else list(tr))
                 else:
                     cams[i] = cam_in[i]
-        for k in range(M):
-            with ctx.on(lanes[1 + k]):
-                for i in range(nb):
-                    tr = trans_mod[k][i]
-                    ms[i][k] = mods[k] if tr is None else \
-                        _run_conv_chain(ctx, mods[k], [tr] if isinstance(tr[0], nn.Conv2d) else list(tr))
+
+        def mod_trans(k):
+            for i in range(nb):
+                tr = trans_mod[k][i]
+                ms[i][k] = mods[k] if tr is None else \
+                    _run_conv_chain(ctx, mods[k], [tr] if isinstance(tr[0], nn.Conv2d) else list(tr))
+        ctx.parallel(lanes, [cam_trans] + [lambda k=k: mod_trans(k) for k in range(M)])
         ctx.join(lanes)
         # phase 2 - one fusion block per branch, in parallel
         xs = [None] * nb
         lanes = ctx.fork(nb)
-        for i in range(nb):
-            with ctx.on(lanes[i]):
-                xs[i] = fusion[i].run(ctx, cams[i], ms[i])
+
+        def fuse(i):
+            xs[i] = fusion[i].run(ctx, cams[i], ms[i])
+        ctx.parallel(lanes, [lambda i=i: fuse(i) for i in range(nb)])
         ctx.join(lanes)
         return xs, ms[0]
 
@@ -1105,14 +1116,18 @@ class HRFuserHRFormerBased(HipModule):
     def _run(self, ctx, srcs):
         M = self.num_fused_modalities
         lanes = ctx.fork(1 + M)
-        with ctx.on(lanes[0]):
-            x = self._stem(ctx, srcs[0], self.conv1, self.bn1, self.conv2, self.bn2, self.layer1)
         mods = [None] * M
-        for k in range(M):
-            with ctx.on(lanes[1 + k]):
-                mods[k] = self._stem(ctx, srcs[1 + k], self.conv_a[k], self.norm_a[k], self.conv_b[k],
-                                     self.norm_b[k], self.layer_a[k])
+        cam = [None]
+
+        def cam_stem():
+            cam[0] = self._stem(ctx, srcs[0], self.conv1, self.bn1, self.conv2, self.bn2, self.layer1)
+
+        def mod_stem(k):
+            mods[k] = self._stem(ctx, srcs[1 + k], self.conv_a[k], self.norm_a[k], self.conv_b[k], self.norm_b[k],
+                                 self.layer_a[k])
+        ctx.parallel(lanes, [cam_stem] + [lambda k=k: mod_stem(k) for k in range(M)])
         ctx.join(lanes)
+        x = cam[0]
         xs, m0 = self._fuse_stage(ctx, x, self.transition1, self.transition_a, self.fusion_a,
                                   self.stage2_cfg['num_branches'], mods, True)
         ys, mods = self._stages(ctx, self.stage2, xs, self.stage_b, m0)
@@ -1167,12 +1182,16 @@ class HRFuserHRFormerBased(HipModule):
         M = self.num_fused_modalities
         lanes = ctx.fork(M)
         mods = [None] * M
-        for k in range(M):
-            with ctx.on(lanes[k]):
-                mods[k] = self._run_stage(ctx, mod_stages[k], [m0[k]])[0]
-        ys = self._run_stage(ctx, cam_stage, xs)
+        ys = [None]
+
+        def mod_stage(k):
+            mods[k] = self._run_stage(ctx, mod_stages[k], [m0[k]])[0]
+
+        def camera():
+            ys[0] = self._run_stage(ctx, cam_stage, xs)
+        ctx.parallel(list(lanes) + [ctx.cur], [lambda k=k: mod_stage(k) for k in range(M)] + [camera])
         ctx.join(lanes)
-        return ys, mods
+        return ys[0], mods
 
 
 @BACKBONES.register_module()

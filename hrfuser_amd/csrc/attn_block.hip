@@ -123,14 +123,83 @@ __device__ __forceinline__ void stage_ln_rows(const hrf_attn_block_t& a, const f
   for (int c = part; c < C; c += 4) wrow[c] = real ? fmaf((row[c] - mean) * rstd, gam[c], bet[c]) : 0.f;
 }
 
+// ---- weights staged in LDS (widths 18 / 36): every GEMM of the block then reads both operands from LDS and the only
+// global round trip of a workgroup is the batch of loads at its start.  Tile layout [N][PW], PW = K rounded up to 4
+// (16-byte rows), pad columns zero.
+template <int K, int PW>
+__device__ __forceinline__ void stage_weight(const float* W, int N, float* sW) {
+  const int n4 = N * (PW / 4);
+  for (int e = threadIdx.x; e < n4; e += 256) {
+    const int n = e / (PW / 4), kb = 4 * (e - n * (PW / 4));
+    const hrf_f4 v = ld_sel(kb + 4 <= K, W, (long)n * K + kb, K - kb);
+    hrf_st4(sW + n * PW + kb, v);
+  }
+}
+
+// wave_gemm with the weight tile in LDS
+template <int K, int PW, int NT>
+__device__ __forceinline__ void wave_gemm_l(const float* sW, int n0, int N, const float* brow, int lane, hrf_f4* acc) {
+  const int i = lane & 15, q = lane >> 4;
+  constexpr int NS = (K + 15) / 16;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int kbase = 16 * s + 4 * q;
+    const bool kin = kbase < PW;
+    hrf_f4 wv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + 16 * t + i;
+      const hrf_f4 w = hrf_ld4(sW + (n < N ? n : 0) * PW + (kin ? kbase : 0));
+      const bool ok = kin && n < N;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wv[t][r] = ok ? w[r] : 0.f;
+    }
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = kbase + r < K ? brow[kbase + r] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = hrf_mfma16(wv[t][r], bv[r], acc[t]);
+  }
+}
+
+// wave_gemm_t with the weight tile in LDS: acc[t] += sum_n brow[n] * sW[n][k0 + 16t + i]
+template <int N, int PW, int NT>
+__device__ __forceinline__ void wave_gemm_tl(const float* sW, int K, const float* brow, int lane, hrf_f4* acc) {
+  const int i = lane & 15, q = lane >> 4;
+  constexpr int NS = (N + 15) / 16;
+#pragma unroll 2
+  for (int s = 0; s < NS; ++s) {
+    const int nbase = 16 * s + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool nv = nbase + r < N;
+      const float bv = nv ? brow[nbase + r] : 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int k = 16 * t + i;
+        const float w = sW[(nv ? nbase + r : 0) * PW + (k < K ? k : 0)];
+        acc[t] = hrf_mfma16((nv && k < K) ? w : 0.f, bv, acc[t]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------- forward
 template <int C, int HEADS>
 __global__ __launch_bounds__(256) void attn_block_fwd_kernel(hrf_attn_block_t a) {
-  constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16;
+  constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16, PW = (C + 3) & ~3;
   constexpr int KSD = (D + 3) / 4, DT = (D + 15) / 16;
   constexpr int TILE = 64 * PC;
+  constexpr bool WL = C <= 36;            // weights staged in LDS (8*C*PW floats in front of the tiles)
   HRF_DYN_SMEM(float, smem);
-  float* sX = smem;                       // source rows -> LayerNorm'd rows -> x' -> LN_2(x')
+  float* sW1 = smem;                      // [4C][PW] w1, [C][PW] wo / wq / wk / wv  (WL only)
+  float* sWo = sW1 + 4 * C * PW;
+  float* sWq = sWo + C * PW;
+  float* sWk = sWq + C * PW;
+  float* sWv = sWk + C * PW;
+  float* sX = smem + (WL ? 8 * C * PW : 0);   // source rows -> LayerNorm'd rows -> x' -> LN_2(x')
   float* sQ = sX + TILE;                  // scaled q -> attention output o
   float* sK = sQ + TILE;
   float* sV = sK + TILE;                  // (+32 floats of slack behind it: V fragments are read 16 columns wide)
@@ -149,6 +218,13 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(hrf_attn_block_t a)
   }
   if (tid < 32) sV[TILE + tid] = 0.f;
   if (tid < 64) { sQ[tid * PC + C] = 0.f; sK[tid * PC + C] = 0.f; sV[tid * PC + C] = 0.f; }   // pitch column: read (masked) by the last k-step
+  if (WL) {                                                         // the block's weights: issued with the first batch of loads
+    if (a.w1 != nullptr) stage_weight<C, PW>(a.w1, 4 * C, sW1);
+    stage_weight<C, PW>(a.wo, C, sWo);
+    stage_weight<C, PW>(a.wq, C, sWq);
+    stage_weight<C, PW>(a.wk, C, sWk);
+    stage_weight<C, PW>(a.wv, C, sWv);
+  }
   __syncthreads();
   const int tok0 = 16 * wave;
 
@@ -158,7 +234,8 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(hrf_attn_block_t a)
   {
     hrf_f4 acc[CT];
     acc_bias<CT>(a.bq, 0, C, lane, acc);
-    wave_gemm<C, CT>(a.wq, 0, C, sX, PC, tok0, lane, acc);
+    if (WL) wave_gemm_l<C, PW, CT>(sWq, 0, C, sX + (tok0 + i) * PC, lane, acc);
+    else wave_gemm<C, CT>(a.wq, 0, C, sX, PC, tok0, lane, acc);
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -172,13 +249,15 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(hrf_attn_block_t a)
   {
     hrf_f4 acc[CT];
     acc_bias<CT>(a.bk, 0, C, lane, acc);
-    wave_gemm<C, CT>(a.wk, 0, C, sX, PC, tok0, lane, acc);
+    if (WL) wave_gemm_l<C, PW, CT>(sWk, 0, C, sX + (tok0 + i) * PC, lane, acc);
+    else wave_gemm<C, CT>(a.wk, 0, C, sX, PC, tok0, lane, acc);
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) sK[(tok0 + i) * PC + n] = acc[t][r]; }
     acc_bias<CT>(a.bv, 0, C, lane, acc);
-    wave_gemm<C, CT>(a.wv, 0, C, sX, PC, tok0, lane, acc);
+    if (WL) wave_gemm_l<C, PW, CT>(sWv, 0, C, sX + (tok0 + i) * PC, lane, acc);
+    else wave_gemm<C, CT>(a.wv, 0, C, sX, PC, tok0, lane, acc);
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -256,7 +335,8 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(hrf_attn_block_t a)
   const long pc = pix >= 0 ? pix : 0;
   hrf_f4 xo[CT];
   acc_bias<CT>(a.bo, 0, C, lane, xo);
-  wave_gemm<C, CT>(a.wo, 0, C, sQ, PC, tok0, lane, xo);
+  if (WL) wave_gemm_l<C, PW, CT>(sWo, 0, C, sQ + (tok0 + i) * PC, lane, xo);
+  else wave_gemm<C, CT>(a.wo, 0, C, sQ, PC, tok0, lane, xo);
   {
     const float rs = (a.rowscale != nullptr ? a.rowscale[pc / a.rows_per_sample] : 1.f) * a.mscale;
 #pragma unroll
@@ -318,7 +398,8 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(hrf_attn_block_t a)
   for (int n0 = 0; n0 < N1; n0 += 16 * FT) {
     hrf_f4 acc[FT];
     acc_bias<FT>(a.b1, n0, N1, lane, acc);
-    wave_gemm<C, FT>(a.w1, n0, N1, sX, PC, tok0, lane, acc);
+    if (WL) wave_gemm_l<C, PW, FT>(sW1, n0, N1, sX + tok * PC, lane, acc);
+    else wave_gemm<C, FT>(a.w1, n0, N1, sX, PC, tok0, lane, acc);
 #pragma unroll
     for (int t = 0; t < FT; ++t) {
       const int nb = n0 + 16 * t + 4 * q;
@@ -347,7 +428,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(hrf_attn_block_t a)
 
 template <int C, int HEADS>
 int launch_fwd(const hrf_attn_block_t& a, int nwin, void* stream) {
-  constexpr size_t smem = ((size_t)4 * 64 * (C + 1) + 32 + HEADS * 176) * sizeof(float);
+  constexpr size_t smem = ((size_t)(C <= 36 ? 8 * C * ((C + 3) & ~3) : 0) + 4 * 64 * (C + 1) + 32 + HEADS * 176) * sizeof(float);
 #ifndef HRF_EMUL
   static bool once = false;
   if (!once) {
@@ -503,29 +584,38 @@ __device__ __forceinline__ void ln_bwd_rows(hrf_f4* dn, const float* sXh, int pi
     }
 }
 
+#ifndef HRF_EMUL
+#define AB_T(k) do { if (a.out_rowstat != nullptr && blockIdx.x == 100 && threadIdx.x == 0) reinterpret_cast<long long*>(a.out_rowstat)[k] = wall_clock64(); } while (0)
+#else
+#define AB_T(k)
+#endif
 template <int C, int HEADS>
 __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a, hrf_bn_bfin_t bf) {
-  constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16;
+  constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16, PW = (C + 3) & ~3;
   constexpr int KSD = (D + 3) / 4, DT = (D + 15) / 16;
-  constexpr int TILE = 64 * PC, N1 = 4 * C, PH = N1 + 1, SP = 65;
+  constexpr int TILE = 64 * PC, N1 = 4 * C, PH = N1 + 1;
+  constexpr bool W1A = N1 * PW <= 2 * TILE;   // w1 fits the (dy, dO) tiles, which are written only after its last use
   HRF_DYN_SMEM(float, smem);
-  float* sX = smem;                       // xhat of x' (LN_2), later xhat of the query source (LN_q)
-  float* sXkv = sX + TILE;                // xhat of the key/value source (cross-attention only)
-  float* sDY = sXkv + TILE;               // dy = d/d(out_proj output) rows
+  float* sWo = smem;                      // [C][PW] out_proj
+  float* sWq = sWo + C * PW;              // [C][PW] q / k / v projections
+  float* sWk = sWq + C * PW;
+  float* sWv = sWk + C * PW;
+  float* sX = sWv + C * PW + (W1A ? 0 : N1 * PW);   // xhat of the query source (LN_q)
+  float* sDY = sX + TILE;                 // dy = d/d(out_proj output) rows
+  float* sW1 = W1A ? sDY : sWv + C * PW;  // [4C][PW] CrossFFN expansion weight (see W1A)
   float* sG = sDY + TILE;                 // dO rows (gradient of the attention output)
-  float* sQ = sG + TILE;                  // scaled q
+  float* sO = sG + TILE;                  // xhat of x' (LN_2) first, then the recomputed attention output
+  float* sQ = sO + TILE;                  // scaled q
   float* sK = sQ + TILE;                  // k, later dk
   float* sV = sK + TILE;                  // v, later dv
-  float* sDQ = sV + TILE + 32;            // dq rows (already multiplied by the q scale)
-  float* sO = sDQ + TILE;                 // recomputed attention output (for d out_proj.weight)
-  float* sD = sO + TILE;                  // [49][SP] dS plane of the current head (relative position bias gradient)
-  float* sH = sD + NTOK * SP + 15;        // [64][PH] dy1 = BatchNorm-backward(du1) rows of the CrossFFN head
+  float* sDQ = sV + TILE;                 // dq rows (already multiplied by the q scale)
+  float* sH = sQ;                         // [64][PH] dy1 rows of the CrossFFN head: dead before q / k / v / dq are written
+  float* sXkv = sDQ + TILE + 32;          // xhat of the key/value source (cross-attention only)
   __shared__ int sPix[64];
   __shared__ float sReal[64], sRs2[64], sRsQ[64], sRsKV[64], sM[64], sIL[64], sDl[64];
   __shared__ float sT[HEADS * 176];
   __shared__ float sGam[3][C], sBet[3][C];                 // LN_2, LN_q, LN_kv affine parameters
   __shared__ float sPar[4][3][2 * C];                      // per wave: (sum dn*xhat | sum dn) of LN_2, LN_q, LN_kv
-  __shared__ float sBin[4 * 176];
   __shared__ float sCo[3 * (4 * C)];                       // BatchNorm-backward coefficients of h1 (cA | cB | cC)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 15, q = lane >> 4;
@@ -537,7 +627,28 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
     const int px = tid < NTOK ? ab_tok_pixel(a, b, wy, wx, tid) : -1;
     sPix[tid] = px; sReal[tid] = px >= 0 ? 1.f : 0.f;
   }
-  for (int e = tid; e < 10 * TILE + 32 + NTOK * SP + 15 + (ffn ? 64 * PH : 0); e += 256) smem[e] = 0.f;
+  AB_T(0);
+  // zero: the tiles whose pad rows / columns are read (rows 49..63, pitch column), the dS plane
+  for (int e = tid; e < 8 * TILE + 32 + (cross ? TILE : 0); e += 256) sX[e] = 0.f;
+  __syncthreads();
+  const int tok0 = 16 * wave, tok = tok0 + i;
+  const int pix = sPix[tok];
+  const long pc = pix >= 0 ? pix : 0;
+  const bool tokv = pix >= 0;
+
+  AB_T(1);
+  // ---- the one batch of global loads: weights, parameters, incoming gradients, source rows
+  hrf_f4 gx[CT];                                                    // d/d(out row), this lane's 4-channel groups
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int nb = 16 * t + 4 * q;
+    gx[t] = ld_sel(16 * (t + 1) <= C, a.gout, pc * C + nb, tokv ? C - nb : 0);
+  }
+  if (ffn) stage_weight<C, PW>(a.w1, N1, sW1);
+  stage_weight<C, PW>(a.wo, C, sWo);
+  stage_weight<C, PW>(a.wq, C, sWq);
+  stage_weight<C, PW>(a.wk, C, sWk);
+  stage_weight<C, PW>(a.wv, C, sWv);
   for (int e = tid; e < HEADS * 176; e += 256) { const int h = e / 176, k = e - h * 176; sT[e] = k < 169 ? a.rpb[k * HEADS + h] : 0.f; }
   for (int e = tid; e < C; e += 256) {
     sGam[0][e] = ffn ? a.ln2_g[e] : 0.f; sBet[0][e] = ffn ? a.ln2_b[e] : 0.f;
@@ -549,38 +660,102 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
     if (bf.gstats != nullptr) hrf_bn_bfin_onload(bf, sCo, sCo + N1, sCo + 2 * N1, tid, 256, blockIdx.x == 0);
     else for (int e = tid; e < N1; e += 256) { sCo[e] = a.cA1[e]; sCo[N1 + e] = a.cB1[e]; sCo[2 * N1 + e] = a.cC1[e]; }
   }
-  __syncthreads();
-  const int tok0 = 16 * wave, tok = tok0 + i;
-  const int pix = sPix[tok];
-  const long pc = pix >= 0 ? pix : 0;
-  const bool tokv = pix >= 0;
-
-  // gx = d/d(out row): the incoming gradient, plus (CrossFFN head) the gradient through w1 and LN_2
-  hrf_f4 gx[CT];
+  constexpr bool EARLY = C <= 18;                                   // register budget: dy1 operands join the first batch
+  constexpr int NHG = EARLY ? (NTOK * (N1 / 4) + 255) / 256 : 1;
+  hrf_f4 hdu[NHG], hh1[NHG];
+  if (EARLY && ffn) {
 #pragma unroll
-  for (int t = 0; t < CT; ++t) {
-    const int nb = 16 * t + 4 * q;
-    gx[t] = ld_sel(16 * (t + 1) <= C, a.gout, pc * C + nb, tokv ? C - nb : 0);
-  }
-  if (ffn) {
-    // dy1 rows (BatchNorm backward applied while staging) and xhat_2
-    for (int e = tid; e < NTOK * (N1 / 4); e += 256) {
-      const int j = e / (N1 / 4), n = 4 * (e - j * (N1 / 4));
-      const int px = sPix[j];
-      const long pp = px >= 0 ? px : 0;
-      const hrf_f4 du = hrf_ld4(a.du1 + pp * N1 + n), hr = hrf_ld4(a.h1 + pp * N1 + n);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sH[j * PH + n + r] = px >= 0 ? fmaf(sCo[n + r], du[r], fmaf(sCo[N1 + n + r], hr[r], sCo[2 * N1 + n + r])) : 0.f;
+    for (int u = 0; u < NHG; ++u) {
+      const int e = tid + 256 * u, ec = e < NTOK * (N1 / 4) ? e : 0;
+      const int j = ec / (N1 / 4), n = 4 * (ec - j * (N1 / 4));
+      const long pp = sPix[j] >= 0 ? sPix[j] : 0;
+      hdu[u] = hrf_ld4(a.du1 + pp * N1 + n); hh1[u] = hrf_ld4(a.h1 + pp * N1 + n);
     }
-    stage_xhat_rows<C>(a, a.out, a.out_eps, sX, sRs2, sPix);
-    __syncthreads();
-    // d LN_2 output = dy1 W1  (this wave's tokens), LayerNorm backward, added to gx
+  }
+  {
+    // raw rows of x' (-> sO), the query source (-> sX) and the key/value source (-> sXkv): loads first, stores after
+    constexpr int NE = (NTOK * C + 255) / 256;
+    float v2[NE], vq[NE], vk[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u, ec = e < NTOK * C ? e : 0;
+      const int j = ec / C, c = ec - j * C;
+      const int px = sPix[j];
+      const long o = (long)(px >= 0 ? px : 0) * C + c;
+      v2[u] = ffn ? a.out[o] : 0.f; vq[u] = a.xq[o]; vk[u] = cross ? a.xkv[o] : 0.f;
+      if (px < 0) { v2[u] = 0.f; vq[u] = 0.f; vk[u] = 0.f; }
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u;
+      if (e < NTOK * C) {
+        const int j = e / C, o = j * PC + (e - j * C);
+        sO[o] = v2[u]; sX[o] = vq[u];
+        if (cross) sXkv[o] = vk[u];
+      }
+    }
+  }
+  AB_T(2);
+  __syncthreads();                                                  // sCo, raw rows
+  if (ffn) {
+    // dy1 rows: BatchNorm backward applied while staging (sH aliases the q / k / v / dq tiles)
+    if (EARLY) {
+#pragma unroll
+      for (int u = 0; u < NHG; ++u) {
+        const int e = tid + 256 * u;
+        if (e < NTOK * (N1 / 4)) {
+          const int j = e / (N1 / 4), n = 4 * (e - j * (N1 / 4));
+          const bool pv = sPix[j] >= 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sH[j * PH + n + r] = pv ? fmaf(sCo[n + r], hdu[u][r], fmaf(sCo[N1 + n + r], hh1[u][r], sCo[2 * N1 + n + r])) : 0.f;
+        }
+      }
+    } else {
+      for (int e = tid; e < NTOK * (N1 / 4); e += 256) {
+        const int j = e / (N1 / 4), n = 4 * (e - j * (N1 / 4));
+        const int px = sPix[j];
+        const long pp = px >= 0 ? px : 0;
+        const hrf_f4 du = hrf_ld4(a.du1 + pp * N1 + n), hr = hrf_ld4(a.h1 + pp * N1 + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sH[j * PH + n + r] = px >= 0 ? fmaf(sCo[n + r], du[r], fmaf(sCo[N1 + n + r], hr[r], sCo[2 * N1 + n + r])) : 0.f;
+      }
+    }
+  }
+  {
+    // xhat rows in place (zeros for tokens outside the image) + rstd, all three tiles in one pass: 4 lanes per token
+    const int t = tid >> 2, part = tid & 3;
+    const bool real = sPix[t] >= 0;
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+      if (which == 0 && !ffn) continue;
+      if (which == 2 && !cross) continue;
+      float* row = (which == 0 ? sO : (which == 1 ? sX : sXkv)) + t * PC;
+      const float eps = which == 0 ? a.out_eps : a.ln_eps;
+      float s = 0.f;
+      for (int c = part; c < C; c += 4) s += row[c];
+      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+      const float mean = s / (float)C;
+      float qq = 0.f;
+      for (int c = part; c < C; c += 4) { const float d = row[c] - mean; qq = fmaf(d, d, qq); }
+      qq += __shfl_xor(qq, 1); qq += __shfl_xor(qq, 2);
+      const float rstd = 1.0f / sqrtf(qq / (float)C + eps);
+      for (int c = part; c < C; c += 4) row[c] = real ? (row[c] - mean) * rstd : 0.f;
+      if (part == 0) (which == 0 ? sRs2 : (which == 1 ? sRsQ : sRsKV))[t] = real ? rstd : 0.f;
+    }
+  }
+  __syncthreads();
+
+  AB_T(3);
+  if (ffn) {
+    // d LN_2 output = dy1 W1 (this wave's tokens), LayerNorm backward, added to gx
     hrf_f4 dn[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-    wave_gemm_t<N1, CT>(a.w1, C, 0, sH, PH, tok0, lane, dn);
-    ln_bwd_rows<C, CT>(dn, sX, PC, tok, tokv, sRs2[tok], sGam[0], sPar[wave][0], lane);
+    wave_gemm_tl<N1, PW, CT>(sW1, C, sH + tok * PH, lane, dn);
+    if (W1A) __syncthreads();                                       // w1 occupies the dy / dO tiles: last use by every wave
+    ln_bwd_rows<C, CT>(dn, sO, PC, tok, tokv, sRs2[tok], sGam[0], sPar[wave][0], lane);
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -590,7 +765,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
       hrf_f4 acc[CT];
 #pragma unroll
       for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-      wave_tgemm<CT, true>(sH, PH, 16 * nt, N1, sX, PC, 0, C, sGam[0], sBet[0], sReal, lane, acc);
+      wave_tgemm<CT, true>(sH, PH, 16 * nt, N1, sO, PC, 0, C, sGam[0], sBet[0], sReal, lane, acc);
       store_wtile<CT>(slot + a.off_w1, 16 * nt, N1, 0, C, lane, acc);
     }
     for (int n = tid; n < N1; n += 256) {
@@ -599,6 +774,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
       slot[a.off_b1 + n] = sacc;
     }
   }
+  AB_T(4);
   // dy rows = gx * dropout mask * scales  (the out_proj output enters the residual through Dropout / DropPath)
   {
     const float rs = (a.rowscale != nullptr ? a.rowscale[pc / a.rows_per_sample] : 1.f) * a.mscale;
@@ -614,67 +790,67 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
       }
     }
   }
-  // dO rows = dy Wo  (own tokens)
   HRF_WAVE_SYNC();                                                  // a token's dy row was stored by four lanes of this wave
   {
+    // dO rows = dy Wo (own tokens)
     hrf_f4 acc[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-    wave_gemm_t<C, CT>(a.wo, C, 0, sDY, PC, tok0, lane, acc);
+    wave_gemm_tl<C, PW, CT>(sWo, C, sDY + tok * PC, lane, acc);
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int k = 16 * t + 4 * q + r; if (k < C) sG[tok * PC + k] = acc[t][r]; }
   }
-  __syncthreads();                                                  // sX (xhat_2) / sH are dead from here on
+  __syncthreads();                                                  // sH / xhat_2 are dead from here on (sH aliases sQ .. sDQ:
+                                                                    // what it leaves in their pad cells is finite, which is all they need)
 
-  // ---- recompute the projections: xhat rows of both sources, q / k / v with the LayerNorm affine applied on read
-  stage_xhat_rows<C>(a, a.xq, a.ln_eps, sX, sRsQ, sPix);
-  if (cross) stage_xhat_rows<C>(a, a.xkv, a.ln_eps, sXkv, sRsKV, sPix);
-  __syncthreads();
+  AB_T(5);
+  // ---- recompute the projections: q / k / v with the LayerNorm affine applied on read (0 for tokens outside the image)
   const float* sXk = cross ? sXkv : sX;
   const int lkv = cross ? 2 : 1;
   {
-    // n rows = xhat * gamma + beta (0 for tokens outside the image) are materialised per k-slab inside the GEMM
     hrf_f4 acc[CT];
-    auto proj = [&](const float* W, const float* bias, const float* xh, int ln, float* dstT, float mul) {
+    auto proj = [&](const float* sW, const float* bias, const float* xh, int ln, float* dstT, float mul) {
       acc_bias<CT>(bias, 0, C, lane, acc);
-      const float* brow = xh + tok * PC;
       const bool real = sReal[tok] != 0.f;
       constexpr int NS = (C + 15) / 16;
-#pragma unroll 2
-      for (int s = 0; s < NS; ++s) {
-        const int kbase = 16 * s + 4 * q, kval = C - kbase;
-        const bool kfull = 16 * (s + 1) <= C;
-        hrf_f4 wv[CT];
 #pragma unroll
-        for (int t = 0; t < CT; ++t) { const int n = 16 * t + i; wv[t] = ld_sel(kfull, W, (long)n * C + kbase, n < C ? kval : 0); }
+      for (int s = 0; s < NS; ++s) {
+        const int kbase = 16 * s + 4 * q;
+        const bool kin = kbase < PW;
         float bv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int k = r < kval ? kbase + r : 0;
-          bv[r] = (r < kval && real) ? fmaf(brow[k], sGam[ln][k], sBet[ln][k]) : 0.f;
+          const int k = kbase + r < C ? kbase + r : 0;
+          bv[r] = (kbase + r < C && real) ? fmaf(xh[tok * PC + k], sGam[ln][k], sBet[ln][k]) : 0.f;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int t = 0; t < CT; ++t) {
+          const int n = 16 * t + i;
+          const hrf_f4 w = hrf_ld4(sW + (n < C ? n : 0) * PW + (kin ? kbase : 0));
+          const bool ok = kin && n < C;
 #pragma unroll
-          for (int t = 0; t < CT; ++t) acc[t] = hrf_mfma16(wv[t][r], bv[r], acc[t]);
+          for (int r = 0; r < 4; ++r) acc[t] = hrf_mfma16(ok ? w[r] : 0.f, bv[r], acc[t]);
+        }
       }
 #pragma unroll
       for (int t = 0; t < CT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) dstT[tok * PC + n] = acc[t][r] * mul; }
     };
-    proj(a.wq, a.bq, sX, 1, sQ, a.scale);
-    proj(a.wk, a.bk, sXk, lkv, sK, 1.f);
-    proj(a.wv, a.bv, sXk, lkv, sV, 1.f);
+    proj(sWq, a.bq, sX, 1, sQ, a.scale);
+    proj(sWk, a.bk, sXk, lkv, sK, 1.f);
+    proj(sWv, a.bv, sXk, lkv, sV, 1.f);
   }
   __syncthreads();
 
+  AB_T(6);
   // ---- attention backward per head (attention.hip's MFMA formulation on the packed tiles)
 #pragma unroll 1
   for (int h = 0; h < HEADS; ++h) {
     const float* bias = sT + h * 176;
+    float* dsp = a.ds_plane + ((long)blockIdx.x * HEADS + h) * (NTOK * NTOK);   // dS[key][query] of this (window, head)
     {  // query-column orientation: wave = queries tok0 .. tok0+15
       hrf_f4 s[4], dp[4];
 #pragma unroll
@@ -745,7 +921,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
           const float ds = s[t][r] * (dp[t][r] - Dl);
           s[t][r] = ds;
           const int j = 16 * t + 4 * q + r;
-          if (j < NTOK && qi < NTOK) sD[j * SP + qi] = ds;
+          if (j < NTOK && qi < NTOK) dsp[j * NTOK + qi] = ds;
         }
       // dQ = dS K (contraction over keys)
 #pragma unroll
@@ -821,31 +997,19 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
         }
       }
     }
-    // relative position bias gradient of head h: gather over the dS plane (169 bins x 4 row groups)
-    for (int it = tid; it < 169 * 4; it += 256) {
-      const int e = it % 169, part = it / 169;
-      const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
-      const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
-      const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
-      float sacc = 0.f;
-      for (int yj = y0 + part; yj <= y1; yj += 4)
-        for (int xj = x0; xj <= x1; ++xj) sacc += sD[(yj * 7 + xj) * SP + (yj + dy) * 7 + xj + dx];
-      sBin[part * 176 + e] = sacc;
-    }
-    __syncthreads();
-    if (tid < 169) slot[a.off_rpb + tid * HEADS + h] = (sBin[tid] + sBin[176 + tid]) + (sBin[352 + tid] + sBin[528 + tid]);
-    __syncthreads();                                                // sD / sBin are rewritten by the next head
   }
+  __syncthreads();                                                  // dk / dv rows of the last head
 
+  AB_T(7);
   // ---- d LN outputs = dq Wq (+ dk Wk + dv Wv), LayerNorm backward, output gradients
   {
     hrf_f4 dn[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-    wave_gemm_t<C, CT>(a.wq, C, 0, sDQ, PC, tok0, lane, dn);
+    wave_gemm_tl<C, PW, CT>(sWq, C, sDQ + tok * PC, lane, dn);
     if (!cross) {
-      wave_gemm_t<C, CT>(a.wk, C, 0, sK, PC, tok0, lane, dn);
-      wave_gemm_t<C, CT>(a.wv, C, 0, sV, PC, tok0, lane, dn);
+      wave_gemm_tl<C, PW, CT>(sWk, C, sK + tok * PC, lane, dn);
+      wave_gemm_tl<C, PW, CT>(sWv, C, sV + tok * PC, lane, dn);
     }
     ln_bwd_rows<C, CT>(dn, sX, PC, tok, tokv, sRsQ[tok], sGam[1], sPar[wave][1], lane);
     if (a.dq != nullptr && tokv) {
@@ -865,8 +1029,8 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
     if (cross) {
 #pragma unroll
       for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-      wave_gemm_t<C, CT>(a.wk, C, 0, sK, PC, tok0, lane, dn);
-      wave_gemm_t<C, CT>(a.wv, C, 0, sV, PC, tok0, lane, dn);
+      wave_gemm_tl<C, PW, CT>(sWk, C, sK + tok * PC, lane, dn);
+      wave_gemm_tl<C, PW, CT>(sWv, C, sV + tok * PC, lane, dn);
       ln_bwd_rows<C, CT>(dn, sXkv, PC, tok, tokv, sRsKV[tok], sGam[2], sPar[wave][2], lane);
       if (a.dkv != nullptr && tokv) {
 #pragma unroll
@@ -899,6 +1063,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
     }
   }
 
+  AB_T(8);
   // ---- weight gradients of the four Linear layers: [out tile of 16][all input channels] per wave, round-robin
   {
     constexpr int NTC = C / 16 + (C % 16 ? 1 : 0);
@@ -929,6 +1094,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
     }
   }
   __syncthreads();
+  AB_T(9);
   // LayerNorm parameter gradients: sum of the four waves' partials
   for (int e = tid; e < 3 * 2 * C; e += 256) {
     const int ln = e / (2 * C), k = e - ln * 2 * C;
@@ -936,16 +1102,20 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a,
     const int off = ln == 0 ? (k < C ? a.off_g2 : a.off_bt2) : (ln == 1 ? (k < C ? a.off_gq : a.off_btq) : (k < C ? a.off_gkv : a.off_btkv));
     if (off >= 0) slot[off + (k < C ? k : k - C)] = v;
   }
+  AB_T(10);
 }
 
 template <int C, int HEADS>
 int launch_bwd(const hrf_attn_block_t& a, const hrf_bn_bfin_t& bf, int nwin, void* stream) {
-  constexpr int TILE = 64 * (C + 1);
-  const size_t smem = ((size_t)10 * TILE + 32 + NTOK * 65 + 15 + (a.w1 != nullptr ? 64 * (4 * C + 1) : 0)) * sizeof(float);
+  constexpr int TILE = 64 * (C + 1), PW = (C + 3) & ~3;
+  static_assert(4 * TILE >= 64 * (4 * C + 1), "dy1 rows alias the q / k / v / dq tiles");
+  const bool cross = a.xkv != a.xq;
+  constexpr int W1X = (4 * C * PW <= 2 * TILE) ? 0 : 4 * C * PW;     // w1 aliases the (dy, dO) tiles when it fits
+  const size_t smem = ((size_t)4 * C * PW + W1X + 8 * TILE + 32 + (cross ? TILE : 0)) * sizeof(float);
 #ifndef HRF_EMUL
   static bool once = false;
   if (!once) {
-    constexpr size_t smax = ((size_t)10 * TILE + 32 + NTOK * 65 + 15 + 64 * (4 * C + 1)) * sizeof(float);
+    constexpr size_t smax = ((size_t)4 * C * PW + W1X + 9 * TILE + 32) * sizeof(float);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_bwd_kernel<C, HEADS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smax) != hipSuccess) return HRF_ERR_LAUNCH;
     once = true;
@@ -953,6 +1123,28 @@ int launch_bwd(const hrf_attn_block_t& a, const hrf_bn_bfin_t& bf, int nwin, voi
 #endif
   HRF_LAUNCH((attn_block_bwd_kernel<C, HEADS>), dim3(nwin), dim3(256), smem, stream, a, bf);
   return hrf_check_launch();
+}
+
+// Relative-position-bias gradient from the dS planes the backward kernel left in memory (a LEAF of the backward graph:
+// issued with the deferred weight gradients, off the dependency chain): drpb[(yi-yj+6)*13 + (xi-xj+6)][h] += dS[j][i].
+// grid = (window chunks, heads); the planes of a chunk pass through LDS, thread e < 169 owns bin e.
+__global__ __launch_bounds__(256) void rpb_grad_kernel(const float* ds, int nwin, int heads, float* drpb, long copy_stride) {
+  __shared__ float sP[NTOK * NTOK];
+  const int h = blockIdx.y, e = threadIdx.x;
+  const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
+  const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
+  const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
+  float acc = 0.f;
+  for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+    const float* p = ds + ((long)w * heads + h) * (NTOK * NTOK);
+    for (int k = threadIdx.x; k < NTOK * NTOK; k += 256) sP[k] = p[k];
+    __syncthreads();
+    if (e < 169)
+      for (int yj = y0; yj <= y1; ++yj)
+        for (int xj = x0; xj <= x1; ++xj) acc += sP[(yj * 7 + xj) * NTOK + (yj + dy) * 7 + xj + dx];
+    __syncthreads();
+  }
+  if (e < 169) hrf_atomic_add(&drpb[(long)(blockIdx.x % HRF_STAT_COPIES) * copy_stride + e * heads + h], acc);
 }
 
 // dst[map[i]] += sum over the slots of one fused layer (blockIdx.y = segment)
@@ -991,7 +1183,7 @@ static void ab_geometry(hrf_attn_block_t& a) {
 extern "C" int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream) {
   if (p == nullptr || !hrf_attn_block_bwd_supported(p->C, p->heads)) return HRF_ERR_ARG;
   hrf_attn_block_t a = *p;
-  if (a.xq == nullptr || a.xkv == nullptr || a.gout == nullptr || a.pslot == nullptr) return HRF_ERR_ARG;
+  if (a.xq == nullptr || a.xkv == nullptr || a.gout == nullptr || a.pslot == nullptr || a.ds_plane == nullptr) return HRF_ERR_ARG;
   if (a.w1 != nullptr && (a.hidden != 4 * a.C || a.h1 == nullptr || a.du1 == nullptr || a.out == nullptr ||
                           (a.bfin1 == nullptr && a.cA1 == nullptr))) return HRF_ERR_ARG;
   hrf_bn_bfin_t bf{};
@@ -1005,6 +1197,13 @@ extern "C" int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream) {
   if (nwin <= 0) return HRF_OK;
   if (a.heads == 1) return launch_bwd<18, 1>(a, bf, nwin, stream);
   return launch_bwd<36, 2>(a, bf, nwin, stream);
+}
+
+extern "C" int hrf_rpb_grad(const float* ds_plane, int nwin, int heads, float* drpb, long copy_stride, void* stream) {
+  if (nwin <= 0 || heads <= 0) return HRF_OK;
+  const int chunks = nwin < 160 ? nwin : 160;
+  HRF_LAUNCH(rpb_grad_kernel, dim3(chunks, heads), dim3(256), 0, stream, ds_plane, nwin, heads, drpb, copy_stride);
+  return hrf_check_launch();
 }
 
 extern "C" int hrf_fold_slots(const float* slots, const long* seg, int nseg, const int* map, float* dst, long max_n, void* stream) {

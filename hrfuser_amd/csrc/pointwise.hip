@@ -68,6 +68,61 @@ __global__ void bn_bwd_finalize_kernel(const double* gstats, const double* gstat
   }
 }
 
+// ---- SyncBN exchange of SEVERAL independent BatchNorms at once (data-parallel training).  The replicated moments of up
+// to PK_MAX layers are folded into ONE packed fp64 buffer (2*C doubles per layer, layer after layer), the host all-reduces
+// that buffer with ONE collective, and one launch finalises all of them from the packed sums.
+constexpr int PK_MAX = 8;
+struct BnPackArgs { const double* src[PK_MAX]; int C[PK_MAX]; int off[PK_MAX]; };
+__global__ __launch_bounds__(256) void bn_pack_kernel(BnPackArgs a, double* packed) {
+  const int e = blockIdx.y, C2 = 2 * a.C[e];
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < C2; c += gridDim.x * 256) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < HRF_STAT_COPIES; ++k) s += a.src[e][(size_t)k * C2 + c];
+    packed[a.off[e] + c] = s;
+  }
+}
+struct BnFinPackArgs { hrf_bn_fin_t f[PK_MAX]; int off[PK_MAX]; };
+__global__ __launch_bounds__(256) void bn_finalize_packed_kernel(BnFinPackArgs a, const double* packed) {
+  const hrf_bn_fin_t& f = a.f[blockIdx.y];
+  const double* st = packed + a.off[blockIdx.y];
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < f.C; c += gridDim.x * 256) {
+    const double mean = st[c] / f.count;
+    double var = st[f.C + c] / f.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    const float sc = g * invstd;
+    f.scale[c] = sc; f.shift[c] = b - (float)mean * sc; f.mean[c] = (float)mean; f.invstd[c] = invstd;
+    if (f.update_running) {
+      const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+      f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+      f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+    }
+  }
+}
+struct BnBFinPackArgs { hrf_bn_bfin_t f[PK_MAX]; int off[PK_MAX]; };
+__global__ __launch_bounds__(256) void bn_bwd_finalize_packed_kernel(BnBFinPackArgs a, const double* packed, const double* packed_local) {
+  const hrf_bn_bfin_t& f = a.f[blockIdx.y];
+  const double* gs = packed + a.off[blockIdx.y];
+  const double* ls = packed_local + a.off[blockIdx.y];
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < f.C; c += gridDim.x * 256) {
+    const double sdu = gs[c], sdux = gs[f.C + c], ldu = ls[c], ldux = ls[f.C + c];
+    const double mu = f.mean[c], is = f.invstd[c], g = f.gamma ? f.gamma[c] : 1.f;
+    const double sduy = (sdux - mu * sdu) * is;
+    // parameter grads from the rank-LOCAL moments (data-parallel grads are averaged afterwards), dy coefficients from the
+    // all-reduced ones
+    if (f.dgamma) f.dgamma[c] += (float)((ldux - mu * ldu) * is);
+    if (f.dbeta) f.dbeta[c] += (float)ldu;
+    if (f.train) {
+      const double am = sdu / f.count, bm = sduy / f.count;
+      f.cA[c] = (float)(g * is); f.cB[c] = (float)(-g * is * is * bm); f.cC[c] = (float)(-g * is * am + g * is * is * bm * mu);
+    } else {
+      f.cA[c] = (float)(g * is); f.cB[c] = 0.f; f.cC[c] = 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------- LayerNorm
 // 16 lanes cooperate on one row (C = 18..624), 4 rows per wave, 16 rows per 256-thread block.
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* x, int rows, int C, float eps, float* rowstat) {
@@ -595,10 +650,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
                                                     long n, float lr, float b1, float b2, float eps, float wd,
                                                     const float* state, float gscale) {
   const float bc1 = state[0], bc2 = state[1];
+  if (lr < 0.f) lr = state[3];                                   // learning rate kept on the device (hipGraph replays follow a schedule)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float wm = wd_mask ? wd_mask[i] : 1.f;
+    if (wm < 0.f) continue;                                      // parameter without a gradient (torch skips `grad is None`)
     const float gr = g[i] * gscale;
     float pi = p[i];
-    pi -= lr * wd * (wd_mask ? wd_mask[i] : 1.f) * pi;           // decoupled weight decay (torch.optim.AdamW)
+    pi -= lr * wd * wm * pi;                                     // decoupled weight decay (torch.optim.AdamW)
     const float mi = b1 * m[i] + (1.f - b1) * gr;
     const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
     m[i] = mi; v[i] = vi;
@@ -808,6 +866,46 @@ extern "C" int hrf_adamw(float* p, const float* g, float* m, float* v, const flo
   if (n <= 0) return HRF_OK;
   HRF_LAUNCH(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, p, g, m, v, wd_mask, n, lr, beta1, beta2, eps,
              weight_decay, state, grad_scale);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_bn_pack(const double* const* stats, const int* C, int n, double* packed, void* stream) {
+  if (n <= 0) return HRF_OK;
+  int off = 0;
+  for (int b = 0; b < n; b += PK_MAX) {
+    BnPackArgs a{};
+    const int m = n - b < PK_MAX ? n - b : PK_MAX;
+    int cmax = 0;
+    for (int k = 0; k < m; ++k) { a.src[k] = stats[b + k]; a.C[k] = C[b + k]; a.off[k] = off; off += 2 * C[b + k]; if (C[b + k] > cmax) cmax = C[b + k]; }
+    HRF_LAUNCH(bn_pack_kernel, dim3(hrf_cdiv(2 * cmax, 256), m), dim3(256), 0, stream, a, packed);
+  }
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_bn_finalize_packed(const hrf_bn_fin_t* fins, int n, const double* packed, void* stream) {
+  if (n <= 0) return HRF_OK;
+  int off = 0;
+  for (int b = 0; b < n; b += PK_MAX) {
+    BnFinPackArgs a{};
+    const int m = n - b < PK_MAX ? n - b : PK_MAX;
+    int cmax = 0;
+    for (int k = 0; k < m; ++k) { a.f[k] = fins[b + k]; a.off[k] = off; off += 2 * fins[b + k].C; if (fins[b + k].C > cmax) cmax = fins[b + k].C; }
+    HRF_LAUNCH(bn_finalize_packed_kernel, dim3(hrf_cdiv(cmax, 256), m), dim3(256), 0, stream, a, packed);
+  }
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_bn_bwd_finalize_packed(const hrf_bn_bfin_t* bfins, int n, const double* packed, const double* packed_local,
+                                          void* stream) {
+  if (n <= 0) return HRF_OK;
+  int off = 0;
+  for (int b = 0; b < n; b += PK_MAX) {
+    BnBFinPackArgs a{};
+    const int m = n - b < PK_MAX ? n - b : PK_MAX;
+    int cmax = 0;
+    for (int k = 0; k < m; ++k) { a.f[k] = bfins[b + k]; a.off[k] = off; off += 2 * bfins[b + k].C; if (bfins[b + k].C > cmax) cmax = bfins[b + k].C; }
+    HRF_LAUNCH(bn_bwd_finalize_packed_kernel, dim3(hrf_cdiv(cmax, 256), m), dim3(256), 0, stream, a, packed, packed_local);
+  }
   return hrf_check_launch();
 }
 

@@ -1,6 +1,7 @@
 """In-process measurement helpers for bench.py: per-launch HIP-event timing of every C-ABI call,
 an algorithmic work model (FLOPs / compulsory bytes) per launch, and the roofline of the
 dominant kernel.  Pure measurement plumbing - nothing here computes results."""
+import ctypes
 import math
 import os
 import time
@@ -68,6 +69,22 @@ def work_model(name, a):
         if name == 'hrf_window_attn_fwd':
             return f"attn_fwd_kernel<{D}>", 2 * unit, f4 * P * a['C'] * 4
         return f"attn_bwd_kernel<{D}>", 5 * unit, f4 * P * a['C'] * 7
+    if name in ('hrf_attn_block_fwd', 'hrf_attn_block_bwd'):
+        C, heads = a['C'], a['heads']
+        rows = float(a['B']) * a['H'] * a['W']
+        nwin = a['B'] * math.ceil(a['H'] / 7) * math.ceil(a['W'] / 7)
+        cross, ffn = bool(a['cross']), bool(a['w1'])
+        attn = 2 * 2.0 * 49 * 49 * (C // heads) * nwin * heads               # q k^T and p v on the 49-token windows
+        fwd = 2.0 * rows * C * C * 4 + attn + (2.0 * rows * C * 4 * C if ffn else 0.0)
+        wts = 4.0 * (4 * C * C + (4 * C * C if ffn else 0))
+        if name == 'hrf_attn_block_fwd':
+            by = f4 * rows * C * (2 + 2 * cross + (4 if ffn else 0)) + wts
+            return f'attn_block_fwd_kernel<{C}, {heads}>', fwd, by
+        slot = 4 * C * C + (4 * C * C if ffn else 0)
+        by = f4 * (rows * C * (4 + 3 * cross + (8 if ffn else 0)) + nwin * (slot + heads * 49 * 49)) + wts
+        return f'attn_block_bwd_kernel<{C}, {heads}>', 3.0 * fwd, by
+    if name == 'hrf_rpb_grad':
+        return 'rpb_grad_kernel', 0.0, f4 * a['nwin'] * a['heads'] * 49 * 49
     rc = None
     if 'rows' in a and 'C' in a:
         rc = float(a['rows']) * a['C']
@@ -110,10 +127,25 @@ class ProfLib:
         fn = getattr(self._lib, name)
         names = [n for _, n in self._lib.protos[name]]
 
+        def describe(args):
+            d = dict(zip(names, args))
+            p = d.get('p')
+            if isinstance(p, ctypes.Structure):           # struct-argument entry points: the shape lives in the struct
+                for f, _ in p._fields_:
+                    v = getattr(p, f)
+                    if f in ('B', 'H', 'W', 'C', 'heads', 'hidden'):
+                        d[f] = v
+                d['cross'] = int(p.xq != p.xkv)
+                d['w1'] = int(bool(p.w1))
+            return d
+
+        if name in _lib._RAW_RETURN or name in ('hrf_wgrad_group_begin', 'hrf_wgrad_group_end', 'hrf_debug_knob'):
+            return fn                                     # queries / plumbing: not launches, and their value matters
+
         def call(*args):
             if not self.timing:
                 fn(*args)
-                self.records.append((name, dict(zip(names, args)), args))
+                self.records.append((name, describe(args), args))
                 return
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
@@ -131,7 +163,8 @@ def _signature(name, a):
 def shape_tag(name, a):
     """Human-readable signature of one launch: entry point + the shape/mode integers that select the
     kernel variant (pointer arguments reduced to present/absent).  Also the key of profiles/*traffic*.json."""
-    keep = ('B', 'H', 'W', 'C', 'Cin', 'Cout', 'KH', 'stride', 'rows', 'heads', 'tf_mode', 'epi', 'mode', 'accumulate')
+    keep = ('B', 'H', 'W', 'C', 'Cin', 'Cout', 'KH', 'stride', 'rows', 'heads', 'tf_mode', 'epi', 'mode', 'accumulate', 'cross', 'w1',
+            'nwin')
     parts = [f'{k}={a[k]}' for k in keep if k in a and isinstance(a[k], (int, float))]
     if 'cA' in a:
         parts.append(f"bnb={int(a['cA'] is not None)}")
@@ -238,13 +271,20 @@ def _row(key, t, peak_f, peak_b):
             'flops_per_launch': fl / n, 'bytes_per_launch': by / n}
 
 
-def roofline_of_dominant(table, peak_f, peak_b, traffic=None):
-    """Roofline entry of the dominant kernel (largest share of GPU time per step).  `achieved` is the
-    family's algorithmic bytes (or flops) per launch over its average launch duration; the heaviest
-    single signature of the family is reported next to it, with the PMC-measured fabric/HBM traffic of
-    exactly that signature when profiles/*hbm_traffic*.json holds one (`traffic`, bytes per launch)."""
+def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None):
+    """Roofline entry of the kernel FAMILY with the largest time per step (isolated per-launch durations).  `achieved` =
+    the family's algorithmic bytes (or flops) per launch / its average launch duration; `dominant_shape` = its heaviest
+    single (entry point, shape).  `traffic` = PMC-measured fabric bytes per launch of that shape when
+    <profiles_dir>/r02_hbm_traffic.json holds it (a SEPARATE `rocprofv3 --pmc` run; the source is stated), else null."""
     key = max(table, key=lambda k: table[k][1])
     row = _row(key, table[key], peak_f, peak_b)
+    row['selection'] = 'kernel family with the largest summed isolated launch time per training step'
+    traffic = {}
+    tpath = os.path.join(profiles_dir, 'r02_hbm_traffic.json') if profiles_dir else None
+    if tpath and os.path.exists(tpath):
+        import json
+        with open(tpath) as fh:
+            traffic = json.load(fh).get('shapes', {})
     sigs = [r for r in getattr(profile_step, 'last_signatures', []) if r['kernel'] == key]
     if sigs:
         top = sigs[0]
@@ -255,11 +295,16 @@ def roofline_of_dominant(table, peak_f, peak_b, traffic=None):
                                  'avg_launch_us': round(top['avg_launch_us'], 2),
                                  'bytes_per_launch': top['bytes_per_launch'], 'flops_per_launch': top['flops_per_launch'],
                                  'achieved': round(ach, 3), 'unit': 'GB/s' if bound_b else 'TFLOP/s',
-                                 'frac': round(ach / ((peak_b / 1e9) if bound_b else (peak_f / 1e12)), 4),
-                                 'traffic': (traffic or {}).get(top['shape'])}
-        if row['dominant_shape']['traffic'] is not None:
-            row['traffic'] = row['dominant_shape']['traffic']
-            row['traffic_note'] = 'PMC (FETCH_SIZE x2 + WRITE_SIZE) of dominant_shape, bytes per launch'
+                                 'frac': round(ach / ((peak_b / 1e9) if bound_b else (peak_f / 1e12)), 4)}
+        t = traffic.get(top['shape'])
+        if t is not None:
+            row['traffic'] = t['bytes_per_launch']
+            row['traffic_source'] = (f'profiles/r02_hbm_traffic.json[{top["shape"]}]: 2 x FETCH_SIZE + WRITE_SIZE of that launch from a '
+                                     'separate rocprofv3 --pmc run (tools/prof_traffic.sh); NOT measured in this bench run')
+    # the next families, for context
+    others = sorted(table.items(), key=lambda kv: -kv[1][1])[1:6]
+    row['next_families'] = [{k2: _row(k, t, peak_f, peak_b)[k2] for k2 in ('kernel', 'bound', 'frac', 'launches_per_step', 'time_per_step_ms')}
+                            for k, t in others]
     return row
 
 

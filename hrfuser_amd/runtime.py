@@ -18,6 +18,11 @@ import os
 
 import torch
 
+try:                                     # coroutines for the lock-step SyncBN schedule (Ctx.parallel); optional
+    import greenlet as _greenlet
+except Exception:                        # pragma: no cover
+    _greenlet = None
+
 from . import _lib
 
 # BatchNorm finalize ON LOAD: the consumer of a train-mode BatchNorm derives scale/shift in its own prologue from the
@@ -29,7 +34,14 @@ _FIN_ONLOAD = os.environ.get('HRF_FIN_ONLOAD', '1') != '0'
 FIN_MAXC = _lib.FIN_MAXC
 LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
 _MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
-_FORCE_COLL = os.environ.get('HRF_FORCE_COLLECTIVES', '0') == '1'
+
+
+def force_collectives():
+    """HRF_FORCE_COLLECTIVES=1: issue the collectives even in a 1-rank group (lets a single-GPU box exercise RCCL inside
+    the lanes / hipGraph capture exactly as an 8-GPU run would).  Read when a forward starts, not at import."""
+    return os.environ.get('HRF_FORCE_COLLECTIVES', '0') == '1'
+
+
 TF_NONE, TF_AFFINE, TF_RELU, TF_GELU, TF_LN = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 _TF2ACT = {TF_NONE: ACT_NONE, TF_AFFINE: ACT_NONE, TF_RELU: ACT_RELU, TF_GELU: ACT_GELU}
@@ -84,7 +96,7 @@ class Act:
 class BNState:
     """One BatchNorm application: raw conv output + the per-channel vectors around it."""
     __slots__ = ('bn', 'C', 'raw', 'count', 'scale', 'shift', 'mean', 'invstd', 'stats', 'gstats',
-                 'coef', 'du', 'train', 'pending')
+                 'coef', 'du', 'train', 'pending', 'lane', 'bx_done')
 
 
 class Lazy:
@@ -163,17 +175,145 @@ class Ctx:
         self._deferred = []
         # test instrumentation (tests/helpers.py: ReLU-mask pinning): a list that receives every ReLU site of the forward
         self.probe = [] if owner.__dict__.get('_relu_probe') else None
+        self.n_collectives = 0
+        # SyncBN: exchanges of mutually independent BatchNorms are BATCHED (one collective for all of them): sibling lanes
+        # run as coroutines in lock-step (parallel()), each parking at its next exchange until the sweep is complete
+        self.coll = self.group is not None and (self.world > 1 or force_collectives())
+        self.pending = []
+        self._glet = _greenlet if (self.coll and os.environ.get('HRF_SYNC_BATCH', '1') != '0') else None
 
     # ---- tape ----------------------------------------------------------------------------------
-    def push(self, fn):
+    def push(self, fn, sync=None):
+        """sync: BNState whose backward exchange (SyncBN) `fn` needs before it can run - run_backward batches those."""
         if self.record:
-            self.tape.append((fn, self.cur))
+            self.tape.append((fn, self.cur, sync))
+
+    # ---- lock-step execution of sibling lanes (SyncBN batching) ---------------------------------------------------
+    def _resume(self, lane):
+        self.cur, self.stream = lane, lane.ptr
+        if self.multi and lane.stream is not None:
+            torch.cuda.set_stream(lane.stream)
+
+    def parallel(self, lanes, bodies):
+        """Run bodies[i]() on lanes[i].  Normally one after the other (the lanes are HIP streams: the GPU overlaps them).
+        With SyncBN the bodies run as coroutines in LOCK-STEP: each one parks at its next BatchNorm exchange
+        (sync_wait), and when every sibling is parked (or done) ONE packed collective serves all of them - the three
+        sensor streams at equal depth, the branches of an HRModule, the chains of an exchange.  Nested calls (the
+        camera stage forking branch lanes while the modality stages run beside it) hand their parked children up to the
+        outer sweep, so the batch spans both levels."""
+        G = self._glet
+        if G is None or not self.training or len(bodies) <= 1:
+            for lane, body in zip(lanes, bodies):
+                with _LaneScope(self, lane):
+                    body()
+            return
+        me = G.getcurrent()
+        home = self.cur
+        nested = getattr(me, 'hrf_lane', None) is not None
+
+        def wrap(lane, body):
+            def run():
+                with _LaneScope(self, lane):
+                    body()
+            g = G.greenlet(run)
+            g.hrf_lane = lane
+            return g
+        alive = [wrap(l, b) for l, b in zip(lanes, bodies)]
+        while alive:
+            for g in list(alive):
+                g.switch()                               # until its next exchange (sync_wait parks it) or its end
+                if g.dead:
+                    alive.remove(g)
+            self._resume(home)
+            if self.pending or alive:
+                if nested:
+                    me.parent.switch()                   # let the outer sweep finish; it flushes for everybody
+                    self._resume(home)
+                else:
+                    self.flush_sync()
+
+    def sync_wait(self, st):
+        """Forward SyncBN exchange of `st`: parked until the lock-step sweep flushes, or flushed at once outside one."""
+        st.lane = self.cur
+        self.pending.append(st)
+        G = self._glet
+        me = G.getcurrent() if G is not None else None
+        if me is not None and getattr(me, 'hrf_lane', None) is not None:
+            lane = self.cur
+            me.parent.switch()
+            self._resume(lane)
+        else:
+            self.flush_sync()
+
+    def _exchange(self, sts, lanes, pack_ptrs, finalize):
+        """One packed collective for the BatchNorms `sts`, issued on the main lane between the lanes involved."""
+        lanes = [l for l in dict.fromkeys(lanes) if l is not self.main and l.stream is not None]
+        if self.multi:
+            for l in lanes:
+                self.main.stream.wait_stream(l.stream)
+        with _LaneScope(self, self.main):
+            n = len(sts)
+            total = sum(2 * st.C for st in sts)
+            packed = _keep(torch.empty(total, device=sts[0].raw.device, dtype=torch.float64))
+            ptrs = (ctypes.c_void_p * n)(*pack_ptrs)
+            cs = (ctypes.c_int * n)(*[st.C for st in sts])
+            self.L.hrf_bn_pack(ptrs, cs, n, packed, self.stream)
+            finalize(packed)
+        if self.multi:
+            for l in lanes:
+                l.stream.wait_stream(self.main.stream)
+
+    def flush_sync(self):
+        sts, self.pending = self.pending, []
+        if not sts:
+            return
+        P = _lib._ptr
+
+        def fin(packed):
+            self.all_reduce(packed)
+            fins = (_lib.BnFin * len(sts))()
+            for k, st in enumerate(sts):
+                bn = st.bn
+                mom = bn.momentum if bn.momentum is not None else 0.1
+                fins[k] = _lib.BnFin(None, P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var), P(st.scale),
+                                     P(st.shift), P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom),
+                                     1 if bn.track_running_stats else 0, 1, st.C)
+            self.L.hrf_bn_finalize_packed(fins, len(sts), packed, self.stream)
+        self._exchange(sts, [st.lane for st in sts], [P(st.stats) for st in sts], fin)
+        for st in sts:
+            st.pending = None
+
+    def flush_bwd(self, sts, lanes):
+        """Backward SyncBN exchange of (sum du, sum du*y) for all of `sts` in one collective."""
+        P = _lib._ptr
+
+        def fin(packed):
+            local = _keep(packed.clone())
+            self.all_reduce(packed)
+            bf = (_lib.BnBFin * len(sts))()
+            for k, st in enumerate(sts):
+                slot = self.owner._bn_slot(st.bn)
+                wg = st.bn.weight.grad if st.bn.weight.requires_grad else None
+                bg = st.bn.bias.grad if st.bn.bias.requires_grad else None
+                bf[k] = _lib.BnBFin(None, P(st.bn.weight), P(st.mean), P(st.invstd), P(wg), P(bg), P(slot['cA']), P(slot['cB']),
+                                    P(slot['cC']), st.count, 1, 1, st.C)
+            self.L.hrf_bn_bwd_finalize_packed(bf, len(sts), packed, local, self.stream)
+        self._exchange(sts, lanes, [P(st.gstats) for st in sts], fin)
+        for st in sts:
+            st.bx_done = True
 
     # ---- lanes ---------------------------------------------------------------------------------
     def fork(self, n):
         """n sibling lanes that start after everything enqueued so far on the current lane."""
         # lanes are always direct children of the main lane: nested stream forks crash hipGraph
         # capture on ROCm 7.x, and a flat fork/join schedule expresses all the parallelism we need
+        if n > 1 and not self.multi and self._glet is not None and self.cur is self.main:
+            # no streams (CPU emulator runs): LOGICAL lanes, so that the SyncBN batching sees which tape entries are
+            # independent of each other
+            uniq = [Lane(None) for _ in range(n)]
+            if self.record:
+                self.tape.append(('F', self.cur, uniq))
+            return uniq
         if not self.multi or n <= 1 or self.cur is not self.main:
             return [self.cur] * n
         m = n if _MAX_LANES <= 0 else min(n, _MAX_LANES)      # HRF_MAX_LANES: fewer streams than siblings
@@ -188,6 +328,10 @@ class Ctx:
 
     def join(self, kids):
         """The current lane continues after all sibling lanes have finished."""
+        if len(kids) > 1 and not self.multi and kids[0] is not self.cur and kids[0].stream is None:
+            if self.record:
+                self.tape.append(('J', self.cur, list(dict.fromkeys(kids))))
+            return
         if not self.multi or len(kids) <= 1 or kids[0] is self.cur:
             return
         kids = list(dict.fromkeys(kids))                    # lanes may repeat under HRF_MAX_LANES
@@ -254,20 +398,48 @@ class Ctx:
         flush_n = int(os.environ.get('HRF_WGRAD_FLUSH', '48')) if (self.multi and os.environ.get('HRF_WGRAD', 'defer') == 'flush') else 0
         if self.multi:
             self.main.stream.wait_stream(torch.cuda.current_stream())
+        # SyncBN: tape entries whose BatchNorm still needs its backward exchange are PARKED (one per lane - entries of
+        # other lanes are independent of them and keep running) and released together: ONE packed collective for all of
+        # them.  Program order inside a lane is kept: the next entry of a parked lane releases the batch first.
+        active, parked = [], []
+
+        def release():
+            if not parked:
+                return
+            todo = [e[2] for e in parked if not e[2].bx_done]
+            if todo:
+                self.flush_bwd(todo, list(active))
+            for fn, lane, _ in parked:
+                with _LaneScope(self, lane):
+                    fn()
+            parked.clear()
         while tape:
             e = tape.pop()
             if e[0] == 'J':                     # reverse of a join = fork
+                release()
                 for k in e[2]:
-                    k.stream.wait_stream(e[1].stream)
+                    if self.multi and k.stream is not None:
+                        k.stream.wait_stream(e[1].stream)
+                    active.append(k)
             elif e[0] == 'F':                   # reverse of a fork = join
+                release()
                 for k in e[2]:
-                    e[1].stream.wait_stream(k.stream)
+                    if self.multi and k.stream is not None:
+                        e[1].stream.wait_stream(k.stream)
+                    if k in active:
+                        active.remove(k)
                 if flush_n and e[1] is self.main and len(self._deferred) >= flush_n:
                     self._flush_deferred()
             else:
-                fn, lane = e
+                fn, lane, sync = e
+                if any(lane is p[1] for p in parked):
+                    release()
+                if sync is not None and self.coll and sync.train and not sync.bx_done:
+                    parked.append(e)
+                    continue
                 with _LaneScope(self, lane):
                     fn()
+        release()
         if self._deferred and os.environ.get('HRF_DEBUG_SKIP_WGRAD') == '1':
             self._deferred = []                 # timing experiments only: drops the weight-gradient phase
         if self._deferred:
@@ -300,11 +472,10 @@ class Ctx:
             torch.cuda.current_stream().wait_stream(self.main.stream)
 
     def all_reduce(self, t):
-        # HRF_FORCE_COLLECTIVES=1: issue the collectives even in a 1-rank group (lets a single-GPU box
-        # exercise RCCL inside the lanes / hipGraph capture exactly as an 8-GPU run would)
-        if self.group is not None and (self.world > 1 or _FORCE_COLL):
+        if self.coll:
             import torch.distributed as dist
             dist.all_reduce(t, group=self.group)
+            self.n_collectives += 1
 
 
 def _balance(items, k):
@@ -403,7 +574,7 @@ def _needs_grad(src):
 
 # ----------------------------------------------------------------------------- BatchNorm plumbing
 def _collectives(ctx):
-    return ctx.group is not None and (ctx.world > 1 or _FORCE_COLL)
+    return ctx.coll
 
 
 def bn_forward(ctx, bn, raw, stats):
@@ -411,7 +582,7 @@ def bn_forward(ctx, bn, raw, stats):
     finalize is left to the consumer's prologue (st.pending, take_fin)."""
     st = BNState()
     C = raw.shape[-1]
-    st.bn, st.C, st.raw, st.du, st.coef, st.pending = bn, C, raw, None, None, None
+    st.bn, st.C, st.raw, st.du, st.coef, st.pending, st.lane, st.bx_done = bn, C, raw, None, None, None, None, False
     slot = ctx.owner._bn_slot(bn)
     st.train = bool(ctx.training and bn.training)
     if st.train:
@@ -420,8 +591,7 @@ def bn_forward(ctx, bn, raw, stats):
         rows = raw.numel() // C
         st.count = float(rows * ctx.world)
         if _collectives(ctx):
-            ctx.all_reduce(st.stats)
-            _finalize_now(ctx, st)
+            ctx.sync_wait(st)                           # batched with the exchanges of the sibling lanes (Ctx.parallel)
         elif _FIN_ONLOAD:
             st.pending = 'fwd'
         else:
@@ -476,6 +646,8 @@ def bn_backward_coef(ctx, st, consumer_follows=True, limit=FIN_MAXC):
     wg = st.bn.weight.grad if st.bn.weight.requires_grad else None
     bg = st.bn.bias.grad if st.bn.bias.requires_grad else None
     coll = st.train and _collectives(ctx)
+    if coll and st.bx_done:                             # exchanged and finalised by run_backward's batch (Ctx.flush_bwd)
+        return st.coef, None
     if _FIN_ONLOAD and consumer_follows and not coll and st.C <= limit:
         P = _lib._ptr
         return st.coef, _lib.BnBFin(P(st.gstats), P(st.bn.weight), P(st.mean), P(st.invstd), P(wg), P(bg), P(cA), P(cB),
@@ -574,7 +746,7 @@ def conv_bn(ctx, src, conv, bn, mode):
     def bwd():
         _conv_backward(ctx, src, w, b, KH, stride, Cout, st.du, Cout, 0, st.raw, st)
         st.du = None
-    ctx.push(bwd)
+    ctx.push(bwd, sync=st)
     return out
 
 
@@ -767,18 +939,16 @@ def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, r
     entries += [('gq', lnq.weight, 0, C), ('btq', lnq.bias, 0, C)]
     if cross:
         entries += [('gkv', lnkv.weight, 0, C), ('btkv', lnkv.bias, 0, C)]
-    entries += [('rpb', rpb, 0, 169 * heads)]
     offs = eng.fs_register(key, nwin, entries)
 
     def bwd():
         a = fill()
         a.gout = P(out.grad)
-        keepalive = None
         if ffn is not None:
             (cA, cB, cC), bfin = bn_backward_coef(ctx, st, consumer_follows=True)
             a.du1, a.cA1, a.cB1, a.cC1 = P(st.du), P(cA), P(cB), P(cC)
             if bfin is not None:
-                keepalive = bfin
+                a._keep_bfin = bfin                     # the struct holds a raw pointer to it
                 a.bfin1 = ctypes.addressof(bfin)
         if cross:
             if res.needs_grad:
@@ -795,13 +965,17 @@ def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, r
             g, acc = xq.grad_target()
             a.dq, a.dq_acc, a.dq_add_res = P(g), acc, 1
         a.pslot, a.slot_stride = eng.fs_buffer(key), offs['_n']
+        dsp = _new((nwin * heads * 49 * 49,), dev)
+        a.ds_plane = P(dsp)
         for nm in ('w1', 'b1', 'g2', 'bt2', 'wo', 'bo', 'wq', 'bq', 'wk', 'bk', 'wv', 'bv', 'gq', 'btq', 'gkv', 'btkv', 'rpb'):
             setattr(a, 'off_' + nm, offs.get(nm, -1))
         L.hrf_attn_block_bwd(a, s)
-        del keepalive
+        if rpb.requires_grad:                       # leaf: gathered from the dS planes with the deferred weight gradients
+            racc, cs = eng.grad_acc(rpb)
+            ctx.side_launch(lambda: L.hrf_rpb_grad(dsp, nwin, heads, racc, cs, ctx.stream), cost=4.0 * dsp.numel())
         if st is not None:
             st.du = None
-    ctx.push(bwd)
+    ctx.push(bwd, sync=st)
     return out, h1
 
 
@@ -844,7 +1018,7 @@ def dwconv_bn(ctx, src, conv, bn, mode):
                 du_, st.raw, cA, cB, cC, x, B, H, W, C, stride, tf, sc, sh, wacc, bacc, cs, ctx.stream),
                 cost=4.0 * B * H * W * C * (1.0 + 2.0 / (stride * stride)))
         st.du = None
-    ctx.push(bwd)
+    ctx.push(bwd, sync=st)
     return out
 
 

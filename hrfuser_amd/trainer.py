@@ -31,11 +31,12 @@ class Trainer:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.group, self.world = group, world_size
         self.n_buckets = n_buckets
-        self.force = R._FORCE_COLL and group is not None
+        self.force = R.force_collectives() and group is not None
         if world_size > 1 or self.force:
             net.set_sync_group(group, world_size)
         self._ready = False
         self.graph = None
+        self.collectives_per_step = 0
 
     # -------------------------------------------------------------------------------------------
     def _setup(self, device):
@@ -46,12 +47,32 @@ class Trainer:
         self.v = torch.zeros(n, device=device)
         self.state = torch.zeros(4, device=device)
         mask = torch.ones(n, device=device)
+        unused = set(getattr(self.net, 'unused_parameter_names', lambda: ())())
         for (name, p), (off, cnt) in zip(self.net.named_parameters(), eng._spans):
             # mmcv DefaultOptimizerConstructor custom_keys: substring match on the parameter name
             if any(k in name for k in NO_DECAY_KEYS):
                 mask[off:off + cnt] = 0.0
+            if name in unused or not p.requires_grad:
+                mask[off:off + cnt] = -1.0            # no gradient ever: torch.optim leaves such parameters untouched
         self.wd_mask = mask
+        self.state[3] = self.lr
         self._ready = True
+
+    def set_lr(self, lr):
+        """Learning rate of the NEXT steps, also for an already captured hipGraph (the kernel reads it from the device)."""
+        self.lr = float(lr)
+        if self._ready:
+            self.state[3:4].fill_(self.lr)
+
+    def optimizer_step(self):
+        """Fused AdamW over the flat arenas (device-side step count and learning rate)."""
+        net = self.net
+        eng = net._engine()
+        L = net._lib_handle()
+        s = _lib.stream_ptr()
+        L.hrf_adamw_tick(self.state, self.betas[0], self.betas[1], s)
+        L.hrf_adamw(eng.flat_p, eng.flat_g, self.m, self.v, self.wd_mask, eng.flat_p.numel(), -1.0,
+                    self.betas[0], self.betas[1], self.eps, self.wd, self.state, 1.0 / self.world, s)
 
     def buckets(self, n):
         """Contiguous slices of the flat gradient arena for the RCCL all-reduce (>= 1 MiB each)."""
@@ -68,15 +89,14 @@ class Trainer:
         for o, c in zip(outs, cots):
             o.grad = R.gpu_clone(c)         # synthetic loss  L = sum_i <out_i, cot_i>   
         ctx.run_backward()
+        ncoll = ctx.n_collectives
         if self.world > 1 or self.force:
             import torch.distributed as dist
             for a, b in self.buckets(eng.flat_g.numel()):
                 dist.all_reduce(eng.flat_g[a:b], group=self.group)
-        s = _lib.stream_ptr()
-        L.hrf_adamw_tick(self.state, self.betas[0], self.betas[1], s)
-        L.hrf_adamw(eng.flat_p, eng.flat_g, self.m, self.v, self.wd_mask, eng.flat_p.numel(), self.lr,
-                    self.betas[0], self.betas[1], self.eps, self.wd, self.state, 1.0 / self.world, s)
-        net.params_updated()
+                ncoll += 1
+        self.collectives_per_step = ncoll
+        self.optimizer_step()
         return outs
 
     def step(self, x, mods, cots):

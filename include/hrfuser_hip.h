@@ -148,7 +148,10 @@ int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const float* k, int l
  *             its window to its own slot pslot[blockIdx * slot_stride + off_*] (plain stores, deterministic);
  *             hrf_fold_slots adds the slots into the gradient arena.  Slot layout (floats; off_* < 0: not produced):
  *             w1 [4C][C], b1 [4C], ln2 gamma / beta [C]; wo [C][C], bo [C]; wq / wk / wv [C][C], bq / bk / bv [C];
- *             LN_q gamma / beta, LN_kv gamma / beta [C]; rpb [169][heads].  hrf_attn_block_bwd_supported: widths 18 / 36.
+ *             LN_q gamma / beta, LN_kv gamma / beta [C].  The relative-position-bias gradient is a leaf: the kernel leaves
+ *             dS[key][query] of every (window, head) in ds_plane [windows][heads][49][49]; hrf_rpb_grad (any time later)
+ *             gathers it into the replicated accumulator drpb [HRF_STAT_COPIES][169][heads] (copy_stride apart).
+ *             hrf_attn_block_bwd_supported: widths 18 / 36.
  * The last five fields are derived by the library.                                                                     */
 typedef struct hrf_attn_block {
   int B, H, W, C, heads;
@@ -162,7 +165,7 @@ typedef struct hrf_attn_block {
   const float* ln2_g; const float* ln2_b; const float* w1; const float* b1; float* h1; double* stats1; int hidden;
   const float* gout; const float* du1; const float* cA1; const float* cB1; const float* cC1; const hrf_bn_bfin_t* bfin1;
   float* dres; int dres_acc; float* dq; int dq_acc; int dq_add_res; float* dkv; int dkv_acc; int dkv_add_res;
-  float* pslot; long slot_stride;
+  float* pslot; long slot_stride; float* ds_plane;
   int off_w1, off_b1, off_g2, off_bt2, off_wo, off_bo, off_wq, off_bq, off_wk, off_bk, off_wv, off_bv;
   int off_gq, off_btq, off_gkv, off_btkv, off_rpb;
   int nWh, nWw, pt, pl; float scale;
@@ -171,6 +174,7 @@ int hrf_attn_block_supported(int C, int heads);
 int hrf_attn_block_bwd_supported(int C, int heads);
 int hrf_attn_block_fwd(const hrf_attn_block_t* p, void* stream);
 int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream);
+int hrf_rpb_grad(const float* ds_plane, int nwin, int heads, float* drpb, long copy_stride, void* stream);
 /* dst[map[i]] += sum_{s < nslots} slots[s*slot_stride + i]  (i < n; map[i] < 0: skipped).  One launch folds the slots of
  * every fused layer of a step: seg = nseg rows of 5 longs {slot offset (floats) into `slots`, nslots, slot_stride, n,
  * offset into `map`} on the device.                                                                                  */
@@ -189,6 +193,16 @@ int hrf_bn_finalize(const double* stats, const float* gamma, const float* beta, 
 int hrf_bn_bwd_finalize(const double* gstats, const double* gstats_local, const float* gamma,
                         const float* mean, const float* invstd, double count, int train, float* dgamma, float* dbeta, float* cA, float* cB,
                         float* cC, int C, void* stream);
+
+/* SyncBN over RCCL, several mutually independent BatchNorms per collective (the three sensor streams at equal depth, the
+ * branches of one HRModule, the fuse layers of one exchange): hrf_bn_pack folds the replicated moments of n layers into
+ * `packed` (2*C doubles per layer, back to back) -> ONE all-reduce of `packed` by the host -> hrf_bn_finalize_packed /
+ * hrf_bn_bwd_finalize_packed finalise all n layers from the packed sums (the `stats` / `gstats` / `write` fields of the
+ * structs are ignored; packed_local = this rank's copy of `packed` taken before the all-reduce: parameter gradients use the
+ * rank-local moments).  stats / C / fins / bfins are HOST arrays of n entries.                                          */
+int hrf_bn_pack(const double* const* stats, const int* C, int n, double* packed, void* stream);
+int hrf_bn_finalize_packed(const hrf_bn_fin_t* fins, int n, const double* packed, void* stream);
+int hrf_bn_bwd_finalize_packed(const hrf_bn_bfin_t* bfins, int n, const double* packed, const double* packed_local, void* stream);
 
 /* ---- LayerNorm over channels (F.layer_norm: hrformer.py:343,351; hrfuser_hrformer_based.py:279-291) */
 int hrf_ln_stats(const float* x, int rows, int C, float eps, float* rowstat, void* stream);
@@ -295,8 +309,12 @@ int hrf_pack_input(const void* in, int is_u8, int B, int H0, int W0, int C, cons
                    void* stream);
 
 /* ---- fused flat-buffer AdamW (configs/hrfuser: AdamW lr 3e-4, wd 0.01, decay_mult 0 masks) ---
- * state = float[4] on device: {1-b1^t, 1-b2^t, t, -}; hrf_adamw_tick advances t on device so a
- * captured hipGraph replays correct bias corrections.                                           */
+ * state = float[4] on device: {1-b1^t, 1-b2^t, t, lr}; hrf_adamw_tick advances t on device so a
+ * captured hipGraph replays correct bias corrections; lr < 0 in the call = take the learning rate from state[3]
+ * (the host updates that one float between replays: warm-up / step schedules work under hipGraph replay).
+ * wd_mask[i]: weight-decay multiplier of element i (0 for `norm` / `relative_position_bias_table` keys); < 0 =
+ * the element belongs to a parameter that never receives a gradient: skipped entirely, as torch.optim skips
+ * parameters whose .grad is None (mmdet runs DDP with find_unused_parameters=True for transition1.0.1.*).        */
 int hrf_adamw_tick(float* state, float beta1, float beta2, void* stream);
 /* dst[map[i]] += sum_k scratch[k*copy_stride + i], k < HRF_STAT_COPIES (see top of file)          */
 int hrf_fold_copies(const float* scratch, long copy_stride, const int* map, float* dst, long n,

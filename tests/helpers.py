@@ -76,10 +76,13 @@ def load_cfgs():
         return json.load(fh)
 
 
-def build_pair(tag, device, seed=0):
-    """(product backbone on `device`, oracle on CPU) with identical seeded parameters."""
+def build_pair(tag, device, seed=0, edit=None):
+    """(product backbone on `device`, oracle on CPU) with identical seeded parameters.  edit(cfg): optional in-place
+    change of the config dict before both are built (e.g. fewer modules per stage for a quick data-parallel test)."""
     from hrfuser_amd import build_backbone
-    cfg = load_cfgs()[tag]
+    cfg = copy.deepcopy(load_cfgs()[tag])
+    if edit is not None:
+        edit(cfg)
     c2 = copy.deepcopy(cfg)
     c2.pop('type')
     orc = O.HRFuserOracle(**c2)

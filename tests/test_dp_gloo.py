@@ -11,6 +11,14 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HW = (64, 64)            # 2 images of 64x64: the stride-32 BatchNorms see 8 samples (32x64 left 4: fp32 noise x 1e4)
+
+
+def _short(cfg):
+    """HRFuser-T with ONE module per stage (every layer type, branch count and exchange still present): the subject here
+    is the data-parallel logic, and the CPU kernel emulator is slow."""
+    for k in ('stage3', 'stage4', 'LidarStageC'):
+        cfg['extra'][k]['num_modules'] = 1
 
 
 def _worker(rank, world, port, ret):
@@ -20,12 +28,13 @@ def _worker(rank, world, port, ret):
     torch.set_num_threads(2)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import hrfuser_oracle as O
-    from helpers import build_pair, use_backend
+    from helpers import build_pair, enable_relu_probe, relu_masks, use_backend
     from hrfuser_amd.trainer import Trainer
     dev = use_backend('emul')
-    net, orc, cfg = build_pair('t_nus', dev)           # SyncBN config
+    net, orc, cfg = build_pair('t_nus', dev, edit=_short)           # SyncBN config
     net.train()
-    B, H, W = 2, 32, 64
+    enable_relu_probe(net)
+    B, (H, W) = 2, HW
     x, mods = O.seeded_inputs(B, H, W, [3, 3], seed=1)
     sl = slice(rank, rank + 1)                          # one image per rank
     g = torch.Generator().manual_seed(5)
@@ -37,7 +46,8 @@ def _worker(rank, world, port, ret):
     eng = net._engine()
     N = lambda t: t.detach().float().cpu().numpy().copy()
     res = dict(out=[N(o.t) for o in outs], grad=N(eng.flat_g), param=N(eng.flat_p),
-               rm=N(net.bn1.running_mean), rv=N(net.bn1.running_var))
+               rm=N(net.bn1.running_mean), rv=N(net.bn1.running_var), ncoll=tr.collectives_per_step)
+    ret[f'masks{rank}'] = [m.cpu().numpy().copy() for m in relu_masks(net)]
     # ---- the neck's arena goes through the same exchange: rank-sum of local gradients
     import hrfpn_oracle as NO
     from hrfuser_amd import HRFPN
@@ -57,14 +67,6 @@ def _worker(rank, world, port, ret):
         sum((y.permute(0, 2, 3, 1) * c).sum() for y, c in zip(ys, ncots)).backward()
         ret['neck_ref'] = N(torch.cat([p.grad.reshape(-1) for p in norc.parameters()]))
     if rank == 0:
-        # single-process reference on the WHOLE batch: oracle fp64 + torch AdamW with the same masks
-        o64 = copy.deepcopy(orc).double().train()
-        ys = o64(x.double(), [m.double() for m in mods])
-        sum((y.permute(0, 2, 3, 1) * c.double()).sum() for y, c in zip(ys, cots)).backward()
-        ret['ref_out'] = [N(y.permute(0, 2, 3, 1)[sl]) for y in ys]
-        ret['ref_grad'] = {n: N(p.grad) for n, p in o64.named_parameters() if p.grad is not None}
-        ret['ref_rm'] = N(o64.bn1.running_mean)
-        ret['ref_rv'] = N(o64.bn1.running_var)
         ret['names'] = [(n, tuple(p.shape)) for n, p in net.named_parameters()]
         ret['spans'] = list(eng._spans)
         ret['res'] = res
@@ -80,26 +82,60 @@ def test_two_rank_syncbn_and_grad_exchange_equal_single_process():
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     res = ret['res']
+    for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hrfuser_oracle as O
+    from helpers import PinnedReLU, build_pair
     T = torch.as_tensor
     rel = lambda a, b: float((T(a).double() - T(b).double()).abs().max() / (T(b).double().abs().max() + 1e-30))
-    for o, r in zip(res['out'], ret['ref_out']):
-        assert rel(o, r) < 1e-3                      # SyncBN: rank-0 slice of the global-batch forward
-    assert rel(res['rm'], ret['ref_rm']) < 1e-4 and rel(res['rv'], ret['ref_rv']) < 1e-4
-    # flat gradient arena after the all-reduce = SUM over ranks of local grads (cotangents were
-    # pre-scaled by world) = gradient of the global-batch loss; AdamW divides by world again.
-    ref_grad = {k: T(v) for k, v in ret['ref_grad'].items()}
+    # single-process reference on the WHOLE batch: the fp64 (and fp32) oracle with the ReLU decisions of the two ranks
+    # pinned (each rank saw one image: their masks concatenate along the batch), so the gradient gate is the tight one
+    _, orc, _ = build_pair('t_nus', torch.device('cpu'), edit=_short)
+    B, (H, W) = 2, HW
+    x, mods = O.seeded_inputs(B, H, W, [3, 3], seed=1)
+    g = torch.Generator().manual_seed(5)
+    shapes = [(B, H // 4 >> i, W // 4 >> i, c) for i, c in enumerate((18, 36, 72, 144))]
+    cots = [torch.randn(s, generator=g) for s in shapes]
+    masks = [torch.cat([T(a), T(b)], 0) for a, b in zip(ret['masks0'], ret['masks1'])]
+    refs = []
+    for dt in (torch.float64, torch.float32):
+        o = copy.deepcopy(orc).to(dt).train()
+        with PinnedReLU(masks):
+            ys = o(x.to(dt), [m.to(dt) for m in mods])
+        sum((y.permute(0, 2, 3, 1) * c.to(dt)).sum() for y, c in zip(ys, cots)).backward()
+        refs.append((o, ys))
+    o64, ys = refs[0]
+    o32 = refs[1][0]
+    for o, r in zip(res['out'], ys):
+        assert rel(o, r.permute(0, 2, 3, 1)[0:1].detach()) < 1e-3      # SyncBN: rank-0 slice of the global-batch forward
+    assert rel(res['rm'], o64.bn1.running_mean) < 1e-4 and rel(res['rv'], o64.bn1.running_var) < 1e-4
+    # flat gradient arena after the all-reduce = SUM over ranks of local grads (cotangents were pre-scaled by world) =
+    # world x gradient of the global-batch loss; AdamW divides by world again.  Per tensor: rel-L2 <= max(1e-3, 3 e_ref).
+    ref64 = {k: v.grad for k, v in o64.named_parameters() if v.grad is not None}
+    ref32 = {k: v.grad for k, v in o32.named_parameters() if v.grad is not None}
     flat = T(res['grad'])
-    gscale = max(float(v.abs().max()) for v in ref_grad.values())
-    worst = 0.0
+    nmax = max(float(v.norm()) for v in ref64.values())
+    gmax = max(float(v.abs().max()) for v in ref64.values())
+    worst = (0.0, 0.0, '')
     for (name, shape), (off, n) in zip(ret['names'], ret['spans']):
-        if name not in ref_grad:
-            assert float(flat[off:off + n].abs().max()) == 0.0       # unused params stay zero
+        gk = flat[off:off + n].view(shape).double() / 2.0            # world * mean-convention
+        if name not in ref64:
+            assert float(gk.abs().max()) == 0.0                        # unused params stay zero
             continue
-        g = flat[off:off + n].view(shape) / 2.0                      # world * mean-convention
-        ref = ref_grad[name]
-        err = float((g - ref).norm()) / (float(ref.norm()) + 2e-3 * gscale * ref.numel() ** 0.5)
-        worst = max(worst, err)
-    assert worst < 2e-2, worst
+        q = ref64[name]
+        if float(q.norm()) < 1e-9 * nmax:                              # analytically zero
+            assert float(gk.abs().max()) <= 1e-4 * gmax, name
+            continue
+        e = float((gk - q).norm() / q.norm())
+        e_ref = float((ref32[name].double() - q).norm() / q.norm())
+        assert e <= max(1e-3, 3 * e_ref), (name, e, e_ref)
+        worst = max(worst, (e / max(e_ref, 1e-30) if e > 1e-3 else 0.0, e, name))
+    print(f'[2-rank gloo] largest e / e_ref among tensors above 1e-3: {worst[0]:.2f} (e = {worst[1]:.2e}, {worst[2]}); '
+          f'{res["ncoll"]} collectives in the step')
     assert ret['wd_mask_sum'] > 0
+    # batching: 330 BatchNorms x 2 directions would be 660 exchanges one by one; the lock-step schedule packs the
+    # independent ones (sensor streams, HRModule branches, exchange chains)
+    assert res['ncoll'] <= 150, res['ncoll']
     # neck: all-reduced arena = gradient of the whole-batch loss (no normalisation layers in HRFPN)
     assert rel(res['neck_grad'], ret['neck_ref']) < 1e-4

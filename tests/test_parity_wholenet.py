@@ -93,28 +93,96 @@ def test_wholenet_gpu_train_small(tag):
 
 
 @pytest.mark.gpu
-def test_wholenet_gpu_train_medium():
-    _fwd_bwd('t_nus', 2, 192, 320, True, 'hip')
+@pytest.mark.parametrize('tag,B,H,W', [('t_nus', 2, 192, 320), ('b_nus', 1, 128, 192), ('t_stf', 1, 128, 224)])
+def test_wholenet_gpu_train_medium(tag, B, H, W):
+    """Several windows per branch and several pixel tiles per launch, forward + every gradient, ReLU masks pinned."""
+    _fwd_bwd(tag, B, H, W, True, 'hip')
+
+
+def _digest_close(f, samples, meta, tol=1e-3):
+    idx = torch.linspace(0, f.numel() - 1, min(4096, f.numel())).long()
+    assert relmax(f[idx], torch.as_tensor(samples)) < tol * max(1.0, meta[2] / float(f[idx].abs().max()))
+    assert abs(float(f.abs().sum()) - meta[1]) <= tol * meta[1]
 
 
 @pytest.mark.gpu
-def test_fullres_digest_gpu():
-    """BASELINE config[0]/[1] shape: 384x640 + lidar + radar, eval B=1 and train B=2 digests."""
+@pytest.mark.parametrize('tag', ['t_nus', 'b_nus', 't_stf'])
+def test_fullres_digest_gpu(tag):
+    """BASELINE configs at FULL size (384x640; STF 384x1248): eval B=1 and train B=2 forward digests of the reference."""
     dev = use_backend('hip')
     gold = np.load(os.path.join(GOLD, 'fullres_digests.npz'))
-    net, orc, cfg = build_pair('t_nus', dev)
-    for mode, B in (('eval_B1', 1), ('train_B2', 2)):
+    gtr = np.load(os.path.join(GOLD, 'fullres_train.npz'))
+    net, orc, cfg = build_pair(tag, dev)
+    mc = cfg.get('mod_in_channels', [3, 3])
+    H, W = (384, 1248) if tag == 't_stf' else (384, 640)
+    for mode, B, src in (('eval_B1', 1, gold), ('train_B2', 2, gtr)):
         net.train(mode.startswith('train'))
-        x, mods = O.seeded_inputs(B, 384, 640, [3, 3], seed=1)
+        x, mods = O.seeded_inputs(B, H, W, mc, seed=1)
         with torch.no_grad():
             ys = net(x.to(dev), [m.to(dev) for m in mods])
         for i, y in enumerate(ys):
-            meta = gold[f't_nus/{mode}/out{i}/meta']
+            meta = src[f'{tag}/{mode}/out{i}/meta']
             assert list(y.shape) == [int(v) for v in meta[3:]]
-            f = y.contiguous().double().reshape(-1).cpu()
-            idx = torch.linspace(0, f.numel() - 1, min(4096, f.numel())).long()
-            assert relmax(f[idx], torch.as_tensor(gold[f't_nus/{mode}/out{i}/samples'])) < 1e-3 * max(1.0, meta[2] / float(f[idx].abs().max()))
-            assert abs(float(f.abs().sum()) - meta[1]) <= 1e-3 * meta[1]
+            _digest_close(y.contiguous().double().reshape(-1).cpu(), src[f'{tag}/{mode}/out{i}/samples'], meta)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['t_nus', 'b_nus', 't_stf'])
+def test_fullres_gradient_digest_gpu(tag):
+    """FULL-size training gradients against the fp64 digests of the REAL reference (oracle/tools/make_golden_fullres.py):
+    every parameter gradient's norm and sum, every input gradient's samples / norm.  The ReLU masks cannot be pinned
+    against a digest, so the per-tensor gate is the digest-level one: |norm - ref| <= 5e-3 * ref (a handful of fp32
+    mask flips moves most full-size norms by ~1e-4 and the small low-resolution tensors they hit directly by up to
+    several 1e-3; an indexing / tiling error moves a norm by O(1)): every norm within 1e-2, at most 2 % of the tensors
+    beyond 2e-3; the worst one and the counts are printed.  HRFuser-B runs one image (the fp64 reference graph of two did not fit the build container)."""
+    dev = use_backend('hip')
+    g = np.load(os.path.join(GOLD, 'fullres_train.npz'))
+    net, orc, cfg = build_pair(tag, dev)
+    mc = cfg.get('mod_in_channels', [3, 3])
+    H, W = (384, 1248) if tag == 't_stf' else (384, 640)
+    Bg = 1 if tag == 'b_nus' else 2
+    key = f'{tag}/grad_B{Bg}'
+    net.train()
+    x, mods = O.seeded_inputs(2, H, W, mc, seed=1)
+    xa = x[:Bg].clone().to(dev).requires_grad_(True)
+    ma = [m[:Bg].clone().to(dev).requires_grad_(True) for m in mods]
+    ya = net(xa, list(ma))
+    for i, y in enumerate(ya):
+        _digest_close(y.detach().contiguous().double().reshape(-1).cpu(), g[f'{key}/out{i}/samples'], g[f'{key}/out{i}/meta'])
+    gen = torch.Generator().manual_seed(5)
+    cots = [torch.randn(t.shape, generator=gen) for t in ya]
+    sum((t * c.to(dev)).sum() for t, c in zip(ya, cots)).backward()
+    names = [str(n) for n in g[f'{key}/param_names']]
+    ref_norm, ref_sum = g[f'{key}/param_norm'], g[f'{key}/param_sum']
+    pa = dict(net.named_parameters())
+    nmax = float(ref_norm.max())
+    worst, above, above2, zeros = (0.0, ''), 0, 0, 0
+    for k, rn, rs in zip(names, ref_norm, ref_sum):
+        gk = pa[k].grad.detach().double().cpu()
+        if rn < 1e-9 * nmax:                       # analytically zero in the reference
+            zeros += 1
+            assert float(gk.norm()) <= 1e-4 * nmax, (tag, k)
+            continue
+        e = abs(float(gk.norm()) - rn) / rn
+        above += e > 1e-3
+        above2 += e > 2e-3
+        worst = max(worst, (e, k))
+        assert e <= 1e-2, (tag, k, e)
+        assert abs(float(gk.sum()) - rs) <= 1e-2 * rn * (gk.numel() ** 0.5), (tag, k, 'sum')
+    print(f'[fullres grad {tag} B={Bg}] {len(names)} tensors ({zeros} analytically zero): worst norm error {worst[0]:.2e} '
+          f'({worst[1]}), {above} above 1e-3, {above2} above 2e-3')
+    assert above2 <= 0.02 * len(names), (tag, above2)
+    for nm, t in zip(['img'] + [f'mod{k}' for k in range(len(ma))], [xa] + ma):
+        meta = g[f'{key}/{nm}/meta']
+        f = t.grad.detach().contiguous().double().reshape(-1).cpu()
+        assert abs(float(f.norm()) - meta[3]) <= 1e-2 * meta[3], (tag, nm)
+        idx = torch.linspace(0, f.numel() - 1, 4096).long()
+        # an input gradient sees EVERY un-pinned mask flip of the net through the stride-32 receptive fields: the strided
+        # samples agree to ~1 % in rel-L2 (the pinned tests at 64x96 .. 192x320 are the tight gate on these tensors)
+        ref = torch.as_tensor(g[f'{key}/{nm}/samples']).double()
+        es = float((f[idx] - ref).norm() / ref.norm())
+        print(f'[fullres grad {tag}] d/d{nm}: norm error {abs(float(f.norm()) - meta[3]) / meta[3]:.2e}, sample rel-L2 {es:.2e}')
+        assert es < 3e-2, (tag, nm, es)
 
 
 @pytest.mark.gpu
