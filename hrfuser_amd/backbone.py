@@ -404,6 +404,26 @@ class Bottleneck(nn.Module):
         return R.materialize(ctx, y, R.ACT_RELU, res=x)
 
 
+class BasicBlock(nn.Module):
+    """resnet.py:14-97 as the convolutional HRModule uses it (stride 1, no downsample): conv3x3-BN-ReLU-conv3x3-BN, + x, ReLU."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, norm_cfg, downsample=None):
+        super().__init__()
+        if downsample is not None or inplanes != planes:
+            raise NotImplementedError('BasicBlock with a downsample path is unused by the HRNet branches')
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, 1, 1, bias=False)
+        self.bn1 = build_bn(norm_cfg, planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = build_bn(norm_cfg, planes)
+        self.downsample = None
+
+    def run(self, ctx, x):
+        y = R.conv_bn(ctx, x, self.conv1, self.bn1, R.TF_RELU)
+        y = R.conv_bn(ctx, y, self.conv2, self.bn2, R.TF_AFFINE)
+        return R.materialize(ctx, y, R.ACT_RELU, res=x)
+
+
 class CrossFFN(nn.Module):
     """hrformer.py:267-295.  Returns the LAZY tail BN(h3) (GELU applied by the caller's residual add)."""
 
@@ -697,6 +717,85 @@ class HRFomerModule(nn.Module):
         return [R.fuse_sum(ctx, tuple(xs[i].t.shape), terms[i]) for i in range(nrows)]
 
 
+class HRModule(nn.Module):
+    """The convolutional HRModule (hrnet.py:14-207): branches of BasicBlocks; exchange = 1x1 conv + BN + nn.Upsample
+    (nearest) upwards (the F.interpolate(bilinear) that follows in hrnet.py:199-203 is the identity when the grids nest,
+    which Pad(size_divisor=32) guarantees; other sizes raise) and chains of DENSE 3x3 stride-2 conv + BN (+ReLU) downwards."""
+
+    def __init__(self, num_branches, block, num_blocks, num_inchannels, num_channels, multiscale_output=True,
+                 norm_cfg=dict(type='BN'), **kw):
+        super().__init__()
+        if num_branches != len(num_blocks):
+            raise ValueError(f'NUM_BRANCHES({num_branches}) != NUM_BLOCKS({len(num_blocks)})')
+        if num_branches != len(num_channels):
+            raise ValueError(f'NUM_BRANCHES({num_branches}) != NUM_CHANNELS({len(num_channels)})')
+        if num_branches != len(num_inchannels):
+            raise ValueError(f'NUM_BRANCHES({num_branches}) != NUM_INCHANNELS({len(num_inchannels)})')
+        self.num_branches = nb = num_branches
+        self.in_channels = ch = list(num_inchannels)
+        self.multiscale_output = multiscale_output
+        self.branches = nn.ModuleList(
+            nn.Sequential(*[block(ch[i], num_channels[i] * block.expansion, norm_cfg) for _ in range(num_blocks[i])])
+            for i in range(nb))
+        self.fuse_layers = None
+        if nb > 1:
+            rows = []
+            for i in range(nb if multiscale_output else 1):
+                row = []
+                for j in range(nb):
+                    if j > i:
+                        row.append(nn.Sequential(nn.Conv2d(ch[j], ch[i], 1, bias=False), build_bn(norm_cfg, ch[i]),
+                                                 nn.Upsample(scale_factor=2 ** (j - i), mode='nearest')))
+                    elif j == i:
+                        row.append(None)
+                    else:
+                        steps = []
+                        for k in range(i - j):
+                            last = k == i - j - 1
+                            cout = ch[i] if last else ch[j]
+                            mods = [nn.Conv2d(ch[j], cout, 3, 2, 1, bias=False), build_bn(norm_cfg, cout)]
+                            if not last:
+                                mods.append(nn.ReLU(inplace=False))
+                            steps.append(nn.Sequential(*mods))
+                        row.append(nn.Sequential(*steps))
+                rows.append(nn.ModuleList(row))
+            self.fuse_layers = nn.ModuleList(rows)
+
+    def run(self, ctx, xs):
+        nb = self.num_branches
+        xs = list(xs)
+        lanes = ctx.fork(nb)
+
+        def branch(i):
+            for blk in self.branches[i]:
+                xs[i] = blk.run(ctx, xs[i])
+        ctx.parallel(lanes, [lambda i=i: branch(i) for i in range(nb)])
+        ctx.join(lanes)
+        if nb == 1:
+            return [xs[0]]
+        nrows = len(self.fuse_layers)
+        terms = [[None] * nb for _ in range(nrows)]
+        lanes = ctx.fork(nb)
+
+        def source(j):                             # one lane per SOURCE branch (its backward accumulates into xs[j] only)
+            for i, row in enumerate(self.fuse_layers):
+                if j == i:
+                    terms[i][j] = ('id', xs[j])
+                elif j > i:
+                    Hi, Wi, Hj, Wj = xs[i].t.shape[1], xs[i].t.shape[2], xs[j].t.shape[1], xs[j].t.shape[2]
+                    if Hi != Hj << (j - i) or Wi != Wj << (j - i):
+                        raise NotImplementedError('HRModule exchange on grids that do not nest (input not a multiple of 32)')
+                    terms[i][j] = ('near', R.conv_bn(ctx, xs[j], row[j][0], row[j][1], R.TF_AFFINE))
+                else:
+                    cur = xs[j]
+                    for step in row[j]:
+                        cur = R.conv_bn(ctx, cur, step[0], step[1], R.TF_RELU if len(step) == 3 else R.TF_AFFINE)
+                    terms[i][j] = ('same', cur)
+        ctx.parallel(lanes, [lambda j=j: source(j) for j in range(nb)])
+        ctx.join(lanes)
+        return [R.fuse_sum(ctx, tuple(xs[i].t.shape), terms[i]) for i in range(nrows)]
+
+
 def _make_transition(pre, cur, norm_cfg):
     """hrnet.py:419-463."""
     layers = []
@@ -868,6 +967,7 @@ class HRFuserHRFormerBased(HipModule):
     """
     blocks_dict = {'BOTTLENECK': Bottleneck, 'HRFORMER': HRFormerBlock, 'CA': HRFuserFusionBlock,
                    'MWCA': HRFuserFusionBlock}
+    _hrformer_trunk = True
 
     def __init__(self, extra, in_channels=3, conv_cfg=None, norm_cfg=dict(type='SyncBN', requires_grad=True),
                  transformer_norm_cfg=dict(type='LN', eps=1e-6), norm_eval=False, with_cp=False,
@@ -895,14 +995,15 @@ class HRFuserHRFormerBased(HipModule):
         self.num_fused_modalities = M = num_fused_modalities
         self.pre_neck_fusion = True if extra.get('LidarStageD') else False          # :364-366 (off in every config)
         ncfg, lcfg = norm_cfg, transformer_norm_cfg
-        # HRFormer.__init__ :666-678 - drop_path_rate is swallowed (always 0 here)
-        for s in ('stage2', 'stage3', 'stage4'):
-            n = extra[s]['num_blocks'][0] * extra[s]['num_modules']
-            extra[s]['drop_path_rates'] = [0.0] * n
-        extra['LidarStageB']['drop_path_rates'] = extra['stage2']['drop_path_rates']
-        extra['LidarStageC']['drop_path_rates'] = extra['stage3']['drop_path_rates']
-        if self.pre_neck_fusion:
-            extra['LidarStageD']['drop_path_rates'] = extra['stage4']['drop_path_rates']
+        if self._hrformer_trunk:
+            # HRFormer.__init__ :666-678 - drop_path_rate is swallowed (always 0 here); `extra` is mutated
+            for s in ('stage2', 'stage3', 'stage4'):
+                n = extra[s]['num_blocks'][0] * extra[s]['num_modules']
+                extra[s]['drop_path_rates'] = [0.0] * n
+            extra['LidarStageB']['drop_path_rates'] = extra['stage2']['drop_path_rates']
+            extra['LidarStageC']['drop_path_rates'] = extra['stage3']['drop_path_rates']
+            if self.pre_neck_fusion:
+                extra['LidarStageD']['drop_path_rates'] = extra['stage4']['drop_path_rates']
 
         # camera stem + stage 1 (hrnet.py:337-371)
         self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)
@@ -1192,6 +1293,30 @@ class HRFuserHRFormerBased(HipModule):
         ctx.parallel(list(lanes) + [ctx.cur], [lambda k=k: mod_stage(k) for k in range(M)] + [camera])
         ctx.join(lanes)
         return ys[0], mods
+
+
+@BACKBONES.register_module()
+class HRFuserHRNetBased(HRFuserHRFormerBased):
+    """Drop-in for mmdet's `HRFuserHRNetBased` (hrfuser_hrnet_based.py:23-315): the same fusion dataflow (`forward` :214-315
+    is the HRFormer-based one line for line, including the transition1[i][0] quirk) over a purely CONVOLUTIONAL HRNet trunk:
+    stages 2-4 and the modality stages B-D are HRModules of `BASIC` blocks (hrnet.py:512-550).  Same registry name,
+    constructor keywords, state-dict keys; no reference config uses it (the golden config is tests/golden/
+    hrfuser_hrnet_cfg.json, oracle bit-exact vs the reference class: oracle/tools/make_golden_hrnet_based.py)."""
+    blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck, 'CA': HRFuserFusionBlock, 'MWCA': HRFuserFusionBlock}
+    _hrformer_trunk = False
+
+    def _make_stage(self, cfg, in_channels, multiscale_output=True):
+        block = self.blocks_dict[cfg['block']]
+        if block is not BasicBlock:
+            raise NotImplementedError('stages 2-4 / LidarStage B-D of HRFuserHRNetBased must use block BASIC')
+        n = cfg['num_modules']
+        mods = []
+        for i in range(n):
+            ms = multiscale_output or i != n - 1
+            mods.append(HRModule(cfg['num_branches'], block, cfg['num_blocks'], in_channels, cfg['num_channels'], ms,
+                                 norm_cfg=self.norm_cfg))
+            in_channels = mods[-1].in_channels
+        return nn.Sequential(*mods), in_channels
 
 
 @BACKBONES.register_module()

@@ -1201,7 +1201,7 @@ extern "C" int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream) {
 
 extern "C" int hrf_rpb_grad(const float* ds_plane, int nwin, int heads, float* drpb, long copy_stride, void* stream) {
   if (nwin <= 0 || heads <= 0) return HRF_OK;
-  const int chunks = nwin < 160 ? nwin : 160;
+  const int chunks = nwin < 1024 ? nwin : 1024;                    // one or two windows per workgroup: the kernel is latency-bound
   HRF_LAUNCH(rpb_grad_kernel, dim3(chunks, heads), dim3(256), 0, stream, ds_plane, nwin, heads, drpb, copy_stride);
   return hrf_check_launch();
 }

@@ -430,9 +430,60 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a) {
         const float top = (1.f - wx) * v00 + wx * v01, bot = (1.f - wx) * v10 + wx * v11;
         const float v = (1.f - wy) * top + wy * bot;
         acc += fmaf(v, t.sc[c], t.sh[c]);
+      } else if (t.type == 4) {
+        // nn.Upsample(scale_factor = H / Hs, mode='nearest') (hrnet.py:135-146): src = floor(dst * Hs / H)
+        const int ys = y / (a.H / t.Hs), xs = x / (a.W / t.Ws);
+        const float v = t.p[(((long)b * t.Hs + ys) * t.Ws + xs) * a.C + c];
+        acc += fmaf(v, t.sc[c], t.sh[c]);
       }
     }
     a.out[i] = fmaxf(acc, 0.f);
+  }
+}
+
+// adjoint of the nearest up-sampling by an integer factor k: du[low pixel] = sum of its k x k block of g, plus the
+// (sum du, sum du*ylow) moments of the BatchNorm in front of it; one thread = one (low-res pixel, channel) at a time
+__global__ __launch_bounds__(256) void nearest_up_bwd_kernel(const float* g, int ldG, int goff, int B, int H, int W, int C,
+                                                             const float* ylow, int Hs, int Ws, float* du, double* stats) {
+  HRF_DYN_SMEM(float, sacc);                              // [2*C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sacc[i] = 0.f;
+  const int cw = C <= 256 ? C : 256, R = C <= 256 ? 256 / C : 1;
+  const int r = threadIdx.x / cw, c0 = threadIdx.x - r * cw;
+  const bool active = r < R;
+  const long npix = (long)B * Hs * Ws;
+  const int ky = H / Hs, kx = W / Ws;
+  float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
+  for (long q0 = (long)blockIdx.x * R; q0 < npix; q0 += (long)gridDim.x * R) {
+    const long q = q0 + r;
+    if (!active || q >= npix) continue;
+    const int qx = (int)(q % Ws), qy = (int)((q / Ws) % Hs), b = (int)(q / ((long)Ws * Hs));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c = c0 + 256 * j;
+      if (c >= C) break;
+      float acc = 0.f;
+      for (int y = qy * ky; y < (qy + 1) * ky; ++y) {
+        const float* grow = g + (((long)b * H + y) * W + (long)qx * kx) * ldG + goff + c;
+        for (int x = 0; x < kx; ++x) acc += grow[(long)x * ldG];
+      }
+      const long i = q * C + c;
+      du[i] = acc;
+      a1[j] += acc;
+      if (ylow != nullptr) a2[j] = fmaf(acc, ylow[i], a2[j]);
+    }
+  }
+  if (stats == nullptr) return;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c = c0 + 256 * j;
+    if (active && c < C) { hrf_atomic_add(&sacc[c], a1[j]); hrf_atomic_add(&sacc[C + c], a2[j]); }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const size_t cp = (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
+    hrf_atomic_add(&stats[cp + c], (double)sacc[c]);
+    hrf_atomic_add(&stats[cp + C + c], (double)sacc[C + c]);
   }
 }
 
@@ -787,6 +838,8 @@ extern "C" int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const 
   a.t[2] = FuseTerm{type2, p2, sc2, sh2, Hs2, Ws2};
   a.t[3] = FuseTerm{type3, p3, sc3, sh3, Hs3, Ws3};
   a.out = out; a.B = B; a.H = H; a.W = W; a.C = C;
+  for (int k = 0; k < 4; ++k)
+    if (a.t[k].type == 4 && (a.t[k].Hs <= 0 || a.t[k].Ws <= 0 || H % a.t[k].Hs || W % a.t[k].Ws)) return HRF_ERR_ARG;
   const long total = (long)B * H * W * C;
   if (total <= 0) return HRF_OK;
   HRF_LAUNCH(fuse_sum_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, a);
@@ -802,6 +855,19 @@ extern "C" int hrf_bilinear_up_bwd(const float* g, int ldG, int goff, int B, int
   int grid = hrf_cdiv(npix, R);
   if (grid > 1024) grid = 1024;
   HRF_LAUNCH(bilinear_up_bwd_kernel, dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), stream, g, ldG, goff,
+             B, H, W, C, ylow, Hs, Ws, du, stats);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_nearest_up_bwd(const float* g, int ldG, int goff, int B, int H, int W, int C, const float* ylow,
+                                  int Hs, int Ws, float* du, double* stats, void* stream) {
+  const long npix = (long)B * Hs * Ws;
+  if (npix * C <= 0) return HRF_OK;
+  if (C > 768 || Hs <= 0 || Ws <= 0 || H % Hs || W % Ws) return HRF_ERR_ARG;
+  const int R = C <= 256 ? 256 / C : 1;
+  int grid = hrf_cdiv(npix, R);
+  if (grid > 1024) grid = 1024;
+  HRF_LAUNCH(nearest_up_bwd_kernel, dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), stream, g, ldG, goff,
              B, H, W, C, ylow, Hs, Ws, du, stats);
   return hrf_check_launch();
 }

@@ -1073,7 +1073,8 @@ def materialize(ctx, lazy, act, res=None, lazy2=None, act_first=False, rowscale=
 
 def fuse_sum(ctx, dims, terms):
     """HRModule exchange for one output branch: ReLU(sum terms).  terms: list of
-    ('id', Act) | ('same', Lazy) | ('up', Lazy)   (hrnet.py:192-206)."""
+    ('id', Act) | ('same', Lazy) | ('up', Lazy: bilinear) | ('near', Lazy: nearest by an integer factor)
+    (hrnet.py:192-206)."""
     L, s = ctx.L, ctx.stream
     B, H, W, C = dims
     dev = terms[0][1].t.device if isinstance(terms[0][1], Act) else terms[0][1].raw.device
@@ -1092,7 +1093,7 @@ def fuse_sum(ctx, dims, terms):
         if kind == 'same':
             args += [2, t.raw, t.st.scale, t.st.shift, 0, 0]
         else:
-            args += [3, t.raw, t.st.scale, t.st.shift, t.raw.shape[1], t.raw.shape[2]]
+            args += [3 if kind == 'up' else 4, t.raw, t.st.scale, t.st.shift, t.raw.shape[1], t.raw.shape[2]]
     for _ in range(4 - len(terms)):
         args += [0, None, None, None, 0, 0]
     L.hrf_fuse_sum(*args, out.t, B, H, W, C, fins if any_fin else None, s)
@@ -1123,7 +1124,8 @@ def fuse_sum(ctx, dims, terms):
             else:
                 st = t.st
                 st.du = _new_like(st.raw)
-                L.hrf_bilinear_up_bwd(g, C, 0, B, H, W, C, st.raw, st.raw.shape[1], st.raw.shape[2], st.du, st.gstats, s)
+                adj = L.hrf_bilinear_up_bwd if kind == 'up' else L.hrf_nearest_up_bwd
+                adj(g, C, 0, B, H, W, C, st.raw, st.raw.shape[1], st.raw.shape[2], st.du, st.gstats, s)
     ctx.push(bwd)
     return out
 

@@ -233,7 +233,8 @@ int hrf_act_bwd(const float* dout, const float* out, const float* y1, const floa
 /* ---- HRModule cross-resolution exchange (hrnet.py:184-207; fuse layers hrformer.py:498-561) ---
  * out = ReLU(sum of up to four terms); term type 0 unused, 1 identity, 2 BN-affine of a same-
  * resolution raw conv output, 3 BN-affine of a bilinearly up-sampled (align_corners=False)
- * low-resolution raw conv output (Hs x Ws).                                                     */
+ * low-resolution raw conv output (Hs x Ws), 4 the same through nn.Upsample(mode='nearest') by the integer factor
+ * H / Hs (the convolutional HRModule, hrnet.py:135-146; H % Hs == 0 and W % Ws == 0).              */
 int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const float* sh0, int Hs0, int Ws0,
                  int type1, const float* p1, const float* sc1, const float* sh1, int Hs1, int Ws1,
                  int type2, const float* p2, const float* sc2, const float* sh2, int Hs2, int Ws2,
@@ -244,6 +245,9 @@ int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const float* sh0,
 /* adjoint of the bilinear up-sampling (gather form) + (sum du, sum du*ylow) moments              */
 int hrf_bilinear_up_bwd(const float* g, int ldG, int goff, int B, int H, int W, int C, const float* ylow, int Hs, int Ws,
                         float* du, double* stats, void* stream);
+/* adjoint of the nearest up-sampling of term type 4 (block sums) + the same moments                       */
+int hrf_nearest_up_bwd(const float* g, int ldG, int goff, int B, int H, int W, int C, const float* ylow, int Hs, int Ws,
+                       float* du, double* stats, void* stream);
 
 /* ---- HRFPN neck pieces (mmdet/models/necks/hrfpn.py:77-100) --------------------
  * hrf_bilinear_up_into: out[pix][off + c] = F.interpolate(x, size=(H,W), mode='bilinear')[pix][c]

@@ -360,6 +360,7 @@ def _inplace_relu_fix(seq):
 # ----------------------------------------------------------------------------- backbone
 class HRFuserOracle(nn.Module):
     """Restatement of HRFuserHRFormerBased (same ctor kwargs, same state-dict keys)."""
+    stage_block = 'HRFORMER'
 
     def __init__(self, extra, in_channels=3, conv_cfg=None,
                  norm_cfg=dict(type='SyncBN', requires_grad=True),
@@ -384,7 +385,7 @@ class HRFuserOracle(nn.Module):
         pre = [s1['num_channels'][0] * 4]
         for si in (2, 3, 4):
             cfg = extra[f'stage{si}']
-            assert cfg['block'] == 'HRFORMER'
+            assert cfg['block'] == self.stage_block
             ch = list(cfg['num_channels'])
             setattr(self, f'transition{si - 1}', make_transition(pre, ch, ncfg))
             ms = multiscale_output if si == 4 else True
@@ -498,6 +499,90 @@ class HRFuserOracle(nn.Module):
         for mod in stage:
             xs = mod(xs)
         return xs
+
+
+class BasicBlock(nn.Module):
+    """resnet.py:14-97 (stride 1, no downsample inside an HRModule branch): conv3x3-BN-ReLU-conv3x3-BN, + x, ReLU."""
+    expansion = 1
+
+    def __init__(self, cin, planes, norm_cfg, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 3, 1, 1, bias=False)
+        self.bn1 = make_bn(norm_cfg, planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = make_bn(norm_cfg, planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = F.relu(self.bn1(self.conv1(x)))
+        return F.relu(self.bn2(self.conv2(y)) + idt)
+
+
+class HRNetModule(nn.Module):
+    """The convolutional HRModule (hrnet.py:14-207): parallel branches of BasicBlocks, cross-resolution exchange with
+    1x1 conv + BN + NEAREST up-sampling (then F.interpolate(bilinear) to the target size, the identity when the sizes
+    nest) and chains of 3x3 stride-2 conv + BN (+ReLU except last)."""
+
+    def __init__(self, channels, num_blocks, norm_cfg, multiscale_output=True):
+        super().__init__()
+        nb = len(channels)
+        self.nb = nb
+        self.branches = nn.ModuleList(
+            nn.Sequential(*[BasicBlock(channels[i], channels[i], norm_cfg) for _ in range(num_blocks[i])]) for i in range(nb))
+        self.fuse_layers = None
+        if nb > 1:
+            rows = []
+            for i in range(nb if multiscale_output else 1):
+                row = []
+                for j in range(nb):
+                    if j > i:
+                        row.append(nn.Sequential(nn.Conv2d(channels[j], channels[i], 1, bias=False), make_bn(norm_cfg, channels[i]),
+                                                 nn.Upsample(scale_factor=2 ** (j - i), mode='nearest')))
+                    elif j == i:
+                        row.append(None)
+                    else:
+                        steps = []
+                        for k in range(i - j):
+                            last = k == i - j - 1
+                            cout = channels[i] if last else channels[j]
+                            mods = [nn.Conv2d(channels[j], cout, 3, 2, 1, bias=False), make_bn(norm_cfg, cout)]
+                            if not last:
+                                mods.append(nn.ReLU(inplace=False))
+                            steps.append(nn.Sequential(*mods))
+                        row.append(nn.Sequential(*steps))
+                rows.append(nn.ModuleList(row))
+            self.fuse_layers = nn.ModuleList(rows)
+
+    def forward(self, xs):
+        if self.nb == 1:
+            return [self.branches[0](xs[0])]
+        xs = [self.branches[i](xs[i]) for i in range(self.nb)]
+        outs = []
+        for i, row in enumerate(self.fuse_layers):
+            acc = 0
+            for j in range(self.nb):
+                if j == i:
+                    acc = acc + xs[j]
+                elif j > i:
+                    acc = acc + F.interpolate(row[j](xs[j]), size=xs[i].shape[2:], mode='bilinear', align_corners=False)
+                else:
+                    acc = acc + row[j](xs[j])
+            outs.append(F.relu(acc))
+        return outs
+
+
+class HRFuserHRNetOracle(HRFuserOracle):
+    """Restatement of HRFuserHRNetBased (hrfuser_hrnet_based.py:23-315): the fusion dataflow of HRFuserOracle over a purely
+    convolutional HRNet trunk (stage blocks 'BASIC': hrnet.py:512-550 builds HRModules of BasicBlocks) - camera stages
+    and modality stages alike.  Same ctor kwargs and state-dict keys as the reference class."""
+    stage_block = 'BASIC'
+
+    @staticmethod
+    def _make_stage(cfg, ncfg, lcfg, multiscale_output):
+        n = cfg['num_modules']
+        return nn.Sequential(*[HRNetModule(list(cfg['num_channels']), cfg['num_blocks'], ncfg, multiscale_output or m != n - 1)
+                               for m in range(n)])
 
 
 class HRFormerOracle(nn.Module):

@@ -1,35 +1,55 @@
-"""Launches the hot kernels of the training step eagerly (4 times each) on their branch-0 shapes so that
-rocprofv3 --pmc can attribute hardware counters (FETCH_SIZE / WRITE_SIZE / SQ_*) to them:
+"""Launches the hot kernels of the training step eagerly (4 times each) on their branch-0 (96x160, 2 images) shapes so
+that rocprofv3 --pmc can attribute hardware counters (FETCH_SIZE / WRITE_SIZE / SQ_*) to them:
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_kernels.py
 
-(see profiles/README.md for the collected numbers and the gfx950 corrections applied)."""
-import sys, torch
+(tools/prof_r02.sh drives it; profiles/README.md lists the collected numbers and the gfx950 corrections applied)."""
 import os
+import sys
+
+import torch
+
+os.environ.setdefault('HRF_LANES', '0')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from hrfuser_amd import _lib
-L=_lib.lib(); dev=torch.device('cuda:0')
-R=lambda *sh: torch.randn(*sh,device=dev)
-sp=_lib.stream_ptr
-B,H,W=2,96,160
-# wgrad 3x3 64->64
-Cin=Cout=64
-x=R(B,H,W,Cin); dy=R(B,H,W,Cout); yr=R(B,H,W,Cout); dw=torch.zeros(Cout,Cin,3,3,device=dev); sc=R(Cin); sh=R(Cin); cA=R(Cout); cB=R(Cout); cC=R(Cout)
-w=R(Cout,Cin,3,3); y=R(B,H,W,Cout); st=torch.zeros(32*Cout,dtype=torch.float64,device=dev)
-dx=R(B,H,W,Cin)
-# attention branch 0
-C=18; P=B*H*W; qkv=R(P,3*C); o=R(P,C); Tt=R(169,1); bq=R(3*C); dqkv=R(P,3*C); dT=torch.zeros(169,1,device=dev); dbq=torch.zeros(3*C,device=dev)
-# dense wgrad 18->72 LN bnb ; lin fwd 18->72
-x18=R(B,H,W,18); dy72=R(B,H,W,72); yr72=R(B,H,W,72); dw2=torch.zeros(72,18,device=dev); rs=R(P,2); s18=R(18); c72=[R(72) for _ in range(3)]; w2=R(72,18,1,1); y72=R(B,H,W,72); st72=torch.zeros(32*72,dtype=torch.float64,device=dev)
-x72=R(B,H,W,72); dy18=R(B,H,W,18); yr18=R(B,H,W,18); dw3=torch.zeros(18,72,device=dev); s72=R(72); c18=[R(18) for _ in range(3)]
+from hrfuser_amd import _lib                                   # noqa: E402
+import hrfuser_amd.backbone as BB                              # noqa: E402
+from hrfuser_amd.testing import BlockHarness                   # noqa: E402
+
+L = _lib.lib()
+dev = torch.device('cuda:0')
+R = lambda *sh: torch.randn(*sh, device=dev)
+sp = _lib.stream_ptr
+B, H, W = 2, 96, 160
+P = B * H * W
+# dominant signature of the step (bench.py roofline.dominant_shape): CrossFFN fc3 weight gradient, 72 -> 18 channels,
+# GELU(BN(.)) operand, BatchNorm-backward on dY
+x72, dy18, yr18 = R(B, H, W, 72), R(B, H, W, 18), R(B, H, W, 18)
+dw3 = torch.zeros(18, 72, device=dev)
+s72, c18 = R(72), [R(18) for _ in range(3)]
+# the 3x3 64 -> 64 convolution of the Bottlenecks: forward, data gradient, weight gradient
+Cin = Cout = 64
+x, dy, yr = R(B, H, W, Cin), R(B, H, W, Cout), R(B, H, W, Cout)
+dw = torch.zeros(Cout, Cin, 3, 3, device=dev)
+sc, sh, cA, cB, cC = R(Cin), R(Cin), R(Cout), R(Cout), R(Cout)
+w, y, dx = R(Cout, Cin, 3, 3), R(B, H, W, Cout), R(B, H, W, Cin)
+st = torch.zeros(32 * Cout, dtype=torch.float64, device=dev)
+# CrossFFN depthwise 3x3 on the 72-channel hidden map and the fc3 forward / data gradient
+wd, bd, y72 = R(72, 1, 3, 3), R(72), R(B, H, W, 72)
+st72 = torch.zeros(32 * 72, dtype=torch.float64, device=dev)
+w3, y18 = R(18, 72, 1, 1), R(B, H, W, 18)
+st18 = torch.zeros(32 * 18, dtype=torch.float64, device=dev)
+# one HRFormerBlock at the branch-0 size: the fused attention block kernels (forward, backward) and the slot fold
+blk = BB.HRFormerBlock(18, 18, 1, norm_cfg=dict(type='BN', requires_grad=True, momentum=0.1), transformer_norm_cfg=dict(type='LN', eps=1e-6))
+hn = BlockHarness(blk, lambda ctx, b, xs: b.run(ctx, xs[0])).to(dev)
+hn.train()
+xb = torch.randn(B, 18, H, W, device=dev, requires_grad=True)
+gb = torch.randn(B, 18, H, W, device=dev)
 for it in range(4):
-    # dominant signature of the step: fc3 weight gradient (GELU(BN(.)) operand, BatchNorm-backward on dY)
-    L.hrf_conv_bwd_weight(dy18,18,0,yr18,*c18,x72,H*W*72,W*72,72,1,B,H,W,72,1,1,18,3,s72,s72,None,dw3,None,sp())
-    L.hrf_conv_bwd_weight(dy,Cout,0,yr,cA,cB,cC,x,H*W*Cin,W*Cin,Cin,1,B,H,W,Cin,3,1,Cout,2,sc,sh,None,dw,None,sp())
-    L.hrf_conv_fwd(x,H*W*Cin,W*Cin,Cin,1,B,H,W,Cin,w,None,3,1,Cout,y,Cout,0,None,None,0,2,sc,sh,None,st,None,None,0.0,sp())
-    L.hrf_conv_bwd_data(dy,Cout,0,yr,cA,cB,cC,None,w,3,1,Cout,B,H,W,Cin,dx,H*W*Cin,W*Cin,Cin,1,0,1,x,Cin,sc,sh,1,st,sp())
-    L.hrf_window_attn_fwd(qkv,3*C,0,qkv,3*C,C,qkv,3*C,2*C,bq[C:2*C],bq[2*C:],Tt,o,C,B,H,W,C,1,sp())
-    L.hrf_window_attn_bwd(qkv,3*C,0,qkv,3*C,C,qkv,3*C,2*C,bq[C:2*C],bq[2*C:],Tt,o,C,dqkv,3*C,0,dqkv,3*C,C,dqkv,3*C,2*C,dbq[C:2*C],dbq[2*C:],dT,0,B,H,W,C,1,sp())
-    L.hrf_conv_bwd_weight(dy72,72,0,yr72,*c72,x18,H*W*18,W*18,18,1,B,H,W,18,1,1,72,4,s18,s18,rs,dw2,None,sp())
-    L.hrf_conv_fwd(x18,H*W*18,W*18,18,1,B,H,W,18,w2,None,1,1,72,y72,72,0,None,None,0,4,s18,s18,rs,st72,None,None,0.0,sp())
+    L.hrf_conv_bwd_weight(dy18, 18, 0, yr18, *c18, x72, H * W * 72, W * 72, 72, 1, B, H, W, 72, 1, 1, 18, 3, s72, s72, None, dw3, None, sp())
+    L.hrf_conv_bwd_weight(dy, Cout, 0, yr, cA, cB, cC, x, H * W * Cin, W * Cin, Cin, 1, B, H, W, Cin, 3, 1, Cout, 2, sc, sh, None, dw, None, sp())
+    L.hrf_conv_fwd(x, H * W * Cin, W * Cin, Cin, 1, B, H, W, Cin, w, None, 3, 1, Cout, y, Cout, 0, None, None, 0, 2, sc, sh, None, st, None, None, 0.0, sp())
+    L.hrf_conv_bwd_data(dy, Cout, 0, yr, cA, cB, cC, None, w, 3, 1, Cout, B, H, W, Cin, dx, H * W * Cin, W * Cin, Cin, 1, 0, 1, x, Cin, sc, sh, 1, st, sp())
+    L.hrf_dwconv_fwd(x72, B, H, W, 72, wd, bd, 1, 3, s72, s72, y72, st72, None, sp())
+    L.hrf_conv_fwd(x72, H * W * 72, W * 72, 72, 1, B, H, W, 72, w3, None, 1, 1, 18, y18, 18, 0, None, None, 0, 3, s72, s72, None, st18, None, None, 0.0, sp())
+    hn(xb)[0].backward(gb)
 torch.cuda.synchronize()

@@ -1,0 +1,44 @@
+# round-2 profiles: kernel trace + stats of the bench command, PMC fabric traffic of the hot kernels (separate passes)
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r02 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-neck --no-eager > $OUT/bench_under_rocprof.log 2>&1
+echo trace rc=$?
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 $GRAFT_REPO_ROOT/tools/pmc_kernels.py > $OUT/pmc_fetch.log 2>&1; echo fetch rc=$?
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 $GRAFT_REPO_ROOT/tools/pmc_kernels.py > $OUT/pmc_write.log 2>&1; echo write rc=$?
+cd $GRAFT_REPO_ROOT
+python3 - <<'PY'
+import csv,glob,collections,os,json,re,shutil
+OUT='gpurun_out/prof_r02'
+def short(n):
+    n=n.replace('(anonymous namespace)::',''); n=re.sub(r'\(.*','',n); return n.replace('void ','')
+for f in glob.glob(OUT+'/trace/**/*kernel_stats.csv', recursive=True): os.replace(f, OUT+'/r02_kernel_stats.csv')
+tr=glob.glob(OUT+'/trace/**/*kernel_trace.csv', recursive=True)
+if tr:
+    rows=list(csv.DictReader(open(tr[0])))
+    agg=collections.defaultdict(lambda:[0,0])
+    for r in rows:
+        d=int(r['End_Timestamp'])-int(r['Start_Timestamp']); k=short(r['Kernel_Name']); agg[k][0]+=1; agg[k][1]+=d
+    with open(OUT+'/r02_kernel_trace_summary.csv','w') as fh:
+        fh.write('kernel,calls,total_ns,avg_ns\n')
+        for k,v in sorted(agg.items(), key=lambda kv:-kv[1][1]): fh.write(f'"{k}",{v[0]},{v[1]},{v[1]/v[0]:.1f}\n')
+    print('trace dispatches',len(rows))
+res={}
+for tag,cn in (('pmc_fetch','FETCH_SIZE'),('pmc_write','WRITE_SIZE')):
+    fs=glob.glob(OUT+f'/{tag}/**/*counter_collection.csv', recursive=True)
+    if not fs: print('no',tag); continue
+    agg=collections.defaultdict(lambda:[0,0.0])
+    for r in csv.DictReader(open(fs[0])):
+        if r.get('Counter_Name')!=cn: continue
+        k=short(r['Kernel_Name'])
+        if 'at::' in k or 'rocclr' in k: continue
+        agg[k][0]+=1; agg[k][1]+=float(r['Counter_Value'])
+    res[cn]={k:{'calls':v[0],'avg_per_launch':v[1]/v[0]} for k,v in agg.items()}
+json.dump(res, open(OUT+'/r02_pmc_raw.json','w'), indent=1)
+for cn,d in res.items():
+    for k,v in d.items(): print(cn,k,v)
+for d in ('trace','pmc_fetch','pmc_write'): shutil.rmtree(OUT+'/'+d, ignore_errors=True)
+PY
+tail -1 $OUT/bench_under_rocprof.log | cut -c1-300
