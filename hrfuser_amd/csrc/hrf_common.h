@@ -90,12 +90,15 @@ __device__ __forceinline__ void hrf_bn_fin_onload(const hrf_bn_fin_t& f, float* 
   const int C = f.C;
   const int c_end = min(C, c_begin + c_count);
   sSc -= c_begin; sSh -= c_begin;
+  const int K = f.copies > 0 ? f.copies : HRF_STAT_COPIES;
   for (int c = c_begin + tid; c < c_end; c += nthreads) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < HRF_STAT_COPIES; ++k) {
-      s1 += f.stats[(size_t)k * 2 * C + c];
-      s2 += f.stats[(size_t)k * 2 * C + C + c];
+    for (int k = 0; k < HRF_STAT_COPIES; ++k) {         // unconditional loads (a load under `if` gets its own round trip)
+      const size_t o = (size_t)(k < K ? k : 0) * 2 * C + c;
+      const double v1 = f.stats[o], v2 = f.stats[o + C];
+      s1 += k < K ? v1 : 0.0;
+      s2 += k < K ? v2 : 0.0;
     }
     const double mean = s1 / f.count;
     double var = s2 / f.count - mean * mean;               // biased variance (train-mode normalisation)
@@ -122,15 +125,21 @@ __device__ __forceinline__ void hrf_bn_bfin_onload(const hrf_bn_bfin_t& f, float
   const int C = f.C;
   const int c_end = min(C, c_begin + c_count);
   sA -= c_begin; sB -= c_begin; sC -= c_begin;
+  const int K = f.copies > 0 ? f.copies : HRF_STAT_COPIES;
   for (int c = c_begin + tid; c < c_end; c += nthreads) {
     double sdu = 0.0, sdux = 0.0;
 #pragma unroll
-    for (int k = 0; k < HRF_STAT_COPIES; ++k) {
-      sdu += f.gstats[(size_t)k * 2 * C + c];
-      sdux += f.gstats[(size_t)k * 2 * C + C + c];
+    for (int k = 0; k < HRF_STAT_COPIES; ++k) {         // unconditional loads (a load under `if` gets its own round trip)
+      const size_t o = (size_t)(k < K ? k : 0) * 2 * C + c;
+      const double v1 = f.gstats[o], v2 = f.gstats[o + C];
+      sdu += k < K ? v1 : 0.0;
+      sdux += k < K ? v2 : 0.0;
     }
     const double mu = f.mean[c], is = f.invstd[c], g = f.gamma ? f.gamma[c] : 1.f;
-    const double sduy = (sdux - mu * sdu) * is;            // sum du * yhat
+    const double sduy = (sdux - mu * sdu) * is;            // sum du * yhat (all ranks under SyncBN)
+    // parameter gradients from the rank-LOCAL moments (data-parallel gradients are summed afterwards)
+    double ldu = sdu, lduy = sduy;
+    if (f.gstats_local != nullptr) { ldu = f.gstats_local[c]; lduy = (f.gstats_local[C + c] - mu * ldu) * is; }
     float a, b2, c2;
     if (f.train) {
       const double am = sdu / f.count, bm = sduy / f.count;
@@ -143,8 +152,8 @@ __device__ __forceinline__ void hrf_bn_bfin_onload(const hrf_bn_bfin_t& f, float
     sA[c] = a; sB[c] = b2; sC[c] = c2;
     if (writer && f.write) {
       f.cA[c] = a; f.cB[c] = b2; f.cC[c] = c2;
-      if (f.dgamma) f.dgamma[c] += (float)sduy;
-      if (f.dbeta) f.dbeta[c] += (float)sdu;
+      if (f.dgamma) f.dgamma[c] += (float)lduy;
+      if (f.dbeta) f.dbeta[c] += (float)ldu;
     }
   }
 }

@@ -96,7 +96,7 @@ class Act:
 class BNState:
     """One BatchNorm application: raw conv output + the per-channel vectors around it."""
     __slots__ = ('bn', 'C', 'raw', 'count', 'scale', 'shift', 'mean', 'invstd', 'stats', 'gstats',
-                 'coef', 'du', 'train', 'pending', 'lane', 'bx_done')
+                 'coef', 'du', 'train', 'pending', 'lane', 'bx_done', 'packed', 'bpacked')
 
 
 class Lazy:
@@ -264,43 +264,50 @@ class Ctx:
                 l.stream.wait_stream(self.main.stream)
 
     def flush_sync(self):
+        """ONE collective for the forward moments of every parked BatchNorm; their consumers then finalise on load
+        from the packed, all-reduced sums (hrf_bn_fin_t.copies = 1) - no finalize launch."""
         sts, self.pending = self.pending, []
         if not sts:
             return
         P = _lib._ptr
+        box = []
 
         def fin(packed):
             self.all_reduce(packed)
-            fins = (_lib.BnFin * len(sts))()
-            for k, st in enumerate(sts):
-                bn = st.bn
-                mom = bn.momentum if bn.momentum is not None else 0.1
-                fins[k] = _lib.BnFin(None, P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var), P(st.scale),
-                                     P(st.shift), P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom),
-                                     1 if bn.track_running_stats else 0, 1, st.C)
-            self.L.hrf_bn_finalize_packed(fins, len(sts), packed, self.stream)
+            box.append(packed)
         self._exchange(sts, [st.lane for st in sts], [P(st.stats) for st in sts], fin)
+        off = 0
         for st in sts:
-            st.pending = None
+            st.packed = (box[0], off)
+            off += 2 * st.C
+            st.pending = 'fwd' if _FIN_ONLOAD else None
+            if not _FIN_ONLOAD:
+                with _LaneScope(self, st.lane):
+                    _finalize_now(self, st)
 
     def flush_bwd(self, sts, lanes):
-        """Backward SyncBN exchange of (sum du, sum du*y) for all of `sts` in one collective."""
+        """Backward SyncBN exchange of (sum du, sum du*y) for all of `sts` in one collective; the data-gradient kernels
+        of the producing convolutions derive their coefficients on load from the packed sums (bn_backward_coef)."""
         P = _lib._ptr
+        box = []
 
         def fin(packed):
             local = _keep(packed.clone())
             self.all_reduce(packed)
-            bf = (_lib.BnBFin * len(sts))()
-            for k, st in enumerate(sts):
-                slot = self.owner._bn_slot(st.bn)
-                wg = st.bn.weight.grad if st.bn.weight.requires_grad else None
-                bg = st.bn.bias.grad if st.bn.bias.requires_grad else None
-                bf[k] = _lib.BnBFin(None, P(st.bn.weight), P(st.mean), P(st.invstd), P(wg), P(bg), P(slot['cA']), P(slot['cB']),
-                                    P(slot['cC']), st.count, 1, 1, st.C)
-            self.L.hrf_bn_bwd_finalize_packed(bf, len(sts), packed, local, self.stream)
+            box.append((packed, local))
         self._exchange(sts, lanes, [P(st.gstats) for st in sts], fin)
+        off = 0
         for st in sts:
+            st.bpacked = (box[0][0], box[0][1], off)
+            off += 2 * st.C
             st.bx_done = True
+
+    def all_reduce(self, t):
+        if self.coll:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.group)
+            self.n_collectives += 1
+
 
     # ---- lanes ---------------------------------------------------------------------------------
     def fork(self, n):
@@ -471,13 +478,6 @@ class Ctx:
         if self.multi:
             torch.cuda.current_stream().wait_stream(self.main.stream)
 
-    def all_reduce(self, t):
-        if self.coll:
-            import torch.distributed as dist
-            dist.all_reduce(t, group=self.group)
-            self.n_collectives += 1
-
-
 def _balance(items, k):
     """Longest-processing-time-first split of (cost, fn) leaf launches over k lanes (the lanes of the deferred
     weight-gradient phase run concurrently; the phase ends with the slowest one)."""
@@ -583,6 +583,7 @@ def bn_forward(ctx, bn, raw, stats):
     st = BNState()
     C = raw.shape[-1]
     st.bn, st.C, st.raw, st.du, st.coef, st.pending, st.lane, st.bx_done = bn, C, raw, None, None, None, None, False
+    st.packed = st.bpacked = None
     slot = ctx.owner._bn_slot(bn)
     st.train = bool(ctx.training and bn.training)
     if st.train:
@@ -606,9 +607,15 @@ def bn_forward(ctx, bn, raw, stats):
 def _finalize_now(ctx, st):
     bn = st.bn
     mom = bn.momentum if bn.momentum is not None else 0.1
-    ctx.L.hrf_bn_finalize(st.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, st.count,
-                          float(bn.eps), float(mom), 1 if bn.track_running_stats else 0,
-                          st.scale, st.shift, st.mean, st.invstd, st.C, ctx.stream)
+    if st.packed is not None:                           # SyncBN: the folded, all-reduced sums
+        P = _lib._ptr
+        fin = _lib.BnFin(None, P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var), P(st.scale), P(st.shift),
+                         P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom), 1 if bn.track_running_stats else 0, 1, st.C)
+        ctx.L.hrf_bn_finalize_packed(fin, 1, st.packed[0].data_ptr() + 8 * st.packed[1], ctx.stream)
+    else:
+        ctx.L.hrf_bn_finalize(st.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, st.count,
+                              float(bn.eps), float(mom), 1 if bn.track_running_stats else 0,
+                              st.scale, st.shift, st.mean, st.invstd, st.C, ctx.stream)
     st.pending = None
 
 
@@ -624,9 +631,10 @@ def take_fin(ctx, st, limit=FIN_MAXC):
     bn = st.bn
     mom = bn.momentum if bn.momentum is not None else 0.1
     P = _lib._ptr
-    fin = _lib.BnFin(P(st.stats), P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var),
+    stats, copies = (P(st.stats), 0) if st.packed is None else (st.packed[0].data_ptr() + 8 * st.packed[1], 1)
+    fin = _lib.BnFin(stats, P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var),
                      P(st.scale), P(st.shift), P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom),
-                     1 if bn.track_running_stats else 0, 1 if st.pending == 'fwd' else 0, st.C)
+                     1 if bn.track_running_stats else 0, 1 if st.pending == 'fwd' else 0, st.C, copies)
     st.pending = 'written'
     return fin
 
@@ -646,7 +654,14 @@ def bn_backward_coef(ctx, st, consumer_follows=True, limit=FIN_MAXC):
     wg = st.bn.weight.grad if st.bn.weight.requires_grad else None
     bg = st.bn.bias.grad if st.bn.bias.requires_grad else None
     coll = st.train and _collectives(ctx)
-    if coll and st.bx_done:                             # exchanged and finalised by run_backward's batch (Ctx.flush_bwd)
+    if coll and st.bx_done:                             # exchanged by run_backward's batch (Ctx.flush_bwd): packed sums
+        packed, local, off = st.bpacked
+        P = _lib._ptr
+        bf = _lib.BnBFin(packed.data_ptr() + 8 * off, P(st.bn.weight), P(st.mean), P(st.invstd), P(wg), P(bg), P(cA), P(cB),
+                         P(cC), st.count, 1, 1, st.C, 1, local.data_ptr() + 8 * off)
+        if _FIN_ONLOAD and consumer_follows and st.C <= limit:
+            return st.coef, bf
+        ctx.L.hrf_bn_bwd_finalize_packed(bf, 1, packed.data_ptr() + 8 * off, local.data_ptr() + 8 * off, ctx.stream)
         return st.coef, None
     if _FIN_ONLOAD and consumer_follows and not coll and st.C <= limit:
         P = _lib._ptr

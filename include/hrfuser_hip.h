@@ -48,12 +48,16 @@ typedef struct hrf_bn_fin {
   const float* gamma; const float* beta; float* running_mean; float* running_var;
   float* scale; float* shift; float* mean; float* invstd;
   double count; float eps; float momentum; int update_running; int write; int C;
+  int copies;                    /* replication of `stats`: 0 = HRF_STAT_COPIES; 1 = already folded (SyncBN: the packed,
+                                    all-reduced moments of hrf_bn_pack) */
 } hrf_bn_fin_t;
 typedef struct hrf_bn_bfin {
   const double* gstats;
   const float* gamma; const float* mean; const float* invstd;
   float* dgamma; float* dbeta; float* cA; float* cB; float* cC;
   double count; int train; int write; int C;
+  int copies;                    /* as in hrf_bn_fin_t */
+  const double* gstats_local;    /* SyncBN: this rank's folded moments (parameter gradients); NULL = gstats */
 } hrf_bn_bfin_t;
 
 #ifdef __cplusplus
