@@ -14,7 +14,7 @@
 // hard requirement - SURVEY.md 7 "hard parts": bf16/fp16 inputs fail the 1e-3 gate).
 // BatchNorm / LayerNorm / activation are never materialised: the loaders read the producer's RAW
 // output and apply the per-channel affine / activation on the fragment ("transform on load"); the
-// epilogues emit the per-channel sums the next BatchNorm needs into 16 replicated accumulators
+// epilogues emit the per-channel sums the next BatchNorm needs into HRF_STAT_COPIES replicated accumulators
 // (same-address global atomics serialise at ~25 ns each on MI355X, see include/hrfuser_hip.h).
 //
 // Shape of the problem (HRFuser-T, 2 images/GPU): M = 480..30720 pixels, K = 18..2304, N = 18..576,
@@ -575,8 +575,7 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
   const WgradDenseArgs& a = grp_args.p[prob];
   const int bid = (int)blockIdx.x - grp_args.bstart[prob];
   constexpr int WU = MT * NT > 16 ? WUMAX / 2 : WUMAX;       // keep the 5x5-tile variants inside 256 VGPRs
-  constexpr int WSP = NT * 16 + 4;                           // LDS pitch of the merge tile (2-way bank aliasing at most)
-  __shared__ float sAcc[2 * MT * 16 * WSP];
+  __shared__ __attribute__((aligned(16))) float sAcc[2 * MT * NT * 256];   // two merge regions, fragment order
   __shared__ float sBias[WNW * MT * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -692,21 +691,36 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
     }
   }
 
-  // merge the 8 waves: region = wave >> 2, four ld/add/st rounds (waves r and r+4 work in parallel)
-  float* S = sAcc + (wave >> 2) * (MT * 16 * WSP);
+  // merge the 8 waves: region = wave >> 2, four rounds (waves r and r+4 work in parallel).  The tile lives in LDS in
+  // FRAGMENT order (one 16-byte word per lane and 16x16 tile: conflict-free b128 accesses) and every round loads all
+  // of its words BEFORE it stores any: a ld/add/st per element is a chain of dependent LDS round trips (the compiler
+  // must assume that a store aliases the next load) - that chain, not the reduction, was the duration of this kernel
+  // (~20 us for every problem size; tools/bench_wgrad.py).
+  hrf_f4* S = reinterpret_cast<hrf_f4*>(sAcc) + (wave >> 2) * (MT * NT * 64);
+  if ((wave & 3) == 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) S[(i * NT + j) * 64 + lane] = acc[i][j];
+  }
+  __syncthreads();
 #pragma unroll 1
-  for (int round = 0; round < 4; ++round) {
+  for (int round = 1; round < 4; ++round) {
     if ((wave & 3) == round) {
+      hrf_f4 old[MT][NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) old[i][j] = S[(i * NT + j) * 64 + lane];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* q = &S[(16 * i + 4 * kq + r) * WSP + 16 * j + c];
-            const float old = *q;
-            *q = round == 0 ? acc[i][j][r] : old + acc[i][j][r];
-          }
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          hrf_f4 v = old[i][j];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += acc[i][j][r];
+          S[(i * NT + j) * 64 + lane] = v;
+        }
     }
     __syncthreads();
   }
@@ -716,10 +730,19 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
     bsm += __shfl_xor(bsm, 16); bsm += __shfl_xor(bsm, 32);
     if (lane < 16) sBias[wave * (MT * 16) + 16 * i + lane] = bsm;
   }
-  for (int e = tid; e < MT * 16 * NT * 16; e += 64 * WNW) {
-    const int row = e / (NT * 16), col = e - row * (NT * 16);
-    if (m0 + row < a.Cout && n0 + col < Np)
-      hrf_atomic_add(&a.dw[(long)(m0 + row) * Np + n0 + col], sAcc[row * WSP + col] + sAcc[MT * 16 * WSP + row * WSP + col]);
+  {
+    const hrf_f4* S0 = reinterpret_cast<const hrf_f4*>(sAcc);
+    for (int e = tid; e < MT * NT * 64; e += 64 * WNW) {
+      const int tile = e >> 6, l = e & 63;
+      const int ti = tile / NT, tj = tile - ti * NT;
+      const hrf_f4 v0 = S0[e], v1 = S0[MT * NT * 64 + e];
+      const int col = n0 + 16 * tj + (l & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * ti + 4 * (l >> 4) + r;
+        if (row < a.Cout && col < Np) hrf_atomic_add(&a.dw[(long)row * Np + col], v0[r] + v1[r]);
+      }
+    }
   }
   __syncthreads();
   if (a.dbias != nullptr && by == 0 && tid < MT * 16 && m0 + tid < a.Cout) {

@@ -79,6 +79,45 @@ __device__ __forceinline__ int hrf_tf_act(int mode) {
   return mode == HRF_TF_AFFINE_RELU ? HRF_ACT_RELU : (mode == HRF_TF_AFFINE_GELU ? HRF_ACT_GELU : HRF_ACT_NONE);
 }
 
+// ------------------------------------------------------------------ BatchNorm finalize arithmetic (shared)
+// One implementation for the stand-alone finalize kernels, their packed (SyncBN) forms and the on-load prologues, kept
+// SHORT on purpose: in a consumer prologue this is a dependent chain in front of the kernel's own work.  No fp64
+// division or square root (30-40 dependent instructions each): the moments are scaled by 1/count (computed while the
+// moment loads are in flight) and 1/sqrt(var+eps) is the fp32 hardware estimate + one Newton step (<= 1.5e-7 relative).
+__device__ __forceinline__ float hrf_rsqrt_nr(float v) {
+  const float r = rsqrtf(v);
+  return r * fmaf(-0.5f * v * r, r, 1.5f);
+}
+__device__ __forceinline__ void hrf_bn_solve(double s1, double s2, double inv_count, float eps, float g, float b,
+                                             float& sc, float& sh, float& meanf, float& invstd, double& var) {
+  const double mean = s1 * inv_count;
+  var = s2 * inv_count - mean * mean;                      // biased variance (train-mode normalisation)
+  if (var < 0.0) var = 0.0;
+  invstd = hrf_rsqrt_nr((float)(var + (double)eps));
+  meanf = (float)mean;
+  sc = g * invstd;
+  sh = b - meanf * sc;
+}
+// running statistics (torch: running_var uses the UNBIASED variance)
+__device__ __forceinline__ void hrf_bn_running(float* rm, float* rv, int c, float momentum, float meanf, double var, double count) {
+  const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+  rm[c] = (1.f - momentum) * rm[c] + momentum * meanf;
+  rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+}
+// dy = cA*du + cB*y + cC from the global (sum du, sum du*y); sduy = sum du*yhat
+__device__ __forceinline__ void hrf_bn_bwd_solve(double sdu, double sdux, double mu, double is, double g, double inv_count,
+                                                 int train, float& a, float& b2, float& c2) {
+  const double gi = g * is;
+  a = (float)gi;
+  if (train) {
+    const double bm = (sdux - mu * sdu) * is * inv_count, gib = gi * is * bm;
+    b2 = (float)(-gib);
+    c2 = (float)(gib * mu - gi * (sdu * inv_count));
+  } else {                                                 // frozen statistics: dy = gamma*invstd*du
+    b2 = 0.f; c2 = 0.f;
+  }
+}
+
 // ------------------------------------------------------------------ BatchNorm finalize on load (consumer side)
 // See hrf_bn_fin_t in include/hrfuser_hip.h.  Every thread of the block calls these in the kernel prologue, followed by
 // a __syncthreads(); the per-channel results land in LDS (sSc/sSh resp. sA/sB/sC, >= f.C floats each) and the kernel then
@@ -91,6 +130,10 @@ __device__ __forceinline__ void hrf_bn_fin_onload(const hrf_bn_fin_t& f, float* 
   const int c_end = min(C, c_begin + c_count);
   sSc -= c_begin; sSh -= c_begin;
   const int K = f.copies > 0 ? f.copies : HRF_STAT_COPIES;
+  const double inv_count = 1.0 / f.count;                  // (independent of the loads below: overlaps their latency)
+  // one thread per channel (consecutive lanes = consecutive channels: a wave's load touches the fewest cache lines - every
+  // block of the grid reads the same ~2*C*16 doubles, and the request count on those hot lines is what this prologue
+  // costs: a 16-lanes-per-channel split was 2-3x slower, tools/bench_fin.py)
   for (int c = c_begin + tid; c < c_end; c += nthreads) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -100,22 +143,15 @@ __device__ __forceinline__ void hrf_bn_fin_onload(const hrf_bn_fin_t& f, float* 
       s1 += k < K ? v1 : 0.0;
       s2 += k < K ? v2 : 0.0;
     }
-    const double mean = s1 / f.count;
-    double var = s2 / f.count - mean * mean;               // biased variance (train-mode normalisation)
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
     const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
-    const float sc = g * invstd;
-    const float sh = b - (float)mean * sc;
+    float sc, sh, meanf, invstd;
+    double var;
+    hrf_bn_solve(s1, s2, inv_count, f.eps, g, b, sc, sh, meanf, invstd, var);
     sSc[c] = sc;
     sSh[c] = sh;
     if (writer && f.write) {
-      f.scale[c] = sc; f.shift[c] = sh; f.mean[c] = (float)mean; f.invstd[c] = invstd;
-      if (f.update_running) {                              // torch: running_var uses the UNBIASED var
-        const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
-        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
-        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
-      }
+      f.scale[c] = sc; f.shift[c] = sh; f.mean[c] = meanf; f.invstd[c] = invstd;
+      if (f.update_running) hrf_bn_running(f.running_mean, f.running_var, c, f.momentum, meanf, var, f.count);
     }
   }
 }
@@ -126,6 +162,7 @@ __device__ __forceinline__ void hrf_bn_bfin_onload(const hrf_bn_bfin_t& f, float
   const int c_end = min(C, c_begin + c_count);
   sA -= c_begin; sB -= c_begin; sC -= c_begin;
   const int K = f.copies > 0 ? f.copies : HRF_STAT_COPIES;
+  const double inv_count = 1.0 / f.count;
   for (int c = c_begin + tid; c < c_end; c += nthreads) {
     double sdu = 0.0, sdux = 0.0;
 #pragma unroll
@@ -136,23 +173,15 @@ __device__ __forceinline__ void hrf_bn_bfin_onload(const hrf_bn_bfin_t& f, float
       sdux += k < K ? v2 : 0.0;
     }
     const double mu = f.mean[c], is = f.invstd[c], g = f.gamma ? f.gamma[c] : 1.f;
-    const double sduy = (sdux - mu * sdu) * is;            // sum du * yhat (all ranks under SyncBN)
-    // parameter gradients from the rank-LOCAL moments (data-parallel gradients are summed afterwards)
-    double ldu = sdu, lduy = sduy;
-    if (f.gstats_local != nullptr) { ldu = f.gstats_local[c]; lduy = (f.gstats_local[C + c] - mu * ldu) * is; }
     float a, b2, c2;
-    if (f.train) {
-      const double am = sdu / f.count, bm = sduy / f.count;
-      a = (float)(g * is);
-      b2 = (float)(-g * is * is * bm);
-      c2 = (float)(-g * is * am + g * is * is * bm * mu);
-    } else {                                               // frozen statistics: dy = gamma*invstd*du
-      a = (float)(g * is); b2 = 0.f; c2 = 0.f;
-    }
+    hrf_bn_bwd_solve(sdu, sdux, mu, is, g, inv_count, f.train, a, b2, c2);
     sA[c] = a; sB[c] = b2; sC[c] = c2;
     if (writer && f.write) {
       f.cA[c] = a; f.cB[c] = b2; f.cC[c] = c2;
-      if (f.dgamma) f.dgamma[c] += (float)lduy;
+      // parameter gradients from the rank-LOCAL moments (data-parallel gradients are summed afterwards)
+      double ldu = sdu, ldux = sdux;
+      if (f.gstats_local != nullptr) { ldu = f.gstats_local[c]; ldux = f.gstats_local[C + c]; }
+      if (f.dgamma) f.dgamma[c] += (float)((ldux - mu * ldu) * is);
       if (f.dbeta) f.dbeta[c] += (float)ldu;
     }
   }

@@ -23,21 +23,15 @@ __global__ void bn_finalize_kernel(const double* stats, const float* gamma, cons
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int k = 0; k < HRF_STAT_COPIES; ++k) { s1 += stats[(size_t)k * 2 * C + c]; s2 += stats[(size_t)k * 2 * C + C + c]; }
-  const double mean = s1 / count;
-  double var = s2 / count - mean * mean;               // biased variance (train-mode normalisation)
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  const float sc = g * invstd;
+  float sc, sh, meanf, invstd;
+  double var;
+  hrf_bn_solve(s1, s2, 1.0 / count, eps, g, b, sc, sh, meanf, invstd, var);
   scale[c] = sc;
-  shift[c] = b - (float)mean * sc;
-  mean_out[c] = (float)mean;
+  shift[c] = sh;
+  mean_out[c] = meanf;
   invstd_out[c] = invstd;
-  if (update_running) {                                  // torch: running_var uses the UNBIASED var
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
+  if (update_running) hrf_bn_running(running_mean, running_var, c, momentum, meanf, var, count);
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* gstats, const double* gstats_local, const float* gamma,
@@ -53,19 +47,13 @@ __global__ void bn_bwd_finalize_kernel(const double* gstats, const double* gstat
   }
   if (!gstats_local) { ldu = sdu; ldux = sdux; }
   const double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.f;
-  const double sduy = (sdux - mu * sdu) * is;            // sum du * yhat
   // parameter grads use the rank-LOCAL moments (data-parallel grads are averaged afterwards);
   // the dy coefficients use the (SyncBN: all-reduced) global moments.
   if (dgamma) dgamma[c] += (float)((ldux - mu * ldu) * is);
   if (dbeta) dbeta[c] += (float)ldu;
-  if (train) {
-    const double a = sdu / count, b = sduy / count;
-    cA[c] = (float)(g * is);
-    cB[c] = (float)(-g * is * is * b);
-    cC[c] = (float)(-g * is * a + g * is * is * b * mu);
-  } else {                                               // frozen statistics: dy = gamma*invstd*du
-    cA[c] = (float)(g * is); cB[c] = 0.f; cC[c] = 0.f;
-  }
+  float a, b2, c2;
+  hrf_bn_bwd_solve(sdu, sdux, mu, is, g, 1.0 / count, train, a, b2, c2);
+  cA[c] = a; cB[c] = b2; cC[c] = c2;
 }
 
 // ---- SyncBN exchange of SEVERAL independent BatchNorms at once (data-parallel training).  The replicated moments of up
@@ -87,18 +75,12 @@ __global__ __launch_bounds__(256) void bn_finalize_packed_kernel(BnFinPackArgs a
   const hrf_bn_fin_t& f = a.f[blockIdx.y];
   const double* st = packed + a.off[blockIdx.y];
   for (int c = blockIdx.x * 256 + threadIdx.x; c < f.C; c += gridDim.x * 256) {
-    const double mean = st[c] / f.count;
-    double var = st[f.C + c] / f.count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
     const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
-    const float sc = g * invstd;
-    f.scale[c] = sc; f.shift[c] = b - (float)mean * sc; f.mean[c] = (float)mean; f.invstd[c] = invstd;
-    if (f.update_running) {
-      const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
-      f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
-      f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
-    }
+    float sc, sh, meanf, invstd;
+    double var;
+    hrf_bn_solve(st[c], st[f.C + c], 1.0 / f.count, f.eps, g, b, sc, sh, meanf, invstd, var);
+    f.scale[c] = sc; f.shift[c] = sh; f.mean[c] = meanf; f.invstd[c] = invstd;
+    if (f.update_running) hrf_bn_running(f.running_mean, f.running_var, c, f.momentum, meanf, var, f.count);
   }
 }
 struct BnBFinPackArgs { hrf_bn_bfin_t f[PK_MAX]; int off[PK_MAX]; };
@@ -109,17 +91,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_packed_kernel(BnBFinPackA
   for (int c = blockIdx.x * 256 + threadIdx.x; c < f.C; c += gridDim.x * 256) {
     const double sdu = gs[c], sdux = gs[f.C + c], ldu = ls[c], ldux = ls[f.C + c];
     const double mu = f.mean[c], is = f.invstd[c], g = f.gamma ? f.gamma[c] : 1.f;
-    const double sduy = (sdux - mu * sdu) * is;
     // parameter grads from the rank-LOCAL moments (data-parallel grads are averaged afterwards), dy coefficients from the
     // all-reduced ones
     if (f.dgamma) f.dgamma[c] += (float)((ldux - mu * ldu) * is);
     if (f.dbeta) f.dbeta[c] += (float)ldu;
-    if (f.train) {
-      const double am = sdu / f.count, bm = sduy / f.count;
-      f.cA[c] = (float)(g * is); f.cB[c] = (float)(-g * is * is * bm); f.cC[c] = (float)(-g * is * am + g * is * is * bm * mu);
-    } else {
-      f.cA[c] = (float)(g * is); f.cB[c] = 0.f; f.cC[c] = 0.f;
-    }
+    float a, b2, c2;
+    hrf_bn_bwd_solve(sdu, sdux, mu, is, g, 1.0 / f.count, f.train, a, b2, c2);
+    f.cA[c] = a; f.cB[c] = b2; f.cC[c] = c2;
   }
 }
 

@@ -28,8 +28,11 @@
  *   - every `stats` / `gstats` argument points to [HRF_STAT_COPIES][2*C] doubles (zeroed by the caller);
  *   - hrf_ln_bwd / hrf_dwconv_bwd_weight take `copy_stride`: element distance between the copies of
  *     their fp32 parameter-gradient accumulators (0 = one copy, plain accumulation into the grads);
- *     hrf_fold_copies adds the summed copies into the gradient arena. */
-#define HRF_STAT_COPIES 16
+ *     hrf_fold_copies adds the summed copies into the gradient arena.
+ * 8 copies: every block of a CONSUMER launch re-reads all copies in its finalize-on-load prologue (below), and the request
+ * count on those hot cache lines is what that prologue costs.  Measured A/B on one box (tools/ab_copies.sh, HRFuser-T
+ * training step): 16 copies 17.20 ms, 8: 16.70, 4: 16.64 (producers 15 % slower), 2: 17.1, 1: 18.3. */
+#define HRF_STAT_COPIES 8
 
 /* BatchNorm finalize ON LOAD (consumer side).  A train-mode BatchNorm needs its batch moments complete before anything
  * can be normalised, i.e. a grid-wide dependency between the producing convolution and its consumer; the kernel boundary
