@@ -631,6 +631,9 @@ class HRFuserFusionBlock(nn.Module):
                              rowscale=self._droppath_scale(ctx, B, dev))
 
 
+_FORK_EXCHANGE = os.environ.get('HRF_FORK_EXCHANGE', '1') != '0'   # exchange chains on sibling lanes (0: serial)
+
+
 class HRFomerModule(nn.Module):
     """hrnet.py:184-207 (HRModule.forward) with HRFormer fuse layers hrformer.py:498-561."""
 
@@ -698,7 +701,7 @@ class HRFomerModule(nn.Module):
         # backward of a lane accumulates into xs[j].grad only (no cross-lane gradient races)
         nrows = len(self.fuse_layers)
         terms = [[None] * nb for _ in range(nrows)]
-        lanes = ctx.fork(nb)
+        lanes = ctx.fork(nb) if _FORK_EXCHANGE else [ctx.cur] * nb
 
         def source(j):
             for i, row in enumerate(self.fuse_layers):

@@ -120,10 +120,14 @@ struct DwBwdDataArgs {
   float* dx; int accumulate;
   int epi; const float* xraw; const float* tf_scale; const float* tf_shift; int act; double* stats;
   hrf_bn_bfin_t bfin;
+  float* dw; float* dbias; long copy_stride;               // WG: weight / bias gradient accumulators (replicated copies)
   int B, H, W, C, Ho, Wo, tilesX, tilesY;
 };
 
-template <int S>
+// WG (stride 1, epi 1): the weight gradient of the SAME convolution from the same pass.  dW[ky][kx] = sum_p x[p] *
+// dy'[p - (ky-1, kx-1)] reads exactly the staged dy' element that dx[p] multiplies with w[ky][kx], and x[p] = act(u) is a
+// by-product of the epilogue's act'(u): nine more FMAs per element instead of a second kernel that re-reads dY, Y and X.
+template <int S, bool WG>
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
   // tile over INPUT pixels 8 x 16; staged dY region: S=1 (10 x 18, origin -1), S=2 (5 x 9, origin y0/2)
   constexpr int TH = 8, RH = S == 1 ? 10 : 5, RW = S == 1 ? 18 : 9;
@@ -184,6 +188,9 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
   if (a.epi == 1 && cv) { sc = a.tf_scale[cg]; sh = a.tf_shift[cg]; }
   const int yi = y0 + r;
   float s1 = 0.f, s2 = 0.f;
+  float wacc[WG ? 10 : 1];
+#pragma unroll
+  for (int k = 0; k < (WG ? 10 : 1); ++k) wacc[k] = 0.f;
   float pre[TW];                                          // epi 1: raw producer output; else previous dx
 #pragma unroll
   for (int q = 0; q < TW; ++q) {
@@ -211,7 +218,17 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
     const long o = (((long)b * a.H + yi) * a.W + xi) * a.C + cg;
     if (a.epi == 1) {
       const float xr = pre[q];
-      acc *= hrf_act_grad(a.act, fmaf(xr, sc, sh));
+      const float u = fmaf(xr, sc, sh);
+      if (WG) {
+        const float xv = ok ? hrf_act(a.act, u) : 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            wacc[dy * 3 + dx] = fmaf(sD[((r + 2 - dy) * RW + (q + 2 - dx)) * CB + c], xv, wacc[dy * 3 + dx]);
+        wacc[9] += ok ? sD[((r + 1) * RW + (q + 1)) * CB + c] : 0.f;
+      }
+      acc *= hrf_act_grad(a.act, u);
       if (ok) { s1 += acc; s2 = fmaf(acc, xr, s2); a.dx[o] = acc; }
     } else {
       if (ok) a.dx[o] = pre[q] + acc;
@@ -227,6 +244,24 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
       for (int g = 0; g < 8; ++g) tot += sStat[g * 2 * CB + tid];
       double* st = a.stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.C;
       hrf_atomic_add(&st[(tid < CB ? 0 : a.C) + c0 + (tid & (CB - 1))], (double)tot);
+    }
+  }
+  if (WG) {
+    __syncthreads();                                      // every read of the staged dy' tile is done: reuse it
+    float* sAcc = sD;                                     // [8 rows][10][CB] (10 KB of the 23 KB tile)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sAcc[(r * 10 + k) * CB + c] = wacc[k];
+    __syncthreads();
+    const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride;
+    for (int i = tid; i < 10 * CB; i += 256) {
+      const int k = i / CB, cc2 = c0 + (i % CB);
+      float tot = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) tot += sAcc[g * 10 * CB + i];
+      if (cc2 < a.C) {
+        if (k < 9) hrf_atomic_add(&a.dw[cp + cc2 * 9 + k], tot);
+        else if (a.dbias) hrf_atomic_add(&a.dbias[cp + cc2], tot);
+      }
     }
   }
 }
@@ -351,11 +386,13 @@ extern "C" int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const 
   return hrf_check_launch();
 }
 
-extern "C" int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const float* cA, const float* cB,
-                                   const float* cC, const hrf_bn_bfin_t* bfin, const float* w, int stride, int B, int H, int W, int C,
-                                   float* dx, int accumulate, int epi, const float* xraw, const float* tf_scale,
-                                   const float* tf_shift, int act, double* stats, void* stream) {
+static int dw_bwd_data_launch(const float* dy, const float* yraw, const float* cA, const float* cB,
+                              const float* cC, const hrf_bn_bfin_t* bfin, const float* w, int stride, int B, int H, int W, int C,
+                              float* dx, int accumulate, int epi, const float* xraw, const float* tf_scale,
+                              const float* tf_shift, int act, double* stats, float* dw, float* dbias, long copy_stride,
+                              void* stream) {
   if (stride != 1 && stride != 2) return HRF_ERR_ARG;
+  if (dw != nullptr && (stride != 1 || epi != 1 || xraw == nullptr)) return HRF_ERR_ARG;
   if (bfin != nullptr && (cA == nullptr || bfin->C != C || bfin->gstats == nullptr)) return HRF_ERR_ARG;
   DwBwdDataArgs a;
   a.bfin = hrf_bn_bfin_t{};
@@ -366,9 +403,28 @@ extern "C" int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const flo
   a.tilesX = hrf_cdiv(W, TW); a.tilesY = hrf_cdiv(H, 8);
   if ((long)B * H * W <= 0) return HRF_OK;
   dim3 grid(a.tilesX * a.tilesY * B, hrf_cdiv(C, CB));
-  if (stride == 1) { HRF_LAUNCH(dw_bwd_data_kernel<1>, grid, dim3(256), 0, stream, a); }
-  else { HRF_LAUNCH(dw_bwd_data_kernel<2>, grid, dim3(256), 0, stream, a); }
+  a.dw = dw; a.dbias = dbias; a.copy_stride = copy_stride;
+  if (dw != nullptr) { HRF_LAUNCH((dw_bwd_data_kernel<1, true>), grid, dim3(256), 0, stream, a); }
+  else if (stride == 1) { HRF_LAUNCH((dw_bwd_data_kernel<1, false>), grid, dim3(256), 0, stream, a); }
+  else { HRF_LAUNCH((dw_bwd_data_kernel<2, false>), grid, dim3(256), 0, stream, a); }
   return hrf_check_launch();
+}
+
+extern "C" int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const float* cA, const float* cB,
+                                   const float* cC, const hrf_bn_bfin_t* bfin, const float* w, int stride, int B, int H, int W, int C,
+                                   float* dx, int accumulate, int epi, const float* xraw, const float* tf_scale,
+                                   const float* tf_shift, int act, double* stats, void* stream) {
+  return dw_bwd_data_launch(dy, yraw, cA, cB, cC, bfin, w, stride, B, H, W, C, dx, accumulate, epi, xraw, tf_scale, tf_shift,
+                            act, stats, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int hrf_dwconv_bwd_data_weight(const float* dy, const float* yraw, const float* cA, const float* cB,
+                                          const float* cC, const hrf_bn_bfin_t* bfin, const float* w, int B, int H, int W, int C,
+                                          float* dx, const float* xraw, const float* tf_scale, const float* tf_shift, int act,
+                                          double* stats, float* dw, float* dbias, long copy_stride, void* stream) {
+  if (dw == nullptr) return HRF_ERR_ARG;
+  return dw_bwd_data_launch(dy, yraw, cA, cB, cC, bfin, w, 1, B, H, W, C, dx, 0, 1, xraw, tf_scale, tf_shift, act, stats, dw,
+                            dbias, copy_stride, stream);
 }
 
 extern "C" int hrf_dwconv_bwd_weight(const float* dy, const float* yraw, const float* cA, const float* cB,

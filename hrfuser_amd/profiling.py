@@ -61,6 +61,9 @@ def work_model(name, a):
         n_in, n_out = a['B'] * a['H'] * a['W'] * a['C'], a['B'] * Ho * Wo * a['C']
         return (f"dw_bwd_data_kernel<{a['stride']}>", 18.0 * n_in,
                 f4 * (n_out * (2 if a['cA'] is not None else 1) + n_in * (2 if a['epi'] else 1)))
+    if name == 'hrf_dwconv_bwd_data_weight':               # stride 1, epi 1: data + weight gradient in one pass
+        n = a['B'] * a['H'] * a['W'] * a['C']
+        return 'dw_bwd_data_kernel<1,wg>', 38.0 * n, f4 * (n * (2 if a['cA'] is not None else 1) + 2 * n)
     if name in ('hrf_window_attn_fwd', 'hrf_window_attn_bwd'):
         nwin = a['B'] * math.ceil(a['H'] / 7) * math.ceil(a['W'] / 7)
         D = a['C'] // a['heads']

@@ -30,6 +30,7 @@ from . import _lib
 # for the backward coefficients (hrf_bn_bfin_t): no hrf_bn_finalize / hrf_bn_bwd_finalize launches on the chain.
 # HRF_FIN_ONLOAD=0 restores the separate launches (A/B measurements; SyncBN always uses them: the moments are
 # exchanged between producer and finalize).
+_DW_FUSED_WG = os.environ.get('HRF_DW_FUSED_WG', '1') != '0'   # depthwise dW from the data-gradient pass
 _FIN_ONLOAD = os.environ.get('HRF_FIN_ONLOAD', '1') != '0'
 FIN_MAXC = _lib.FIN_MAXC
 LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
@@ -1015,16 +1016,25 @@ def dwconv_bn(ctx, src, conv, bn, mode):
         needs = isinstance(src, Lazy) or src.needs_grad
         (cA, cB, cC), bfin = bn_backward_coef(ctx, st, consumer_follows=needs, limit=1 << 30)
         # data gradient first: with `bfin` it publishes cA/cB/cC for the weight-gradient launch below
+        fused_wg = False
         if isinstance(src, Lazy):
             ps = src.st
             ps.du = _new_like(ps.raw)
-            L.hrf_dwconv_bwd_data(st.du, st.raw, cA, cB, cC, bfin, w, stride, B, H, W, C, ps.du, 0, 1, ps.raw,
-                                  ps.scale, ps.shift, _TF2ACT[src.mode], ps.gstats, s)
+            fused_wg = stride == 1 and w.requires_grad and _DW_FUSED_WG
+            if fused_wg:                          # weight / bias gradient from the same pass (no leaf launch)
+                eng = ctx.owner._engine()
+                wacc, cs = eng.grad_acc(w)
+                bacc = eng.grad_acc(b)[0] if b is not None else None
+                L.hrf_dwconv_bwd_data_weight(st.du, st.raw, cA, cB, cC, bfin, w, B, H, W, C, ps.du, ps.raw, ps.scale,
+                                             ps.shift, _TF2ACT[src.mode], ps.gstats, wacc, bacc, cs, s)
+            else:
+                L.hrf_dwconv_bwd_data(st.du, st.raw, cA, cB, cC, bfin, w, stride, B, H, W, C, ps.du, 0, 1, ps.raw,
+                                      ps.scale, ps.shift, _TF2ACT[src.mode], ps.gstats, s)
         elif src.needs_grad:
             g, acc = src.grad_target()
             L.hrf_dwconv_bwd_data(st.du, st.raw, cA, cB, cC, bfin, w, stride, B, H, W, C, g, acc, 0, None, None,
                                   None, 0, None, s)
-        if w.requires_grad:
+        if w.requires_grad and not fused_wg:
             du_ = st.du
             eng = ctx.owner._engine()
             wacc, cs = eng.grad_acc(w)

@@ -111,6 +111,14 @@ int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const float* cA, con
                         const float* cC, const hrf_bn_bfin_t* bfin, const float* w, int stride, int B, int H, int W, int C,
                         float* dx, int accumulate, int epi, const float* xraw, const float* tf_scale,
                         const float* tf_shift, int act, double* stats, void* stream);
+/* hrf_dwconv_bwd_data (stride 1, epi = 1: the input was act(tf_scale*xraw+tf_shift)) that ALSO accumulates the weight /
+ * bias gradient of the same convolution (what hrf_dwconv_bwd_weight computes from dy, yraw, x = act(.)): dW[ky][kx] =
+ * sum_p x[p]*dy'[p-(ky-1,kx-1)] uses the staged dy' element dx[p] needs anyway, and x[p] is a by-product of act'.
+ * dw / dbias (nullable bias): [HRF_STAT_COPIES] replicated fp32 accumulators, `copy_stride` apart (see above). */
+int hrf_dwconv_bwd_data_weight(const float* dy, const float* yraw, const float* cA, const float* cB,
+                               const float* cC, const hrf_bn_bfin_t* bfin, const float* w, int B, int H, int W, int C,
+                               float* dx, const float* xraw, const float* tf_scale, const float* tf_shift, int act,
+                               double* stats, float* dw, float* dbias, long copy_stride, void* stream);
 int hrf_dwconv_bwd_weight(const float* dy, const float* yraw, const float* cA, const float* cB,
                           const float* cC, const float* x, int B, int H, int W, int C, int stride,
                           int tf_mode, const float* tf_scale, const float* tf_shift, float* dw,

@@ -202,7 +202,7 @@ def run_conv(case, backend):
     assert r(dw, wq.grad) < TOL and r(db, bq.grad) < TOL
 
 
-DW_CASES = [(2, 9, 11, 72, 1, 3, True, True, True), (2, 17, 35, 40, 1, 0, False, False, False),
+DW_CASES = [(2, 9, 11, 72, 1, 3, True, True, True), (2, 17, 35, 40, 1, 0, False, False, False), (2, 19, 21, 18, 1, 3, False, True, True),
             (2, 10, 13, 18, 2, 0, False, True, False), (2, 11, 15, 36, 2, 2, False, True, True),
             (1, 16, 32, 33, 2, 1, False, False, True)]
 
@@ -277,6 +277,17 @@ def run_dw(case, backend):
     L.hrf_fold_copies(scr, n, amap, arena, n, _lib.stream_ptr())
     assert r(arena[5:5 + 9 * C] - 1, wq.grad.reshape(-1)) < TOL and r(arena[5 + 9 * C:] - 1, bq.grad) < TOL
     assert float(arena[:5].sum()) == 5.0
+    if epi and S == 1 and tf:
+        # data gradient + weight gradient of the same convolution in ONE pass (hrf_dwconv_bwd_data_weight)
+        dx2, gst2, scr2 = torch.zeros(B, H, W, C, device=dev), zstat(C, dev), torch.zeros(KC * n, device=dev)
+        L.hrf_dwconv_bwd_data_weight(D(du), D(yraw), *co, None, D(w), B, H, W, C, dx2, D(xr), D(sc), D(sh), act, gst2,
+                                     scr2, scr2[9 * C:] if has_bias else None, n, _lib.stream_ptr())
+        assert r(dx2, gu) < TOL and r(fold(gst2), fold(gst)) < 1e-6
+        arena2 = torch.zeros(n, device=dev)
+        L.hrf_fold_copies(scr2, n, torch.arange(n, dtype=torch.int32).to(dev), arena2, n, _lib.stream_ptr())
+        assert r(arena2[:9 * C], wq.grad.reshape(-1)) < TOL
+        if has_bias:
+            assert r(arena2[9 * C:], bq.grad) < TOL
 
 
 ATTN_CASES = [(2, 10, 13, 18, 1), (1, 7, 7, 36, 2), (2, 15, 8, 72, 4), (1, 9, 16, 78, 2), (1, 6, 10, 64, 8),
