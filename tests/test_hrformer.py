@@ -85,18 +85,33 @@ def _run(tag, B, H, W, train, backend, drop=False):
             for i, (a, b) in enumerate(zip(ya, yb)):
                 assert a.shape == b.shape and T.relmax(a, b) < 1e-3, (i, T.relmax(a, b))
             return
+        # forward gate against the UNPINNED fp64 oracle; gradient gate flip-free (the oracle runs take the product's ReLU
+        # decisions, helpers.PinnedReLU) with the per-tensor rule of SURVEY 8c, as in test_parity_wholenet._fwd_bwd
         o64 = copy.deepcopy(orc).double()
         xa = x.clone().to(dev).requires_grad_(True)
         xb = x.double().requires_grad_(True)
-        ya, yb = net(xa), o64(xb)
+        T.enable_relu_probe(net)
+        ya = net(xa)
+        with torch.no_grad():
+            yfree = o64(xb.detach())
+        for i, (a, b) in enumerate(zip(ya, yfree)):
+            assert T.relmax(a, b) < 1e-3, (i, T.relmax(a, b))
+        masks = T.relu_masks(net)
+        with T.PinnedReLU(masks) as pin64:
+            yb = o64(xb)
+        o32 = copy.deepcopy(orc)
+        xc = x.clone().requires_grad_(True)
+        with T.PinnedReLU(masks):
+            yc = o32(xc)
         g = torch.Generator().manual_seed(5)
         cots = [torch.randn(t.shape, generator=g) for t in yb]
         sum((t * c.to(dev)).sum() for t, c in zip(ya, cots)).backward()
         sum((t * c.double()).sum() for t, c in zip(yb, cots)).backward()
-        for i, (a, b) in enumerate(zip(ya, yb)):
-            assert T.relmax(a, b) < 1e-3, (i, T.relmax(a, b))
-        assert T.grad_close(xa.grad, xb.grad, tol=2e-3)
-        T.grad_check(net.named_parameters(), o64.named_parameters(), tol=3e-3)
+        sum((t * c).sum() for t, c in zip(yc, cots)).backward()
+        print(f'[{tag} {B}x{H}x{W}] {pin64.sites} ReLU sites pinned, {pin64.flips} element(s) decided differently by fp64')
+        e, e_ref = T.rel_l2(xa.grad, xb.grad), T.rel_l2(xc.grad, xb.grad)
+        assert e <= max(1e-3, 3 * e_ref), (e, e_ref)
+        T.tight_grad_gate(net.named_parameters(), o64.named_parameters(), o32.named_parameters(), 1e-3, f'{tag} train')
     finally:
         T.use_backend('hip')
 
@@ -139,11 +154,14 @@ def test_hrformer_droppath_gpu(monkeypatch):
     x, _ = O.seeded_inputs(2, 64, 96, [3], seed=1)
     xa = x.clone().to(dev).requires_grad_(True)
     xb = x.clone().requires_grad_(True)
-    ya, yb = net(xa), orc(xb)
+    T.enable_relu_probe(net)
+    ya = net(xa)
+    with T.PinnedReLU(T.relu_masks(net)):                  # flip-free: the oracle takes the product's ReLU decisions
+        yb = orc(xb)
     for i, (a, b) in enumerate(zip(ya, yb)):
         assert T.relmax(a, b) < 1e-3, (i, T.relmax(a, b))
     g = torch.Generator().manual_seed(5)
     cots = [torch.randn(t.shape, generator=g) for t in yb]
     sum((t * c.to(dev)).sum() for t, c in zip(ya, cots)).backward()
     sum((t * c).sum() for t, c in zip(yb, cots)).backward()
-    assert T.grad_close(xa.grad, xb.grad, tol=5e-3)
+    assert T.rel_l2(xa.grad, xb.grad) < 2e-3, T.rel_l2(xa.grad, xb.grad)
