@@ -303,7 +303,7 @@ def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None):
         if t is not None:
             row['traffic'] = t['bytes_per_launch']
             row['traffic_source'] = (f'profiles/r02_hbm_traffic.json[{top["shape"]}]: 2 x FETCH_SIZE + WRITE_SIZE of that launch from a '
-                                     'separate rocprofv3 --pmc run (tools/prof_traffic.sh); NOT measured in this bench run')
+                                     'separate rocprofv3 --pmc run (tools/prof_r02.sh); NOT measured in this bench run')
     # the next families, for context
     others = sorted(table.items(), key=lambda kv: -kv[1][1])[1:6]
     row['next_families'] = [{k2: _row(k, t, peak_f, peak_b)[k2] for k2 in ('kernel', 'bound', 'frac', 'launches_per_step', 'time_per_step_ms')}
