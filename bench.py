@@ -307,7 +307,8 @@ def main():
                                    + ('SyncBN+RCCL all-reduce' if world > 1 else 'BN, single GPU'),
                        'global_batch': B * world, 'parallelism': f'dp{world}',
                        'launch': 'hipGraph replay' if use_graph else 'eager',
-                       'collectives_per_step': trainer.collectives_per_step},
+                       'collectives_per_step': trainer.collectives_per_step,
+                       'exchange_lanes_hist': {f'{k[0]}{"m" if k[1] else ""}': v for k, v in sorted(getattr(trainer, 'exchange_hist', {}).items())}},
             'step_ms': step_ms, 'finite': finite, 'fwd_ms_per_img': fwd_ms, 'eager_autograd': eager,
             'roofline': roof, 'step_roofline': step_roof, 'cpu_baseline': cpu, 'neck': neck, 'extract_feat': feat,
         }
@@ -324,7 +325,8 @@ def main():
             pass
         # RCCL/HIP teardown of a process that holds captured graphs with collectives can abort at
         # interpreter exit on ROCm 7.0; the result line is already out, so leave without destructors.
-        os._exit(0)
+        if os.environ.get('HRF_BENCH_SOFT_EXIT', '0') != '1':     # (profilers need the normal exit path to flush)
+            os._exit(0)
 
 
 if __name__ == '__main__':

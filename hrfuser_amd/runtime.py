@@ -32,6 +32,7 @@ from . import _lib
 # exchanged between producer and finalize).
 _DW_FUSED_WG = os.environ.get('HRF_DW_FUSED_WG', '1') != '0'   # depthwise dW from the data-gradient pass
 _FIN_ONLOAD = os.environ.get('HRF_FIN_ONLOAD', '1') != '0'
+_XHUB = os.environ.get('HRF_XHUB', '1') != '0'      # SyncBN exchange on a participating lane instead of always the main lane
 FIN_MAXC = _lib.FIN_MAXC
 LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
 _MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
@@ -177,6 +178,7 @@ class Ctx:
         # test instrumentation (tests/helpers.py: ReLU-mask pinning): a list that receives every ReLU site of the forward
         self.probe = [] if owner.__dict__.get('_relu_probe') else None
         self.n_collectives = 0
+        self.xhist = {}                 # (lanes in an exchange, hub is the main lane) -> count
         # SyncBN: exchanges of mutually independent BatchNorms are BATCHED (one collective for all of them): sibling lanes
         # run as coroutines in lock-step (parallel()), each parking at its next exchange until the sweep is complete
         self.coll = self.group is not None and (self.world > 1 or force_collectives())
@@ -247,12 +249,19 @@ class Ctx:
             self.flush_sync()
 
     def _exchange(self, sts, lanes, pack_ptrs, finalize):
-        """One packed collective for the BatchNorms `sts`, issued on the main lane between the lanes involved."""
-        lanes = [l for l in dict.fromkeys(lanes) if l is not self.main and l.stream is not None]
+        """One packed collective for the BatchNorms `sts`, issued on the main lane between the lanes involved; a batch that
+        lives on ONE lane is issued on that lane (no cross-stream edge: each costs ~10 us inside the captured graph).
+        Sibling-to-sibling waits (a non-main hub for several lanes) crash hipStreamEndCapture on ROCm 7.x like nested
+        forks do, so multi-lane batches keep the main lane as their hub."""
+        lanes = [l for l in dict.fromkeys(lanes) if l.stream is not None or l is self.main]
+        hub = self.main
+        if _XHUB and self.multi and len(lanes) == 1:
+            hub = lanes[0]
+        others = [l for l in lanes if l is not hub and l.stream is not None]
         if self.multi:
-            for l in lanes:
-                self.main.stream.wait_stream(l.stream)
-        with _LaneScope(self, self.main):
+            for l in others:
+                hub.stream.wait_stream(l.stream)
+        with _LaneScope(self, hub):
             n = len(sts)
             total = sum(2 * st.C for st in sts)
             packed = _keep(torch.empty(total, device=sts[0].raw.device, dtype=torch.float64))
@@ -261,8 +270,9 @@ class Ctx:
             self.L.hrf_bn_pack(ptrs, cs, n, packed, self.stream)
             finalize(packed)
         if self.multi:
-            for l in lanes:
-                l.stream.wait_stream(self.main.stream)
+            for l in others:
+                l.stream.wait_stream(hub.stream)
+        self.xhist[(len(lanes), hub is self.main)] = self.xhist.get((len(lanes), hub is self.main), 0) + 1
 
     def flush_sync(self):
         """ONE collective for the forward moments of every parked BatchNorm; their consumers then finalise on load
@@ -416,7 +426,8 @@ class Ctx:
                 return
             todo = [e[2] for e in parked if not e[2].bx_done]
             if todo:
-                self.flush_bwd(todo, list(active))
+                # only the lanes of the parked entries take part (an entry's inputs are ordered before it on ITS lane)
+                self.flush_bwd(todo, [e[1] for e in parked if not e[2].bx_done] if _XHUB else list(active))
             for fn, lane, _ in parked:
                 with _LaneScope(self, lane):
                     fn()

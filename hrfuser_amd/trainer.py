@@ -96,6 +96,7 @@ class Trainer:
                 dist.all_reduce(eng.flat_g[a:b], group=self.group)
                 ncoll += 1
         self.collectives_per_step = ncoll
+        self.exchange_hist = dict(ctx.xhist)
         self.optimizer_step()
         return outs
 

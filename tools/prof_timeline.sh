@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/timeline
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-roofline --no-neck --no-eager > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-roofline --no-neck --no-eager $BENCH_EXTRA > $OUT/bench.log 2>&1
 echo trace rc=$?
 cd $GRAFT_REPO_ROOT
 F=$(find $OUT/trace -name '*kernel_trace.csv' | head -1)
