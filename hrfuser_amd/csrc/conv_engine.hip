@@ -568,14 +568,22 @@ constexpr int WNW = 8;     // waves per block (512 threads)
 // TAP: 3x3 convolution (pad 1): the N index is n' = ci*9 + tap (the OIHW memory order, so the block's
 // output atomics stay coalesced); every lane owns its own (ci, tap) and gathers the X operand from
 // the correspondingly shifted input pixel (exact zero outside the image).
-template <int MT, int NT, bool BNB, int ACT, bool TAP>
+// TAPM 2 ("tap-blocked", NT = 9): tile j of the wave IS tap j and its 16 lanes are 16 CONSECUTIVE input channels of the
+// shifted pixel - a 64-byte run per pixel instead of 16 scattered dwords (the n' = ci*9+tap order makes every lane of a
+// fragment load its own (ci, tap): 64 cache-line lookups per wave instruction, which is what the 3x3 problems spent
+// their time on), every dY fragment is reused by the 9 taps, and a block's output is 144 CONTIGUOUS floats per output
+// channel (16 ci x 9 taps in OIHW order), written by a transposing final pass.
+template <int MT, int NT, bool BNB, int ACT, int TAPM>
 __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_args) {
+  constexpr bool TAP = TAPM != 0, TAPB = TAPM == 2;
+  static_assert(!TAPB || NT == 9, "tap-blocked: one tile per tap");
   int prob = 0;
   while (prob + 1 < grp_args.nprob && (int)blockIdx.x >= grp_args.bstart[prob + 1]) ++prob;   // (wave-uniform, <= 15 steps)
   const WgradDenseArgs& a = grp_args.p[prob];
   const int bid = (int)blockIdx.x - grp_args.bstart[prob];
-  constexpr int WU = MT * NT > 16 ? WUMAX / 2 : WUMAX;       // keep the 5x5-tile variants inside 256 VGPRs
-  __shared__ __attribute__((aligned(16))) float sAcc[2 * MT * NT * 256];   // two merge regions, fragment order
+  constexpr int WU = MT * NT > 25 ? 2 : (MT * NT > 16 ? WUMAX / 2 : WUMAX);   // keep the many-tile variants inside 256 VGPRs
+  constexpr int NREG = MT * NT > 25 ? 1 : 2;                 // merge regions in LDS (one: 7 rounds instead of 3)
+  __shared__ __attribute__((aligned(16))) float sAcc[NREG * MT * NT * 256];   // merge region(s), fragment order
   __shared__ float sBias[WNW * MT * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
   const int grp = slot % G, bz = (slot / G) * 8 + xcd;
   if (bz >= a.sp) return;                                   // padding blocks (sp rounded up to 8)
   const int bx = grp % a.gx, by = grp / a.gx;
-  const int m0 = bx * (16 * MT), n0 = by * (16 * NT);
+  const int m0 = bx * (16 * MT), n0 = TAPB ? by * 16 : by * (16 * NT);     // TAPB: n0 = first input channel of the block
   const int Np = TAP ? a.Cin * 9 : a.Cin;
   const int pbeg = bz * a.chunk, pend = min(a.Mpix, pbeg + a.chunk);
   const bool ln = a.tf_rowstat != nullptr;
@@ -607,11 +615,12 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
   }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int np = n0 + 16 * j + c;
-    bval[j] = np < Np;
+    const int np = TAPB ? n0 + c : n0 + 16 * j + c;
+    bval[j] = TAPB ? np < a.Cin : np < Np;
     int ci = bval[j] ? np : 0;
     tdy[j] = 0; tdx[j] = 0;
-    if (TAP) { const int tp = ci % 9; ci /= 9; tdy[j] = tp / 3 - 1; tdx[j] = tp - (tp / 3) * 3 - 1; }
+    if (TAPB) { tdy[j] = j / 3 - 1; tdx[j] = j - (j / 3) * 3 - 1; }
+    else if (TAP) { const int tp = ci % 9; ci /= 9; tdy[j] = tp / 3 - 1; tdx[j] = tp - (tp / 3) * 3 - 1; }
     boff[j] = TAP ? (tdy[j] * a.W + tdx[j]) * a.ldX + ci : ci;     // TAP: + offset of the shifted input pixel
     sc[j] = 1.f; sh[j] = 0.f;
     if (a.tf_scale != nullptr) { sc[j] = a.tf_scale[ci]; sh[j] = a.tf_shift[ci]; }
@@ -696,8 +705,9 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
   // of its words BEFORE it stores any: a ld/add/st per element is a chain of dependent LDS round trips (the compiler
   // must assume that a store aliases the next load) - that chain, not the reduction, was the duration of this kernel
   // (~20 us for every problem size; tools/bench_wgrad.py).
-  hrf_f4* S = reinterpret_cast<hrf_f4*>(sAcc) + (wave >> 2) * (MT * NT * 64);
-  if ((wave & 3) == 0) {
+  constexpr int WPR = WNW / NREG;                            // waves per merge region
+  hrf_f4* S = reinterpret_cast<hrf_f4*>(sAcc) + (wave / WPR) * (MT * NT * 64);
+  if (wave % WPR == 0) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -705,8 +715,8 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
   }
   __syncthreads();
 #pragma unroll 1
-  for (int round = 1; round < 4; ++round) {
-    if ((wave & 3) == round) {
+  for (int round = 1; round < WPR; ++round) {
+    if (wave % WPR == round) {
       hrf_f4 old[MT][NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -730,17 +740,29 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
     bsm += __shfl_xor(bsm, 16); bsm += __shfl_xor(bsm, 32);
     if (lane < 16) sBias[wave * (MT * 16) + 16 * i + lane] = bsm;
   }
-  {
+  if (TAPB) {
+    // transposing pass: per output channel the block owns 144 contiguous floats (16 ci x 9 taps, OIHW)
+    for (int e = tid; e < MT * 16 * 144; e += 64 * WNW) {
+      const int row = e / 144, o = e - row * 144;
+      const int cil = o / 9, tap = o - cil * 9;
+      const int ti = row >> 4, rr = row & 15;
+      const int w = ((ti * NT + tap) * 64 + (rr >> 2) * 16 + cil) * 4 + (rr & 3);
+      float v = sAcc[w];
+      if (NREG == 2) v += sAcc[MT * NT * 256 + w];
+      if (m0 + row < a.Cout && n0 + cil < a.Cin) hrf_atomic_add(&a.dw[(long)(m0 + row) * Np + (n0 + cil) * 9 + tap], v);
+    }
+  } else {
     const hrf_f4* S0 = reinterpret_cast<const hrf_f4*>(sAcc);
     for (int e = tid; e < MT * NT * 64; e += 64 * WNW) {
       const int tile = e >> 6, l = e & 63;
       const int ti = tile / NT, tj = tile - ti * NT;
-      const hrf_f4 v0 = S0[e], v1 = S0[MT * NT * 64 + e];
+      hrf_f4 v0 = S0[e];
+      if (NREG == 2) { const hrf_f4 v1 = S0[MT * NT * 64 + e]; v0[0] += v1[0]; v0[1] += v1[1]; v0[2] += v1[2]; v0[3] += v1[3]; }
       const int col = n0 + 16 * tj + (l & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + 16 * ti + 4 * (l >> 4) + r;
-        if (row < a.Cout && col < Np) hrf_atomic_add(&a.dw[(long)row * Np + col], v0[r] + v1[r]);
+        if (row < a.Cout && col < Np) hrf_atomic_add(&a.dw[(long)row * Np + col], v0[r]);
       }
     }
   }
@@ -972,11 +994,16 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
       }
       return best;
     };
-    const int mt = pick_tiles(Cout, !tap3), nt = pick_tiles(tap3 ? Cin * 9 : Cin, !tap3);
-    d.gyc = hrf_cdiv(tap3 ? Cin * 9 : Cin, 16 * nt);
+    // 3x3 with >= 8 input channels: tap-blocked variant (one tile per tap, 16 consecutive input channels per block)
+    const bool tapb = tap3 && Cin >= 64 && g_knob[1] != 2;      // (debug knob 1 = 2: the ci*9+tap variant)
+    const int mt = tapb ? (Cout <= 32 ? 2 : (Cout <= 48 ? 3 : 4)) : pick_tiles(Cout, !tap3);
+    const int nt = tapb ? 9 : pick_tiles(tap3 ? Cin * 9 : Cin, !tap3);
+    d.gyc = tapb ? hrf_cdiv(Cin, 16) : hrf_cdiv(tap3 ? Cin * 9 : Cin, 16 * nt);
     int sp = hrf_cdiv(a.Mpix, 4 * WNW * WUMAX);
     // atomic fan-in per output element (128 x 25 ns = 3 us tail); the 3x3 path already has 9x the blocks
-    const int cap2 = g_knob[3] > 0 ? g_knob[3] : (tap3 ? 32 : 128);
+    const int gxy0 = hrf_cdiv(Cout, 16 * mt) * d.gyc;
+    const int cap_tapb = gxy0 >= 64 ? 8 : (512 / gxy0 > 128 ? 128 : 512 / gxy0);       // ~512 blocks
+    const int cap2 = g_knob[3] > 0 ? g_knob[3] : (tapb ? cap_tapb : (tap3 ? 32 : 128));
     if (sp > cap2) sp = cap2;
     if (sp < 1) sp = 1;
     const int gxy = hrf_cdiv(Cout, 16 * mt) * d.gyc;
@@ -990,7 +1017,7 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     d.gx = hrf_cdiv(Cout, 16 * mt); d.gy = d.gyc; d.sp = sp;
     const int nblocks = d.gx * d.gy * hrf_cdiv(sp, 8) * 8;
     const int act = tf_mode == HRF_TF_AFFINE_RELU ? 1 : (tf_mode == HRF_TF_AFFINE_GELU ? 2 : 0);
-    const int key = ((((mt * 8 + nt) * 2 + (cA != nullptr ? 1 : 0)) * 4 + act) * 2) + (tap3 ? 1 : 0);
+    const int key = ((((mt * 8 + (tapb ? 7 : nt)) * 2 + (cA != nullptr ? 1 : 0)) * 4 + act) * 2) + (tap3 ? 1 : 0);   // nt code 7 = tap-blocked (NT 9)
     if (g_wg_collect) {                                      // queued: launched by hrf_wgrad_group_end
       g_wg_pending.push_back(WgPending{key, nblocks, d});
       return HRF_OK;
@@ -1025,16 +1052,20 @@ static int wgrad_dense_launch(int key, const WgradGroup& d, int total_blocks, vo
     if (bnb) { HRF_WD_ACT(MT_, NT_, true, TAP_) } else { HRF_WD_ACT(MT_, NT_, false, TAP_) }
 #define HRF_WD_NT(MT_)                                    \
     switch (nt) {                                         \
-      case 2: HRF_WD_BNB(MT_, 2, false) break;            \
-      case 3: HRF_WD_BNB(MT_, 3, false) break;            \
-      case 4: HRF_WD_BNB(MT_, 4, false) break;            \
-      default: HRF_WD_BNB(MT_, 5, false) break;           \
+      case 2: HRF_WD_BNB(MT_, 2, 0) break;                \
+      case 3: HRF_WD_BNB(MT_, 3, 0) break;                \
+      case 4: HRF_WD_BNB(MT_, 4, 0) break;                \
+      default: HRF_WD_BNB(MT_, 5, 0) break;               \
     }
-    if (tap3) {
-      if (mt == 2 && nt == 2) { HRF_WD_BNB(2, 2, true) }
-      else if (mt == 2) { HRF_WD_BNB(2, 4, true) }
-      else if (nt == 2) { HRF_WD_BNB(4, 2, true) }
-      else { HRF_WD_BNB(4, 4, true) }
+    if (tap3 && nt == 7) {
+      if (mt == 2) { HRF_WD_BNB(2, 9, 2) }
+      else if (mt == 3) { HRF_WD_BNB(3, 9, 2) }
+      else { HRF_WD_BNB(4, 9, 2) }
+    } else if (tap3) {
+      if (mt == 2 && nt == 2) { HRF_WD_BNB(2, 2, 1) }
+      else if (mt == 2) { HRF_WD_BNB(2, 4, 1) }
+      else if (nt == 2) { HRF_WD_BNB(4, 2, 1) }
+      else { HRF_WD_BNB(4, 4, 1) }
     } else {
       switch (mt) {
         case 2: HRF_WD_NT(2) break;
