@@ -203,12 +203,23 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
     const int xi = x0 + q;
     const bool ok = cv && yi < a.H && xi < a.W;
     float acc = 0.f;
+    // WG: x[p] = act(u) and act'(u) from ONE evaluation; every staged dy' element is read once for both products
+    float xv = 0.f, gv = 1.f;
+    if (WG) {
+      hrf_act_both(a.act, fmaf(pre[q], sc, sh), xv, gv);
+      xv = ok ? xv : 0.f;
+    }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         if (S == 1) {
-          acc = fmaf(sD[((r + 2 - dy) * RW + (q + 2 - dx)) * CB + c], wr[dy * 3 + dx], acc);
+          const float d = sD[((r + 2 - dy) * RW + (q + 2 - dx)) * CB + c];
+          acc = fmaf(d, wr[dy * 3 + dx], acc);
+          if (WG) {
+            wacc[dy * 3 + dx] = fmaf(d, xv, wacc[dy * 3 + dx]);
+            if (dy == 1 && dx == 1) wacc[9] += ok ? d : 0.f;
+          }
         } else {
           const int ty2 = r + 1 - dy, tx2 = q + 1 - dx;   // relative to (y0, x0), both even
           if (ty2 >= 0 && tx2 >= 0 && ((ty2 | tx2) & 1) == 0)
@@ -218,17 +229,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
     const long o = (((long)b * a.H + yi) * a.W + xi) * a.C + cg;
     if (a.epi == 1) {
       const float xr = pre[q];
-      const float u = fmaf(xr, sc, sh);
-      if (WG) {
-        const float xv = ok ? hrf_act(a.act, u) : 0.f;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx)
-            wacc[dy * 3 + dx] = fmaf(sD[((r + 2 - dy) * RW + (q + 2 - dx)) * CB + c], xv, wacc[dy * 3 + dx]);
-        wacc[9] += ok ? sD[((r + 1) * RW + (q + 1)) * CB + c] : 0.f;
-      }
-      acc *= hrf_act_grad(a.act, u);
+      acc *= WG ? gv : hrf_act_grad(a.act, fmaf(xr, sc, sh));
       if (ok) { s1 += acc; s2 = fmaf(acc, xr, s2); a.dx[o] = acc; }
     } else {
       if (ok) a.dx[o] = pre[q] + acc;

@@ -70,6 +70,21 @@ __device__ __forceinline__ float hrf_act(int act, float u) {
 __device__ __forceinline__ float hrf_act_grad(int act, float u) {
   return act == HRF_ACT_RELU ? (u > 0.f ? 1.f : 0.f) : (act == HRF_ACT_GELU ? hrf_gelu_grad(u) : 1.f);
 }
+// act(u) and act'(u) from one evaluation (the erf / exp of GELU are shared)
+__device__ __forceinline__ void hrf_act_both(int act, float u, float& val, float& grad) {
+  if (act == HRF_ACT_GELU) {
+    const float cdf = 0.5f * (1.0f + hrf_erf(u * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+    val = u * cdf;
+    grad = cdf + u * pdf;
+  } else if (act == HRF_ACT_RELU) {
+    val = fmaxf(u, 0.f);
+    grad = u > 0.f ? 1.f : 0.f;
+  } else {
+    val = u;
+    grad = 1.f;
+  }
+}
 // apply an AFFINE* transform (mode 1..3)
 __device__ __forceinline__ float hrf_tf_affine(int mode, float v, float sc, float sh) {
   float u = fmaf(v, sc, sh);

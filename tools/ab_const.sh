@@ -1,0 +1,12 @@
+# A/B of a compile-time constant on ONE box: ab_const.sh <file> <sed-pattern-with-@V@> <values...>; rebuilds in place
+cd $GRAFT_REPO_ROOT
+F=$1; PAT=$2; shift 2
+cp $F /tmp/ab_orig
+for rep in 1 2; do for v in "$@"; do
+  cp /tmp/ab_orig $F
+  sed -i "$(echo "$PAT" | sed "s/@V@/$v/g")" $F
+  python -c "from hrfuser_amd import build_ext; build_ext.build()" > /dev/null 2>&1
+  echo -n "value $v : "
+  python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-neck --no-eager --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['step_ms']['median'])"
+done; done
+cp /tmp/ab_orig $F

@@ -57,3 +57,10 @@ s18, t18, o18 = R(18), R(18), R(B, H, W, 18)
 t('affine_act_res 18 (tail)',
   lambda: L.hrf_affine_act_res(y18, s18, t18, None, None, None, dy18, None, 0, 0, 0, o18, P, 18, None, 0.0, None, None, sp()),
   lambda: L.hrf_affine_act_res(y18, s18, t18, None, None, None, dy18, None, 0, 0, 0, o18, P, 18, None, 0.0, fin18, None, sp()))
+scr = torch.zeros(8 * 720, device=dev)
+t('dw_bwd_data 72: plain vs +weight gradient',
+  lambda: L.hrf_dwconv_bwd_data(dy72, y72, *c72, None, wd, 1, B, H, W, 72, dx72, 0, 1, x72, s72, t72, 2, st72, sp()),
+  lambda: L.hrf_dwconv_bwd_data_weight(dy72, y72, *c72, None, wd, B, H, W, 72, dx72, x72, s72, t72, 2, st72, scr, scr[648:], 720, sp()))
+t('dw_bwd_data 72: plain vs +weight gradient, no stats',
+  lambda: L.hrf_dwconv_bwd_data(dy72, y72, *c72, None, wd, 1, B, H, W, 72, dx72, 0, 1, x72, s72, t72, 2, None, sp()),
+  lambda: L.hrf_dwconv_bwd_data_weight(dy72, y72, *c72, None, wd, B, H, W, 72, dx72, x72, s72, t72, 2, None, scr, scr[648:], 720, sp()))
