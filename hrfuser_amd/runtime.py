@@ -32,7 +32,10 @@ from . import _lib
 # exchanged between producer and finalize).
 _DW_FUSED_WG = os.environ.get('HRF_DW_FUSED_WG', '1') != '0'   # depthwise dW from the data-gradient pass
 _FIN_ONLOAD = os.environ.get('HRF_FIN_ONLOAD', '1') != '0'
-_XHUB = os.environ.get('HRF_XHUB', '1') != '0'      # SyncBN exchange on a participating lane instead of always the main lane
+# SyncBN exchange of a one-lane batch on that lane instead of the main lane (no cross-stream edge).  OFF by default: collectives
+# of one communicator must execute in the same order on every rank, and two lanes' collectives are unordered on the GPU -
+# only the main lane serialises them.  (Safe, and ~3 % faster, in the forced one-rank measurement mode.)
+_XHUB = os.environ.get('HRF_XHUB', '0') != '0'
 FIN_MAXC = _lib.FIN_MAXC
 LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
 _MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
@@ -249,10 +252,11 @@ class Ctx:
             self.flush_sync()
 
     def _exchange(self, sts, lanes, pack_ptrs, finalize):
-        """One packed collective for the BatchNorms `sts`, issued on the main lane between the lanes involved; a batch that
-        lives on ONE lane is issued on that lane (no cross-stream edge: each costs ~10 us inside the captured graph).
+        """One packed collective for the BatchNorms `sts`, issued on the main lane between the lanes involved (every
+        cross-stream edge costs ~10 us inside the captured graph, but the main lane is what keeps the collectives of the
+        communicator in ONE order on every rank).  HRF_XHUB=1: a batch that lives on one lane is issued on that lane.
         Sibling-to-sibling waits (a non-main hub for several lanes) crash hipStreamEndCapture on ROCm 7.x like nested
-        forks do, so multi-lane batches keep the main lane as their hub."""
+        forks do."""
         lanes = [l for l in dict.fromkeys(lanes) if l.stream is not None or l is self.main]
         hub = self.main
         if _XHUB and self.multi and len(lanes) == 1:
@@ -427,7 +431,7 @@ class Ctx:
             todo = [e[2] for e in parked if not e[2].bx_done]
             if todo:
                 # only the lanes of the parked entries take part (an entry's inputs are ordered before it on ITS lane)
-                self.flush_bwd(todo, [e[1] for e in parked if not e[2].bx_done] if _XHUB else list(active))
+                self.flush_bwd(todo, [e[1] for e in parked if not e[2].bx_done])
             for fn, lane, _ in parked:
                 with _LaneScope(self, lane):
                     fn()

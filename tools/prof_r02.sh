@@ -42,7 +42,7 @@ for cn,d in res.items():
 # fabric traffic per launch: FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE reports half of the bytes of wide
 # coalesced reads (MI355X_MICROARCH.md, HBM section: 128-B requests tallied at 64 B), hence 2 x FETCH + WRITE
 F, Wr = res.get('FETCH_SIZE', {}), res.get('WRITE_SIZE', {})
-SHAPES = {'wgrad_dense_kernel<2, 5, true, 2, false>': ('conv_bwd_weight[B=2,H=96,W=160,Cin=72,Cout=18,KH=1,stride=1,tf_mode=3,bnb=1]', 13276224)}
+SHAPES = {'wgrad_dense_kernel<2, 5, true, 2, 0>': ('conv_bwd_weight[B=2,H=96,W=160,Cin=72,Cout=18,KH=1,stride=1,tf_mode=3,bnb=1]', 13276224)}
 traffic = {'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over tools/pmc_kernels.py (each hot kernel '
                      'launched eagerly on its branch-0 shape, 2x96x160); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch',
            'kernels': {}, 'shapes': {}}
