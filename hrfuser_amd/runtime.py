@@ -333,6 +333,8 @@ class Ctx:
             # no streams (CPU emulator runs): LOGICAL lanes, so that the SyncBN batching sees which tape entries are
             # independent of each other
             uniq = [Lane(None) for _ in range(n)]
+            for l in uniq:
+                l.ptr = self.cur.ptr        # (HRF_LANES=0 on a GPU: logical lanes launch on the parent's stream)
             if self.record:
                 self.tape.append(('F', self.cur, uniq))
             return uniq
