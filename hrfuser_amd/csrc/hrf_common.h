@@ -194,10 +194,10 @@ __device__ __forceinline__ void hrf_bn_bfin_onload(const hrf_bn_bfin_t& f, float
     if (writer && f.write) {
       f.cA[c] = a; f.cB[c] = b2; f.cC[c] = c2;
       // parameter gradients from the rank-LOCAL moments (data-parallel gradients are summed afterwards)
-      double ldu = sdu, ldux = sdux;
-      if (f.gstats_local != nullptr) { ldu = f.gstats_local[c]; ldux = f.gstats_local[C + c]; }
-      if (f.dgamma) f.dgamma[c] += (float)((ldux - mu * ldu) * is);
-      if (f.dbeta) f.dbeta[c] += (float)ldu;
+      double ldu = sdu, ldux = sdux, ps = f.pgrad_scale != 0.f ? (double)f.pgrad_scale : 1.0;
+      if (f.gstats_local != nullptr) { ldu = f.gstats_local[c]; ldux = f.gstats_local[C + c]; ps = 1.0; }
+      if (f.dgamma) f.dgamma[c] += (float)(ps * (ldux - mu * ldu) * is);
+      if (f.dbeta) f.dbeta[c] += (float)(ps * ldu);
     }
   }
 }

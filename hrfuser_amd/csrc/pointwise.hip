@@ -87,14 +87,15 @@ struct BnBFinPackArgs { hrf_bn_bfin_t f[PK_MAX]; int off[PK_MAX]; };
 __global__ __launch_bounds__(256) void bn_bwd_finalize_packed_kernel(BnBFinPackArgs a, const double* packed, const double* packed_local) {
   const hrf_bn_bfin_t& f = a.f[blockIdx.y];
   const double* gs = packed + a.off[blockIdx.y];
-  const double* ls = packed_local + a.off[blockIdx.y];
+  const double* ls = packed_local != nullptr ? packed_local + a.off[blockIdx.y] : gs;
+  // parameter grads from the rank-LOCAL moments (data-parallel grads are summed afterwards) or, without a local copy,
+  // pgrad_scale (= 1/world) of the global value; dy coefficients from the all-reduced sums
+  const double ps = packed_local != nullptr ? 1.0 : (f.pgrad_scale != 0.f ? (double)f.pgrad_scale : 1.0);
   for (int c = blockIdx.x * 256 + threadIdx.x; c < f.C; c += gridDim.x * 256) {
     const double sdu = gs[c], sdux = gs[f.C + c], ldu = ls[c], ldux = ls[f.C + c];
     const double mu = f.mean[c], is = f.invstd[c], g = f.gamma ? f.gamma[c] : 1.f;
-    // parameter grads from the rank-LOCAL moments (data-parallel grads are averaged afterwards), dy coefficients from the
-    // all-reduced ones
-    if (f.dgamma) f.dgamma[c] += (float)((ldux - mu * ldu) * is);
-    if (f.dbeta) f.dbeta[c] += (float)ldu;
+    if (f.dgamma) f.dgamma[c] += (float)(ps * (ldux - mu * ldu) * is);
+    if (f.dbeta) f.dbeta[c] += (float)(ps * ldu);
     float a, b2, c2;
     hrf_bn_bwd_solve(sdu, sdux, mu, is, g, 1.0 / f.count, f.train, a, b2, c2);
     f.cA[c] = a; f.cB[c] = b2; f.cC[c] = c2;

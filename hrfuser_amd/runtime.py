@@ -307,9 +307,10 @@ class Ctx:
         box = []
 
         def fin(packed):
-            local = _keep(packed.clone())
+            # no rank-local copy: dgamma / dbeta come from the all-reduced sums, scaled by 1/world (hrf_bn_bfin_t.pgrad_scale);
+            # the gradient all-reduce that follows restores the sum over ranks
             self.all_reduce(packed)
-            box.append((packed, local))
+            box.append((packed, None))
         self._exchange(sts, lanes, [P(st.gstats) for st in sts], fin)
         off = 0
         for st in sts:
@@ -675,11 +676,12 @@ def bn_backward_coef(ctx, st, consumer_follows=True, limit=FIN_MAXC):
     if coll and st.bx_done:                             # exchanged by run_backward's batch (Ctx.flush_bwd): packed sums
         packed, local, off = st.bpacked
         P = _lib._ptr
+        lptr = local.data_ptr() + 8 * off if local is not None else None
         bf = _lib.BnBFin(packed.data_ptr() + 8 * off, P(st.bn.weight), P(st.mean), P(st.invstd), P(wg), P(bg), P(cA), P(cB),
-                         P(cC), st.count, 1, 1, st.C, 1, local.data_ptr() + 8 * off)
+                         P(cC), st.count, 1, 1, st.C, 1, lptr, 1.0 / max(1, ctx.world))
         if _FIN_ONLOAD and consumer_follows and st.C <= limit:
             return st.coef, bf
-        ctx.L.hrf_bn_bwd_finalize_packed(bf, 1, packed.data_ptr() + 8 * off, local.data_ptr() + 8 * off, ctx.stream)
+        ctx.L.hrf_bn_bwd_finalize_packed(bf, 1, packed.data_ptr() + 8 * off, lptr, ctx.stream)
         return st.coef, None
     if _FIN_ONLOAD and consumer_follows and not coll and st.C <= limit:
         P = _lib._ptr

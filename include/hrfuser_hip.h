@@ -61,6 +61,9 @@ typedef struct hrf_bn_bfin {
   double count; int train; int write; int C;
   int copies;                    /* as in hrf_bn_fin_t */
   const double* gstats_local;    /* SyncBN: this rank's folded moments (parameter gradients); NULL = gstats */
+  float pgrad_scale;             /* gstats_local == NULL: dgamma / dbeta += pgrad_scale * (value from gstats); 0 means 1.
+                                    SyncBN without a rank-local copy: the all-reduced sums give the GLOBAL dgamma / dbeta,
+                                    every rank adds 1/world of it and the gradient all-reduce restores the sum */
 } hrf_bn_bfin_t;
 
 #ifdef __cplusplus
@@ -217,7 +220,7 @@ int hrf_bn_bwd_finalize(const double* gstats, const double* gstats_local, const 
  * rank-local moments).  stats / C / fins / bfins are HOST arrays of n entries.                                          */
 int hrf_bn_pack(const double* const* stats, const int* C, int n, double* packed, void* stream);
 int hrf_bn_finalize_packed(const hrf_bn_fin_t* fins, int n, const double* packed, void* stream);
-int hrf_bn_bwd_finalize_packed(const hrf_bn_bfin_t* bfins, int n, const double* packed, const double* packed_local, void* stream);
+int hrf_bn_bwd_finalize_packed(const hrf_bn_bfin_t* bfins, int n, const double* packed, const double* packed_local /* nullable: see pgrad_scale */, void* stream);
 
 /* ---- LayerNorm over channels (F.layer_norm: hrformer.py:343,351; hrfuser_hrformer_based.py:279-291) */
 int hrf_ln_stats(const float* x, int rows, int C, float eps, float* rowstat, void* stream);
