@@ -1074,6 +1074,8 @@ def materialize(ctx, lazy, act, res=None, lazy2=None, act_first=False, rowscale=
     act_first=False: out = act(BN(raw) + res + BN2(raw2))        (Bottleneck tail / transition ReLU)
     """
     L, s = ctx.L, ctx.stream
+    if not act_first and act not in (ACT_NONE, ACT_RELU):
+        raise _lib.HRFuserHipError('materialize: an activation applied last must be ReLU or none (its backward uses the output mask)')
     st = lazy.st
     B, H, W, C = st.raw.shape
     rows = B * H * W

@@ -49,6 +49,49 @@ def _cases():
             lambda k, b, x: b.run(k, x[0], x[1:]),
             lambda ch=ch, h=h, M=M: O.HRFuserFusionBlock(ch, h, 4, NORM, LN, 0.2, M, 0.1),
             lambda m, i: m(i[0], list(i[1:])), [(2, ch, H, W)] * (M + 1))
+    # a10: CrossFFN on its own with its residual (hrformer.py:267-295,371), the three BatchNorms chained through
+    # transform-on-load
+    class _OrcFFN(torch.nn.Module):
+        def __init__(self, ch):
+            super().__init__()
+            self.ffn = O.CrossFFN(ch, 4 * ch, NORM)
+
+        def forward(self, x):
+            B_, C, H, W = x.shape
+            return x + self.ffn(x.flatten(2).transpose(1, 2), H, W).transpose(1, 2).reshape(B_, C, H, W)
+
+    class _ProdFFN(torch.nn.Module):
+        def __init__(self, ch):
+            super().__init__()
+            self.ffn = B.CrossFFN(ch, 4 * ch, ch, norm_cfg=NORM)
+
+        def run(self, ctx, x):
+            import hrfuser_amd.runtime as R
+            return R.materialize(ctx, self.ffn.run(ctx, x), R.ACT_GELU, res=x, act_first=True)     # x + GELU(BN3(.))
+    for (ch, H, W) in ((18, 9, 11), (36, 10, 13)):
+        c[f'crossffn_c{ch}'] = (lambda ch=ch: _ProdFFN(ch), lambda k, b, x: b.run(k, x[0]), lambda ch=ch: _OrcFFN(ch),
+                                lambda m, i: m(i[0]), [(2, ch, H, W)])
+
+    # a4: transition layers (hrnet.py:419-463): channel change at equal resolution + a new branch through 3x3 stride-2
+    # convolutions from the LAST previous branch
+    class _OrcTrans(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.t = O.make_transition([16, 32], [8, 32, 24, 40], NORM)
+
+        def forward(self, a, b):
+            return [self.t[0](a), self.t[2](b), self.t[3](b)]
+
+    class _ProdTrans(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.t = B._make_transition([16, 32], [8, 32, 24, 40], NORM)
+
+        def run(self, ctx, xs):
+            return [B._run_conv_chain(ctx, xs[0], [self.t[0]]), B._run_conv_chain(ctx, xs[1], list(self.t[2])),
+                    B._run_conv_chain(ctx, xs[1], list(self.t[3]))]
+    c['transition'] = (lambda: _ProdTrans(), lambda k, b, x: b.run(k, x), lambda: _OrcTrans(),
+                       lambda m, i: m(i[0], i[1]), [(2, 16, 18, 22), (2, 32, 9, 11)])
     for nb in (2, 3, 4):
         c[f'hrmodule_{nb}b'] = (
             lambda nb=nb: B.HRFomerModule(nb, B.HRFormerBlock, (1,) * nb, list(CH[:nb]), CH[:nb], HD[:nb],
