@@ -290,6 +290,9 @@ class Engine:
             self.nbt_flat.add_(1)
 
     def begin_forward(self, training, pre=True):
+        # every forward re-uses the per-BatchNorm slots and the step's buffers: a tape recorded by an EARLIER forward of this
+        # module must not be back-propagated afterwards (Ctx.run_backward checks the generation and raises)
+        self.gen = getattr(self, 'gen', 0) + 1
         R.use_keep_list(self.keep)
         R.release_step_buffers()
         self.fs_step = []
@@ -936,6 +939,7 @@ class HipModule(nn.Module, EngineOwner):
         eng.ready(dev)
         eng.begin_forward(self.training)
         ctx = R.Ctx(self, self.training, record)
+        ctx.gen = eng.gen
         with torch.no_grad():
             srcs = self._wrap_inputs(inputs)
             outs = self._run(ctx, srcs)

@@ -413,6 +413,13 @@ class Ctx:
         self._side_i += k
 
     def run_backward(self):
+        eng = self.owner._engine()
+        if getattr(self, 'gen', None) is not None and self.gen != getattr(eng, 'gen', self.gen):
+            raise _lib.HRFuserHipError(
+                'backward of a forward pass that is no longer the latest one of this module: every forward re-uses the '
+                'BatchNorm statistics slots and step buffers of its engine, so `net(x1); net(x2); loss.backward()` would '
+                'back-propagate x1 with the statistics of x2.  Run backward before the next forward of the same module '
+                '(or use two module instances).')
         tape = self.tape
         self.tape = []
         use_keep_list(self.owner._engine().keep)

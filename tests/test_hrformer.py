@@ -165,3 +165,24 @@ def test_hrformer_droppath_gpu(monkeypatch):
     sum((t * c.to(dev)).sum() for t, c in zip(ya, cots)).backward()
     sum((t * c).sum() for t, c in zip(yb, cots)).backward()
     assert T.rel_l2(xa.grad, xb.grad) < 2e-3, T.rel_l2(xa.grad, xb.grad)
+
+
+def test_stale_backward_raises_emul():
+    """Every forward re-uses the engine's BatchNorm slots and step buffers: back-propagating an EARLIER forward after a
+    later one must fail loudly, not produce gradients from the wrong statistics."""
+    from hrfuser_amd import _lib
+    dev = T.use_backend('emul')
+    try:
+        net, _ = _pair('hrformer_t_bn', dev)
+        net.train()
+        x, _ = O.seeded_inputs(1, 32, 32, [3], seed=1)
+        x1 = x.clone().requires_grad_(True)
+        y1 = net(x1)
+        net(x.clone() * 0.5)
+        with pytest.raises(_lib.HRFuserHipError, match='no longer the latest'):
+            sum(t.sum() for t in y1).backward()
+        y3 = net(x1)                                   # the latest forward still back-propagates
+        sum(t.sum() for t in y3).backward()
+        assert x1.grad is not None and torch.isfinite(x1.grad).all()
+    finally:
+        T.use_backend('hip')
