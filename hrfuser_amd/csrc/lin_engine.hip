@@ -22,6 +22,7 @@
 
 namespace {
 
+constexpr int LIN_BWD_EPI_MAX_NT = 5;
 constexpr int SB = 2;     // 16-deep K slabs whose loads are issued before the first use
 
 // Out-of-range fragment groups are read from this zero block instead of being masked after the
@@ -348,7 +349,10 @@ int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
 int hrf_lin_bwd_data_launch(const LinBwdDataArgs& a, void* stream) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return -1;
   const int T = (a.N + 15) / 16;
-  const int ntw = pick_ntw(a.M, T);
+  int ntw = pick_ntw(a.M, T);
+  // the epilogue variants keep their raw-input tile and the activation temporaries next to the accumulators: 9 tiles per
+  // wave do not fit the register file (HRFuser-B, 312 output channels: 150 us at 10 TFLOP/s); more channel groups instead
+  if (a.epi == 1 && ntw > LIN_BWD_EPI_MAX_NT) ntw = LIN_BWD_EPI_MAX_NT;
   const dim3 grid(hrf_cdiv(a.M, 64), hrf_cdiv(T, ntw));
   if (a.cA != nullptr) { HRF_LB_V4(true) } else { HRF_LB_V4(false) }
   return hrf_check_launch();

@@ -7,6 +7,6 @@ for rep in 1 2; do for v in "$@"; do
   sed -i "$(echo "$PAT" | sed "s/@V@/$v/g")" $F
   python -c "from hrfuser_amd import build_ext; build_ext.build()" > /dev/null 2>&1
   echo -n "value $v : "
-  python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-neck --no-eager --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['step_ms']['median'])"
+  python bench.py ${BENCH_ARGS:---steps 60 --warmup 10} --no-cpu-baseline --no-neck --no-eager --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['step_ms']['median'])"
 done; done
 cp /tmp/ab_orig $F
