@@ -584,7 +584,9 @@ __device__ __forceinline__ void ln_bwd_rows(hrf_f4* dn, const float* sXh, int pi
     }
 }
 
-#ifndef HRF_EMUL
+// phase stamps of workgroup 100 for tools/time_ab_phases.py: compiled in only with -DHRF_AB_TIMING (the stamps overwrite
+// the first rows of out_rowstat)
+#if defined(HRF_AB_TIMING) && !defined(HRF_EMUL)
 #define AB_T(k) do { if (a.out_rowstat != nullptr && blockIdx.x == 100 && threadIdx.x == 0) reinterpret_cast<long long*>(a.out_rowstat)[k] = wall_clock64(); } while (0)
 #else
 #define AB_T(k)

@@ -1,4 +1,5 @@
-"""Phase timestamps (wall_clock64, 100 MHz) of one workgroup of attn_block_bwd_kernel<18,1> at the s4 grid."""
+"""Phase timestamps (wall_clock64, 100 MHz) of one workgroup of attn_block_bwd_kernel<18,1> at the s4 grid.
+Needs a library built with the stamps compiled in:  HRF_EXTRA_FLAGS=-DHRF_AB_TIMING python -m hrfuser_amd.build_ext --force"""
 import os, sys, torch, ctypes
 os.environ.setdefault('HRF_LANES', '0')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
