@@ -896,7 +896,7 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
     const int rc = hrf_lin_bwd_data_launch(l, stream);
     if (rc >= 0) return rc;
   }
-  if (KH == 3 && stride == 1 && Cout >= (g_knob[5] > 0 ? g_knob[5] : 32) && sC == 1 && sY == W * sX && sB == H * sY && g_knob[6] == 0) {
+  if (KH == 3 && stride == 1 && Cout >= (g_knob[5] > 0 ? g_knob[5] : 16) && sC == 1 && sY == W * sX && sB == H * sY && g_knob[6] == 0) {
     Conv3Args c{};
     c.in = dy + doff; c.ldIn = ldD; c.in2 = cA != nullptr ? yraw + doff : nullptr; c.t0 = cA; c.t1 = cB; c.t2 = cC;
     c.w = w; c.wCin = Cin; c.out = dx; c.ldOut = sX; c.accumulate = accumulate; c.epi = epi; c.xraw = xraw; c.ldXr = ldXr;
@@ -904,7 +904,7 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
     c.B = B; c.H = H; c.W = W; c.Cin = Cout; c.Cout = Cin;
     return hrf_conv3_bwd_data_launch(c, stream);
   }
-  if (KH == 3 && stride == 2 && Cout >= (g_knob[5] > 0 ? g_knob[5] : 32) && sC == 1 && sY == W * sX && sB == H * sY && g_knob[6] == 0) {
+  if (KH == 3 && stride == 2 && Cout >= (g_knob[5] > 0 ? g_knob[5] : 16) && sC == 1 && sY == W * sX && sB == H * sY && g_knob[6] == 0) {
     Conv3Args c{};
     c.in = dy + doff; c.ldIn = ldD; c.in2 = cA != nullptr ? yraw + doff : nullptr; c.t0 = cA; c.t1 = cB; c.t2 = cC;
     c.w = w; c.wCin = Cin; c.out = dx; c.ldOut = sX; c.accumulate = accumulate; c.epi = epi; c.xraw = xraw; c.ldXr = ldXr;
