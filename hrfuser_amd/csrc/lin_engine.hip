@@ -23,6 +23,8 @@
 namespace {
 
 constexpr int LIN_BWD_EPI_MAX_NT = 5;
+// forward: 5 tiles per wave at most (HRFuser-B: 56.3 -> 55.5 ms; 9 tiles starve the launch of waves)
+constexpr int LIN_FWD_MAX_NT = 5;
 constexpr int SB = 2;     // 16-deep K slabs whose loads are issued before the first use
 
 // Out-of-range fragment groups are read from this zero block instead of being masked after the
@@ -316,13 +318,16 @@ inline int pick_ntw(int M, int T) {
 bool hrf_lin_fwd_emits_ln(const LinFwdArgs& a) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return false;
   const int T = (a.N + 15) / 16;
-  return hrf_cdiv(T, pick_ntw(a.M, T)) == 1;
+  int ntw = pick_ntw(a.M, T);
+  if (ntw > LIN_FWD_MAX_NT) ntw = LIN_FWD_MAX_NT;
+  return hrf_cdiv(T, ntw) == 1;
 }
 
 int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return -1;
   const int T = (a.N + 15) / 16;
-  const int ntw = pick_ntw(a.M, T);
+  int ntw = pick_ntw(a.M, T);
+  if (ntw > LIN_FWD_MAX_NT) ntw = LIN_FWD_MAX_NT;
   const dim3 grid(hrf_cdiv(a.M, 64), hrf_cdiv(T, ntw));
   switch (a.tf_mode) {
     case HRF_TF_NONE: HRF_LF_V4(HRF_TF_NONE) break;
