@@ -359,6 +359,16 @@ class EngineOwner:
             return lane
         return pool
 
+    def _lane_group(self, lane, base_group):
+        """HRF_SYNC_LANE_COMMS=1: the communicator of a lane (same ranks as `base_group`), created on first use - every
+        rank runs the same program, so the collective `new_group` calls happen in the same order everywhere."""
+        groups = self.__dict__.setdefault('_hrf_lane_groups', {})
+        g = groups.get(id(lane))
+        if g is None:
+            import torch.distributed as dist
+            g = groups[id(lane)] = dist.new_group(ranks=dist.get_process_group_ranks(base_group))
+        return g
+
     def _side_pool(self):
         pool = self.__dict__.get('_hrf_side')
         if pool is None:

@@ -36,6 +36,10 @@ _FIN_ONLOAD = os.environ.get('HRF_FIN_ONLOAD', '1') != '0'
 # of one communicator must execute in the same order on every rank, and two lanes' collectives are unordered on the GPU -
 # only the main lane serialises them.  (Safe, and ~3 % faster, in the forced one-rank measurement mode.)
 _XHUB = os.environ.get('HRF_XHUB', '0') != '0'
+# EXPERIMENT (opt-in, validated on one GPU only): one RCCL communicator PER LANE.  Collectives of different communicators
+# may run concurrently, and every lane's collectives are ordered on its own stream on every rank - so a BatchNorm exchange
+# needs no hop to the main lane at all (no batching either: the lanes' exchanges overlap instead of being merged).
+_LANE_COMMS = os.environ.get('HRF_SYNC_LANE_COMMS', '0') == '1'
 FIN_MAXC = _lib.FIN_MAXC
 LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
 _MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
@@ -186,7 +190,8 @@ class Ctx:
         # run as coroutines in lock-step (parallel()), each parking at its next exchange until the sweep is complete
         self.coll = self.group is not None and (self.world > 1 or force_collectives())
         self.pending = []
-        self._glet = _greenlet if (self.coll and os.environ.get('HRF_SYNC_BATCH', '1') != '0') else None
+        self._glet = _greenlet if (self.coll and os.environ.get('HRF_SYNC_BATCH', '1') != '0' and not _LANE_COMMS) else None
+        self._xlane = None
 
     # ---- tape ----------------------------------------------------------------------------------
     def push(self, fn, sync=None):
@@ -259,7 +264,7 @@ class Ctx:
         forks do."""
         lanes = [l for l in dict.fromkeys(lanes) if l.stream is not None or l is self.main]
         hub = self.main
-        if _XHUB and self.multi and len(lanes) == 1:
+        if (_XHUB or _LANE_COMMS) and self.multi and len(lanes) == 1:
             hub = lanes[0]
         others = [l for l in lanes if l is not hub and l.stream is not None]
         if self.multi:
@@ -272,7 +277,9 @@ class Ctx:
             ptrs = (ctypes.c_void_p * n)(*pack_ptrs)
             cs = (ctypes.c_int * n)(*[st.C for st in sts])
             self.L.hrf_bn_pack(ptrs, cs, n, packed, self.stream)
+            self._xlane = hub
             finalize(packed)
+            self._xlane = None
         if self.multi:
             for l in others:
                 l.stream.wait_stream(hub.stream)
@@ -321,7 +328,10 @@ class Ctx:
     def all_reduce(self, t):
         if self.coll:
             import torch.distributed as dist
-            dist.all_reduce(t, group=self.group)
+            group = self.group
+            if _LANE_COMMS and self._xlane is not None and self._xlane is not self.main and self._xlane.stream is not None:
+                group = self.owner._lane_group(self._xlane, self.group)
+            dist.all_reduce(t, group=group)
             self.n_collectives += 1
 
 
@@ -468,8 +478,11 @@ class Ctx:
                 if any(lane is p[1] for p in parked):
                     release()
                 if sync is not None and self.coll and sync.train and not sync.bx_done:
-                    parked.append(e)
-                    continue
+                    if _LANE_COMMS:                  # exchanged at once on the entry's own lane / communicator
+                        self.flush_bwd([sync], [lane])
+                    else:
+                        parked.append(e)
+                        continue
                 with _LaneScope(self, lane):
                     fn()
         release()

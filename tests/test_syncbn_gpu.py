@@ -61,7 +61,8 @@ torch.cuda.synchronize()
 assert rel_l2(eng.flat_g, g_eager) < 1e-5, rel_l2(eng.flat_g, g_eager)
 for p, q in zip(tr._graph_outs, y_eager):
     assert relmax(p.t, q) < 1e-5
-assert 0 < ncoll <= 240, ncoll                                   # 330 BatchNorms x 2 directions, batched + 4 gradient buckets
+lane_comms = os.environ.get('HRF_SYNC_LANE_COMMS', '0') == '1'   # experiment: unbatched exchanges on per-lane communicators
+assert 0 < ncoll <= (700 if lane_comms else 240), ncoll          # 330 BatchNorms x 2 directions, batched + 4 gradient buckets
 print('SYNCBN_GPU_OK collectives_per_step', ncoll)
 sys.stdout.flush()
 dist.barrier()
