@@ -308,6 +308,9 @@ def main():
                        'global_batch': B * world, 'parallelism': f'dp{world}',
                        'launch': 'hipGraph replay' if use_graph else 'eager',
                        'collectives_per_step': trainer.collectives_per_step,
+                       'sync_schedule': (None if not (world > 1 or force_coll) else
+                                         ('one communicator per lane, unbatched (HRF_SYNC_LANE_COMMS=1)' if os.environ.get('HRF_SYNC_LANE_COMMS', '0') == '1'
+                                          else 'packed exchanges on the main lane')),
                        'exchange_lanes_hist': {f'{k[0]}{"m" if k[1] else ""}': v for k, v in sorted(getattr(trainer, 'exchange_hist', {}).items())}},
             'step_ms': step_ms, 'finite': finite, 'fwd_ms_per_img': fwd_ms, 'eager_autograd': eager,
             'roofline': roof, 'step_roofline': step_roof, 'cpu_baseline': cpu, 'neck': neck, 'extract_feat': feat,
