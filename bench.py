@@ -42,7 +42,7 @@ PEAK_HBM = 8.0e12            # HBM3E spec peak
 WORK = {'t_nus': (106.2, 3 * 5.58), 'b_nus': (750.2, 3 * 20.04), 't_stf': (265.4, 3 * 13.58)}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -58,7 +58,13 @@ def parse():
     ap.add_argument('--no-eager', action='store_true', help='skip the eager torch.autograd route timing')
     ap.add_argument('--profile-steps', type=int, default=1)
     ap.add_argument('--dump-kernels', default='', help='write the per-kernel table (JSON) to this path')
-    return ap.parse_args()
+    ap.add_argument('--no-sync-ab', action='store_true', help='N > 1: skip the A/B of the per-lane-communicator SyncBN schedule')
+    ap.add_argument('--sync-ab-child', action='store_true', help=argparse.SUPPRESS)     # internal: the A/B child job
+    ap.add_argument('--sync-ab-timeout', type=float, default=420.0)
+    ap.add_argument('--backend', default=os.environ.get('HRF_BENCH_BACKEND', 'nccl'),
+                    help="torch.distributed backend: 'nccl' (= RCCL, the product path) | 'gloo' (flow tests of the N > 1 path on a "
+                         "box with fewer GPUs than ranks: the ranks share GPU 0, eager launches)")
+    return ap.parse_args(argv)
 
 
 def load_cfg(tag):
@@ -107,15 +113,131 @@ def cpu_baseline(tag, B, H, W, mc, iters=3):
             'ms_per_step': best['ms_per_step'], 'runs': runs}
 
 
-def main():
-    args = parse()
+# --------------------------------------------------------------------------------------------------------------------
+# Multi-rank launch.  The reference starts its ranks with tools/dist_train.sh:22-24 (torch.distributed.launch
+# --nproc_per_node=$GPUS); here `python bench.py --gpus N` does the same for itself when no launcher did: it starts
+# `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process group before anything in this
+# process touches the GPU (a process that has initialised HIP must never exec another program), relays rank 0's JSON
+# line and exits with the children's status.
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def rank_command(argv, gpus, port):
+    """The command line of the N-rank job (one process per GPU over RCCL): what tools/dist_train.sh forms for the reference."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def run_ranks(argv, gpus, env=None, timeout=None):
+    """Start the N-rank job in its own process group, wait for it (or kill exactly that group on timeout).
+    -> (return code | None on timeout, the last JSON object line of its stdout | None, tail of its other output)"""
+    import signal
+    import subprocess
+    cmd = rank_command(argv, gpus, free_port())
+    e = dict(os.environ if env is None else env)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+              'TORCHELASTIC_RUN_ID', 'TORCHELASTIC_RESTART_COUNT', 'TORCHELASTIC_MAX_RESTARTS'):
+        e.pop(k, None)                                     # a job started from inside a rank must not inherit its rendezvous
+    e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC (RCCL between processes on this driver)
+    e.setdefault('OMP_NUM_THREADS', '4')
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=e, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)            # the process GROUP we started, nothing else
+        except ProcessLookupError:
+            pass
+        out, _ = proc.communicate()
+        rc = None
+    line, rest = None, []
+    for ln in (out or '').splitlines():
+        if ln.startswith('{') and ln.rstrip().endswith('}'):
+            try:
+                line = json.loads(ln)
+                continue
+            except ValueError:
+                pass
+        rest.append(ln)
+    return rc, line, '\n'.join(rest[-15:])
+
+
+def run_sync_ab(argv, gpus, timeout):
+    """A/B of the SyncBN schedule with one RCCL communicator per lane (HRF_SYNC_LANE_COMMS=1) in a FRESH child job
+    with a timeout: the child first checks that one step's gradient arena equals the main-lane schedule's (rel-L2 < 1e-6),
+    then times the captured step.  Reported beside the headline, never as the headline; a hang or failure is text."""
+    env = dict(os.environ)
+    env['HRF_SYNC_LANE_COMMS'] = '1'
+    env.pop('HRF_FORCE_COLLECTIVES', None)
+    t0 = time.time()
+    rc, line, rest = run_ranks(list(argv) + ['--sync-ab-child'], gpus, env=env, timeout=timeout)
+    if rc is None:
+        return {'schedule': 'one communicator per lane (HRF_SYNC_LANE_COMMS=1)', 'error': f'no result within {timeout:.0f} s (child process group killed)'}
+    if line is None or 'sync_ab' not in line:
+        return {'schedule': 'one communicator per lane (HRF_SYNC_LANE_COMMS=1)', 'error': f'child exited with {rc} and no result: {rest[-400:]}'}
+    res = line['sync_ab']
+    res['wall_s'] = round(time.time() - t0, 1)
+    return res
+
+
+def strip_flag(argv, flag, has_value=False):
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a == flag:
+            skip = has_value
+            continue
+        if has_value and a.startswith(flag + '='):
+            continue
+        out.append(a)
+    return out
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher.  Runs before any GPU call of this process."""
+    n = args.gpus
+    have = torch.cuda.device_count()                       # counting devices does not initialise HIP on this image
+    share = args.backend == 'gloo'
+    if have < n and not share:
+        print(f'[bench] --gpus {n} needs {n} GPUs on this node, {have} visible: nothing was run '
+              f'(one process per GPU over RCCL; --backend gloo runs a flow test with the ranks sharing GPU 0)', file=sys.stderr)
+        return 3
+    env = dict(os.environ)
+    env['HRF_BENCH_LAUNCHED_BY_BENCH'] = '1'                # the ranks leave the schedule A/B to this parent
+    rc, line, rest = run_ranks(argv, n, env=env)
+    if rest:
+        print(rest, file=sys.stderr)
+    if rc != 0 or line is None:
+        print(f'[bench] the {n}-rank job exited with {rc}' + ('' if line is not None else ' and printed no result line'), file=sys.stderr)
+        return rc if rc else 1
+    if not args.no_sync_ab and line.get('sync_ab') is None:
+        line['sync_ab'] = run_sync_ab(strip_flag(argv, '--dump-kernels', True), n, args.sync_ab_timeout)
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+def init_ranks(args):
+    """-> rank, world, device, group (None on one rank without forced collectives), force_coll"""
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    if world != args.gpus:
+        raise SystemExit(f'[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    share = args.backend == 'gloo'
+    ndev = torch.cuda.device_count()
+    if world > 1 and not share and local >= ndev:
+        raise SystemExit(f'[bench] rank {rank}: LOCAL_RANK {local} but only {ndev} GPUs are visible (one process per GPU)')
+    dev = torch.device('cuda', 0 if share else local)
+    torch.cuda.set_device(dev)
     group = None
     force_coll = os.environ.get('HRF_FORCE_COLLECTIVES', '0') == '1'
     if world > 1 or force_coll:
@@ -124,14 +246,17 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev)          # 'nccl' is RCCL on ROCm
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)      # 'nccl' is RCCL on ROCm
         group = dist.group.WORLD
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    return rank, world, dev, group, force_coll
 
+
+def build_workload(args, rank, world, dev, group, force_coll):
     from hrfuser_amd import build_backbone
     from hrfuser_amd.trainer import Trainer, make_cotangents
-    from hrfuser_amd import profiling
-
     tag = args.model if (world == 1 and not force_coll) else args.model.replace('_bn', '')
     cfg = load_cfg(tag)
     stf = tag.startswith('t_stf')
@@ -154,20 +279,10 @@ def main():
         mods = [m.contiguous(memory_format=torch.channels_last) for m in mods]
     cots = make_cotangents(net, x, mods)
     trainer = Trainer(net, lr=1e-3 if stf else 3e-4, group=group, world_size=world)
+    return tag, cfg, stf, H, W, mc, net, B, x, mods, cots, trainer
 
-    use_graph = not args.no_graph
-    capture_note = None
-    if use_graph:
-        try:
-            trainer.capture(x, mods, cots)
-        except Exception as e:                                    # e.g. collective not capturable
-            capture_note = f'hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); timed EAGER'
-            if rank == 0:
-                print(f'[bench] {capture_note}', file=sys.stderr)
-            use_graph = False
-            torch.cuda.synchronize()
-    run = trainer.replay if use_graph else (lambda: trainer.step(x, mods, cots))
 
+def time_steps(args, run, world, dev):
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -190,9 +305,91 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+    per = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps))
+    return dt, per
+
+
+def leave(world, force_coll):
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if world > 1 or force_coll:
+        import torch.distributed as dist
+        try:
+            dist.barrier()
+        except Exception:
+            pass
+        # RCCL/HIP teardown of a process that holds captured graphs with collectives can abort at
+        # interpreter exit on ROCm 7.0; the result line is already out, so leave without destructors.
+        if os.environ.get('HRF_BENCH_SOFT_EXIT', '0') != '1':     # (profilers need the normal exit path to flush)
+            os._exit(0)
+
+
+def sync_ab_child(args):
+    """The A/B job of run_sync_ab (HRF_SYNC_LANE_COMMS=1 in the environment, N ranks): gradient equivalence of the two
+    SyncBN schedules on one eager step each, then the captured step of the per-lane-communicator schedule, timed like the
+    headline.  Rank 0 prints {"sync_ab": {...}}."""
+    from hrfuser_amd import runtime as R
+    rank, world, dev, group, force_coll = init_ranks(args)
+    tag, cfg, stf, H, W, mc, net, B, x, mods, cots, trainer = build_workload(args, rank, world, dev, group, force_coll)
+    res = {'schedule': 'one communicator per lane, unbatched (HRF_SYNC_LANE_COMMS=1)'}
+    try:
+        eng = net._engine()
+        R.set_lane_comms(False)
+        trainer.step(x, mods, cots)                               # sizes of the random pools are known after one step
+        torch.cuda.synchronize()
+
+        def grads(lane):
+            R.set_lane_comms(lane)
+            torch.manual_seed(777)                                # the same Dropout / DropPath draws for both schedules
+            trainer.step(x, mods, cots, grads_only=True)
+            torch.cuda.synchronize()
+            return eng.flat_g.clone(), trainer.collectives_per_step
+        g_main, n_main = grads(False)
+        g_lane, n_lane = grads(True)
+        err = float((g_lane.double() - g_main.double()).norm() / g_main.double().norm().clamp_min(1e-300))
+        res.update({'grad_rel_l2_vs_main_lane': err, 'collectives_per_step': n_lane, 'main_lane_collectives_per_step': n_main})
+        if not (err < 1e-6):
+            raise RuntimeError(f'gradient arena differs from the main-lane schedule: rel-L2 {err:.3e}')
+        use_graph = not args.no_graph and args.backend == 'nccl'
+        if use_graph:
+            trainer.capture(x, mods, cots)
+        run = trainer.replay if use_graph else (lambda: trainer.step(x, mods, cots))
+        dt, per = time_steps(args, run, world, dev)
+        res.update({'ms_per_step': round(dt / args.steps * 1e3, 4), 'images_per_sec': round(B * world * args.steps / dt, 3),
+                    'launch': 'hipGraph replay' if use_graph else 'eager', 'finite': bool(torch.isfinite(eng.flat_p).all())})
+    except Exception as e:
+        res['error'] = f'{type(e).__name__}: {str(e)[:300]}'
+    if rank == 0:
+        print(json.dumps({'sync_ab': res}), flush=True)
+    leave(world, True)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args, argv))                         # nothing above touched the GPU
+    if args.sync_ab_child:
+        return sync_ab_child(args)
+    rank, world, dev, group, force_coll = init_ranks(args)
+    from hrfuser_amd import profiling
+    tag, cfg, stf, H, W, mc, net, B, x, mods, cots, trainer = build_workload(args, rank, world, dev, group, force_coll)
+
+    use_graph = not args.no_graph and args.backend == 'nccl'
+    capture_note = None
+    if use_graph:
+        try:
+            trainer.capture(x, mods, cots)
+        except Exception as e:                                    # e.g. collective not capturable
+            capture_note = f'hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); timed EAGER'
+            if rank == 0:
+                print(f'[bench] {capture_note}', file=sys.stderr)
+            use_graph = False
+            torch.cuda.synchronize()
+    run = trainer.replay if use_graph else (lambda: trainer.step(x, mods, cots))
+    dt, per = time_steps(args, run, world, dev)
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
-    per = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps))
     pick = lambda f: round(per[min(len(per) - 1, int(f * len(per)))], 4)
     step_ms = {'median': pick(0.5), 'p10': pick(0.1), 'p90': pick(0.9),
                'timer': 'HIP events on the launch stream around each of the timed steps'}
@@ -244,8 +441,12 @@ def main():
             with open(args.dump_kernels, 'w') as fh:
                 json.dump({'kernels': profiling.table_json(table, PEAK_F32_MFMA, PEAK_HBM),
                            'signatures': profiling.profile_step.last_signatures[:80], 'launches_per_step': nl}, fh, indent=1)
+        issued, carried = profiling.merged_launch_counts(trainer, x, mods, cots)
         if roof is not None:
-            roof['library_launches_per_step'] = nl
+            # C-ABI calls of a step, and what reaches the GPU after the equal-shape calls of the sensor streams were merged
+            roof['library_calls_per_step'] = nl
+            roof['library_launches_per_step'] = nl - (carried - issued)
+            roof['merged_launches'] = {'launches': issued, 'calls_carried': carried}
 
     gfl, gby = WORK.get(tag.replace('_bn', ''), (None, None))
     step_roof = None
@@ -308,28 +509,31 @@ def main():
                        'global_batch': B * world, 'parallelism': f'dp{world}',
                        'launch': 'hipGraph replay' if use_graph else 'eager',
                        'collectives_per_step': trainer.collectives_per_step,
-                       'sync_schedule': (None if not (world > 1 or force_coll) else
-                                         ('one communicator per lane, unbatched (HRF_SYNC_LANE_COMMS=1)' if os.environ.get('HRF_SYNC_LANE_COMMS', '0') == '1'
-                                          else 'packed exchanges on the main lane')),
+                       'sync_schedule': getattr(trainer, 'sync_schedule', None) if (world > 1 or force_coll) else None,
+                       'backend': ('RCCL (torch.distributed nccl)' if args.backend == 'nccl' else args.backend + ' (flow test, ranks share GPU 0)') if (world > 1 or force_coll) else None,
                        'exchange_lanes_hist': {f'{k[0]}{"m" if k[1] else ""}': v for k, v in sorted(getattr(trainer, 'exchange_hist', {}).items())}},
             'step_ms': step_ms, 'finite': finite, 'fwd_ms_per_img': fwd_ms, 'eager_autograd': eager,
             'roofline': roof, 'step_roofline': step_roof, 'cpu_baseline': cpu, 'neck': neck, 'extract_feat': feat,
         }
         if capture_note:
             line['config']['capture_note'] = capture_note
-        print(json.dumps(line), flush=True)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    if world > 1 or force_coll:
+    if world > 1 and not args.no_sync_ab and os.environ.get('HRF_BENCH_LAUNCHED_BY_BENCH') != '1':
+        # started by an external launcher (the driver's torch.distributed.run): rank 0 runs the schedule A/B itself, as a
+        # child job, once every rank is done with the GPU-heavy part (a child process, never an exec)
         import torch.distributed as dist
-        try:
-            dist.barrier()
-        except Exception:
-            pass
-        # RCCL/HIP teardown of a process that holds captured graphs with collectives can abort at
-        # interpreter exit on ROCm 7.0; the result line is already out, so leave without destructors.
-        if os.environ.get('HRF_BENCH_SOFT_EXIT', '0') != '1':     # (profilers need the normal exit path to flush)
-            os._exit(0)
+        dist.barrier()
+        torch.cuda.synchronize()
+        if rank != 0:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)                                        # no barrier kernel left spinning beside the child job
+        line['sync_ab'] = run_sync_ab(strip_flag(strip_flag(argv, '--dump-kernels', True), '--sync-ab-child'), world, args.sync_ab_timeout)
+        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os._exit(0)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    leave(world, force_coll)
 
 
 if __name__ == '__main__':

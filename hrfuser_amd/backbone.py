@@ -201,7 +201,8 @@ class Engine:
         """Called by the forward of a fused layer: slot layout {name: offset, '_n': slot size} of layer `key`;
         entries = [(name, parameter, first element, count)]."""
         lay = self.fs_layers.get(key)
-        if lay is None or lay['nslots'] != nslots:
+        rg = tuple(bool(p.requires_grad) for _, p, _, _ in entries)      # freezing / unfreezing a parameter re-maps its slot
+        if lay is None or lay['nslots'] != nslots or lay['rg'] != rg:
             offs, idx, o = {}, [], 0
             for name, p, first, cnt in entries:
                 offs[name] = o
@@ -210,7 +211,7 @@ class Engine:
                            else torch.full((cnt,), -1, dtype=torch.int32))
                 o += cnt
             offs['_n'] = o
-            lay = self.fs_layers[key] = dict(nslots=nslots, offs=offs, map=torch.cat(idx), n=o)
+            lay = self.fs_layers[key] = dict(nslots=nslots, offs=offs, map=torch.cat(idx), n=o, rg=rg)
             self.fs_sig = None
         self.fs_step.append(key)
         return lay['offs']
@@ -387,6 +388,8 @@ class EngineOwner:
     def set_sync_group(self, group, world):
         """Enable SyncBN semantics: BN statistics are all-reduced over `group` (RCCL)."""
         self.sync_group, self.sync_world = group, world
+        if group is not None:
+            R.check_sync_schedule(group, world)
 
     def params_updated(self):
         """Kept for callers that signal a weight update; nothing is cached across steps any more."""
@@ -701,7 +704,9 @@ class HRFomerModule(nn.Module):
     def run(self, ctx, xs):
         nb = self.num_branches
         xs = list(xs)
-        lanes = ctx.fork(nb)                       # parallel branches (hrnet.py:189-190)
+        # parallel branches (hrnet.py:189-190); with launch merging the finest branch stays on the current lane, where the
+        # modality stages run as well: equal calls of the three sensor streams become one multi-problem launch
+        lanes = ctx.fork(nb, keep_first=ctx.bundle)
 
         def branch(i):
             for blk in self.branches[i]:
@@ -714,7 +719,7 @@ class HRFomerModule(nn.Module):
         # backward of a lane accumulates into xs[j].grad only (no cross-lane gradient races)
         nrows = len(self.fuse_layers)
         terms = [[None] * nb for _ in range(nrows)]
-        lanes = ctx.fork(nb) if _FORK_EXCHANGE else [ctx.cur] * nb
+        lanes = ctx.fork(nb, keep_first=ctx.bundle) if _FORK_EXCHANGE else [ctx.cur] * nb
 
         def source(j):
             for i, row in enumerate(self.fuse_layers):
@@ -780,7 +785,7 @@ class HRModule(nn.Module):
     def run(self, ctx, xs):
         nb = self.num_branches
         xs = list(xs)
-        lanes = ctx.fork(nb)
+        lanes = ctx.fork(nb, keep_first=ctx.bundle)
 
         def branch(i):
             for blk in self.branches[i]:
@@ -791,7 +796,7 @@ class HRModule(nn.Module):
             return [xs[0]]
         nrows = len(self.fuse_layers)
         terms = [[None] * nb for _ in range(nrows)]
-        lanes = ctx.fork(nb)
+        lanes = ctx.fork(nb, keep_first=ctx.bundle)
 
         def source(j):                             # one lane per SOURCE branch (its backward accumulates into xs[j] only)
             for i, row in enumerate(self.fuse_layers):
@@ -1173,8 +1178,8 @@ class HRFuserHRFormerBased(HipModule):
         cams = [None] * nb
         ms = [[None] * M for _ in range(nb)]
         # phase 1 - transitions: lane 0 = camera, lane 1+k = modality k (each lane only ever
-        # back-propagates into its own source tensor)
-        lanes = ctx.fork(1 + M)
+        # back-propagates into its own source tensor); equal-shape strands share the lane and merge their launches
+        lanes = ctx.bundle_lanes(1 + M)
 
         def cam_trans():
             for i in range(nb):
@@ -1200,7 +1205,7 @@ class HRFuserHRFormerBased(HipModule):
         ctx.join(lanes)
         # phase 2 - one fusion block per branch, in parallel
         xs = [None] * nb
-        lanes = ctx.fork(nb)
+        lanes = ctx.fork(nb, keep_first=ctx.bundle)
 
         def fuse(i):
             xs[i] = fusion[i].run(ctx, cams[i], ms[i])
@@ -1233,7 +1238,7 @@ class HRFuserHRFormerBased(HipModule):
 
     def _run(self, ctx, srcs):
         M = self.num_fused_modalities
-        lanes = ctx.fork(1 + M)
+        lanes = ctx.bundle_lanes(1 + M)              # camera stem + modality stems: equal shapes, one lane, merged launches
         mods = [None] * M
         cam = [None]
 
@@ -1298,7 +1303,7 @@ class HRFuserHRFormerBased(HipModule):
         stages are enqueued on their own lanes first; the camera stage then runs from the main lane,
         each of its modules forking branch lanes from main (flat, never nested)."""
         M = self.num_fused_modalities
-        lanes = ctx.fork(M)
+        lanes = ctx.bundle_lanes(M)
         mods = [None] * M
         ys = [None]
 

@@ -13,6 +13,7 @@
 // Mapping: one 256-thread block per (window, head); all contractions run on v_mfma_f32_16x16x4_f32 with the 49 tokens
 // padded to 64 (attn_fwd_mfma_kernel / attn_bwd_mfma_kernel below).
 #include "hrf_common.h"
+#include "hrf_group.h"
 #include "../../include/hrfuser_hip.h"
 
 namespace {
@@ -96,7 +97,8 @@ __device__ __forceinline__ void stage_tiles(const AttnArgs& a, int b, int wy, in
 // (contraction slot q of MFMA (t, r) <-> key 16t + 4q + r), so P never moves: O = P V is 16 x ceil(D/16) MFMAs whose B
 // operand is a V row read from LDS.  K/V/Q tiles are staged once per block (pitch 16*ceil(D/16) + 1).
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(HrfGroup<AttnArgs> grp) {
+  const AttnArgs& a = grp.p[blockIdx.z];
   constexpr int KS = (D + 3) / 4;             // contraction steps of Q K^T
   constexpr int DT = (D + 15) / 16;           // 16-wide output tiles of P V
   constexpr int P = DT * 16 + 1;              // LDS pitch (floats)
@@ -193,7 +195,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
 // position-bias gather; dK / dV rows pass through LDS so that the padded keys of boundary windows are summed in the
 // block before they reach the projection-bias gradients.
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(HrfGroup<AttnArgs> grp) {
+  const AttnArgs& a = grp.p[blockIdx.z];
   constexpr int KS = (D + 3) / 4, DT = (D + 15) / 16, P = DT * 16 + 1;
   __shared__ float sQ[64 * P];
   __shared__ float sK[64 * P];
@@ -419,11 +422,11 @@ inline void window_geom(AttnArgs& a) {
 
 #define HRF_ATTN_DISPATCH(KERN)                                                              \
   switch (D) {                                                                               \
-    case 8:  HRF_LAUNCH((KERN<8>), dim3(nwin, heads), dim3(256), 0, stream, a); break;       \
-    case 16: HRF_LAUNCH((KERN<16>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
-    case 18: HRF_LAUNCH((KERN<18>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
-    case 32: HRF_LAUNCH((KERN<32>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
-    case 39: HRF_LAUNCH((KERN<39>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
+    case 8:  HRF_LAUNCH_G((KERN<8>), dim3(nwin, heads), dim3(256), 0, stream, a); break;       \
+    case 16: HRF_LAUNCH_G((KERN<16>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
+    case 18: HRF_LAUNCH_G((KERN<18>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
+    case 32: HRF_LAUNCH_G((KERN<32>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
+    case 39: HRF_LAUNCH_G((KERN<39>), dim3(nwin, heads), dim3(256), 0, stream, a); break;      \
     default: return HRF_ERR_ARG;                                                             \
   }
 
@@ -431,6 +434,7 @@ extern "C" int hrf_window_attn_fwd(const float* q, int ldq, int qoff, const floa
                                    const float* v, int ldv, int voff, const float* kpad, const float* vpad,
                                    const float* rpb, float* o, int ldo, int B, int H, int W, int C, int heads,
                                    void* stream) {
+  HRF_GROUP_CALL();
   if (heads <= 0 || C % heads) return HRF_ERR_ARG;
   const int D = C / heads;
   AttnArgs a{};
@@ -450,6 +454,7 @@ extern "C" int hrf_window_attn_bwd(const float* q, int ldq, int qoff, const floa
                                    float* dq, int lddq, int dqoff, float* dk, int lddk, int dkoff,
                                    float* dv, int lddv, int dvoff, float* dkpad, float* dvpad, float* drpb,
                                    long copy_stride, int B, int H, int W, int C, int heads, void* stream) {
+  HRF_GROUP_CALL();
   if (heads <= 0 || C % heads) return HRF_ERR_ARG;
   const int D = C / heads;
   AttnArgs a{};

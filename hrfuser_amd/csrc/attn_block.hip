@@ -22,6 +22,7 @@
 // attention.hip reading head h at column offset h*D).  Tokens outside the image are exact zeros AFTER LayerNorm in the
 // reference, i.e. their q/k/v equal the projection biases: the LDS rows are zeroed, the GEMM does the rest.
 #include "hrf_common.h"
+#include "hrf_group.h"
 #include "../../include/hrfuser_hip.h"
 
 namespace {
@@ -188,7 +189,8 @@ __device__ __forceinline__ void wave_gemm_tl(const float* sW, int K, const float
 
 // ---------------------------------------------------------------------------------------------------------- forward
 template <int C, int HEADS>
-__global__ __launch_bounds__(256) void attn_block_fwd_kernel(hrf_attn_block_t a) {
+__global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<hrf_attn_block_t> grp) {
+  const hrf_attn_block_t& a = grp.p[blockIdx.z];
   constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16, PW = (C + 3) & ~3;
   constexpr int KSD = (D + 3) / 4, DT = (D + 15) / 16;
   constexpr int TILE = 64 * PC;
@@ -437,8 +439,7 @@ int launch_fwd(const hrf_attn_block_t& a, int nwin, void* stream) {
     once = true;
   }
 #endif
-  HRF_LAUNCH((attn_block_fwd_kernel<C, HEADS>), dim3(nwin), dim3(256), smem, stream, a);
-  return hrf_check_launch();
+  return HRF_LAUNCH_G((attn_block_fwd_kernel<C, HEADS>), dim3(nwin), dim3(256), (unsigned)smem, stream, a);
 }
 
 
@@ -591,8 +592,15 @@ __device__ __forceinline__ void ln_bwd_rows(hrf_f4* dn, const float* sXh, int pi
 #else
 #define AB_T(k)
 #endif
+struct AbBwdArgs {
+  hrf_attn_block_t a;
+  hrf_bn_bfin_t bf;     // BatchNorm-backward coefficients of the CrossFFN head derived on load (gstats != null)
+};
+
 template <int C, int HEADS>
-__global__ __launch_bounds__(256) void attn_block_bwd_kernel(hrf_attn_block_t a, hrf_bn_bfin_t bf) {
+__global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs> grp) {
+  const hrf_attn_block_t& a = grp.p[blockIdx.z].a;
+  const hrf_bn_bfin_t& bf = grp.p[blockIdx.z].bf;
   constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16, PW = (C + 3) & ~3;
   constexpr int KSD = (D + 3) / 4, DT = (D + 15) / 16;
   constexpr int TILE = 64 * PC, N1 = 4 * C, PH = N1 + 1;
@@ -1123,8 +1131,9 @@ int launch_bwd(const hrf_attn_block_t& a, const hrf_bn_bfin_t& bf, int nwin, voi
     once = true;
   }
 #endif
-  HRF_LAUNCH((attn_block_bwd_kernel<C, HEADS>), dim3(nwin), dim3(256), smem, stream, a, bf);
-  return hrf_check_launch();
+  AbBwdArgs ab;
+  ab.a = a; ab.bf = bf;
+  return HRF_LAUNCH_G((attn_block_bwd_kernel<C, HEADS>), dim3(nwin), dim3(256), (unsigned)smem, stream, ab);
 }
 
 // Relative-position-bias gradient from the dS planes the backward kernel left in memory (a LEAF of the backward graph:
@@ -1183,6 +1192,7 @@ static void ab_geometry(hrf_attn_block_t& a) {
 }
 
 extern "C" int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream) {
+  HRF_GROUP_CALL();
   if (p == nullptr || !hrf_attn_block_bwd_supported(p->C, p->heads)) return HRF_ERR_ARG;
   hrf_attn_block_t a = *p;
   if (a.xq == nullptr || a.xkv == nullptr || a.gout == nullptr || a.pslot == nullptr || a.ds_plane == nullptr) return HRF_ERR_ARG;
@@ -1215,6 +1225,7 @@ extern "C" int hrf_fold_slots(const float* slots, const long* seg, int nseg, con
 }
 
 extern "C" int hrf_attn_block_fwd(const hrf_attn_block_t* p, void* stream) {
+  HRF_GROUP_CALL();
   if (p == nullptr || !hrf_attn_block_supported(p->C, p->heads)) return HRF_ERR_ARG;
   hrf_attn_block_t a = *p;
   if (a.xq == nullptr || a.xkv == nullptr || a.res == nullptr || a.out == nullptr) return HRF_ERR_ARG;

@@ -11,6 +11,7 @@
 // 16-pixel MFMA row tile (2 waves per SIMD: the LDS/VALU latency of one hides under the other's MFMAs).
 #include "hrf_common.h"
 #include "hrf_lin.h"
+#include "hrf_group.h"
 #include "../../include/hrfuser_hip.h"
 
 namespace {
@@ -32,7 +33,8 @@ __device__ float g_zero1[4] = {0.f, 0.f, 0.f, 0.f};
 // KH = 1 (not instantiated): the same engine on wide 1x1 convolutions measured no better than the
 //         register-only row-GEMM kernel (64<->256 channels at 30720 pixels: 30.6 vs 30.3 us).
 template <int NT, int MODE, int KH>
-__global__ __launch_bounds__(64 * NWV) void conv3_kernel(Conv3Args a) {
+__global__ __launch_bounds__(64 * NWV) void conv3_kernel(HrfGroup<Conv3Args> grp) {
+  const Conv3Args& a = grp.p[blockIdx.z];
   constexpr int IWm = KH == 1 ? TW : (MODE == 2 ? TW + 1 : IW);     // staged source tile width / pixel count
   constexpr int NPm = KH == 1 ? TH * TW : (MODE == 2 ? (TH + 1) * (TW + 1) : NPIX);
   constexpr int ORG = (KH == 1 || MODE == 2) ? 0 : -1;              // source tile origin relative to (y0, x0)
@@ -236,8 +238,8 @@ static int conv3_launch(Conv3Args a, void* stream) {
   a.tilesX = hrf_cdiv(MODE == 2 ? (a.W + 1) / 2 : a.W, TW); a.tilesY = hrf_cdiv(MODE == 2 ? (a.H + 1) / 2 : a.H, TH);
   const int nt = conv3_nt(a.Cout);
   const dim3 grid(a.tilesX * a.tilesY * a.B * (MODE == 2 ? 4 : 1), hrf_cdiv(a.Cout, nt * 16));
-  if (nt == 2) { HRF_LAUNCH((conv3_kernel<2, MODE, KH>), grid, dim3(64 * NWV), 0, stream, a); }
-  else { HRF_LAUNCH((conv3_kernel<4, MODE, KH>), grid, dim3(64 * NWV), 0, stream, a); }
+  if (nt == 2) { HRF_LAUNCH_G((conv3_kernel<2, MODE, KH>), grid, dim3(64 * NWV), 0, stream, a); }
+  else { HRF_LAUNCH_G((conv3_kernel<4, MODE, KH>), grid, dim3(64 * NWV), 0, stream, a); }
   return hrf_check_launch();
 }
 

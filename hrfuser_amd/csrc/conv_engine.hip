@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <vector>
 #include "hrf_common.h"
+#include "hrf_group.h"
 #include "hrf_lin.h"
 #include "../../include/hrfuser_hip.h"
 
@@ -57,7 +58,8 @@ struct ConvFwdArgs {
 
 // --------------------------------------------------------------------------------- forward
 template <int NT, int KH, int TF>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
+__global__ __launch_bounds__(256) void conv_fwd_kernel(HrfGroup<ConvFwdArgs> grp) {
+  const ConvFwdArgs& a = grp.p[blockIdx.z];
   constexpr int BN = NT * 16, RP = BM / 4, RQ = BN / 4;
   __shared__ float As[BM * LDK];
   __shared__ float Bs[BN * LDK];
@@ -222,7 +224,8 @@ struct ConvBwdDataArgs {
 };
 
 template <int NT, int KH, bool BNB>
-__global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
+__global__ __launch_bounds__(256) void conv_bwd_data_kernel(HrfGroup<ConvBwdDataArgs> grp) {
+  const ConvBwdDataArgs& a = grp.p[blockIdx.z];
   constexpr int BN = NT * 16, RP = BM / 4, RQ = BN / 4;
   __shared__ float As[BM * LDK];
   __shared__ float Bs[BN * LDK];
@@ -788,7 +791,7 @@ inline int pick_nt(int C) {
 }  // namespace
 
 #define HRF_CF_LAUNCH(NT_, KH_, TF_) \
-  HRF_LAUNCH((conv_fwd_kernel<NT_, KH_, TF_>), dim3(hrf_cdiv(a.M, BM), hrf_cdiv(Cout, NT_ * 16)), dim3(256), 0, stream, a)
+  HRF_LAUNCH_G((conv_fwd_kernel<NT_, KH_, TF_>), dim3(hrf_cdiv(a.M, BM), hrf_cdiv(Cout, NT_ * 16)), dim3(256), 0, stream, a)
 #define HRF_CF_NT(KH_, TF_)                          \
   switch (nt) {                                      \
     case 2: HRF_CF_LAUNCH(2, KH_, TF_); break;       \
@@ -809,6 +812,7 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
                             int tf_mode, const float* tf_scale, const float* tf_shift,
                             const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat,
                             float ln_eps, void* stream) {
+  HRF_GROUP_CALL();
   if ((KH != 1 && KH != 3) || (stride != 1 && stride != 2)) return HRF_ERR_ARG;
   if (tf_mode < 0 || tf_mode > 4) return HRF_ERR_ARG;
   if (ln_rowstat != nullptr && (ldY != Cout || yoff != 0)) return HRF_ERR_ARG;   // row statistics of a full output row
@@ -858,7 +862,7 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
 }
 
 #define HRF_BD_LAUNCH(NT_, KH_, BNB_) \
-  HRF_LAUNCH((conv_bwd_data_kernel<NT_, KH_, BNB_>), dim3(hrf_cdiv(a.M, BM), hrf_cdiv(Cin, NT_ * 16)), dim3(256), 0, stream, a)
+  HRF_LAUNCH_G((conv_bwd_data_kernel<NT_, KH_, BNB_>), dim3(hrf_cdiv(a.M, BM), hrf_cdiv(Cin, NT_ * 16)), dim3(256), 0, stream, a)
 #define HRF_BD_NT(KH_, BNB_)                         \
   switch (nt) {                                      \
     case 2: HRF_BD_LAUNCH(2, KH_, BNB_); break;      \
@@ -873,6 +877,7 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
                                  float* dx, int sB, int sY, int sX, int sC, int accumulate,
                                  int epi, const float* xraw, int ldXr, const float* tf_scale,
                                  const float* tf_shift, int act, double* stats, void* stream) {
+  HRF_GROUP_CALL();
   if ((KH != 1 && KH != 3) || (stride != 1 && stride != 2)) return HRF_ERR_ARG;
   if (bfin != nullptr && (cA == nullptr || bfin->C != Cout || Cout > HRF_FIN_MAXC || bfin->gstats == nullptr)) return HRF_ERR_ARG;
   ConvBwdDataArgs a;

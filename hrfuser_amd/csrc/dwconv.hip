@@ -7,6 +7,7 @@
 // bank conflicts.  The producer BatchNorm+GELU/ReLU is applied ONCE per element while staging the
 // halo tile ("transform on load"), never per tap.
 #include "hrf_common.h"
+#include "hrf_group.h"
 #include "../../include/hrfuser_hip.h"
 
 namespace {
@@ -26,7 +27,8 @@ struct DwFwdArgs {
 };
 
 template <int S>
-__global__ __launch_bounds__(256) void dw_fwd_kernel(DwFwdArgs a) {
+__global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
+  const DwFwdArgs& a = grp.p[blockIdx.z];
   constexpr int TH = DwTile<S>::TH, IH = DwTile<S>::IH, IW = DwTile<S>::IW;
   __shared__ float sIn[IH * IW * CB];
   __shared__ float sStat[8 * 2 * CB];                    // per row-group partial moments (no LDS atomics)
@@ -128,7 +130,8 @@ struct DwBwdDataArgs {
 // dy'[p - (ky-1, kx-1)] reads exactly the staged dy' element that dx[p] multiplies with w[ky][kx], and x[p] = act(u) is a
 // by-product of the epilogue's act'(u): nine more FMAs per element instead of a second kernel that re-reads dY, Y and X.
 template <int S, bool WG>
-__global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwBwdDataArgs a) {
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs> grp) {
+  const DwBwdDataArgs& a = grp.p[blockIdx.z];
   // tile over INPUT pixels 8 x 16; staged dY region: S=1 (10 x 18, origin -1), S=2 (5 x 9, origin y0/2)
   constexpr int TH = 8, RH = S == 1 ? 10 : 5, RW = S == 1 ? 18 : 9;
   __shared__ float sD[RH * RW * CB];
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) {
 extern "C" int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias,
                               int stride, int tf_mode, const float* tf_scale, const float* tf_shift, float* y,
                               double* stats, const hrf_bn_fin_t* tf_fin, void* stream) {
+  HRF_GROUP_CALL();
   if (stride != 1 && stride != 2) return HRF_ERR_ARG;
   if (tf_fin != nullptr && (tf_mode < HRF_TF_AFFINE || tf_mode > HRF_TF_AFFINE_GELU || tf_fin->C != C || tf_fin->stats == nullptr)) return HRF_ERR_ARG;
   DwFwdArgs a;
@@ -382,8 +386,8 @@ extern "C" int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const 
   a.tilesX = hrf_cdiv(a.Wo, TW); a.tilesY = hrf_cdiv(a.Ho, th);
   if ((long)B * a.Ho * a.Wo <= 0) return HRF_OK;
   dim3 grid(a.tilesX * a.tilesY * B, hrf_cdiv(C, CB));
-  if (stride == 1) { HRF_LAUNCH(dw_fwd_kernel<1>, grid, dim3(256), 0, stream, a); }
-  else { HRF_LAUNCH(dw_fwd_kernel<2>, grid, dim3(256), 0, stream, a); }
+  if (stride == 1) { HRF_LAUNCH_G(dw_fwd_kernel<1>, grid, dim3(256), 0, stream, a); }
+  else { HRF_LAUNCH_G(dw_fwd_kernel<2>, grid, dim3(256), 0, stream, a); }
   return hrf_check_launch();
 }
 
@@ -405,9 +409,9 @@ static int dw_bwd_data_launch(const float* dy, const float* yraw, const float* c
   if ((long)B * H * W <= 0) return HRF_OK;
   dim3 grid(a.tilesX * a.tilesY * B, hrf_cdiv(C, CB));
   a.dw = dw; a.dbias = dbias; a.copy_stride = copy_stride;
-  if (dw != nullptr) { HRF_LAUNCH((dw_bwd_data_kernel<1, true>), grid, dim3(256), 0, stream, a); }
-  else if (stride == 1) { HRF_LAUNCH((dw_bwd_data_kernel<1, false>), grid, dim3(256), 0, stream, a); }
-  else { HRF_LAUNCH((dw_bwd_data_kernel<2, false>), grid, dim3(256), 0, stream, a); }
+  if (dw != nullptr) { HRF_LAUNCH_G((dw_bwd_data_kernel<1, true>), grid, dim3(256), 0, stream, a); }
+  else if (stride == 1) { HRF_LAUNCH_G((dw_bwd_data_kernel<1, false>), grid, dim3(256), 0, stream, a); }
+  else { HRF_LAUNCH_G((dw_bwd_data_kernel<2, false>), grid, dim3(256), 0, stream, a); }
   return hrf_check_launch();
 }
 
@@ -415,6 +419,7 @@ extern "C" int hrf_dwconv_bwd_data(const float* dy, const float* yraw, const flo
                                    const float* cC, const hrf_bn_bfin_t* bfin, const float* w, int stride, int B, int H, int W, int C,
                                    float* dx, int accumulate, int epi, const float* xraw, const float* tf_scale,
                                    const float* tf_shift, int act, double* stats, void* stream) {
+  HRF_GROUP_CALL();
   return dw_bwd_data_launch(dy, yraw, cA, cB, cC, bfin, w, stride, B, H, W, C, dx, accumulate, epi, xraw, tf_scale, tf_shift,
                             act, stats, nullptr, nullptr, 0, stream);
 }
@@ -423,6 +428,7 @@ extern "C" int hrf_dwconv_bwd_data_weight(const float* dy, const float* yraw, co
                                           const float* cC, const hrf_bn_bfin_t* bfin, const float* w, int B, int H, int W, int C,
                                           float* dx, const float* xraw, const float* tf_scale, const float* tf_shift, int act,
                                           double* stats, float* dw, float* dbias, long copy_stride, void* stream) {
+  HRF_GROUP_CALL();
   if (dw == nullptr) return HRF_ERR_ARG;
   return dw_bwd_data_launch(dy, yraw, cA, cB, cC, bfin, w, 1, B, H, W, C, dx, 0, 1, xraw, tf_scale, tf_shift, act, stats, dw,
                             dbias, copy_stride, stream);

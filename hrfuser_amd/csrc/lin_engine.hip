@@ -18,6 +18,7 @@
 // utils/transformer.py:932-1018, resnet.py:263-302, hrnet.py:417-455 and their autograd backward.
 #include "hrf_common.h"
 #include "hrf_lin.h"
+#include "hrf_group.h"
 #include "../../include/hrfuser_hip.h"
 
 namespace {
@@ -105,7 +106,8 @@ __device__ __forceinline__ void flush_moments(const float* sStat, double* stats,
 // --------------------------------------------------------------------------------- forward
 // NT = 16-channel output tiles per wave (compile time: the unrolled code carries no guards)
 template <int NT, int TF>
-__global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
+__global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) {
+  const LinFwdArgs& a = grp.p[blockIdx.z];
   __shared__ float sStat[4 * 2 * NT * 16];
   __shared__ __attribute__((aligned(16))) float sFin[(TF >= HRF_TF_AFFINE && TF <= HRF_TF_AFFINE_GELU) ? 2 * HRF_FIN_MAXC : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,7 +206,8 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinFwdArgs a) {
 
 // --------------------------------------------------------------------------------- backward data
 template <int NT, bool BNB>
-__global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataArgs a) {
+__global__ __launch_bounds__(256) void lin_bwd_data_kernel(HrfGroup<LinBwdDataArgs> grp) {
+  const LinBwdDataArgs& a = grp.p[blockIdx.z];
   __shared__ float sStat[4 * 2 * NT * 16];
   __shared__ __attribute__((aligned(16))) float sFin[BNB ? 3 * HRF_FIN_MAXC : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -304,7 +307,7 @@ inline int pick_ntw(int M, int T) {
 
 }  // namespace
 
-#define HRF_LF_LAUNCH(NT_, TF_, V4_) HRF_LAUNCH((lin_fwd_kernel<NT_, TF_>), grid, dim3(256), 0, stream, a)
+#define HRF_LF_LAUNCH(NT_, TF_, V4_) HRF_LAUNCH_G((lin_fwd_kernel<NT_, TF_>), grid, dim3(256), 0, stream, a)
 #define HRF_LF_NT(TF_, V4_)                          \
   switch (ntw) {                                     \
     case 1: HRF_LF_LAUNCH(1, TF_, V4_); break;       \
@@ -340,7 +343,7 @@ int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
   return hrf_check_launch();
 }
 
-#define HRF_LB_LAUNCH(NT_, BNB_, V4_) HRF_LAUNCH((lin_bwd_data_kernel<NT_, BNB_>), grid, dim3(256), 0, stream, a)
+#define HRF_LB_LAUNCH(NT_, BNB_, V4_) HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_>), grid, dim3(256), 0, stream, a)
 #define HRF_LB_NT(BNB_, V4_)                         \
   switch (ntw) {                                     \
     case 1: HRF_LB_LAUNCH(1, BNB_, V4_); break;      \

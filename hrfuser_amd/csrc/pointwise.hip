@@ -9,6 +9,7 @@
 // Reference ops replaced: F.batch_norm, F.layer_norm, F.relu/gelu, torch.add, F.interpolate
 // (bilinear, align_corners=False) call sites listed in SURVEY.md 2.1a.
 #include "hrf_common.h"
+#include "hrf_group.h"
 #include "../../include/hrfuser_hip.h"
 
 namespace {
@@ -104,7 +105,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_packed_kernel(BnBFinPackA
 
 // ------------------------------------------------------------------------------- LayerNorm
 // 16 lanes cooperate on one row (C = 18..624), 4 rows per wave, 16 rows per 256-thread block.
-__global__ __launch_bounds__(256) void ln_stats_kernel(const float* x, int rows, int C, float eps, float* rowstat) {
+struct LnStatsArgs {
+  const float* x;
+  int rows;
+  int C;
+  float eps;
+  float* rowstat;
+};
+__global__ __launch_bounds__(256) void ln_stats_kernel(HrfGroup<LnStatsArgs> grp) {
+  const LnStatsArgs& pa_ = grp.p[blockIdx.z];
+  const float* x = pa_.x;
+  int rows = pa_.rows;
+  int C = pa_.C;
+  float eps = pa_.eps;
+  float* rowstat = pa_.rowstat;
   const int sub = threadIdx.x & 15;
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   const bool rv = row < rows;
@@ -127,10 +141,33 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* x, int rows,
 // so the per-channel sums live in registers across the row loop (one LDS atomic per channel per
 // thread at the very end) and each element of da / x is loaded exactly once, all loads of a row
 // issued before the first use.
+struct LnBwdArgs {
+  const float* da;
+  const float* x;
+  const float* rowstat;
+  const float* gamma;
+  int rows;
+  int C;
+  float* dx;
+  int accumulate;
+  float* dgamma;
+  float* dbeta;
+  long copy_stride;
+};
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* da, const float* x, const float* rowstat,
-                                                     const float* gamma, int rows, int C, float* dx,
-                                                     int accumulate, float* dgamma, float* dbeta, long copy_stride) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(HrfGroup<LnBwdArgs> grp) {
+  const LnBwdArgs& pa_ = grp.p[blockIdx.z];
+  const float* da = pa_.da;
+  const float* x = pa_.x;
+  const float* rowstat = pa_.rowstat;
+  const float* gamma = pa_.gamma;
+  int rows = pa_.rows;
+  int C = pa_.C;
+  float* dx = pa_.dx;
+  int accumulate = pa_.accumulate;
+  float* dgamma = pa_.dgamma;
+  float* dbeta = pa_.dbeta;
+  long copy_stride = pa_.copy_stride;
   __shared__ float sacc[2 * 16 * NCH];
   for (int i = threadIdx.x; i < 2 * 16 * NCH; i += 256) sacc[i] = 0.f;
   const int sub = threadIdx.x & 15;
@@ -196,11 +233,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* da, const floa
 // ------------------------------------------------------------------------------- BN apply + act + residual
 // act_first=1: out = res + rowscale*act(sc1*y1+sh1)            (CrossFFN tail: x + GELU(BN(h3)))
 // act_first=0: out = act(sc1*y1+sh1 [+ res] [+ sc2*y2+sh2])    (Bottleneck tail / transition ReLU)
-__global__ __launch_bounds__(256) void affine_act_res_kernel(const float* y1, const float* sc1, const float* sh1,
-                                                             const float* y2, const float* sc2, const float* sh2,
-                                                             const float* res, const float* rowscale, int rows_per_sample,
-                                                             int act, int act_first, float* out, long total, int C,
-                                                             hrf_bn_fin_t fin1, hrf_bn_fin_t fin2) {
+struct AffineActResArgs {
+  const float* y1;
+  const float* sc1;
+  const float* sh1;
+  const float* y2;
+  const float* sc2;
+  const float* sh2;
+  const float* res;
+  const float* rowscale;
+  int rows_per_sample;
+  int act;
+  int act_first;
+  float* out;
+  long total;
+  int C;
+  hrf_bn_fin_t fin1;
+  hrf_bn_fin_t fin2;
+};
+__global__ __launch_bounds__(256) void affine_act_res_kernel(HrfGroup<AffineActResArgs> grp) {
+  const AffineActResArgs& pa_ = grp.p[blockIdx.z];
+  const float* y1 = pa_.y1;
+  const float* sc1 = pa_.sc1;
+  const float* sh1 = pa_.sh1;
+  const float* y2 = pa_.y2;
+  const float* sc2 = pa_.sc2;
+  const float* sh2 = pa_.sh2;
+  const float* res = pa_.res;
+  const float* rowscale = pa_.rowscale;
+  int rows_per_sample = pa_.rows_per_sample;
+  int act = pa_.act;
+  int act_first = pa_.act_first;
+  float* out = pa_.out;
+  long total = pa_.total;
+  int C = pa_.C;
+  hrf_bn_fin_t fin1 = pa_.fin1;
+  hrf_bn_fin_t fin2 = pa_.fin2;
   // BatchNorm(s) of the inputs finalised on load (hrf_bn_fin_t)
   __shared__ float sFin[4 * HRF_FIN_MAXC];
   if (fin1.stats != nullptr) { hrf_bn_fin_onload(fin1, sFin, sFin + HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0); sc1 = sFin; sh1 = sFin + HRF_FIN_MAXC; }
@@ -224,10 +292,37 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(const float* y1, co
 
 // out = res + rowscale*act(sc1*y1+sh1) (CrossFFN tail) AND the LayerNorm row statistics of `out` for the
 // next block's norm1: 16 lanes per row, lane `sub` owns channels sub, sub+16, ...
+struct FfnTailArgs {
+  const float* y1;
+  const float* sc1;
+  const float* sh1;
+  const float* res;
+  const float* rowscale;
+  int rows_per_sample;
+  int act;
+  float* out;
+  int rows;
+  int C;
+  float eps;
+  float* rowstat;
+  hrf_bn_fin_t fin1;
+};
 template <int NCH>
-__global__ __launch_bounds__(256) void ffn_tail_kernel(const float* y1, const float* sc1, const float* sh1, const float* res,
-                                                       const float* rowscale, int rows_per_sample, int act, float* out,
-                                                       int rows, int C, float eps, float* rowstat, hrf_bn_fin_t fin1) {
+__global__ __launch_bounds__(256) void ffn_tail_kernel(HrfGroup<FfnTailArgs> grp) {
+  const FfnTailArgs& pa_ = grp.p[blockIdx.z];
+  const float* y1 = pa_.y1;
+  const float* sc1 = pa_.sc1;
+  const float* sh1 = pa_.sh1;
+  const float* res = pa_.res;
+  const float* rowscale = pa_.rowscale;
+  int rows_per_sample = pa_.rows_per_sample;
+  int act = pa_.act;
+  float* out = pa_.out;
+  int rows = pa_.rows;
+  int C = pa_.C;
+  float eps = pa_.eps;
+  float* rowstat = pa_.rowstat;
+  hrf_bn_fin_t fin1 = pa_.fin1;
   __shared__ float sFin[2 * HRF_FIN_MAXC];
   if (fin1.stats != nullptr) {                             // BatchNorm of y1 finalised on load (hrf_bn_fin_t)
     hrf_bn_fin_onload(fin1, sFin, sFin + HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0);
@@ -274,11 +369,42 @@ __global__ __launch_bounds__(256) void ffn_tail_kernel(const float* y1, const fl
 // A thread keeps ONE channel for its whole life (C <= 256: 256/C rows per pass, thread = (row, c);
 // wider rows: channels c, c+256, c+512 of one row per pass), so the moments accumulate in registers
 // and LDS/global atomics are paid once per thread / block, not per element.
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* dout, const float* out, const float* y1,
-                                                      const float* sc, const float* sh, const float* rowscale,
-                                                      int rows_per_sample, int mode, float* g, const float* y2,
-                                                      const float* y3, double* st1, double* st2, double* st3,
-                                                      long rows, int C) {
+struct ActBwdArgs {
+  const float* dout;
+  const float* out;
+  const float* y1;
+  const float* sc;
+  const float* sh;
+  const float* rowscale;
+  int rows_per_sample;
+  int mode;
+  float* g;
+  const float* y2;
+  const float* y3;
+  double* st1;
+  double* st2;
+  double* st3;
+  long rows;
+  int C;
+};
+__global__ __launch_bounds__(256) void act_bwd_kernel(HrfGroup<ActBwdArgs> grp) {
+  const ActBwdArgs& pa_ = grp.p[blockIdx.z];
+  const float* dout = pa_.dout;
+  const float* out = pa_.out;
+  const float* y1 = pa_.y1;
+  const float* sc = pa_.sc;
+  const float* sh = pa_.sh;
+  const float* rowscale = pa_.rowscale;
+  int rows_per_sample = pa_.rows_per_sample;
+  int mode = pa_.mode;
+  float* g = pa_.g;
+  const float* y2 = pa_.y2;
+  const float* y3 = pa_.y3;
+  double* st1 = pa_.st1;
+  double* st2 = pa_.st2;
+  double* st3 = pa_.st3;
+  long rows = pa_.rows;
+  int C = pa_.C;
   HRF_DYN_SMEM(float, sacc);                              // [4*C]: sum g, sum g*y1, sum g*y2, sum g*y3
   for (int i = threadIdx.x; i < 4 * C; i += 256) sacc[i] = 0.f;
   const int cw = C <= 256 ? C : 256, R = C <= 256 ? 256 / C : 1;
@@ -346,9 +472,30 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* dout, const f
 
 // out = res + res2 + y * mask * mscale * rowscale[b]   (Dropout / DropPath arithmetic; the Bernoulli
 // draws come from torch's graph-safe Philox generator, only the arithmetic runs here)
-__global__ __launch_bounds__(256) void scale_add_kernel(const float* y, const float* mask, float mscale,
-                                                        const float* rowscale, int rows_per_sample, const float* res,
-                                                        const float* res2, float* out, long total, int C) {
+struct ScaleAddArgs {
+  const float* y;
+  const float* mask;
+  float mscale;
+  const float* rowscale;
+  int rows_per_sample;
+  const float* res;
+  const float* res2;
+  float* out;
+  long total;
+  int C;
+};
+__global__ __launch_bounds__(256) void scale_add_kernel(HrfGroup<ScaleAddArgs> grp) {
+  const ScaleAddArgs& pa_ = grp.p[blockIdx.z];
+  const float* y = pa_.y;
+  const float* mask = pa_.mask;
+  float mscale = pa_.mscale;
+  const float* rowscale = pa_.rowscale;
+  int rows_per_sample = pa_.rows_per_sample;
+  const float* res = pa_.res;
+  const float* res2 = pa_.res2;
+  float* out = pa_.out;
+  long total = pa_.total;
+  int C = pa_.C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     float v = y[i] * mscale;
     if (mask) v *= mask[i];
@@ -373,17 +520,21 @@ __device__ __forceinline__ void bil_src(int dst, int in, int out, int& i0, int& 
   w1 = s - (float)i0;
 }
 
-__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a) {
+__global__ __launch_bounds__(256) void fuse_sum_kernel(HrfGroup<FuseArgs> grp) {
+  const FuseArgs& a = grp.p[blockIdx.z];
   const long total = (long)a.B * a.H * a.W * a.C;
   // BatchNorms of the conv-produced terms finalised on load (hrf_bn_fin_t; C <= HRF_FIN_MAXC / 2 per term)
   __shared__ float sFin[4 * HRF_FIN_MAXC];
   bool any = false;
+  const float* tsc[4];
+  const float* tsh[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    tsc[k] = a.t[k].sc; tsh[k] = a.t[k].sh;
     if (a.fin[k].stats != nullptr) {
       float* base = sFin + k * HRF_FIN_MAXC;
       hrf_bn_fin_onload(a.fin[k], base, base + HRF_FIN_MAXC / 2, threadIdx.x, 256, blockIdx.x == 0);
-      a.t[k].sc = base; a.t[k].sh = base + HRF_FIN_MAXC / 2;
+      tsc[k] = base; tsh[k] = base + HRF_FIN_MAXC / 2;
       any = true;
     }
   }
@@ -397,7 +548,7 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a) {
     for (int k = 0; k < 4; ++k) {
       const FuseTerm& t = a.t[k];
       if (t.type == 1) acc += t.p[i];
-      else if (t.type == 2) acc += fmaf(t.p[i], t.sc[c], t.sh[c]);
+      else if (t.type == 2) acc += fmaf(t.p[i], tsc[k][c], tsh[k][c]);
       else if (t.type == 3) {
         int y0, y1, x0, x1; float wy, wx;
         bil_src(y, t.Hs, a.H, y0, y1, wy);
@@ -408,12 +559,12 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a) {
         // same association as ATen upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
         const float top = (1.f - wx) * v00 + wx * v01, bot = (1.f - wx) * v10 + wx * v11;
         const float v = (1.f - wy) * top + wy * bot;
-        acc += fmaf(v, t.sc[c], t.sh[c]);
+        acc += fmaf(v, tsc[k][c], tsh[k][c]);
       } else if (t.type == 4) {
         // nn.Upsample(scale_factor = H / Hs, mode='nearest') (hrnet.py:135-146): src = floor(dst * Hs / H)
         const int ys = y / (a.H / t.Hs), xs = x / (a.W / t.Ws);
         const float v = t.p[(((long)b * t.Hs + ys) * t.Ws + xs) * a.C + c];
-        acc += fmaf(v, t.sc[c], t.sh[c]);
+        acc += fmaf(v, tsc[k][c], tsh[k][c]);
       }
     }
     a.out[i] = fmaxf(acc, 0.f);
@@ -470,9 +621,34 @@ __global__ __launch_bounds__(256) void nearest_up_bwd_kernel(const float* g, int
 // tensor), plus the (sum, sum*ylow) moments for the BatchNorm that precedes the up-sampling.
 // A thread keeps ONE channel for its whole life (C <= 256: 256/C low-res pixels per pass), so the
 // moments accumulate in registers (the first version paid two LDS atomics per element: 31 us).
-__global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const float* g, int ldG, int goff, int B, int H, int W, int C,
-                                                              const float* ylow, int Hs, int Ws, float* du,
-                                                              double* stats) {
+struct BilUpBwdArgs {
+  const float* g;
+  int ldG;
+  int goff;
+  int B;
+  int H;
+  int W;
+  int C;
+  const float* ylow;
+  int Hs;
+  int Ws;
+  float* du;
+  double* stats;
+};
+__global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(HrfGroup<BilUpBwdArgs> grp) {
+  const BilUpBwdArgs& pa_ = grp.p[blockIdx.z];
+  const float* g = pa_.g;
+  int ldG = pa_.ldG;
+  int goff = pa_.goff;
+  int B = pa_.B;
+  int H = pa_.H;
+  int W = pa_.W;
+  int C = pa_.C;
+  const float* ylow = pa_.ylow;
+  int Hs = pa_.Hs;
+  int Ws = pa_.Ws;
+  float* du = pa_.du;
+  double* stats = pa_.stats;
   HRF_DYN_SMEM(float, sacc);                              // [2*C]
   for (int i = threadIdx.x; i < 2 * C; i += 256) sacc[i] = 0.f;
   const int cw = C <= 256 ? C : 256, R = C <= 256 ? 256 / C : 1;
@@ -732,20 +908,22 @@ extern "C" int hrf_bn_bwd_finalize(const double* gstats, const double* gstats_lo
 }
 
 extern "C" int hrf_ln_stats(const float* x, int rows, int C, float eps, float* rowstat, void* stream) {
+  HRF_GROUP_CALL();
   if (rows <= 0) return HRF_OK;
-  HRF_LAUNCH(ln_stats_kernel, dim3(hrf_cdiv(rows, 16)), dim3(256), 0, stream, x, rows, C, eps, rowstat);
+  HRF_LAUNCH_G(ln_stats_kernel, dim3(hrf_cdiv(rows, 16)), dim3(256), 0, stream, (LnStatsArgs{x, rows, C, eps, rowstat}));
   return hrf_check_launch();
 }
 
 extern "C" int hrf_ln_bwd(const float* da, const float* x, const float* rowstat, const float* gamma, int rows, int C,
                           float* dx, int accumulate, float* dgamma, float* dbeta, long copy_stride, void* stream) {
+  HRF_GROUP_CALL();
   if (rows <= 0) return HRF_OK;
   if (C > 640) return HRF_ERR_ARG;
   int grid = hrf_cdiv(hrf_cdiv(rows, 16), g_pw_knob[0] > 0 ? g_pw_knob[0] : 2);
   if (grid > 2048) grid = 2048;
   const int nch = hrf_cdiv(C, 16);
-#define HRF_LNB(N_) HRF_LAUNCH(ln_bwd_kernel<N_>, dim3(grid), dim3(256), 0, stream, da, x, rowstat, gamma, rows, C, dx, \
-                               accumulate, dgamma, dbeta, copy_stride)
+#define HRF_LNB(N_) HRF_LAUNCH_G(ln_bwd_kernel<N_>, dim3(grid), dim3(256), 0, stream, \
+                                 (LnBwdArgs{da, x, rowstat, gamma, rows, C, dx, accumulate, dgamma, dbeta, copy_stride}))
   if (nch <= 2) { HRF_LNB(2); } else if (nch <= 3) { HRF_LNB(3); } else if (nch <= 5) { HRF_LNB(5); }
   else if (nch <= 10) { HRF_LNB(10); } else if (nch <= 20) { HRF_LNB(20); } else { HRF_LNB(40); }
   return hrf_check_launch();
@@ -756,6 +934,7 @@ extern "C" int hrf_affine_act_res(const float* y1, const float* sc1, const float
                                   int rows_per_sample, int act, int act_first, float* out, long rows, int C,
                                   float* ln_rowstat, float ln_eps, const hrf_bn_fin_t* fin1, const hrf_bn_fin_t* fin2,
                                   void* stream) {
+  HRF_GROUP_CALL();
   const long total = rows * C;
   if (total <= 0) return HRF_OK;
   if ((fin1 != nullptr && (fin1->C != C || C > HRF_FIN_MAXC || fin1->stats == nullptr)) ||
@@ -764,14 +943,14 @@ extern "C" int hrf_affine_act_res(const float* y1, const float* sc1, const float
   if (ln_rowstat != nullptr && act_first && y2 == nullptr && C <= 640) {
     const int nch = hrf_cdiv(C, 16);
     const dim3 grid(hrf_cdiv(rows, 16));
-#define HRF_FT(N_) HRF_LAUNCH(ffn_tail_kernel<N_>, grid, dim3(256), 0, stream, y1, sc1, sh1, res, rowscale, rows_per_sample, act, \
-                              out, (int)rows, C, ln_eps, ln_rowstat, f1)
+#define HRF_FT(N_) HRF_LAUNCH_G(ffn_tail_kernel<N_>, grid, dim3(256), 0, stream, \
+                                (FfnTailArgs{y1, sc1, sh1, res, rowscale, rows_per_sample, act, out, (int)rows, C, ln_eps, ln_rowstat, f1}))
     if (nch <= 2) { HRF_FT(2); } else if (nch <= 3) { HRF_FT(3); } else if (nch <= 5) { HRF_FT(5); }
     else if (nch <= 10) { HRF_FT(10); } else if (nch <= 20) { HRF_FT(20); } else { HRF_FT(40); }
     return hrf_check_launch();
   }
-  HRF_LAUNCH(affine_act_res_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, y1, sc1, sh1, y2, sc2, sh2, res,
-             rowscale, rows_per_sample, act, act_first, out, total, C, f1, f2);
+  HRF_LAUNCH_G(affine_act_res_kernel, dim3(ew_grid(total)), dim3(256), 0, stream,
+               (AffineActResArgs{y1, sc1, sh1, y2, sc2, sh2, res, rowscale, rows_per_sample, act, act_first, out, total, C, f1, f2}));
   if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(out, (int)rows, C, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();
 }
@@ -779,23 +958,25 @@ extern "C" int hrf_affine_act_res(const float* y1, const float* sc1, const float
 extern "C" int hrf_scale_add(const float* y, const float* mask, float mscale, const float* rowscale,
                              int rows_per_sample, const float* res, const float* res2, float* out, long rows, int C,
                              void* stream) {
+  HRF_GROUP_CALL();
   const long total = rows * C;
   if (total <= 0) return HRF_OK;
-  HRF_LAUNCH(scale_add_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, y, mask, mscale, rowscale, rows_per_sample,
-             res, res2, out, total, C);
+  HRF_LAUNCH_G(scale_add_kernel, dim3(ew_grid(total)), dim3(256), 0, stream,
+               (ScaleAddArgs{y, mask, mscale, rowscale, rows_per_sample, res, res2, out, total, C}));
   return hrf_check_launch();
 }
 
 extern "C" int hrf_act_bwd(const float* dout, const float* out, const float* y1, const float* sc, const float* sh,
                            const float* rowscale, int rows_per_sample, int mode, float* g, const float* y2,
                            const float* y3, double* st1, double* st2, double* st3, long rows, int C, void* stream) {
+  HRF_GROUP_CALL();
   if (rows * C <= 0) return HRF_OK;
   if (C > 768) return HRF_ERR_ARG;
   const int R = C <= 256 ? 256 / C : 1;
   int grid = hrf_cdiv(hrf_cdiv(rows, R), g_pw_knob[1] > 0 ? g_pw_knob[1] : 4);   // passes per block
   if (grid > 2048) grid = 2048;
-  HRF_LAUNCH(act_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), stream, dout, out, y1, sc, sh,
-             rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, rows, C);
+  HRF_LAUNCH_G(act_bwd_kernel, dim3(grid), dim3(256), (unsigned)(4 * C * sizeof(float)), stream,
+               (ActBwdArgs{dout, out, y1, sc, sh, rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, rows, C}));
   return hrf_check_launch();
 }
 
@@ -804,6 +985,7 @@ extern "C" int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const 
                             int type2, const float* p2, const float* sc2, const float* sh2, int Hs2, int Ws2,
                             int type3, const float* p3, const float* sc3, const float* sh3, int Hs3, int Ws3,
                             float* out, int B, int H, int W, int C, const hrf_bn_fin_t* fins, void* stream) {
+  HRF_GROUP_CALL();
   FuseArgs a;
   for (int k = 0; k < 4; ++k) {
     a.fin[k] = hrf_bn_fin_t{};
@@ -821,20 +1003,21 @@ extern "C" int hrf_fuse_sum(int type0, const float* p0, const float* sc0, const 
     if (a.t[k].type == 4 && (a.t[k].Hs <= 0 || a.t[k].Ws <= 0 || H % a.t[k].Hs || W % a.t[k].Ws)) return HRF_ERR_ARG;
   const long total = (long)B * H * W * C;
   if (total <= 0) return HRF_OK;
-  HRF_LAUNCH(fuse_sum_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, a);
+  HRF_LAUNCH_G(fuse_sum_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, a);
   return hrf_check_launch();
 }
 
 extern "C" int hrf_bilinear_up_bwd(const float* g, int ldG, int goff, int B, int H, int W, int C, const float* ylow,
                                    int Hs, int Ws, float* du, double* stats, void* stream) {
+  HRF_GROUP_CALL();
   const long npix = (long)B * Hs * Ws;
   if (npix * C <= 0) return HRF_OK;
   if (C > 768) return HRF_ERR_ARG;
   const int R = C <= 256 ? 256 / C : 1;
   int grid = hrf_cdiv(npix, R);
   if (grid > 1024) grid = 1024;
-  HRF_LAUNCH(bilinear_up_bwd_kernel, dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), stream, g, ldG, goff,
-             B, H, W, C, ylow, Hs, Ws, du, stats);
+  HRF_LAUNCH_G(bilinear_up_bwd_kernel, dim3(grid), dim3(256), (unsigned)(2 * C * sizeof(float)), stream,
+               (BilUpBwdArgs{g, ldG, goff, B, H, W, C, ylow, Hs, Ws, du, stats}));
   return hrf_check_launch();
 }
 

@@ -142,7 +142,8 @@ class ProfLib:
                 d['w1'] = int(bool(p.w1))
             return d
 
-        if name in _lib._RAW_RETURN or name in ('hrf_wgrad_group_begin', 'hrf_wgrad_group_end', 'hrf_debug_knob'):
+        if name in _lib._RAW_RETURN or name in ('hrf_wgrad_group_begin', 'hrf_wgrad_group_end', 'hrf_debug_knob', 'hrf_group_begin',
+                                                'hrf_group_end'):
             return fn                                     # queries / plumbing: not launches, and their value matters
 
         def call(*args):
@@ -212,18 +213,20 @@ def profile_step(trainer, x, mods, cots, steps=1):
     trainer.step(x, mods, cots)                    # eager warm-up (allocator, caches)
     torch.cuda.synchronize()
     _lib.lib = lambda: prof
-    os_lanes = os.environ.get('HRF_LANES')
+    saved = {k: os.environ.get(k) for k in ('HRF_LANES', 'HRF_GROUP')}
     os.environ['HRF_LANES'] = '0'                  # record on one stream; replay order is irrelevant
+    os.environ['HRF_GROUP'] = '0'                  # one record per C-ABI call: the table prices single-problem launches
     try:
         for _ in range(steps):
             trainer.step(x, mods, cots)
         torch.cuda.synchronize()
     finally:
         _lib.lib = real
-        if os_lanes is None:
-            os.environ.pop('HRF_LANES', None)
-        else:
-            os.environ['HRF_LANES'] = os_lanes
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     sigs = {}
     for name, a, args in prof.records:
         sg = _signature(name, a)
@@ -259,6 +262,20 @@ def profile_step(trainer, x, mods, cots, steps=1):
     sig_rows.sort(key=lambda r: -r['time_per_step_ms'])
     profile_step.last_signatures = sig_rows       # per-(entry point, shape) rows of the same measurement
     return table
+
+
+def merged_launch_counts(trainer, x, mods, cots):
+    """One eager step with the multi-problem launches as configured: (launches issued by hrf_group_end, C-ABI calls'
+    launches they carried) - the step's launch count is its call count minus (carried - issued)."""
+    L = _lib.lib()
+    if not hasattr(L, 'hrf_group_count'):
+        return 0, 0
+    torch.cuda.synchronize()
+    c0 = [L.hrf_group_count(k) for k in range(2)]
+    trainer.step(x, mods, cots)
+    torch.cuda.synchronize()
+    c1 = [L.hrf_group_count(k) for k in range(2)]
+    return c1[0] - c0[0], c1[1] - c0[1]
 
 
 def _row(key, t, peak_f, peak_b):

@@ -40,6 +40,46 @@ _XHUB = os.environ.get('HRF_XHUB', '0') != '0'
 # may run concurrently, and every lane's collectives are ordered on its own stream on every rank - so a BatchNorm exchange
 # needs no hop to the main lane at all (no batching either: the lanes' exchanges overlap instead of being merged).
 _LANE_COMMS = os.environ.get('HRF_SYNC_LANE_COMMS', '0') == '1'
+
+
+def set_lane_comms(on):
+    """Switch the SyncBN schedule of the NEXT forward passes of this process (bench.py's sync_ab child compares the two
+    schedules in one process).  Every rank must make the same choice."""
+    global _LANE_COMMS
+    _LANE_COMMS = bool(on)
+
+
+def lane_comms():
+    return _LANE_COMMS
+
+
+def sync_schedule_fingerprint():
+    """What decides the ORDER and NUMBER of SyncBN collectives a rank issues: ranks that disagree on any of these would
+    hang or reduce mismatched buffers."""
+    return [1 if _greenlet is not None else 0, 0 if os.environ.get('HRF_SYNC_BATCH', '1') == '0' else 1,
+            1 if _XHUB else 0, 1 if _LANE_COMMS else 0, 1 if _FIN_ONLOAD else 0, _lib.STAT_COPIES]
+
+
+def check_sync_schedule(group, world):
+    """Called when SyncBN is switched on (EngineOwner.set_sync_group): the batched exchange schedule needs `greenlet`
+    (a missing module used to degrade silently to one collective per BatchNorm), and every rank must run the same
+    schedule - the fingerprint is all-reduced (MIN and MAX) and a disagreement raises before the first exchange."""
+    if _greenlet is None and os.environ.get('HRF_SYNC_BATCH', '1') != '0' and not _LANE_COMMS:
+        raise _lib.HRFuserHipError(
+            'SyncBN: the batched exchange schedule needs the `greenlet` module, which is not importable here.  Install it, '
+            'or set HRF_SYNC_BATCH=0 on EVERY rank to run one collective per BatchNorm (about 3x the collectives).')
+    if group is None or world <= 1:
+        return
+    import torch.distributed as dist
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    fp = torch.tensor(sync_schedule_fingerprint(), dtype=torch.int64, device=dev)
+    lo, hi = fp.clone(), fp.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not bool((lo == hi).all()):
+        raise _lib.HRFuserHipError(
+            f'SyncBN: the ranks disagree on the exchange schedule (greenlet, HRF_SYNC_BATCH, HRF_XHUB, HRF_SYNC_LANE_COMMS, '
+            f'HRF_FIN_ONLOAD, HRF_STAT_COPIES): min {lo.tolist()} max {hi.tolist()}, this rank {fp.tolist()}')
 FIN_MAXC = _lib.FIN_MAXC
 LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
 _MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
@@ -152,9 +192,10 @@ class RawInput:
 
 
 class Lane:
-    """An execution lane = one HIP stream.  Independent parts of the network (camera branches,
-    modality streams, per-source exchange chains) run on sibling lanes so that the many small,
-    latency-bound launches of HRFuser-T overlap on the 256 CUs instead of queueing serially."""
+    """An execution lane = one HIP stream.  Independent parts of the network (camera branches, per-source exchange
+    chains, the deferred weight-gradient phase) run on sibling lanes so that the many small, latency-bound launches of
+    HRFuser-T overlap on the 256 CUs instead of queueing serially.  Parts of EQUAL shape (the camera stream's finest
+    branch and the modality streams) share a lane instead and merge their launches (Ctx.parallel / Strand)."""
     __slots__ = ('stream', 'ptr')
 
     def __init__(self, stream):
@@ -162,14 +203,70 @@ class Lane:
         self.ptr = stream.cuda_stream if stream is not None else 0
 
 
+class Strand:
+    """One independent chain of the dataflow graph: a body handed to Ctx.parallel, its lane, and its own reverse tape.
+    Sibling strands run as coroutines in LOCK-STEP at the granularity of library calls: every strand runs up to its next
+    C-ABI call and parks; the sweep then issues the parked calls - those of equal entry point on the same lane between
+    hrf_group_begin / hrf_group_end, which merges them into ONE multi-problem launch (the three sensor streams at equal
+    depth) - and resumes everybody.  BatchNorm exchanges (SyncBN) park the same way and are flushed as one packed
+    collective when no strand can run.  The backward pass runs the recorded strand tree in reverse through the same
+    machinery, so the data-gradient launches of sibling strands merge too."""
+    __slots__ = ('lane', 'tape', 'glet', 'pending', 'wait', 'parent', 'kids_alive', 'cur')
+
+    def __init__(self, lane, parent=None):
+        self.lane, self.parent = lane, parent
+        self.tape = []
+        self.glet = None
+        self.pending = None           # (name, fn, args) of the parked library call
+        self.wait = None              # None: runnable | 'call' | 'sync' | 'kids'
+        self.kids_alive = 0
+        self.cur = lane               # lane in effect when the strand parked (restored on resume)
+
+
+# entry points whose launches may be merged with an equal launch of a sibling strand (csrc/hrf_group.h: the kernels take
+# their arguments as an array of up to HRF_GROUP_MAX problems, blockIdx.z selects the problem)
+_GROUPABLE = frozenset((
+    'hrf_conv_fwd', 'hrf_conv_bwd_data', 'hrf_dwconv_fwd', 'hrf_dwconv_bwd_data', 'hrf_dwconv_bwd_data_weight',
+    'hrf_attn_block_fwd', 'hrf_attn_block_bwd', 'hrf_affine_act_res', 'hrf_act_bwd', 'hrf_scale_add', 'hrf_ln_stats',
+    'hrf_ln_bwd', 'hrf_window_attn_fwd', 'hrf_window_attn_bwd', 'hrf_fuse_sum', 'hrf_bilinear_up_bwd'))
+_NO_PARK = frozenset(_lib._RAW_RETURN) | frozenset((
+    'hrf_wgrad_group_begin', 'hrf_wgrad_group_end', 'hrf_group_begin', 'hrf_group_end', 'hrf_debug_knob'))
+
+
+class _LibProxy:
+    """What the ops see as `ctx.L`: inside a lock-step sweep a library call parks its strand (the sweep issues it, possibly
+    merged with its siblings' calls); everywhere else it goes straight to the library."""
+
+    def __init__(self, ctx, lib):
+        self.__dict__['_ctx'] = ctx
+        self.__dict__['_lib'] = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self.__dict__['_lib'], name)
+        if name in _NO_PARK:
+            self.__dict__[name] = fn
+            return fn
+        ctx = self.__dict__['_ctx']
+
+        def call(*a):
+            s = ctx._parkable()
+            if s is None:
+                return fn(*a)
+            s.pending = (name, fn, a)
+            s.wait = 'call'
+            ctx._yield(s)
+        self.__dict__[name] = call
+        return call
+
+
 class Ctx:
-    """Per-forward execution context: library handle, current lane/stream, mode, reverse tape."""
+    """Per-forward execution context: library handle, current lane/stream, mode, strand tree with the reverse tapes."""
 
     def __init__(self, owner, training, record):
-        self.L = owner._lib_handle()
+        self.lib = owner._lib_handle()
+        self.L = _LibProxy(self, self.lib)
         self.training = training
         self.record = record            # build the backward tape?
-        self.tape = []
         self.owner = owner
         self.group = owner.sync_group if training else None
         self.world = owner.sync_world if (training and owner.sync_group is not None) else 1
@@ -178,6 +275,8 @@ class Ctx:
         self.main = Lane(torch.cuda.current_stream() if torch.cuda.is_available() else None)
         self.cur = self.main
         self.stream = self.main.ptr
+        self.root = Strand(self.main)
+        self.strand = self.root
         self._free = list(owner._lane_pool()) if self.multi else []
         self._side_i = 0
         self._side_used = {}
@@ -186,75 +285,198 @@ class Ctx:
         self.probe = [] if owner.__dict__.get('_relu_probe') else None
         self.n_collectives = 0
         self.xhist = {}                 # (lanes in an exchange, hub is the main lane) -> count
-        # SyncBN: exchanges of mutually independent BatchNorms are BATCHED (one collective for all of them): sibling lanes
-        # run as coroutines in lock-step (parallel()), each parking at its next exchange until the sweep is complete
         self.coll = self.group is not None and (self.world > 1 or force_collectives())
-        self.pending = []
-        self._glet = _greenlet if (self.coll and os.environ.get('HRF_SYNC_BATCH', '1') != '0' and not _LANE_COMMS) else None
+        self.pending = []               # forward BatchNorm exchanges parked by the strands (SyncBN)
+        self.bpending = []              # backward ones: (BNState, lane)
+        # lock-step strands need coroutines; HRF_LOCKSTEP=0 (or no greenlet) runs the bodies one after the other: no merged
+        # launches, and one SyncBN collective per BatchNorm
+        self._glet = _greenlet if os.environ.get('HRF_LOCKSTEP', '1') != '0' else None
+        self.sync_batch = self._glet is not None and os.environ.get('HRF_SYNC_BATCH', '1') != '0' and not _LANE_COMMS
+        self.merge = self._glet is not None and os.environ.get('HRF_GROUP', '1') != '0' and hasattr(self.lib, 'hrf_group_begin')
+        # equal-shape siblings share the current lane (their launches merge) instead of getting a stream each
+        self.bundle = self.merge and os.environ.get('HRF_BUNDLE', '1') != '0'
+        self._sweeper = None            # greenlet running the sweep (None: not inside parallel())
+        self._strands = []              # live strands of the running sweep, all levels
         self._xlane = None
+        self.n_merged = [0, 0]          # (merged launches issued, calls they carried): reported by bench.py
+
+    @property
+    def tape(self):
+        return self.root.tape
+
+    def schedule_desc(self):
+        """What this pass actually did (bench.py `config.sync_schedule`): not the environment's wish."""
+        if not self.coll:
+            return None
+        if _LANE_COMMS:
+            return 'one communicator per lane, unbatched exchanges (HRF_SYNC_LANE_COMMS=1)'
+        if self.sync_batch:
+            return f'packed exchanges on the main lane, lock-step strands (greenlet {getattr(_greenlet, "__version__", "?")})'
+        return 'one exchange per BatchNorm on the main lane (no lock-step: HRF_SYNC_BATCH=0 / HRF_LOCKSTEP=0)'
 
     # ---- tape ----------------------------------------------------------------------------------
     def push(self, fn, sync=None):
         """sync: BNState whose backward exchange (SyncBN) `fn` needs before it can run - run_backward batches those."""
         if self.record:
-            self.tape.append((fn, self.cur, sync))
+            self.strand.tape.append((fn, self.cur, sync))
 
-    # ---- lock-step execution of sibling lanes (SyncBN batching) ---------------------------------------------------
+    # ---- lock-step execution of sibling strands ---------------------------------------------------------------------
     def _resume(self, lane):
         self.cur, self.stream = lane, lane.ptr
         if self.multi and lane.stream is not None:
             torch.cuda.set_stream(lane.stream)
 
-    def parallel(self, lanes, bodies):
-        """Run bodies[i]() on lanes[i].  Normally one after the other (the lanes are HIP streams: the GPU overlaps them).
-        With SyncBN the bodies run as coroutines in LOCK-STEP: each one parks at its next BatchNorm exchange
-        (sync_wait), and when every sibling is parked (or done) ONE packed collective serves all of them - the three
-        sensor streams at equal depth, the branches of an HRModule, the chains of an exchange.  Nested calls (the
-        camera stage forking branch lanes while the modality stages run beside it) hand their parked children up to the
-        outer sweep, so the batch spans both levels."""
-        G = self._glet
-        if G is None or not self.training or len(bodies) <= 1:
-            for lane, body in zip(lanes, bodies):
-                with _LaneScope(self, lane):
-                    body()
-            return
-        me = G.getcurrent()
-        home = self.cur
-        nested = getattr(me, 'hrf_lane', None) is not None
+    def _parkable(self):
+        """The strand of the running coroutine when its library calls are to be parked, else None."""
+        if self._sweeper is None:
+            return None
+        g = self._glet.getcurrent()
+        return None if g is self._sweeper else getattr(g, 'hrf_strand', None)
 
-        def wrap(lane, body):
-            def run():
-                with _LaneScope(self, lane):
+    def _yield(self, s):
+        """Park strand `s` (the running coroutine) and hand control to the sweep; returns when the sweep resumes it."""
+        s.cur = self.cur
+        self._sweeper.switch()
+        self.strand = s
+        self._resume(s.cur)
+
+    def parallel(self, lanes, bodies, kids=None):
+        """Run bodies[i]() as a strand on lanes[i] (`kids`: the recorded strands whose tapes a backward pass re-runs).
+        Without coroutines, or for a single body, one after the other."""
+        me = self.strand
+        home = self.cur
+        fresh = kids is None
+        if fresh:
+            kids = [Strand(l, me) for l in lanes]
+            if self.record:
+                me.tape.append(('P', home, kids))
+        G = self._glet
+        if G is None or len(bodies) <= 1:
+            for k, body in zip(kids, bodies):
+                self.strand = k
+                with _LaneScope(self, k.lane):
                     body()
-            g = G.greenlet(run)
-            g.hrf_lane = lane
-            return g
-        alive = [wrap(l, b) for l, b in zip(lanes, bodies)]
-        while alive:
-            for g in list(alive):
-                g.switch()                               # until its next exchange (sync_wait parks it) or its end
-                if g.dead:
-                    alive.remove(g)
+            self.strand = me
+            return kids
+
+        def wrap(k, body):
+            def run():
+                self.strand = k
+                with _LaneScope(self, k.lane):
+                    body()
+            g = G.greenlet(run, parent=self._sweeper if self._sweeper is not None else G.getcurrent())
+            g.hrf_strand = k
+            k.glet, k.parent, k.wait, k.pending = g, me, None, None
+            return k
+        top = self._sweeper is None
+        if top:
+            self._sweeper = G.getcurrent()
+        for k, body in zip(kids, bodies):
+            self._strands.append(wrap(k, body))
+        me.kids_alive += len(kids)
+        if top:
+            try:
+                self._sweep()
+            finally:
+                self._sweeper = None
+                self._strands = []
+            self.strand = me
             self._resume(home)
-            if self.pending or alive:
-                if nested:
-                    me.parent.switch()                   # let the outer sweep finish; it flushes for everybody
-                    self._resume(home)
-                else:
+        else:
+            me.wait = 'kids'
+            while me.kids_alive > 0:
+                self._yield(me)
+            me.wait = None
+        return kids
+
+    def _sweep(self):
+        """Round-robin over the live strands of all levels: each runs to its next library call / exchange / end; then the
+        parked calls are issued (merged where siblings on one lane make the same call), and - when nothing can run - the
+        parked BatchNorm exchanges are flushed as ONE collective."""
+        strands = self._strands
+        while strands:
+            ran = False
+            for s in list(strands):
+                if s.wait is not None and not (s.wait == 'kids' and s.kids_alive == 0):
+                    continue
+                ran = True
+                self.strand = s
+                self._resume(s.cur)
+                s.glet.switch()
+                if s.glet.dead:
+                    strands.remove(s)
+                    if s.parent is not None:
+                        s.parent.kids_alive -= 1
+            issued = self._issue_round()
+            if not ran and not issued:
+                if self.pending:
                     self.flush_sync()
+                elif self.bpending:
+                    self._flush_bpending()
+                else:
+                    raise _lib.HRFuserHipError('lock-step scheduler: no strand can run and nothing is pending')
+                for s in strands:
+                    if s.wait == 'sync':
+                        s.wait = None
+
+    def _issue_round(self):
+        pend = [s for s in self._strands if s.wait == 'call']
+        if not pend:
+            return False
+        buckets = {}
+        for s in pend:
+            buckets.setdefault((s.cur.ptr, id(s.cur) if s.cur.stream is not None else 0, s.pending[0]), []).append(s)
+        lib = self.lib
+        for (ptr, _, name), ss in buckets.items():
+            if len(ss) > 1 and self.merge and name in _GROUPABLE:
+                if self.multi and ss[0].cur.stream is not None:
+                    torch.cuda.set_stream(ss[0].cur.stream)
+                lib.hrf_group_begin()
+                try:
+                    for s in ss:
+                        s.pending[1](*s.pending[2])
+                finally:
+                    lib.hrf_group_end(ptr)
+                self.n_merged[0] += 1
+                self.n_merged[1] += len(ss)
+            else:
+                for s in ss:
+                    if self.multi and s.cur.stream is not None:
+                        torch.cuda.set_stream(s.cur.stream)
+                    s.pending[1](*s.pending[2])
+            for s in ss:
+                s.pending, s.wait = None, None
+        return True
 
     def sync_wait(self, st):
         """Forward SyncBN exchange of `st`: parked until the lock-step sweep flushes, or flushed at once outside one."""
         st.lane = self.cur
         self.pending.append(st)
-        G = self._glet
-        me = G.getcurrent() if G is not None else None
-        if me is not None and getattr(me, 'hrf_lane', None) is not None:
-            lane = self.cur
-            me.parent.switch()
-            self._resume(lane)
+        s = self._parkable() if self.sync_batch else None
+        if s is not None:
+            s.wait = 'sync'
+            self._yield(s)
         else:
             self.flush_sync()
+
+    def sync_wait_bwd(self, st, lane):
+        """Backward counterpart: the exchange of (sum du, sum du*y) of `st`, needed by the tape entry about to run."""
+        if _LANE_COMMS:                                  # exchanged at once on the entry's own lane / communicator
+            self.flush_bwd([st], [lane])
+            return
+        self.bpending.append((st, lane))
+        s = self._parkable() if self.sync_batch else None
+        if s is not None:
+            s.wait = 'sync'
+            self._yield(s)
+        else:
+            self._flush_bpending()
+
+    def _flush_bpending(self):
+        items, self.bpending = self.bpending, []
+        todo = [(st, lane) for st, lane in items if not st.bx_done]
+        if todo:
+            self.flush_bwd([st for st, _ in todo], [lane for _, lane in todo])
 
     def _exchange(self, sts, lanes, pack_ptrs, finalize):
         """One packed collective for the BatchNorms `sts`, issued on the main lane between the lanes involved (every
@@ -276,7 +498,7 @@ class Ctx:
             packed = _keep(torch.empty(total, device=sts[0].raw.device, dtype=torch.float64))
             ptrs = (ctypes.c_void_p * n)(*pack_ptrs)
             cs = (ctypes.c_int * n)(*[st.C for st in sts])
-            self.L.hrf_bn_pack(ptrs, cs, n, packed, self.stream)
+            self.lib.hrf_bn_pack(ptrs, cs, n, packed, self.stream)
             self._xlane = hub
             finalize(packed)
             self._xlane = None
@@ -293,6 +515,7 @@ class Ctx:
             return
         P = _lib._ptr
         box = []
+        home, hstrand = self.cur, self.strand
 
         def fin(packed):
             self.all_reduce(packed)
@@ -306,12 +529,15 @@ class Ctx:
             if not _FIN_ONLOAD:
                 with _LaneScope(self, st.lane):
                     _finalize_now(self, st)
+        self.strand = hstrand
+        self._resume(home)
 
     def flush_bwd(self, sts, lanes):
         """Backward SyncBN exchange of (sum du, sum du*y) for all of `sts` in one collective; the data-gradient kernels
         of the producing convolutions derive their coefficients on load from the packed sums (bn_backward_coef)."""
         P = _lib._ptr
         box = []
+        home, hstrand = self.cur, self.strand
 
         def fin(packed):
             # no rank-local copy: dgamma / dbeta come from the all-reduced sums, scaled by 1/world (hrf_bn_bfin_t.pgrad_scale);
@@ -324,6 +550,8 @@ class Ctx:
             st.bpacked = (box[0][0], box[0][1], off)
             off += 2 * st.C
             st.bx_done = True
+        self.strand = hstrand
+        self._resume(home)
 
     def all_reduce(self, t):
         if self.coll:
@@ -334,10 +562,10 @@ class Ctx:
             dist.all_reduce(t, group=group)
             self.n_collectives += 1
 
-
     # ---- lanes ---------------------------------------------------------------------------------
-    def fork(self, n):
-        """n sibling lanes that start after everything enqueued so far on the current lane."""
+    def fork(self, n, keep_first=False):
+        """n sibling lanes that start after everything enqueued so far on the current lane.  keep_first: the first
+        sibling stays on the current lane (its launches can then merge with equal-shape strands bundled on that lane)."""
         # lanes are always direct children of the main lane: nested stream forks crash hipGraph
         # capture on ROCm 7.x, and a flat fork/join schedule expresses all the parallelism we need
         if n > 1 and not self.multi and self._glet is not None and self.cur is self.main:
@@ -346,34 +574,48 @@ class Ctx:
             uniq = [Lane(None) for _ in range(n)]
             for l in uniq:
                 l.ptr = self.cur.ptr        # (HRF_LANES=0 on a GPU: logical lanes launch on the parent's stream)
+            if keep_first:
+                uniq[0] = self.cur
             if self.record:
-                self.tape.append(('F', self.cur, uniq))
+                self.strand.tape.append(('F', self.cur, [l for l in uniq if l is not self.cur]))
             return uniq
         if not self.multi or n <= 1 or self.cur is not self.main:
             return [self.cur] * n
+        first = [self.cur] if keep_first else []
+        n -= len(first)
         m = n if _MAX_LANES <= 0 else min(n, _MAX_LANES)      # HRF_MAX_LANES: fewer streams than siblings
         while len(self._free) < m:
             self._free.append(self.owner._lane_pool(grow=True))
         uniq = [self._free.pop() for _ in range(m)]
         for k in uniq:
             k.stream.wait_stream(self.cur.stream)
-        if self.record:
-            self.tape.append(('F', self.cur, uniq))
-        return [uniq[i % m] for i in range(n)]
+        if self.record and uniq:
+            self.strand.tape.append(('F', self.cur, uniq))
+        return first + [uniq[i % m] for i in range(n)]
+
+    def bundle_lanes(self, n):
+        """Lanes for n strands of EQUAL shape (camera stem + modality stems, the modality stages beside the camera stage):
+        all on the current lane when launch merging is on - their equal calls become one multi-problem launch, in order on
+        one queue, no cross-queue edges - otherwise a stream each."""
+        if self.bundle:
+            return [self.cur] * n
+        return self.fork(n)
 
     def join(self, kids):
         """The current lane continues after all sibling lanes have finished."""
-        if len(kids) > 1 and not self.multi and kids[0] is not self.cur and kids[0].stream is None:
+        kids = [k for k in dict.fromkeys(kids) if k is not self.cur]     # lanes may repeat (HRF_MAX_LANES, bundles)
+        if not kids:
+            return
+        if kids[0].stream is None:                                       # logical lanes
             if self.record:
-                self.tape.append(('J', self.cur, list(dict.fromkeys(kids))))
+                self.strand.tape.append(('J', self.cur, kids))
             return
-        if not self.multi or len(kids) <= 1 or kids[0] is self.cur:
+        if not self.multi:
             return
-        kids = list(dict.fromkeys(kids))                    # lanes may repeat under HRF_MAX_LANES
         for k in kids:
             self.cur.stream.wait_stream(k.stream)
         if self.record:
-            self.tape.append(('J', self.cur, kids))
+            self.strand.tape.append(('J', self.cur, kids))
         self._free.extend(kids)
 
     def on(self, lane):
@@ -422,6 +664,32 @@ class Ctx:
                         self.L.hrf_wgrad_group_end(self.stream)
         self._side_i += k
 
+    def _run_tape(self, strand):
+        """Reverse pass over one strand's tape (runs inside that strand's coroutine, or at top level for the root)."""
+        tape = strand.tape
+        flush_n = self._flush_n if strand is self.root else 0
+        while tape:
+            e = tape.pop()
+            if e[0] == 'J':                     # reverse of a join = fork
+                for k in e[2]:
+                    if self.multi and k.stream is not None:
+                        k.stream.wait_stream(e[1].stream)
+            elif e[0] == 'F':                   # reverse of a fork = join
+                for k in e[2]:
+                    if self.multi and k.stream is not None:
+                        e[1].stream.wait_stream(k.stream)
+                if flush_n and e[1] is self.main and len(self._deferred) >= flush_n:
+                    self._flush_deferred()
+            elif e[0] == 'P':                   # sibling strands: their tapes run in lock-step, like their forward bodies
+                kids = e[2]
+                self.parallel([k.lane for k in kids], [lambda k=k: self._run_tape(k) for k in kids], kids=kids)
+            else:
+                fn, lane, sync = e
+                if sync is not None and self.coll and sync.train and not sync.bx_done:
+                    self.sync_wait_bwd(sync, lane)
+                with _LaneScope(self, lane):
+                    fn()
+
     def run_backward(self):
         eng = self.owner._engine()
         if getattr(self, 'gen', None) is not None and self.gen != getattr(eng, 'gen', self.gen):
@@ -430,68 +698,26 @@ class Ctx:
                 'BatchNorm statistics slots and step buffers of its engine, so `net(x1); net(x2); loss.backward()` would '
                 'back-propagate x1 with the statistics of x2.  Run backward before the next forward of the same module '
                 '(or use two module instances).')
-        tape = self.tape
-        self.tape = []
         use_keep_list(self.owner._engine().keep)
         self.owner._engine().fs_prepare()
         # HRF_WGRAD=flush: every time all lanes are joined into the main lane and enough weight gradients are queued,
         # issue them (grouped) on low-priority side lanes forked from main - they fill the CUs the latency-bound
         # data-gradient chain leaves idle instead of forming a phase of their own at the end
-        flush_n = int(os.environ.get('HRF_WGRAD_FLUSH', '48')) if (self.multi and os.environ.get('HRF_WGRAD', 'defer') == 'flush') else 0
+        self._flush_n = int(os.environ.get('HRF_WGRAD_FLUSH', '48')) if (self.multi and os.environ.get('HRF_WGRAD', 'defer') == 'flush') else 0
+        entry = torch.cuda.current_stream() if self.multi else None      # (autograd calls this from its own thread / stream)
         if self.multi:
-            self.main.stream.wait_stream(torch.cuda.current_stream())
-        # SyncBN: tape entries whose BatchNorm still needs its backward exchange are PARKED (one per lane - entries of
-        # other lanes are independent of them and keep running) and released together: ONE packed collective for all of
-        # them.  Program order inside a lane is kept: the next entry of a parked lane releases the batch first.
-        active, parked = [], []
-
-        def release():
-            if not parked:
-                return
-            todo = [e[2] for e in parked if not e[2].bx_done]
-            if todo:
-                # only the lanes of the parked entries take part (an entry's inputs are ordered before it on ITS lane)
-                self.flush_bwd(todo, [e[1] for e in parked if not e[2].bx_done])
-            for fn, lane, _ in parked:
-                with _LaneScope(self, lane):
-                    fn()
-            parked.clear()
-        while tape:
-            e = tape.pop()
-            if e[0] == 'J':                     # reverse of a join = fork
-                release()
-                for k in e[2]:
-                    if self.multi and k.stream is not None:
-                        k.stream.wait_stream(e[1].stream)
-                    active.append(k)
-            elif e[0] == 'F':                   # reverse of a fork = join
-                release()
-                for k in e[2]:
-                    if self.multi and k.stream is not None:
-                        e[1].stream.wait_stream(k.stream)
-                    if k in active:
-                        active.remove(k)
-                if flush_n and e[1] is self.main and len(self._deferred) >= flush_n:
-                    self._flush_deferred()
-            else:
-                fn, lane, sync = e
-                if any(lane is p[1] for p in parked):
-                    release()
-                if sync is not None and self.coll and sync.train and not sync.bx_done:
-                    if _LANE_COMMS:                  # exchanged at once on the entry's own lane / communicator
-                        self.flush_bwd([sync], [lane])
-                    else:
-                        parked.append(e)
-                        continue
-                with _LaneScope(self, lane):
-                    fn()
-        release()
+            self.main.stream.wait_stream(entry)
+        # the strand tree of the forward pass, in reverse: 'P' entries re-run the sibling strands' tapes in lock-step
+        # (merged data-gradient launches; SyncBN backward exchanges parked and flushed as ONE packed collective)
+        self.strand = self.root
+        self._run_tape(self.root)
         if self._deferred and os.environ.get('HRF_DEBUG_SKIP_WGRAD') == '1':
             self._deferred = []                 # timing experiments only: drops the weight-gradient phase
         if self._deferred:
             items, self._deferred = self._deferred, []
             k = int(os.environ.get('HRF_WGRAD_LANES', '4'))
             group = os.environ.get('HRF_WGRAD_GROUP', '1') != '0'
+            self.strand = self.root
             lanes = self.fork(k)
             parts = _balance(items, k) if os.environ.get('HRF_WGRAD_BALANCE', '1') != '0' else \
                 [[fn for _, fn in items[j::k]] for j in range(k)]
@@ -508,6 +734,7 @@ class Ctx:
                         if group:
                             self.L.hrf_wgrad_group_end(self.stream)
             self.join(lanes)
+            self.root.tape.clear()              # (fork / join recorded markers: the pass is over)
         if self.multi:
             for lane in self._side_used.values():
                 self.main.stream.wait_stream(lane.stream)
@@ -515,7 +742,9 @@ class Ctx:
         with _LaneScope(self, self.main):
             self.owner._engine().fold_grads(self.L, self.main.ptr)
         if self.multi:
-            torch.cuda.current_stream().wait_stream(self.main.stream)
+            torch.cuda.set_stream(entry)
+            entry.wait_stream(self.main.stream)
+
 
 def _balance(items, k):
     """Longest-processing-time-first split of (cost, fn) leaf launches over k lanes (the lanes of the deferred
@@ -530,6 +759,9 @@ def _balance(items, k):
 
 
 class _LaneScope:
+    """`with ctx.on(lane)`: launches (and torch ops) go to `lane` inside the block.  Explicit set_stream calls instead of
+    torch.cuda.stream(): strands are suspended inside such blocks, and each resume re-establishes its own lane."""
+
     def __init__(self, ctx, lane):
         self.ctx, self.lane = ctx, lane
 
@@ -537,17 +769,15 @@ class _LaneScope:
         c = self.ctx
         self.prev = c.cur
         c.cur, c.stream = self.lane, self.lane.ptr
-        self.tctx = None
         if c.multi and self.lane.stream is not None:
-            self.tctx = torch.cuda.stream(self.lane.stream)
-            self.tctx.__enter__()
+            torch.cuda.set_stream(self.lane.stream)
         return self.lane
 
     def __exit__(self, *exc):
-        if self.tctx is not None:
-            self.tctx.__exit__(*exc)
         c = self.ctx
         c.cur, c.stream = self.prev, self.prev.ptr
+        if c.multi and self.prev.stream is not None:
+            torch.cuda.set_stream(self.prev.stream)
         return False
 
 
@@ -665,7 +895,13 @@ def take_fin(ctx, st, limit=FIN_MAXC):
     if st is None or st.pending is None:
         return None
     if st.C > limit:
-        _finalize_now(ctx, st)
+        # a later consumer with a smaller `limit` than the designated writer's: scale / shift are in memory already
+        # (ordered by the lane or the join between the two consumers) - finalising again would apply the running-statistics
+        # momentum update twice in one step
+        if st.pending == 'fwd':
+            _finalize_now(ctx, st)
+        else:
+            st.pending = None
         return None
     bn = st.bn
     mom = bn.momentum if bn.momentum is not None else 0.1
@@ -1006,7 +1242,11 @@ def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, r
                 a._keep_bfin = bfin                     # the struct holds a raw pointer to it
                 a.bfin1 = ctypes.addressof(bfin)
         if cross:
-            if res.needs_grad:
+            # every gradient buffer gets exactly ONE write from this launch: when the residual row IS the query row (the
+            # k = 0 modality of a fusion block: acc starts as x) the residual gradient rides on the dq write (dq_add_res)
+            # instead of a second, aliasing dres store (the two stores overwrote each other for M = 1)
+            res_is_q = res is xq
+            if res.needs_grad and not res_is_q:
                 g, acc = res.grad_target()
                 a.dres, a.dres_acc = P(g), acc
             if xkv.needs_grad:
@@ -1014,7 +1254,7 @@ def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, r
                 a.dkv, a.dkv_acc, a.dkv_add_res = P(g), acc, 1 if res2 is not None else 0
             if xq.needs_grad:
                 g, acc = xq.grad_target()
-                a.dq, a.dq_acc, a.dq_add_res = P(g), acc, 0
+                a.dq, a.dq_acc, a.dq_add_res = P(g), acc, 1 if res_is_q else 0
         elif xq.needs_grad:
             assert res is xq
             g, acc = xq.grad_target()

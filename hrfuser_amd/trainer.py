@@ -80,7 +80,7 @@ class Trainer:
         step = (n + nb - 1) // nb
         return [(i, min(n, i + step)) for i in range(0, n, step)]
 
-    def _step_impl(self, x, mods, cots):
+    def _step_impl(self, x, mods, cots, grads_only=False):
         net = self.net
         eng = net._engine()
         L = net._lib_handle()
@@ -97,14 +97,17 @@ class Trainer:
                 ncoll += 1
         self.collectives_per_step = ncoll
         self.exchange_hist = dict(ctx.xhist)
-        self.optimizer_step()
+        self.sync_schedule = ctx.schedule_desc()
+        if not grads_only:
+            self.optimizer_step()
         return outs
 
-    def step(self, x, mods, cots):
-        """One eager training step (forward, backward, gradient exchange, AdamW)."""
+    def step(self, x, mods, cots, grads_only=False):
+        """One eager training step (forward, backward, gradient exchange, AdamW; grads_only: no optimizer step - the
+        all-reduced gradient arena of the step stays in net._engine().flat_g)."""
         if not self._ready:
             self._setup(x.device)
-        return self._step_impl(x, mods, cots)
+        return self._step_impl(x, mods, cots, grads_only)
 
     # -------------------------------------------------------------------------------------------
     def capture(self, x, mods, cots, warmup=2):

@@ -319,6 +319,24 @@ int hrf_wgrad_group_end(void* stream);
  * Cin, Cout, H, W, stride, KH); returns the number of rows written and clears the log. */
 long hrf_wgrad_group_report(double* out, long cap_rows);
 
+/* Multi-problem launches for the EQUAL-SHAPE layers of sibling sensor streams.  The reference runs the camera stream's
+ * finest branch and the M modality streams through layers of identical shape with different weights
+ * (hrfuser_hrformer_based.py:536-544 stems, :564-565 stage 2 || LidarStageB, :585-586 stage 3 || LidarStageC), each as its own
+ * sequence of ATen launches.  Here the hot kernels take their arguments as an array of up to 4 problems (blockIdx.z selects
+ * the problem; csrc/hrf_group.h): between hrf_group_begin() and hrf_group_end(stream) the launches of the calls to
+ *   hrf_conv_fwd, hrf_conv_bwd_data, hrf_dwconv_fwd, hrf_dwconv_bwd_data(_weight), hrf_attn_block_fwd / _bwd,
+ *   hrf_window_attn_fwd / _bwd, hrf_affine_act_res, hrf_act_bwd, hrf_scale_add, hrf_ln_stats, hrf_ln_bwd, hrf_fuse_sum,
+ *   hrf_bilinear_up_bwd
+ * are queued (their `stream` argument is ignored) and hrf_group_end issues them on `stream`: launches of the same kernel
+ * instantiation and launch geometry that sit at the same position of DIFFERENT calls become ONE launch; everything else is
+ * issued as it would have been, the launches of one call in their order.  The caller brackets MUTUALLY INDEPENDENT calls
+ * only.  Results are identical to separate launches.  Per-thread state; begin / end must pair on one thread.
+ * hrf_group_count(what): process-wide totals since load - 0 launches issued by hrf_group_end, 1 calls' launches they
+ * carried, 2 hrf_group_end calls (measurement aid). */
+int hrf_group_begin(void);
+int hrf_group_end(void* stream);
+long hrf_group_count(int what);
+
 /* Device-side input pipeline: the image side of Normalize -> RandomFlip -> Pad(size_divisor) -> RandomDrop ->
  * DefaultFormatBundle (mmdet/datasets/pipelines/transforms.py:706-753,440-466,649-664,487-514; formating.py:212-227) for ONE
  * sensor of a batch in one pass: in = [B][H0][W0][C] HWC images (float32, or uint8 when is_u8), out = [B][Hp][Wp][C]

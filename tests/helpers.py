@@ -47,19 +47,6 @@ def rel_l2(a, b, floor=0.0):
     return float((a - b).norm() / (b.norm() + floor))
 
 
-def grad_close(a, b, tol=1e-3, max_flip_frac=0.02):
-    """Gradient comparison robust to fp32 ReLU-mask flips: a pre-activation within fp32 noise of 0
-    may land on either side in two correct fp32 implementations, which changes the gradient inside
-    ONE receptive field.  Pass if max-rel error <= tol, or if the elements beyond tol are a small
-    localized fraction of the tensor (and the tensor-wide rel-L2 stays small)."""
-    a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    scale = float(b.abs().max()) + 1e-30
-    bad = ((a - b).abs() > tol * scale).double().mean().item()
-    if bad == 0.0:
-        return True
-    return bad <= max_flip_frac and float((a - b).norm() / (b.norm() + 1e-30)) < 0.1
-
-
 def disable_stochastic(*nets):
     for net in nets:
         for m in net.modules():
@@ -76,9 +63,10 @@ def load_cfgs():
         return json.load(fh)
 
 
-def build_pair(tag, device, seed=0, edit=None):
+def build_pair(tag, device, seed=0, edit=None, stochastic=False):
     """(product backbone on `device`, oracle on CPU) with identical seeded parameters.  edit(cfg): optional in-place
-    change of the config dict before both are built (e.g. fewer modules per stage for a quick data-parallel test)."""
+    change of the config dict before both are built (e.g. fewer modules per stage for a quick data-parallel test).
+    stochastic: keep Dropout / DropPath live (the caller pins their draws)."""
     from hrfuser_amd import build_backbone
     cfg = copy.deepcopy(load_cfgs()[tag])
     if edit is not None:
@@ -90,8 +78,49 @@ def build_pair(tag, device, seed=0, edit=None):
     net = build_backbone(copy.deepcopy(cfg))
     net.load_state_dict(orc.state_dict())
     net.to(device)
-    disable_stochastic(net, orc)
+    if not stochastic:
+        disable_stochastic(net, orc)
     return net, orc, cfg
+
+
+def pin_fusion_stochastic(net, oracles, B, H, W, seed=21, p_drop=0.1, keep=0.8):
+    """Pin the random draws of every fusion block of a WHOLE backbone on both sides: per block and modality
+    a Dropout keep-mask with real zeros, per residual path an mmcv DropPath scale floor(keep + U) / keep per sample.
+    Product: the block's own `_droppath_scale` returns its scales in order and the engine serves the masks from one
+    FIFO per tensor shape (the fusion stages run one after the other, their branches differ in shape - so the order
+    inside a queue is the reference's order even though sibling branches execute in lock-step).  Oracles: the same
+    tensors at the reference's call sites (hrfuser_hrformer_based.py:147-150,311-317), re-usable across runs."""
+    g = torch.Generator().manual_seed(seed)
+    dev = next(net.parameters()).device
+    fifo = {}
+    for tag in ('fusion_a', 'fusion_b', 'fusion_c'):
+        for i, pb in enumerate(getattr(net, tag)):
+            M = pb.num_fused_modalities
+            C = pb.norm3.weight.numel()
+            Hi, Wi = (H // 4) >> i, (W // 4) >> i
+            masks = [(torch.rand(B, Hi, Wi, C, generator=g) >= p_drop).float() for _ in range(M)]
+            scales = [torch.floor(keep + torch.rand(B, generator=g)) / keep for _ in range(M + 1)]
+            scales[i % (M + 1)][0] = 0.0                                 # every block really drops a sample on one path
+            for m in masks:
+                fifo.setdefault((B, Hi, Wi, C), []).append(m.to(dev))
+            pq = [s.to(dev) for s in scales]
+            pb._droppath_scale = (lambda q: (lambda ctx, Bn, d: q.pop(0)))(pq)
+            for orc in oracles:
+                ob = getattr(orc, tag)[i]
+                dt = next(orc.parameters()).dtype
+                oq, cnt = [s.to(dt) for s in scales], [0]
+
+                def pinned_droppath(x, oq=oq, cnt=cnt):
+                    s = oq[cnt[0] % len(oq)]
+                    cnt[0] += 1
+                    return x * s.view(-1, *([1] * (x.ndim - 1)))
+                ob.drop_path.forward = pinned_droppath
+                for k in range(M):
+                    mw = O.window_partition(masks[k].reshape(B, Hi * Wi, C).to(dt), Hi, Wi)
+                    ob.attn[k].attn.proj_drop.forward = (lambda mk: (lambda x: x * mk / (1.0 - p_drop)))(mw)
+    eng = net._engine()
+    eng.dropout_mask = lambda shape, p: fifo[tuple(shape)].pop(0).reshape(shape)
+    return fifo
 
 
 class PinnedReLU:
@@ -103,9 +132,10 @@ class PinnedReLU:
     flip-free: the product records the sign mask of every ReLU it applied (runtime.collect_relu_masks), and while this
     context is active `torch.nn.functional.relu` (reached by F.relu and nn.ReLU alike) returns `u * mask_product`.
     The mask of a call is found by content: the recorded mask of the same shape that agrees best with (u > 0); the
-    agreement must be essentially total (<= max(4, 2e-3 * numel) differing elements), so a wrong pairing or a
+    agreement must be essentially total (<= max(4, 1e-4 * numel) differing elements per site), so a wrong pairing or a
     genuinely different activation pattern fails the test instead of being pinned over.  `flips` counts the imposed
-    differences."""
+    differences; check() asserts what is measured on MI355X (0-11 flips per run): the TOTAL over all sites stays below
+    max(3, 1e-5 * total elements) - a kernel that mis-signs 0.1 % of a map cannot be pinned over."""
 
     def __init__(self, masks):
         self.by_shape = {}
@@ -113,6 +143,12 @@ class PinnedReLU:
             self.by_shape.setdefault(tuple(m.shape), []).append(m.detach().cpu())
         self.flips = 0
         self.sites = 0
+        self.numel = 0
+
+    def check(self, tag=''):
+        lim = max(3, 1e-5 * self.numel)
+        assert self.flips <= lim, (tag, f'{self.flips} pinned ReLU decisions over {self.sites} sites / {self.numel} elements (limit {lim:.1f})')
+        return self.flips
 
     def _relu(self, u, inplace=False):
         cands = self.by_shape.get(tuple(u.shape))
@@ -123,9 +159,10 @@ class PinnedReLU:
             d = int((m != tgt).sum())
             if bad is None or d < bad:
                 best, bad = m, d
-        assert bad <= max(4, 2e-3 * tgt.numel()), f'ReLU site {tuple(u.shape)}: best product mask differs in {bad} elements'
+        assert bad <= max(4, 1e-4 * tgt.numel()), f'ReLU site {tuple(u.shape)}: best product mask differs in {bad} elements'
         self.flips += bad
         self.sites += 1
+        self.numel += tgt.numel()
         return u * best.to(u.dtype)
 
     def __enter__(self):
@@ -176,22 +213,3 @@ def tight_grad_gate(named_prod, named_ref64, named_ref32, tol=1e-3, tag=''):
     print(f'[grad gate {tag}] {len(ref)} tensors, {zeros} analytically zero, worst rel-L2 {worst[0]:.2e} ({worst[1]}), '
           f'{above} above {tol:g} (all within 3x the oracle\'s own fp32 error)')
     return worst, above
-
-
-def grad_check(prod_named, orc_named, tol=1e-3, abs_frac=2e-3):
-    """Per-tensor gradient gate: rel-L2 <= tol, with an absolute floor for analytically-zero
-    gradients (k-bias, biases in front of a train-mode BN: SURVEY App. E)."""
-    pb = {k: v for k, v in orc_named if v.grad is not None}
-    pa = dict(prod_named)
-    gscale = max(float(v.grad.abs().max()) for v in pb.values())
-    worst = (0.0, '')
-    for k, q in pb.items():
-        g = pa[k].grad
-        assert g is not None, k
-        err = float((g.detach().double().cpu() - q.grad.double()).norm())
-        den = float(q.grad.double().norm()) + abs_frac * gscale * (q.numel() ** 0.5)
-        e = err / den
-        if e > worst[0]:
-            worst = (e, k)
-    assert worst[0] <= tol, worst
-    return worst

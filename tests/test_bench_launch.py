@@ -1,0 +1,65 @@
+"""bench.py starts its own ranks: `python bench.py --gpus N` without a launcher must form the N-rank job the
+reference's tools/dist_train.sh:22-24 forms (one process per GPU), before anything touches the GPU, and fail CLEANLY when the
+node has fewer GPUs.  GPU: the whole N = 2 flow on one GPU (ranks share GPU 0 over gloo: SyncBN exchanges, gradient
+all-reduce and the schedule A/B child run through the real kernels)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_rank_command_and_flags():
+    import bench
+    cmd = bench.rank_command(['--gpus', '8', '--steps', '20', '--warmup', '5'], 8, 29511)
+    assert cmd[0] == sys.executable and cmd[1:3] == ['-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and '--nproc-per-node=8' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29511'
+    i = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[i + 1:] == ['--gpus', '8', '--steps', '20', '--warmup', '5']
+    assert bench.strip_flag(['--a', '--dump-kernels', 'x.json', '--b'], '--dump-kernels', True) == ['--a', '--b']
+    assert bench.strip_flag(['--a', '--dump-kernels=x.json', '--b'], '--dump-kernels', True) == ['--a', '--b']
+    assert bench.strip_flag(['--a', '--no-graph'], '--no-graph') == ['--a']
+    args = bench.parse(['--gpus', '4'])
+    assert args.gpus == 4 and args.backend == 'nccl' and not args.sync_ab_child
+
+
+def test_too_few_gpus_fails_cleanly():
+    """No GPU here (and one on the GPU box): `--gpus 2` must say so and exit non-zero - not assert, not hang, not spawn."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('node has two GPUs')
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 3, (p.returncode, p.stderr[-500:])
+    assert 'needs 2 GPUs' in p.stderr and 'Traceback' not in p.stderr and 'AssertionError' not in p.stderr
+    assert p.stdout.strip() == ''
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_gloo():
+    """N = 2 end to end on ONE GPU: self-launch, SyncBN (packed exchanges, lock-step strands), gradient all-reduce, JSON relay,
+    and the A/B child of the per-lane-communicator schedule with its gradient-equivalence check - over gloo (RCCL refuses two
+    ranks on one device), eager launches."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+                        '--height', '64', '--width', '96', '--no-roofline', '--sync-ab-timeout', '600'],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-1000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 4 and line['finite'] is True
+    assert line['config']['collectives_per_step'] > 4 and 'packed exchanges' in line['config']['sync_schedule']
+    ab = line['sync_ab']
+    assert 'error' not in ab, ab
+    assert ab['grad_rel_l2_vs_main_lane'] < 1e-6 and ab['ms_per_step'] > 0
+    print(json.dumps({k: line[k] for k in ('value', 'ms_per_step', 'sync_ab')}))

@@ -7,20 +7,25 @@ import pytest
 import torch
 
 import hrfuser_oracle as O
-from helpers import ROOT, build_pair, grad_check, relmax, use_backend
+from helpers import ROOT, build_pair, relmax, use_backend
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 
-def _fwd_bwd(tag, B, H, W, train, backend, check_grads=True, gold_key=None):
+def _fwd_bwd(tag, B, H, W, train, backend, check_grads=True, gold_key=None, pair=None, pin=None, unused=True):
+    """pair: (net, oracle, cfg) built by the caller (default: build_pair(tag)); pin(net, [oracles]): pins stochastic layers
+    on the product and on every oracle copy before anything runs."""
     from helpers import PinnedReLU, enable_relu_probe, relu_masks, rel_l2, tight_grad_gate
     dev = use_backend(backend)
-    net, orc, cfg = build_pair(tag, dev)
+    net, orc, cfg = pair(dev) if pair is not None else build_pair(tag, dev)
     mc = cfg.get('mod_in_channels', [3, 3])
     x, mods = O.seeded_inputs(B, H, W, mc, seed=1)
     net.train(train)
     orc.train(train)
     o64 = copy.deepcopy(orc).double()
+    o32 = copy.deepcopy(orc)
+    if pin is not None:
+        pin(net, [o64, o32])
     xa = x.clone().to(dev).requires_grad_(check_grads)
     ma = [m.clone().to(dev).requires_grad_(check_grads) for m in mods]
     enable_relu_probe(net)
@@ -46,7 +51,6 @@ def _fwd_bwd(tag, B, H, W, train, backend, check_grads=True, gold_key=None):
     masks = relu_masks(net)
     with PinnedReLU(masks) as pin64:
         yb = o64(xb, list(mb))
-    o32 = copy.deepcopy(orc)
     xc = x.clone().requires_grad_(True)
     mc32 = [m.clone().requires_grad_(True) for m in mods]
     with PinnedReLU(masks):
@@ -59,13 +63,16 @@ def _fwd_bwd(tag, B, H, W, train, backend, check_grads=True, gold_key=None):
     tol = 1e-3
     print(f'[{tag} train={train} {B}x{H}x{W}] {pin64.sites} ReLU sites pinned, {pin64.flips} element(s) where the '
           f'fp64 oracle would have decided differently')
+    pin64.check(f'{tag} train={train}')
     for name, p, q, r32 in zip(['img'] + [f'mod{k}' for k in range(len(ma))], [xa] + ma, [xb] + mb, [xc] + mc32):
         e, e_ref = rel_l2(p.grad, q.grad), rel_l2(r32.grad, q.grad)
         assert e <= max(tol, 3 * e_ref), (tag, train, name, e, e_ref)
     tight_grad_gate(net.named_parameters(), o64.named_parameters(), o32.named_parameters(), tol, f'{tag} train={train}')
     # quirk App. D-1: transition1.0.1 never receives a gradient
     pa = dict(net.named_parameters())
-    assert float(pa['transition1.0.1.weight'].grad.abs().max()) == 0.0
+    if unused:
+        assert float(pa['transition1.0.1.weight'].grad.abs().max()) == 0.0
+    return net, o64
 
 
 def test_wholenet_emul_eval():
@@ -226,26 +233,57 @@ def test_pre_neck_fusion_construction():
 @pytest.mark.gpu
 @pytest.mark.parametrize('train', [False, True])
 def test_pre_neck_fusion_gpu(train):
-    """hrfuser_hrformer_based.py:609-625: modality stage D, a fourth fusion after camera stage 4, ReLU."""
-    from helpers import grad_close
-    dev = use_backend('hip')
-    net, orc = _stage_d_pair(dev)
-    net.train(train)
-    orc.train(train)
-    x, mods = O.seeded_inputs(2, 64, 96, [3, 3], seed=1)
-    o64 = copy.deepcopy(orc).double()
-    xa = x.clone().to(dev).requires_grad_(train)
-    xb = x.double().requires_grad_(train)
-    with torch.set_grad_enabled(train):
-        ya = net(xa, [m.to(dev) for m in mods])
-        yb = o64(xb, [m.double() for m in mods])
-    for i, (p, q) in enumerate(zip(ya, yb)):
-        assert relmax(p, q) < 1e-3, (i, relmax(p, q))
-        assert float(p.detach().min()) >= 0.0                         # the final ReLU
-    if train:
-        g = torch.Generator().manual_seed(5)
-        cots = [torch.randn(t.shape, generator=g) for t in yb]
-        sum((t * c.to(dev)).sum() for t, c in zip(ya, cots)).backward()
-        sum((t * c.double()).sum() for t, c in zip(yb, cots)).backward()
-        assert grad_close(xa.grad, xb.grad, tol=5e-3)
-        grad_check(net.named_parameters(), o64.named_parameters(), tol=5e-3)
+    """hrfuser_hrformer_based.py:609-625: modality stage D, a fourth fusion after camera stage 4, ReLU - outputs at 1e-3 and
+    every gradient under the flip-free per-tensor gate of the whole-net tests."""
+    def pair(dev):
+        net, orc = _stage_d_pair(dev)
+        return net, orc, {'mod_in_channels': [3, 3]}
+    net, _ = _fwd_bwd('t_nus_bn_stage_d', 2, 64, 96, train, 'hip', pair=pair)
+    with torch.no_grad():
+        x, mods = O.seeded_inputs(2, 64, 96, [3, 3], seed=1)
+        ys = net(x.cuda(), [m.cuda() for m in mods])
+    assert all(float(y.min()) >= 0.0 for y in ys)                          # the final ReLU
+
+
+def _norm_eval_pair(dev):
+    def edit(cfg):
+        cfg['norm_eval'] = True
+    return build_pair('t_nus_bn', dev, edit=edit, stochastic=True)
+
+
+def test_norm_eval_flags():
+    """hrnet.py:588-596: train() with norm_eval=True leaves every BatchNorm in eval mode, everything else in training mode
+    (row a15) - the same flags on the product and on the oracle."""
+    net, orc, _ = _norm_eval_pair(torch.device('cpu'))
+    for m in (net, orc):
+        m.train()
+        bns = [k for k in m.modules() if isinstance(k, torch.nn.modules.batchnorm._BatchNorm)]
+        assert bns and not any(k.training for k in bns)
+        assert all(k.training for k in m.modules() if isinstance(k, torch.nn.Dropout))
+        m.eval()
+        assert not any(k.training for k in m.modules())
+
+
+@pytest.mark.gpu
+def test_norm_eval_train_gpu():
+    """The fine-tuning mode of the released checkpoints (README.md:110; hrnet.py:588-596): norm_eval=True, net.train() -
+    frozen-statistics BatchNorm (affine from the running statistics, no moment exchange, BatchNorm backward without batch
+    terms) mixed with LIVE Dropout / DropPath in one tape.  Draws pinned on both sides; outputs and every gradient against
+    the oracle built the same way; the running statistics must not move."""
+    from helpers import pin_fusion_stochastic
+    state = {}
+
+    def pair(dev):
+        net, orc, cfg = _norm_eval_pair(dev)
+        state['net'] = net
+        return net, orc, cfg
+
+    def pin(net, oracles):
+        assert not any(m.training for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
+        assert net.fusion_a[0].attn[0].attn.proj_drop.training and net.fusion_a[0].attn[0].attn.proj_drop.p == 0.1
+        state['before'] = {k: v.clone() for k, v in net.state_dict().items() if 'running_' in k or 'num_batches' in k}
+        state['fifo'] = pin_fusion_stochastic(net, oracles, 2, 64, 96)
+    net, _ = _fwd_bwd('t_nus_bn', 2, 64, 96, True, 'hip', pair=pair, pin=pin)
+    assert all(len(q) == 0 for q in state['fifo'].values())                # every pinned Dropout mask was consumed
+    after = net.state_dict()
+    assert state['before'] and all(torch.equal(v, after[k]) for k, v in state['before'].items())

@@ -14,7 +14,7 @@ import copy, os, sys, torch
 ROOT = %r
 for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29641', RANK='0', WORLD_SIZE='1', HRF_FORCE_COLLECTIVES='1')
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2] if len(sys.argv) > 2 else '29641', RANK='0', WORLD_SIZE='1', HRF_FORCE_COLLECTIVES='1')
 import torch.distributed as dist
 dev = torch.device('cuda:0')
 torch.cuda.set_device(dev)
@@ -23,14 +23,16 @@ import hrfuser_oracle as O
 from helpers import PinnedReLU, build_pair, enable_relu_probe, relu_masks, rel_l2, relmax, tight_grad_gate, use_backend
 from hrfuser_amd.trainer import Trainer
 use_backend('hip')
-net, orc, cfg = build_pair('t_nus', dev)                        # norm_cfg type SyncBN
+TAG = sys.argv[1] if len(sys.argv) > 1 else 't_nus'
+net, orc, cfg = build_pair(TAG, dev)                            # norm_cfg type SyncBN
+assert cfg['norm_cfg']['type'] == 'SyncBN'
 net.train(); orc.train()
 enable_relu_probe(net)
 B, H, W = 2, 64, 96
-x, mods = O.seeded_inputs(B, H, W, [3, 3], seed=1)
+x, mods = O.seeded_inputs(B, H, W, cfg.get('mod_in_channels', [3, 3]), seed=1)
 xd, md = x.to(dev), [m.to(dev) for m in mods]
 g = torch.Generator().manual_seed(5)
-cots = [torch.randn((B, H // 4 >> i, W // 4 >> i, c), generator=g) for i, c in enumerate((18, 36, 72, 144))]
+cots = [torch.randn((B, H // 4 >> i, W // 4 >> i, c), generator=g) for i, c in enumerate(cfg['extra']['stage4']['num_channels'])]
 cd = [c.to(dev) for c in cots]
 tr = Trainer(net, lr=0.0, weight_decay=0.0, group=dist.group.WORLD, world_size=1)    # lr 0: every step sees the same weights
 assert tr.force
@@ -51,7 +53,7 @@ for dt in (torch.float64, torch.float32):
 o64, ys = refs[0]
 for p, q in zip(y_eager, ys):
     assert relmax(p, q.permute(0, 2, 3, 1).detach()) < 1e-3
-tight_grad_gate(net.named_parameters(), o64.named_parameters(), refs[1][0].named_parameters(), 1e-3, 'SyncBN over 1-rank RCCL, eager')
+tight_grad_gate(net.named_parameters(), o64.named_parameters(), refs[1][0].named_parameters(), 1e-3, TAG + ' SyncBN over 1-rank RCCL, eager')
 # ---- the same step captured into ONE hipGraph (collectives inside) and replayed
 net.__dict__['_relu_probe'] = False
 tr.capture(xd, md, cd)
@@ -62,8 +64,8 @@ assert rel_l2(eng.flat_g, g_eager) < 1e-5, rel_l2(eng.flat_g, g_eager)
 for p, q in zip(tr._graph_outs, y_eager):
     assert relmax(p.t, q) < 1e-5
 lane_comms = os.environ.get('HRF_SYNC_LANE_COMMS', '0') == '1'   # experiment: unbatched exchanges on per-lane communicators
-assert 0 < ncoll <= (700 if lane_comms else 240), ncoll          # 330 BatchNorms x 2 directions, batched + 4 gradient buckets
-print('SYNCBN_GPU_OK collectives_per_step', ncoll)
+assert 0 < ncoll <= (800 if lane_comms else {'t_nus': 240, 'b_nus': 300, 't_stf': 300}[TAG]), ncoll   # 330-374 BatchNorms x 2 directions, batched + gradient buckets
+print('SYNCBN_GPU_OK', TAG, 'collectives_per_step', ncoll, tr.sync_schedule)
 sys.stdout.flush()
 dist.barrier()
 os._exit(0)
@@ -71,7 +73,11 @@ os._exit(0)
 
 
 @pytest.mark.gpu
-def test_syncbn_forced_rccl_eager_and_graph_gpu():
-    r = subprocess.run([sys.executable, '-c', WORKER % ROOT], capture_output=True, text=True, timeout=1500)
+@pytest.mark.parametrize('tag', ['t_nus', 'b_nus', 't_stf'])
+def test_syncbn_forced_rccl_eager_and_graph_gpu(tag):
+    """t_nus; b_nus (BatchNorms wider than HRF_FIN_MAXC take the stand-alone packed finalize forms); t_stf (M = 3: the widest
+    exchange batches)."""
+    port = {'t_nus': '29641', 'b_nus': '29643', 't_stf': '29645'}[tag]
+    r = subprocess.run([sys.executable, '-c', WORKER % ROOT, tag, port], capture_output=True, text=True, timeout=1500)
     sys.stdout.write(r.stdout[-3000:])
     assert 'SYNCBN_GPU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
