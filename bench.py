@@ -411,24 +411,49 @@ def main(argv=None):
         net.train()
 
     eager = None
+    module_graph = None
     if rank == 0 and world == 1 and not force_coll and not args.no_eager:
-        # what `backbone(img, mods)` + `loss.backward()` costs through torch.autograd (the drop-in route), eager launches
+        # what `backbone(img, mods)` + `loss.backward()` costs through torch.autograd (the drop-in route an mmdet user gets):
+        # with eager launches, and with the module-boundary hipGraphs (captured from the third call of a signature on)
+        def autograd_route(graphs, n_warm, n_timed):
+            saved = os.environ.get('HRF_MODULE_GRAPH')
+            os.environ['HRF_MODULE_GRAPH'] = '1' if graphs else '0'
+            try:
+                for it in range(n_warm + n_timed):
+                    if it == n_warm:
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                    ys = net(x, list(mods))
+                    loss = sum((y * c.permute(0, 3, 1, 2)).sum() for y, c in zip(ys, cots))
+                    eng.flat_g.zero_()
+                    loss.backward()
+                    trainer.optimizer_step()
+                torch.cuda.synchronize()
+                return round((time.perf_counter() - t1) / n_timed * 1e3, 3)
+            finally:
+                if saved is None:
+                    os.environ.pop('HRF_MODULE_GRAPH', None)
+                else:
+                    os.environ['HRF_MODULE_GRAPH'] = saved
         try:
-            for it in range(3 + 10):
-                if it == 3:
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                ys = net(x, list(mods))
-                loss = sum((y * c.permute(0, 3, 1, 2)).sum() for y, c in zip(ys, cots))
-                eng.flat_g.zero_()
-                loss.backward()
-                trainer.optimizer_step()
-            torch.cuda.synchronize()
-            eager = {'ms_per_step': round((time.perf_counter() - t1) / 10 * 1e3, 3),
+            eager = {'ms_per_step': autograd_route(False, 3, 10),
                      'route': 'backbone(img, mods) -> synthetic loss -> loss.backward() (torch.autograd.Function bridge) -> '
-                              'fused AdamW; eager launches, no hipGraph'}
+                              'fused AdamW; eager launches, no hipGraph (HRF_MODULE_GRAPH=0)'}
         except Exception as e:
             eager = {'error': f'{type(e).__name__}: {str(e)[:160]}'}
+            torch.cuda.synchronize()
+        try:
+            import warnings
+            with warnings.catch_warnings(record=True) as wl:
+                warnings.simplefilter('always')
+                ms = autograd_route(True, 5, 20)
+            ents = [e for k, e in net.__dict__.get('_hrf_graphs', {}).items() if k != '_setup']
+            module_graph = {'ms_per_step': ms, 'captured': any(e.fwd is not None and e.bwd is not None for e in ents),
+                            'route': 'the same calls; the module replays one forward and one backward hipGraph per input signature '
+                                     '(copy-in / copy-out at the module boundary), captured at the third call',
+                            'warnings': [str(w.message)[:160] for w in wl][:3]}
+        except Exception as e:
+            module_graph = {'error': f'{type(e).__name__}: {str(e)[:160]}'}
             torch.cuda.synchronize()
 
     roof = None
@@ -447,6 +472,14 @@ def main(argv=None):
             roof['library_calls_per_step'] = nl
             roof['library_launches_per_step'] = nl - (carried - issued)
             roof['merged_launches'] = {'launches': issued, 'calls_carried': carried}
+
+    stages = None
+    if rank == 0 and world == 1 and use_graph and not args.no_roofline and (H, W) == (384, 1248 if stf else 640):
+        try:
+            stages = profiling.stage_table(trainer, x, mods, cots, tag, PEAK_F32_MFMA, PEAK_HBM)
+        except Exception as e:
+            stages = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+            torch.cuda.synchronize()
 
     gfl, gby = WORK.get(tag.replace('_bn', ''), (None, None))
     step_roof = None
@@ -512,8 +545,9 @@ def main(argv=None):
                        'sync_schedule': getattr(trainer, 'sync_schedule', None) if (world > 1 or force_coll) else None,
                        'backend': ('RCCL (torch.distributed nccl)' if args.backend == 'nccl' else args.backend + ' (flow test, ranks share GPU 0)') if (world > 1 or force_coll) else None,
                        'exchange_lanes_hist': {f'{k[0]}{"m" if k[1] else ""}': v for k, v in sorted(getattr(trainer, 'exchange_hist', {}).items())}},
-            'step_ms': step_ms, 'finite': finite, 'fwd_ms_per_img': fwd_ms, 'eager_autograd': eager,
-            'roofline': roof, 'step_roofline': step_roof, 'cpu_baseline': cpu, 'neck': neck, 'extract_feat': feat,
+            'step_ms': step_ms, 'finite': finite, 'fwd_ms_per_img': fwd_ms, 'eager_autograd': eager, 'module_graph': module_graph,
+            'roofline': roof, 'step_roofline': step_roof, 'stage_roofline': stages, 'cpu_baseline': cpu, 'neck': neck,
+            'extract_feat': feat,
         }
         if capture_note:
             line['config']['capture_note'] = capture_note

@@ -222,6 +222,11 @@ class Engine:
         keys = tuple(self.fs_step)
         self.fs_step = []
         self.fs_used = list(keys)
+        self.fs_tables(keys)
+
+    def fs_tables(self, keys):
+        """Arena + segment table for the fused layers `keys` (host-to-device copies: a module-boundary graph capture calls
+        this BEFORE it starts capturing the backward pass)."""
         if not keys or keys == self.fs_sig:
             return
         seg, maps, off, moff = [], [], 0, 0
@@ -288,7 +293,16 @@ class Engine:
         library launch, so that a recorded replay program can be preceded by exactly this call."""
         if training:
             self._rng_begin()
-            self.nbt_flat.add_(1)
+            # num_batches_tracked moves only for BatchNorms that are IN training mode (norm_eval keeps them frozen:
+            # hrnet.py:588-596; F.batch_norm(training=False) leaves the buffer alone)
+            flags = tuple(m.training for m in self._bns if m.num_batches_tracked is not None)
+            if all(flags):
+                self.nbt_flat.add_(1)
+            elif any(flags):
+                inc = self.__dict__.get('_nbt_inc')
+                if inc is None or inc[0] != flags:
+                    inc = self.__dict__['_nbt_inc'] = (flags, torch.tensor([int(f) for f in flags], dtype=torch.long).to(self.device))
+                self.nbt_flat.add_(inc[1])
 
     def begin_forward(self, training, pre=True):
         # every forward re-uses the per-BatchNorm slots and the step's buffers: a tape recorded by an EARLIER forward of this
@@ -706,7 +720,7 @@ class HRFomerModule(nn.Module):
         xs = list(xs)
         # parallel branches (hrnet.py:189-190); with launch merging the finest branch stays on the current lane, where the
         # modality stages run as well: equal calls of the three sensor streams become one multi-problem launch
-        lanes = ctx.fork(nb, keep_first=ctx.bundle)
+        lanes = ctx.fork(nb, keep_first=ctx.keep_first)
 
         def branch(i):
             for blk in self.branches[i]:
@@ -719,7 +733,7 @@ class HRFomerModule(nn.Module):
         # backward of a lane accumulates into xs[j].grad only (no cross-lane gradient races)
         nrows = len(self.fuse_layers)
         terms = [[None] * nb for _ in range(nrows)]
-        lanes = ctx.fork(nb, keep_first=ctx.bundle) if _FORK_EXCHANGE else [ctx.cur] * nb
+        lanes = ctx.fork(nb, keep_first=ctx.keep_first) if _FORK_EXCHANGE else [ctx.cur] * nb
 
         def source(j):
             for i, row in enumerate(self.fuse_layers):
@@ -785,7 +799,7 @@ class HRModule(nn.Module):
     def run(self, ctx, xs):
         nb = self.num_branches
         xs = list(xs)
-        lanes = ctx.fork(nb, keep_first=ctx.bundle)
+        lanes = ctx.fork(nb, keep_first=ctx.keep_first)
 
         def branch(i):
             for blk in self.branches[i]:
@@ -796,7 +810,7 @@ class HRModule(nn.Module):
             return [xs[0]]
         nrows = len(self.fuse_layers)
         terms = [[None] * nb for _ in range(nrows)]
-        lanes = ctx.fork(nb, keep_first=ctx.bundle)
+        lanes = ctx.fork(nb, keep_first=ctx.keep_first)
 
         def source(j):                             # one lane per SOURCE branch (its backward accumulates into xs[j] only)
             for i, row in enumerate(self.fuse_layers):
@@ -941,10 +955,32 @@ def fctx_module_input_grad(src):
     return src.grad.permute(0, 3, 1, 2)        # NHWC Act of a block harness -> logical NCHW
 
 
+class _GraphEntry:
+    """One captured (shape, mode) instance of a module: static input / cotangent buffers, the forward hipGraph, the tape of the
+    capture-time forward and - from the first backward on - the backward hipGraph replaying that tape's launches."""
+    __slots__ = ('fwd', 'bwd', 'ins', 'ctx', 'outs', 'srcs', 'gouts', 'keep', 'gen', 'calls', 'needs', 'failed', 'ctx_record')
+
+
+class _GraphedFn(torch.autograd.Function):
+    """torch.autograd bridge of a captured module instance: copy-in, replay, copy-out (forward and backward)."""
+
+    @staticmethod
+    def forward(fctx, module, ent, anchor, *inputs):
+        fctx.hrf = (module, ent)
+        fctx.set_materialize_grads(False)
+        return module._graph_forward(ent, inputs)
+
+    @staticmethod
+    def backward(fctx, *gouts):
+        module, ent = fctx.hrf
+        fctx.hrf = None
+        return (None, None, None) + module._graph_backward(ent, gouts)
+
+
 class HipModule(nn.Module, EngineOwner):
     """Root of a module tree executed on the HIP engine (the backbone, or a sub-block under test)."""
 
-    def _execute(self, inputs, record):
+    def _execute(self, inputs, record, needs=None):
         dev = inputs[0].device
         if dev.type != 'cuda' and _lib.lib().require_cuda:
             raise _lib.HRFuserHipError(
@@ -955,12 +991,126 @@ class HipModule(nn.Module, EngineOwner):
         eng.begin_forward(self.training)
         ctx = R.Ctx(self, self.training, record)
         ctx.gen = eng.gen
+        st = self.__dict__.get('_stage_stamps')
+        if st is not None:
+            st.reset()
         with torch.no_grad():
             srcs = self._wrap_inputs(inputs)
+            if needs is not None:                       # static graph inputs: the flags of the caller's tensors
+                for src, n in zip(srcs, needs):
+                    src.needs_grad = bool(n)
+            ctx.mark('start')
             outs = self._run(ctx, srcs)
             if ctx.probe is not None:
                 self.__dict__['_relu_masks'] = R.collect_relu_masks(ctx)
         return ctx, outs, srcs
+
+    def enable_stage_stamps(self, on=True):
+        """Measurement aid (bench.py per-stage report): GPU timestamps at the stage boundaries of every following pass
+        (runtime.StageStamps); returns the stamp object, or None when switched off."""
+        if not on:
+            self.__dict__.pop('_stage_stamps', None)
+            return None
+        dev = next(self.parameters()).device
+        st = self.__dict__['_stage_stamps'] = R.StageStamps(dev)
+        return st
+
+    # ---- captured graphs at the module boundary -----------------------------------------------------------------------
+    # What mmdet calls is `backbone(img, mods)` + `loss.backward()` (two_stage.py:76-84): ~1 000 host-paced launches per
+    # direction when issued eagerly.  A module instance that sees the SAME (shapes, mode, requires-grad pattern) again is
+    # captured - forward into one hipGraph, the backward of that forward into a second one - and replayed from then on with
+    # copy-in / copy-out of the inputs, outputs, cotangents and input gradients.  HRF_MODULE_GRAPH=0 switches it off; a
+    # failed capture falls back to eager launches with a warning.
+    _graphable = False                 # the backbones opt in (sub-block harnesses and the neck launch eagerly)
+    _graph_warmup = 2                  # eager calls of a key before it is captured (allocator, random-pool sizes, slot tables)
+
+    def reset_graphs(self):
+        """Drop every captured instance (call after structural changes: freezing parameters, loading another device)."""
+        self.__dict__.pop('_hrf_graphs', None)
+
+    def _graph_key(self, inputs, record):
+        flags = tuple(m.training for m in self._engine()._bns) if self._engine()._bns else ()
+        return (self.training, record, tuple((tuple(t.shape), tuple(t.stride()), bool(t.requires_grad)) for t in inputs),
+                hash(flags), R.force_collectives(), self.sync_group is not None)
+
+    def _graph_entry(self, inputs, record):
+        """-> the _GraphEntry to run this call through, or None for an eager call."""
+        if not self._graphable or not inputs[0].is_cuda or os.environ.get('HRF_MODULE_GRAPH', '1') == '0' or \
+                self.__dict__.get('_relu_probe') or self.__dict__.get('_stage_stamps') is not None or \
+                torch.cuda.is_current_stream_capturing():
+            return None
+        cache = self.__dict__.setdefault('_hrf_graphs', {})
+        eng = self._engine()
+        if cache.get('_setup') is not eng.flat_p:           # parameters re-homed (device move, new arena): start over
+            cache.clear()
+            cache['_setup'] = eng.flat_p
+        key = self._graph_key(inputs, record)
+        ent = cache.get(key)
+        if ent is None:
+            ent = cache[key] = _GraphEntry()
+            ent.fwd = ent.bwd = ent.ctx = None
+            ent.calls, ent.failed = 0, False
+        ent.calls += 1
+        if ent.failed or ent.calls <= self._graph_warmup:
+            return None
+        return ent
+
+    def _graph_forward(self, ent, inputs):
+        eng = self._engine()
+        if ent.fwd is None:
+            ent.ins = [torch.empty_like(t) for t in inputs]
+            ent.needs = [bool(t.requires_grad) for t in inputs]
+            ent.keep = []
+        for d, t in zip(ent.ins, inputs):
+            d.copy_(t)
+        if ent.fwd is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            saved = eng.keep
+            eng.keep = ent.keep                              # the capture's step buffers live as long as the entry
+            try:
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    ent.ctx, ent.outs, ent.srcs = self._execute(tuple(ent.ins), ent.ctx_record, ent.needs)
+            finally:
+                eng.keep = saved
+            ent.fwd = g
+            ent.gouts = None
+        ent.fwd.replay()
+        eng.gen = getattr(eng, 'gen', 0) + 1                 # a replay overwrites the BatchNorm slots like any forward
+        ent.gen = eng.gen
+        return tuple(o.t.clone().permute(0, 3, 1, 2) for o in ent.outs)
+
+    def _graph_backward(self, ent, gouts):
+        eng = self._engine()
+        if ent.gen != getattr(eng, 'gen', ent.gen):
+            raise _lib.HRFuserHipError(
+                'backward of a forward pass that is no longer the latest one of this module (the BatchNorm statistics slots '
+                'were overwritten by a later forward): run backward before the next forward of the same module')
+        if ent.gouts is None:
+            ent.gouts = [torch.zeros_like(o.t) for o in ent.outs]
+        for d, g in zip(ent.gouts, gouts):
+            if g is None:
+                d.zero_()
+            else:
+                d.copy_(g.permute(0, 2, 3, 1))
+        if ent.bwd is None:
+            eng.fs_tables(tuple(eng.fs_step))                # (host-to-device table copies: not inside the capture)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            saved = eng.keep
+            eng.keep = ent.keep
+            ent.ctx.gen = eng.gen
+            try:
+                with torch.cuda.graph(g, pool=ent.fwd.pool(), capture_error_mode='thread_local'):
+                    R.use_keep_list(ent.keep)
+                    for o, d in zip(ent.outs, ent.gouts):
+                        o.grad = R.gpu_clone(d)
+                    ent.ctx.run_backward()
+            finally:
+                eng.keep = saved
+            ent.bwd = g
+        ent.bwd.replay()
+        return tuple((fctx_module_input_grad(s).clone() if (s.needs_grad and s.grad is not None) else None) for s in ent.srcs)
 
     def _call_engine(self, inputs):
         # NCHW-contiguous (the reference's layout) or channels-last storage (what hrfuser_amd.pipeline / the HIP modules
@@ -975,6 +1125,25 @@ class HipModule(nn.Module, EngineOwner):
             if anchor is None or anchor.device != inputs[0].device:
                 anchor = torch.zeros(1, device=inputs[0].device, requires_grad=True)
                 self.__dict__['_hrf_anchor'] = anchor
+        record = anchor is not None
+        ent = None
+        if self._graphable and inputs[0].is_cuda:
+            self._engine().ready(inputs[0].device)
+            ent = self._graph_entry(inputs, record)
+        if ent is not None:
+            ent.ctx_record = record
+            try:
+                return list(_GraphedFn.apply(self, ent, anchor, *inputs))
+            except _lib.HRFuserHipError:
+                raise
+            except Exception as e:                              # capture refused: this key launches eagerly from now on
+                if ent.fwd is not None and ent.bwd is not None:
+                    raise
+                ent.failed = True
+                ent.fwd = ent.bwd = ent.ctx = None
+                torch.cuda.synchronize()
+                warnings.warn(f'{type(self).__name__}: hipGraph capture at the module boundary failed '
+                              f'({type(e).__name__}: {str(e)[:160]}); this input signature launches eagerly')
         res = _BackboneFn.apply(self, anchor, *inputs)
         return list(res)
 
@@ -990,6 +1159,7 @@ class HRFuserHRFormerBased(HipModule):
     blocks_dict = {'BOTTLENECK': Bottleneck, 'HRFORMER': HRFormerBlock, 'CA': HRFuserFusionBlock,
                    'MWCA': HRFuserFusionBlock}
     _hrformer_trunk = True
+    _graphable = True
 
     def __init__(self, extra, in_channels=3, conv_cfg=None, norm_cfg=dict(type='SyncBN', requires_grad=True),
                  transformer_norm_cfg=dict(type='LN', eps=1e-6), norm_eval=False, with_cp=False,
@@ -1173,13 +1343,13 @@ class HRFuserHRFormerBased(HipModule):
             x = blk.run(ctx, x)
         return x
 
-    def _fuse_stage(self, ctx, cam_in, trans_cam, trans_mod, fusion, nb, mods, first):
+    def _fuse_stage(self, ctx, cam_in, trans_cam, trans_mod, fusion, nb, mods, first, tag=''):
         M = self.num_fused_modalities
         cams = [None] * nb
         ms = [[None] * M for _ in range(nb)]
         # phase 1 - transitions: lane 0 = camera, lane 1+k = modality k (each lane only ever
         # back-propagates into its own source tensor); equal-shape strands share the lane and merge their launches
-        lanes = ctx.bundle_lanes(1 + M)
+        lanes = ctx.bundle_lanes(1 + M, 'trans')
 
         def cam_trans():
             for i in range(nb):
@@ -1203,14 +1373,16 @@ class HRFuserHRFormerBased(HipModule):
                     _run_conv_chain(ctx, mods[k], [tr] if isinstance(tr[0], nn.Conv2d) else list(tr))
         ctx.parallel(lanes, [cam_trans] + [lambda k=k: mod_trans(k) for k in range(M)])
         ctx.join(lanes)
+        ctx.mark('transitions_' + tag)
         # phase 2 - one fusion block per branch, in parallel
         xs = [None] * nb
-        lanes = ctx.fork(nb, keep_first=ctx.bundle)
+        lanes = ctx.fork(nb, keep_first=ctx.keep_first)
 
         def fuse(i):
             xs[i] = fusion[i].run(ctx, cams[i], ms[i])
         ctx.parallel(lanes, [lambda i=i: fuse(i) for i in range(nb)])
         ctx.join(lanes)
+        ctx.mark('fusion_' + tag)
         return xs, ms[0]
 
     def _bare_conv(self, ctx, x, conv):
@@ -1238,7 +1410,7 @@ class HRFuserHRFormerBased(HipModule):
 
     def _run(self, ctx, srcs):
         M = self.num_fused_modalities
-        lanes = ctx.bundle_lanes(1 + M)              # camera stem + modality stems: equal shapes, one lane, merged launches
+        lanes = ctx.bundle_lanes(1 + M, 'stems')     # camera stem + modality stems: equal shapes, one lane, merged launches
         mods = [None] * M
         cam = [None]
 
@@ -1250,20 +1422,25 @@ class HRFuserHRFormerBased(HipModule):
                                  self.layer_a[k])
         ctx.parallel(lanes, [cam_stem] + [lambda k=k: mod_stem(k) for k in range(M)])
         ctx.join(lanes)
+        ctx.mark('stems')                                # stem_cam + layer1 + stem_mod + layer_a
         x = cam[0]
         xs, m0 = self._fuse_stage(ctx, x, self.transition1, self.transition_a, self.fusion_a,
-                                  self.stage2_cfg['num_branches'], mods, True)
+                                  self.stage2_cfg['num_branches'], mods, True, 'a')
         ys, mods = self._stages(ctx, self.stage2, xs, self.stage_b, m0)
+        ctx.mark('stage2+stage_b')
         xs, m0 = self._fuse_stage(ctx, ys, self.transition2, self.transition_b, self.fusion_b,
-                                  self.stage3_cfg['num_branches'], mods, False)
+                                  self.stage3_cfg['num_branches'], mods, False, 'b')
         ys, mods = self._stages(ctx, self.stage3, xs, self.stage_c, m0)
+        ctx.mark('stage3+stage_c')
         xs, m0 = self._fuse_stage(ctx, ys, self.transition3, self.transition_c, self.fusion_c,
-                                  self.stage4_cfg['num_branches'], mods, False)
+                                  self.stage4_cfg['num_branches'], mods, False, 'c')
         if not self.pre_neck_fusion:
-            return self._run_stage(ctx, self.stage4, xs)
+            outs = self._run_stage(ctx, self.stage4, xs)
+            ctx.mark('stage4')
+            return outs
         ys, mods = self._stages(ctx, self.stage4, xs, self.stage_d, m0)
         nb = self.stage4_cfg['num_branches']
-        xs, _ = self._fuse_stage(ctx, ys, [None] * nb, self.transition_d, self.fusion_d, nb, mods, False)
+        xs, _ = self._fuse_stage(ctx, ys, [None] * nb, self.transition_d, self.fusion_d, nb, mods, False, 'd')
         lanes = ctx.fork(nb)
         outs = [None] * nb
         for i in range(nb):
@@ -1303,7 +1480,7 @@ class HRFuserHRFormerBased(HipModule):
         stages are enqueued on their own lanes first; the camera stage then runs from the main lane,
         each of its modules forking branch lanes from main (flat, never nested)."""
         M = self.num_fused_modalities
-        lanes = ctx.bundle_lanes(M)
+        lanes = ctx.bundle_lanes(M, 'stages')
         mods = [None] * M
         ys = [None]
 
@@ -1350,6 +1527,7 @@ class HRFormer(HipModule):
     (hrformer.py:666-678) and `transition1[i]` runs whole (hrnet.py:563-566)."""
 
     blocks_dict = {'BOTTLENECK': Bottleneck, 'HRFORMERBLOCK': HRFormerBlock}
+    _graphable = True
     _make_stage = HRFuserHRFormerBased._make_stage
     init_weights = HRFuserHRFormerBased.init_weights
     refresh_inputs = HRFuserHRFormerBased.refresh_inputs

@@ -98,7 +98,7 @@ __device__ __forceinline__ void stage_tiles(const AttnArgs& a, int b, int wy, in
 // operand is a V row read from LDS.  K/V/Q tiles are staged once per block (pitch 16*ceil(D/16) + 1).
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(HrfGroup<AttnArgs> grp) {
-  const AttnArgs& a = grp.p[blockIdx.z];
+  const AttnArgs& a = grp.sel();
   constexpr int KS = (D + 3) / 4;             // contraction steps of Q K^T
   constexpr int DT = (D + 15) / 16;           // 16-wide output tiles of P V
   constexpr int P = DT * 16 + 1;              // LDS pitch (floats)
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(HrfGroup<AttnArgs> g
 // block before they reach the projection-bias gradients.
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(HrfGroup<AttnArgs> grp) {
-  const AttnArgs& a = grp.p[blockIdx.z];
+  const AttnArgs& a = grp.sel();
   constexpr int KS = (D + 3) / 4, DT = (D + 15) / 16, P = DT * 16 + 1;
   __shared__ float sQ[64 * P];
   __shared__ float sK[64 * P];

@@ -190,7 +190,7 @@ __device__ __forceinline__ void wave_gemm_tl(const float* sW, int K, const float
 // ---------------------------------------------------------------------------------------------------------- forward
 template <int C, int HEADS>
 __global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<hrf_attn_block_t> grp) {
-  const hrf_attn_block_t& a = grp.p[blockIdx.z];
+  const hrf_attn_block_t& a = grp.sel();
   constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16, PW = (C + 3) & ~3;
   constexpr int KSD = (D + 3) / 4, DT = (D + 15) / 16;
   constexpr int TILE = 64 * PC;
@@ -599,8 +599,8 @@ struct AbBwdArgs {
 
 template <int C, int HEADS>
 __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs> grp) {
-  const hrf_attn_block_t& a = grp.p[blockIdx.z].a;
-  const hrf_bn_bfin_t& bf = grp.p[blockIdx.z].bf;
+  const hrf_attn_block_t& a = grp.sel().a;
+  const hrf_bn_bfin_t& bf = grp.sel().bf;
   constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16, PW = (C + 3) & ~3;
   constexpr int KSD = (D + 3) / 4, DT = (D + 15) / 16;
   constexpr int TILE = 64 * PC, N1 = 4 * C, PH = N1 + 1;

@@ -34,7 +34,7 @@ __device__ float g_zero1[4] = {0.f, 0.f, 0.f, 0.f};
 //         register-only row-GEMM kernel (64<->256 channels at 30720 pixels: 30.6 vs 30.3 us).
 template <int NT, int MODE, int KH>
 __global__ __launch_bounds__(64 * NWV) void conv3_kernel(HrfGroup<Conv3Args> grp) {
-  const Conv3Args& a = grp.p[blockIdx.z];
+  const Conv3Args& a = grp.sel();
   constexpr int IWm = KH == 1 ? TW : (MODE == 2 ? TW + 1 : IW);     // staged source tile width / pixel count
   constexpr int NPm = KH == 1 ? TH * TW : (MODE == 2 ? (TH + 1) * (TW + 1) : NPIX);
   constexpr int ORG = (KH == 1 || MODE == 2) ? 0 : -1;              // source tile origin relative to (y0, x0)

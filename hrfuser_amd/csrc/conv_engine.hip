@@ -59,7 +59,7 @@ struct ConvFwdArgs {
 // --------------------------------------------------------------------------------- forward
 template <int NT, int KH, int TF>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(HrfGroup<ConvFwdArgs> grp) {
-  const ConvFwdArgs& a = grp.p[blockIdx.z];
+  const ConvFwdArgs& a = grp.sel();
   constexpr int BN = NT * 16, RP = BM / 4, RQ = BN / 4;
   __shared__ float As[BM * LDK];
   __shared__ float Bs[BN * LDK];
@@ -225,7 +225,7 @@ struct ConvBwdDataArgs {
 
 template <int NT, int KH, bool BNB>
 __global__ __launch_bounds__(256) void conv_bwd_data_kernel(HrfGroup<ConvBwdDataArgs> grp) {
-  const ConvBwdDataArgs& a = grp.p[blockIdx.z];
+  const ConvBwdDataArgs& a = grp.sel();
   constexpr int BN = NT * 16, RP = BM / 4, RQ = BN / 4;
   __shared__ float As[BM * LDK];
   __shared__ float Bs[BN * LDK];
@@ -837,6 +837,9 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     l.res = res; l.res2 = res2; l.ldR = ldR; l.tf_mode = tf_mode; l.tf_scale = tf_scale; l.tf_shift = tf_shift;
     l.tf_rowstat = tf_rowstat; l.stats = stats; l.M = a.M; l.K = Cin; l.N = Cout; l.ln_out = ln_rowstat; l.ln_eps = ln_eps;
     l.fin = a.fin;
+    const int rc2 = hrf_lin2_fwd_launch(l, stream);          // wide problems: LDS-tiled engine (lin2_engine.hip)
+    if (rc2 == HRF_OK && l.ln_out != nullptr && !hrf_lin2_fwd_emits_ln(l)) return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream);
+    if (rc2 >= 0) return rc2;
     const int rc = hrf_lin_fwd_launch(l, stream);
     if (rc == HRF_OK && l.ln_out != nullptr && !hrf_lin_fwd_emits_ln(l)) return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream);
     if (rc >= 0) return rc;
@@ -898,6 +901,8 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
     l.dx = dx; l.ldDx = sX; l.accumulate = accumulate; l.epi = epi; l.xraw = xraw; l.ldXr = ldXr;
     l.tf_scale = tf_scale; l.tf_shift = tf_shift; l.act = act; l.stats = stats; l.bfin = a.bfin;
     l.M = a.M; l.K = Cout; l.N = Cin;
+    const int rc2 = hrf_lin2_bwd_data_launch(l, stream);
+    if (rc2 >= 0) return rc2;
     const int rc = hrf_lin_bwd_data_launch(l, stream);
     if (rc >= 0) return rc;
   }
@@ -928,7 +933,9 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
 
 extern "C" int hrf_pw_knob(int key, int value);
 extern "C" int hrf_conv3w_knob(int key, int value);
+extern "C" int hrf_lin2_knob(int key, int value);
 extern "C" int hrf_debug_knob(int key, int value) {
+  if (key >= 28 && key < 32) return hrf_lin2_knob(key - 28, value);    // lin2_engine.hip: 28 = 1 force / 2 disable the LDS-tiled row GEMM
   if (key >= 16 && key < 20) return hrf_pw_knob(key - 16, value);      // pointwise.hip tuning aids
   if (key >= 24 && key < 28) return hrf_conv3w_knob(key - 24, value);  // conv3w_engine.hip tuning aids
   if (key < 0 || key >= 8) return HRF_ERR_ARG;

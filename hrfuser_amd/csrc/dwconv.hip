@@ -28,7 +28,7 @@ struct DwFwdArgs {
 
 template <int S>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
-  const DwFwdArgs& a = grp.p[blockIdx.z];
+  const DwFwdArgs& a = grp.sel();
   constexpr int TH = DwTile<S>::TH, IH = DwTile<S>::IH, IW = DwTile<S>::IW;
   __shared__ float sIn[IH * IW * CB];
   __shared__ float sStat[8 * 2 * CB];                    // per row-group partial moments (no LDS atomics)
@@ -131,7 +131,7 @@ struct DwBwdDataArgs {
 // by-product of the epilogue's act'(u): nine more FMAs per element instead of a second kernel that re-reads dY, Y and X.
 template <int S, bool WG>
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs> grp) {
-  const DwBwdDataArgs& a = grp.p[blockIdx.z];
+  const DwBwdDataArgs& a = grp.sel();
   // tile over INPUT pixels 8 x 16; staged dY region: S=1 (10 x 18, origin -1), S=2 (5 x 9, origin y0/2)
   constexpr int TH = 8, RH = S == 1 ? 10 : 5, RW = S == 1 ? 18 : 9;
   __shared__ float sD[RH * RW * CB];

@@ -96,4 +96,7 @@ extern "C" int hrf_group_end(void* stream) {
   return rc;
 }
 
-extern "C" long hrf_group_count(int what) { return (what >= 0 && what < 3) ? g_count[what] : -1; }
+extern "C" long hrf_group_count(int what) {
+  if (what == 3) return HRF_GROUP_MAX;                 // problems per launch this library was compiled for (1: pass-through)
+  return (what >= 0 && what < 3) ? g_count[what] : -1;
+}

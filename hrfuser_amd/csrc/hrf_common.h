@@ -145,7 +145,8 @@ __device__ __forceinline__ void hrf_bn_fin_onload(const hrf_bn_fin_t& f, float* 
   const int c_end = min(C, c_begin + c_count);
   sSc -= c_begin; sSh -= c_begin;
   const int K = f.copies > 0 ? f.copies : HRF_STAT_COPIES;
-  const double inv_count = 1.0 / f.count;                  // (independent of the loads below: overlaps their latency)
+  const double count = f.count_ptr != nullptr ? *f.count_ptr : f.count;   // SyncBN: the all-reduced count of the ranks
+  const double inv_count = 1.0 / count;                    // (independent of the loads below: overlaps their latency)
   // one thread per channel (consecutive lanes = consecutive channels: a wave's load touches the fewest cache lines - every
   // block of the grid reads the same ~2*C*16 doubles, and the request count on those hot lines is what this prologue
   // costs: a 16-lanes-per-channel split was 2-3x slower, tools/bench_fin.py)
@@ -166,7 +167,7 @@ __device__ __forceinline__ void hrf_bn_fin_onload(const hrf_bn_fin_t& f, float* 
     sSh[c] = sh;
     if (writer && f.write) {
       f.scale[c] = sc; f.shift[c] = sh; f.mean[c] = meanf; f.invstd[c] = invstd;
-      if (f.update_running) hrf_bn_running(f.running_mean, f.running_var, c, f.momentum, meanf, var, f.count);
+      if (f.update_running) hrf_bn_running(f.running_mean, f.running_var, c, f.momentum, meanf, var, count);
     }
   }
 }
@@ -177,7 +178,7 @@ __device__ __forceinline__ void hrf_bn_bfin_onload(const hrf_bn_bfin_t& f, float
   const int c_end = min(C, c_begin + c_count);
   sA -= c_begin; sB -= c_begin; sC -= c_begin;
   const int K = f.copies > 0 ? f.copies : HRF_STAT_COPIES;
-  const double inv_count = 1.0 / f.count;
+  const double inv_count = 1.0 / (f.count_ptr != nullptr ? *f.count_ptr : f.count);
   for (int c = c_begin + tid; c < c_end; c += nthreads) {
     double sdu = 0.0, sdux = 0.0;
 #pragma unroll

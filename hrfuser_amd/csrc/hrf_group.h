@@ -16,11 +16,24 @@
 #include <cstring>
 #include "hrf_rt.h"
 
-#define HRF_GROUP_MAX 4
+// Problems per launch.  The PRODUCT build uses 1: on MI355X the merged launches measured SLOWER than one HIP stream per sensor
+// (same box, HRFuser-T training step: 15.9 ms on separate lanes; 17.2 ms with the stems merged, 17.9 ms with stems, transitions
+// and the modality stages merged - lock-step sensor streams hit the same resource at the same time and a kernel boundary
+// becomes a barrier for all of them), and the 4x kernarg segment alone cost 0.9 ms per step (a multi-stream hipGraph copies
+// every node's kernarg on the host at each replay: tools/microbench/graph_nodes.hip, 2.8 -> 3.7 us per node at 2.5 KB).
+// -DHRF_GROUP_MAX=4 (HRF_EXTRA_FLAGS, and the CPU emulator build of the tests) compiles the multi-problem form.
+#ifndef HRF_GROUP_MAX
+#define HRF_GROUP_MAX 1
+#endif
 
 template <class A>
 struct HrfGroup {
   A p[HRF_GROUP_MAX];
+#if HRF_GROUP_MAX == 1
+  __device__ __forceinline__ const A& sel() const { return p[0]; }
+#else
+  __device__ __forceinline__ const A& sel() const { return p[blockIdx.z]; }
+#endif
 };
 
 typedef int (*hrf_grp_issue_t)(const void* kern, dim3 grid, dim3 block, unsigned smem, void* stream,

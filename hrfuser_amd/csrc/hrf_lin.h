@@ -31,6 +31,10 @@ struct LinBwdDataArgs {
 int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream);
 bool hrf_lin_fwd_emits_ln(const LinFwdArgs& a);       // true when the launch above covers whole rows per wave
 int hrf_lin_bwd_data_launch(const LinBwdDataArgs& a, void* stream);
+// lin2_engine.hip: the same contract on an LDS-tiled data path, for wide problems (min(K, N) >= 64, M >= 1024); tried first
+int hrf_lin2_fwd_launch(const LinFwdArgs& a, void* stream);
+bool hrf_lin2_fwd_emits_ln(const LinFwdArgs& a);
+int hrf_lin2_bwd_data_launch(const LinBwdDataArgs& a, void* stream);
 
 // ---- conv3_engine.hip: 3x3 / stride-1 / pad-1 convolution (forward and backward-data) on NHWC rows,
 // input halo tile staged ONCE per channel slab (no im2col re-reads), weights streamed through LDS.

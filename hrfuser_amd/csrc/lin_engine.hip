@@ -107,7 +107,7 @@ __device__ __forceinline__ void flush_moments(const float* sStat, double* stats,
 // NT = 16-channel output tiles per wave (compile time: the unrolled code carries no guards)
 template <int NT, int TF>
 __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) {
-  const LinFwdArgs& a = grp.p[blockIdx.z];
+  const LinFwdArgs& a = grp.sel();
   __shared__ float sStat[4 * 2 * NT * 16];
   __shared__ __attribute__((aligned(16))) float sFin[(TF >= HRF_TF_AFFINE && TF <= HRF_TF_AFFINE_GELU) ? 2 * HRF_FIN_MAXC : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) 
 // --------------------------------------------------------------------------------- backward data
 template <int NT, bool BNB>
 __global__ __launch_bounds__(256) void lin_bwd_data_kernel(HrfGroup<LinBwdDataArgs> grp) {
-  const LinBwdDataArgs& a = grp.p[blockIdx.z];
+  const LinBwdDataArgs& a = grp.sel();
   __shared__ float sStat[4 * 2 * NT * 16];
   __shared__ __attribute__((aligned(16))) float sFin[BNB ? 3 * HRF_FIN_MAXC : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

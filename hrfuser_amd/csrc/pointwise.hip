@@ -61,9 +61,10 @@ __global__ void bn_bwd_finalize_kernel(const double* gstats, const double* gstat
 // to PK_MAX layers are folded into ONE packed fp64 buffer (2*C doubles per layer, layer after layer), the host all-reduces
 // that buffer with ONE collective, and one launch finalises all of them from the packed sums.
 constexpr int PK_MAX = 8;
-struct BnPackArgs { const double* src[PK_MAX]; int C[PK_MAX]; int off[PK_MAX]; };
+struct BnPackArgs { const double* src[PK_MAX]; int C[PK_MAX]; int off[PK_MAX]; double rows[PK_MAX]; int roff[PK_MAX]; };
 __global__ __launch_bounds__(256) void bn_pack_kernel(BnPackArgs a, double* packed) {
   const int e = blockIdx.y, C2 = 2 * a.C[e];
+  if (a.roff[e] >= 0 && blockIdx.x == 0 && threadIdx.x == 0) packed[a.roff[e]] = a.rows[e];   // this rank's sample count
   for (int c = blockIdx.x * 256 + threadIdx.x; c < C2; c += gridDim.x * 256) {
     double s = 0.0;
 #pragma unroll
@@ -79,9 +80,10 @@ __global__ __launch_bounds__(256) void bn_finalize_packed_kernel(BnFinPackArgs a
     const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
     float sc, sh, meanf, invstd;
     double var;
-    hrf_bn_solve(st[c], st[f.C + c], 1.0 / f.count, f.eps, g, b, sc, sh, meanf, invstd, var);
+    const double count = f.count_ptr != nullptr ? *f.count_ptr : f.count;
+    hrf_bn_solve(st[c], st[f.C + c], 1.0 / count, f.eps, g, b, sc, sh, meanf, invstd, var);
     f.scale[c] = sc; f.shift[c] = sh; f.mean[c] = meanf; f.invstd[c] = invstd;
-    if (f.update_running) hrf_bn_running(f.running_mean, f.running_var, c, f.momentum, meanf, var, f.count);
+    if (f.update_running) hrf_bn_running(f.running_mean, f.running_var, c, f.momentum, meanf, var, count);
   }
 }
 struct BnBFinPackArgs { hrf_bn_bfin_t f[PK_MAX]; int off[PK_MAX]; };
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_packed_kernel(BnBFinPackA
     if (f.dgamma) f.dgamma[c] += (float)(ps * (ldux - mu * ldu) * is);
     if (f.dbeta) f.dbeta[c] += (float)(ps * ldu);
     float a, b2, c2;
-    hrf_bn_bwd_solve(sdu, sdux, mu, is, g, 1.0 / f.count, f.train, a, b2, c2);
+    hrf_bn_bwd_solve(sdu, sdux, mu, is, g, 1.0 / (f.count_ptr != nullptr ? *f.count_ptr : f.count), f.train, a, b2, c2);
     f.cA[c] = a; f.cB[c] = b2; f.cC[c] = c2;
   }
 }
@@ -113,7 +115,7 @@ struct LnStatsArgs {
   float* rowstat;
 };
 __global__ __launch_bounds__(256) void ln_stats_kernel(HrfGroup<LnStatsArgs> grp) {
-  const LnStatsArgs& pa_ = grp.p[blockIdx.z];
+  const LnStatsArgs& pa_ = grp.sel();
   const float* x = pa_.x;
   int rows = pa_.rows;
   int C = pa_.C;
@@ -156,7 +158,7 @@ struct LnBwdArgs {
 };
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(HrfGroup<LnBwdArgs> grp) {
-  const LnBwdArgs& pa_ = grp.p[blockIdx.z];
+  const LnBwdArgs& pa_ = grp.sel();
   const float* da = pa_.da;
   const float* x = pa_.x;
   const float* rowstat = pa_.rowstat;
@@ -252,7 +254,7 @@ struct AffineActResArgs {
   hrf_bn_fin_t fin2;
 };
 __global__ __launch_bounds__(256) void affine_act_res_kernel(HrfGroup<AffineActResArgs> grp) {
-  const AffineActResArgs& pa_ = grp.p[blockIdx.z];
+  const AffineActResArgs& pa_ = grp.sel();
   const float* y1 = pa_.y1;
   const float* sc1 = pa_.sc1;
   const float* sh1 = pa_.sh1;
@@ -309,7 +311,7 @@ struct FfnTailArgs {
 };
 template <int NCH>
 __global__ __launch_bounds__(256) void ffn_tail_kernel(HrfGroup<FfnTailArgs> grp) {
-  const FfnTailArgs& pa_ = grp.p[blockIdx.z];
+  const FfnTailArgs& pa_ = grp.sel();
   const float* y1 = pa_.y1;
   const float* sc1 = pa_.sc1;
   const float* sh1 = pa_.sh1;
@@ -388,7 +390,7 @@ struct ActBwdArgs {
   int C;
 };
 __global__ __launch_bounds__(256) void act_bwd_kernel(HrfGroup<ActBwdArgs> grp) {
-  const ActBwdArgs& pa_ = grp.p[blockIdx.z];
+  const ActBwdArgs& pa_ = grp.sel();
   const float* dout = pa_.dout;
   const float* out = pa_.out;
   const float* y1 = pa_.y1;
@@ -485,7 +487,7 @@ struct ScaleAddArgs {
   int C;
 };
 __global__ __launch_bounds__(256) void scale_add_kernel(HrfGroup<ScaleAddArgs> grp) {
-  const ScaleAddArgs& pa_ = grp.p[blockIdx.z];
+  const ScaleAddArgs& pa_ = grp.sel();
   const float* y = pa_.y;
   const float* mask = pa_.mask;
   float mscale = pa_.mscale;
@@ -521,7 +523,7 @@ __device__ __forceinline__ void bil_src(int dst, int in, int out, int& i0, int& 
 }
 
 __global__ __launch_bounds__(256) void fuse_sum_kernel(HrfGroup<FuseArgs> grp) {
-  const FuseArgs& a = grp.p[blockIdx.z];
+  const FuseArgs& a = grp.sel();
   const long total = (long)a.B * a.H * a.W * a.C;
   // BatchNorms of the conv-produced terms finalised on load (hrf_bn_fin_t; C <= HRF_FIN_MAXC / 2 per term)
   __shared__ float sFin[4 * HRF_FIN_MAXC];
@@ -636,7 +638,7 @@ struct BilUpBwdArgs {
   double* stats;
 };
 __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(HrfGroup<BilUpBwdArgs> grp) {
-  const BilUpBwdArgs& pa_ = grp.p[blockIdx.z];
+  const BilUpBwdArgs& pa_ = grp.sel();
   const float* g = pa_.g;
   int ldG = pa_.ldG;
   int goff = pa_.goff;
@@ -1097,14 +1099,19 @@ extern "C" int hrf_adamw(float* p, const float* g, float* m, float* v, const flo
   return hrf_check_launch();
 }
 
-extern "C" int hrf_bn_pack(const double* const* stats, const int* C, int n, double* packed, void* stream) {
+extern "C" int hrf_bn_pack(const double* const* stats, const int* C, int n, const double* rows, double* packed, void* stream) {
   if (n <= 0) return HRF_OK;
-  int off = 0;
+  int off = 0, tail = 0;
+  for (int k = 0; k < n; ++k) tail += 2 * C[k];                 // the counts sit behind the sums
   for (int b = 0; b < n; b += PK_MAX) {
     BnPackArgs a{};
     const int m = n - b < PK_MAX ? n - b : PK_MAX;
     int cmax = 0;
-    for (int k = 0; k < m; ++k) { a.src[k] = stats[b + k]; a.C[k] = C[b + k]; a.off[k] = off; off += 2 * C[b + k]; if (C[b + k] > cmax) cmax = C[b + k]; }
+    for (int k = 0; k < m; ++k) {
+      a.src[k] = stats[b + k]; a.C[k] = C[b + k]; a.off[k] = off; off += 2 * C[b + k]; if (C[b + k] > cmax) cmax = C[b + k];
+      a.roff[k] = rows != nullptr ? tail + b + k : -1;
+      a.rows[k] = rows != nullptr ? rows[b + k] : 0.0;
+    }
     HRF_LAUNCH(bn_pack_kernel, dim3(hrf_cdiv(2 * cmax, 256), m), dim3(256), 0, stream, a, packed);
   }
   return hrf_check_launch();
@@ -1134,6 +1141,22 @@ extern "C" int hrf_bn_bwd_finalize_packed(const hrf_bn_bfin_t* bfins, int n, con
     for (int k = 0; k < m; ++k) { a.f[k] = bfins[b + k]; a.off[k] = off; off += 2 * bfins[b + k].C; if (bfins[b + k].C > cmax) cmax = bfins[b + k].C; }
     HRF_LAUNCH(bn_bwd_finalize_packed_kernel, dim3(hrf_cdiv(cmax, 256), m), dim3(256), 0, stream, a, packed, packed_local);
   }
+  return hrf_check_launch();
+}
+
+// GPU timestamp (the constant-rate 100 MHz counter behind wall_clock64()) written by one thread when the stream reaches this
+// point - works inside a replayed hipGraph, where HIP events cannot be timed: per-stage durations of the real captured step
+__global__ void stamp_kernel(long long* dst) {
+#ifdef HRF_EMUL
+  *dst = 0;
+#else
+  *dst = (long long)wall_clock64();
+#endif
+}
+
+extern "C" int hrf_stamp(long long* dst, void* stream) {
+  if (dst == nullptr) return HRF_ERR_ARG;
+  HRF_LAUNCH(stamp_kernel, dim3(1), dim3(1), 0, stream, dst);
   return hrf_check_launch();
 }
 

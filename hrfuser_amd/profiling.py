@@ -264,6 +264,93 @@ def profile_step(trainer, x, mods, cots, steps=1):
     return table
 
 
+# forward work per image and stage (GFLOP, eager-equivalent fp32 MB = leaf-op bytes + attention-matrix bytes),
+# grouped by the regions the engine executes one after the other (the camera stem / layer1 and the modality stems / layer_a
+# run bundled; stage k of the camera runs beside modality stage b / c).
+_B2 = {
+    't_nus': {'stem_cam': (1.35, 196), 'layer1_cam': (4.40, 322), 'stem_mod': (2.69, 155), 'layer_a_mod': (8.81, 645), 'transitions': (6.26, 158),
+              'fusion_a': (0.53, 191), 'stage2': (0.73, 279), 'stage_b': (0.78, 358), 'fusion_b': (0.74, 225), 'stage3': (3.14, 1003),
+              'stage_c': (2.35, 1075), 'fusion_c': (0.94, 242), 'stage4': (2.70, 734)},
+    'b_nus': {'stem_cam': (1.35, 196), 'layer1_cam': (4.40, 322), 'stem_mod': (2.69, 155), 'layer_a_mod': (8.81, 645), 'transitions': (34.73, 368),
+              'fusion_a': (6.99, 693), 'stage2': (10.31, 1074), 'stage_b': (10.36, 1378), 'fusion_b': (10.49, 815), 'stage3': (62.60, 5160),
+              'stage_c': (41.45, 5514), 'fusion_c': (13.89, 876), 'stage4': (42.02, 2841)},
+    't_stf': {'stem_cam': (2.62, 458), 'layer1_cam': (8.59, 629), 'stem_mod': (7.45, 449), 'layer_a_mod': (25.76, 1886), 'transitions': (16.36, 424),
+              'fusion_a': (1.35, 466), 'stage2': (1.41, 542), 'stage_b': (2.30, 1049), 'fusion_b': (1.91, 552), 'stage3': (6.13, 1955),
+              'stage_c': (6.89, 3146), 'fusion_c': (2.41, 594), 'stage4': (5.28, 1434)},
+}
+_REGIONS = [('stems', ('stem_cam', 'layer1_cam', 'stem_mod', 'layer_a_mod')), ('transitions', ('transitions',)),
+            ('fusion_a', ('fusion_a',)), ('stage2+stage_b', ('stage2', 'stage_b')), ('fusion_b', ('fusion_b',)),
+            ('stage3+stage_c', ('stage3', 'stage_c')), ('fusion_c', ('fusion_c',)), ('stage4', ('stage4',))]
+
+
+def stage_table(trainer, x, mods, cots, tag, peak_f, peak_b, replays=10):
+    """Per-stage durations of the CAPTURED training step and their roofline fractions (north star: "achieved fraction of
+    HBM and MFMA roofline reported per stage").  The step is captured once more with GPU timestamps at the stage boundaries
+    (hrf_stamp: readable after a hipGraph replay, unlike HIP events), replayed, and the medians of the stamp differences are
+    priced against SURVEY App. B-2's per-stage FLOPs / eager-equivalent bytes.  Forward rows use the stage's forward work;
+    backward rows its data-gradient work (= 1x forward), the weight gradients (= 1x forward of ALL stages) run as one
+    deferred phase with its own row."""
+    net = trainer.net
+    work = _B2.get(tag.replace('_bn', ''))
+    old_graph, old_outs = trainer.graph, getattr(trainer, '_graph_outs', None)
+    st = net.enable_stage_stamps()
+    try:
+        trainer.capture(x, mods, cots, warmup=1)
+        runs = []
+        for _ in range(replays):
+            trainer.replay()
+            torch.cuda.synchronize()
+            runs.append(st.read())
+    finally:
+        net.enable_stage_stamps(False)
+        trainer.graph, trainer._graph_outs = old_graph, old_outs
+    names = [(d, n) for d, n, _ in runs[0]]
+    med = []
+    for i in range(len(names)):
+        v = sorted(r[i][2] for r in runs)
+        med.append(v[len(v) // 2])
+    t = {nm: v for nm, v in zip(names, med)}
+    B = x.shape[0]
+    order = [n for d, n in names if d == 'fwd']
+    fwd, bwd = {}, {}
+    for i in range(1, len(order)):
+        fwd[order[i]] = t[('fwd', order[i])] - t[('fwd', order[i - 1])]
+        bwd[order[i]] = t[('bwd', order[i - 1])] - t[('bwd', order[i])]
+    turn = t[('bwd', order[-1])] - t[('fwd', order[-1])]           # cotangent hand-over between the passes
+    wg = t[('bwd', 'weight_gradients')] - t[('bwd', 'start')]
+    end = t.get(('step', 'step_end'))
+    rows = []
+
+    def frac(gflop, mb, us):
+        if work is None or us <= 0:
+            return None, None
+        return round(B * gflop * 1e9 / (us * 1e-6) / peak_f, 4), round(B * mb * 1e6 / (us * 1e-6) / peak_b, 4)
+    tot_g = tot_mb = 0.0
+    for reg, parts in _REGIONS:
+        keys = [k for k in order if k == reg or (reg == 'transitions' and k.startswith('transitions_'))]
+        if not keys:
+            continue
+        f_us, b_us = sum(fwd[k] for k in keys), sum(bwd[k] for k in keys)
+        g = sum(work[p][0] for p in parts) if work else 0.0
+        mb = sum(work[p][1] for p in parts) if work else 0.0
+        tot_g, tot_mb = tot_g + g, tot_mb + mb
+        ff, fb = frac(g, mb, f_us)
+        bf, bb = frac(g, mb, b_us)
+        rows.append({'name': reg, 'fwd_ms': round(f_us / 1e3, 4), 'bwd_ms': round(b_us / 1e3, 4), 'fwd_gflop': round(B * g, 2),
+                     'fwd_eager_MB': round(B * mb, 1), 'fwd_flops_frac': ff, 'fwd_bytes_frac': fb, 'bwd_flops_frac': bf, 'bwd_bytes_frac': bb})
+    wf, wb = frac(tot_g, tot_mb, wg)
+    rows.append({'name': 'weight_gradients (deferred phase, all stages)', 'fwd_ms': None, 'bwd_ms': round(wg / 1e3, 4),
+                 'fwd_gflop': round(B * tot_g, 2), 'fwd_eager_MB': round(B * tot_mb, 1), 'bwd_flops_frac': wf, 'bwd_bytes_frac': wb})
+    out = {'stages': rows, 'turnaround_ms': round(turn / 1e3, 4),
+           'grad_exchange_adamw_ms': round((end - t[('bwd', 'weight_gradients')]) / 1e3, 4) if end is not None else None,
+           'step_ms_with_stamps': round((end if end is not None else t[('bwd', 'weight_gradients')]) / 1e3, 4),
+           'timer': f'hrf_stamp (100 MHz GPU counter) at the stage boundaries of the captured step, median of {replays} replays; '
+                    'fractions = SURVEY App. B-2 forward GFLOP / eager-equivalent MB of the stage x images over the measured time, '
+                    'against 157.3 TFLOP/s and 8 TB/s; backward rows price the data-gradient work (1x forward), the deferred '
+                    'weight-gradient phase the weight-gradient work of all stages (1x forward)'}
+    return out
+
+
 def merged_launch_counts(trainer, x, mods, cots):
     """One eager step with the multi-problem launches as configured: (launches issued by hrf_group_end, C-ABI calls'
     launches they carried) - the step's launch count is its call count minus (carried - issued)."""

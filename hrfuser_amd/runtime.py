@@ -145,7 +145,7 @@ class Act:
 class BNState:
     """One BatchNorm application: raw conv output + the per-channel vectors around it."""
     __slots__ = ('bn', 'C', 'raw', 'count', 'scale', 'shift', 'mean', 'invstd', 'stats', 'gstats',
-                 'coef', 'du', 'train', 'pending', 'lane', 'bx_done', 'packed', 'bpacked')
+                 'coef', 'du', 'train', 'pending', 'lane', 'bx_done', 'packed', 'bpacked', 'count_ptr')
 
 
 class Lazy:
@@ -189,6 +189,31 @@ class RawInput:
     def shape(self):
         B, C, H, W = self.t.shape
         return (B, H, W, C)
+
+
+class StageStamps:
+    """GPU timestamps at the stage boundaries of a pass (measurement aid; bench.py per-stage roofline).  `take` launches
+    hrf_stamp on the current stream: inside a captured hipGraph every replay rewrites the same slots, so the durations of the
+    REAL captured step can be read back after a replay - HIP events cannot be timed there.  100 MHz counter."""
+
+    def __init__(self, device, cap=256):
+        self.buf = torch.zeros(cap, dtype=torch.int64, device=device)
+        self.marks = []
+
+    def reset(self):
+        self.marks = []
+
+    def take(self, ctx, direction, name):
+        i = len(self.marks)
+        if i >= self.buf.numel():
+            return
+        self.marks.append((direction, name))
+        ctx.lib.hrf_stamp(self.buf.data_ptr() + 8 * i, ctx.stream)
+
+    def read(self):
+        """-> [(direction, name, microseconds since the first stamp)]"""
+        t = self.buf[:len(self.marks)].cpu().tolist()
+        return [(d, n, (v - t[0]) / 100.0) for (d, n), v in zip(self.marks, t)]
 
 
 class Lane:
@@ -290,11 +315,19 @@ class Ctx:
         self.bpending = []              # backward ones: (BNState, lane)
         # lock-step strands need coroutines; HRF_LOCKSTEP=0 (or no greenlet) runs the bodies one after the other: no merged
         # launches, and one SyncBN collective per BatchNorm
-        self._glet = _greenlet if os.environ.get('HRF_LOCKSTEP', '1') != '0' else None
-        self.sync_batch = self._glet is not None and os.environ.get('HRF_SYNC_BATCH', '1') != '0' and not _LANE_COMMS
-        self.merge = self._glet is not None and os.environ.get('HRF_GROUP', '1') != '0' and hasattr(self.lib, 'hrf_group_begin')
+        glet = _greenlet if os.environ.get('HRF_LOCKSTEP', '1') != '0' else None
+        self.sync_batch = self.coll and glet is not None and os.environ.get('HRF_SYNC_BATCH', '1') != '0' and not _LANE_COMMS
+        # multi-problem launches need a library compiled for them (hrf_group_count(3) = problems per launch; the shipped
+        # build has 1: merged launches measured slower than a stream per sensor on MI355X)
+        self.merge = glet is not None and os.environ.get('HRF_GROUP', '1') != '0' and hasattr(self.lib, 'hrf_group_begin') \
+            and self.lib.hrf_group_count(3) > 1
+        self._glet = glet if (self.merge or self.sync_batch or os.environ.get('HRF_LOCKSTEP') == '1') else None
         # equal-shape siblings share the current lane (their launches merge) instead of getting a stream each
         self.bundle = self.merge and os.environ.get('HRF_BUNDLE', '1') != '0'
+        # which sibling sets are bundled (A/B knob): stems, trans(itions), stages; keep_first: the finest camera branch
+        # stays on the current lane so that it merges with the modality stages bundled there
+        self.bundle_what = set(os.environ.get('HRF_BUNDLE_WHAT', 'stems,trans,stages').split(',')) if self.bundle else set()
+        self.keep_first = self.bundle and 'stages' in self.bundle_what and os.environ.get('HRF_KEEP_FIRST', '1') != '0'
         self._sweeper = None            # greenlet running the sweep (None: not inside parallel())
         self._strands = []              # live strands of the running sweep, all levels
         self._xlane = None
@@ -313,6 +346,17 @@ class Ctx:
         if self.sync_batch:
             return f'packed exchanges on the main lane, lock-step strands (greenlet {getattr(_greenlet, "__version__", "?")})'
         return 'one exchange per BatchNorm on the main lane (no lock-step: HRF_SYNC_BATCH=0 / HRF_LOCKSTEP=0)'
+
+    def mark(self, name):
+        """End of stage `name` in the forward pass (root level, main lane).  With stage stamps enabled on the owner
+        (HipModule.enable_stage_stamps) a GPU timestamp is taken here and again when the backward pass comes back to this
+        point (= the start of that stage's backward)."""
+        st = self.owner.__dict__.get('_stage_stamps')
+        if st is None or self.strand is not self.root:
+            return
+        st.take(self, 'fwd', name)
+        if self.record:
+            self.root.tape.append((lambda: st.take(self, 'bwd', name), self.cur, None))
 
     # ---- tape ----------------------------------------------------------------------------------
     def push(self, fn, sync=None):
@@ -478,7 +522,7 @@ class Ctx:
         if todo:
             self.flush_bwd([st for st, _ in todo], [lane for _, lane in todo])
 
-    def _exchange(self, sts, lanes, pack_ptrs, finalize):
+    def _exchange(self, sts, lanes, pack_ptrs, finalize, rows=False):
         """One packed collective for the BatchNorms `sts`, issued on the main lane between the lanes involved (every
         cross-stream edge costs ~10 us inside the captured graph, but the main lane is what keeps the collectives of the
         communicator in ONE order on every rank).  HRF_XHUB=1: a batch that lives on one lane is issued on that lane.
@@ -495,10 +539,13 @@ class Ctx:
         with _LaneScope(self, hub):
             n = len(sts)
             total = sum(2 * st.C for st in sts)
-            packed = _keep(torch.empty(total, device=sts[0].raw.device, dtype=torch.float64))
+            # behind the sums: this rank's sample count of every layer - the same all-reduce yields the GLOBAL counts, so
+            # ranks with unequal batches normalise like torch.nn.SyncBatchNorm (which all-gathers the counts)
+            packed = _keep(torch.empty(total + (n if rows else 0), device=sts[0].raw.device, dtype=torch.float64))
             ptrs = (ctypes.c_void_p * n)(*pack_ptrs)
             cs = (ctypes.c_int * n)(*[st.C for st in sts])
-            self.lib.hrf_bn_pack(ptrs, cs, n, packed, self.stream)
+            rw = (ctypes.c_double * n)(*[float(st.raw.numel() // st.C) for st in sts]) if rows else None
+            self.lib.hrf_bn_pack(ptrs, cs, n, rw, packed, self.stream)
             self._xlane = hub
             finalize(packed)
             self._xlane = None
@@ -520,10 +567,12 @@ class Ctx:
         def fin(packed):
             self.all_reduce(packed)
             box.append(packed)
-        self._exchange(sts, [st.lane for st in sts], [P(st.stats) for st in sts], fin)
+        self._exchange(sts, [st.lane for st in sts], [P(st.stats) for st in sts], fin, rows=True)
         off = 0
-        for st in sts:
+        tail = sum(2 * st.C for st in sts)
+        for i, st in enumerate(sts):
             st.packed = (box[0], off)
+            st.count_ptr = box[0].data_ptr() + 8 * (tail + i)          # the all-reduced sample count of this layer
             off += 2 * st.C
             st.pending = 'fwd' if _FIN_ONLOAD else None
             if not _FIN_ONLOAD:
@@ -593,11 +642,11 @@ class Ctx:
             self.strand.tape.append(('F', self.cur, uniq))
         return first + [uniq[i % m] for i in range(n)]
 
-    def bundle_lanes(self, n):
+    def bundle_lanes(self, n, what='stems'):
         """Lanes for n strands of EQUAL shape (camera stem + modality stems, the modality stages beside the camera stage):
         all on the current lane when launch merging is on - their equal calls become one multi-problem launch, in order on
         one queue, no cross-queue edges - otherwise a stream each."""
-        if self.bundle:
+        if self.bundle and what in self.bundle_what:
             return [self.cur] * n
         return self.fork(n)
 
@@ -741,6 +790,9 @@ class Ctx:
             self._side_used = {}
         with _LaneScope(self, self.main):
             self.owner._engine().fold_grads(self.L, self.main.ptr)
+            st = self.owner.__dict__.get('_stage_stamps')
+            if st is not None:
+                st.take(self, 'bwd', 'weight_gradients')      # end of the deferred weight-gradient phase + folds
         if self.multi:
             torch.cuda.set_stream(entry)
             entry.wait_stream(self.main.stream)
@@ -853,6 +905,7 @@ def bn_forward(ctx, bn, raw, stats):
     C = raw.shape[-1]
     st.bn, st.C, st.raw, st.du, st.coef, st.pending, st.lane, st.bx_done = bn, C, raw, None, None, None, None, False
     st.packed = st.bpacked = None
+    st.count_ptr = None
     slot = ctx.owner._bn_slot(bn)
     st.train = bool(ctx.training and bn.training)
     if st.train:
@@ -879,7 +932,8 @@ def _finalize_now(ctx, st):
     if st.packed is not None:                           # SyncBN: the folded, all-reduced sums
         P = _lib._ptr
         fin = _lib.BnFin(None, P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var), P(st.scale), P(st.shift),
-                         P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom), 1 if bn.track_running_stats else 0, 1, st.C)
+                         P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom), 1 if bn.track_running_stats else 0, 1, st.C,
+                         1, st.count_ptr)
         ctx.L.hrf_bn_finalize_packed(fin, 1, st.packed[0].data_ptr() + 8 * st.packed[1], ctx.stream)
     else:
         ctx.L.hrf_bn_finalize(st.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, st.count,
@@ -909,7 +963,7 @@ def take_fin(ctx, st, limit=FIN_MAXC):
     stats, copies = (P(st.stats), 0) if st.packed is None else (st.packed[0].data_ptr() + 8 * st.packed[1], 1)
     fin = _lib.BnFin(stats, P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var),
                      P(st.scale), P(st.shift), P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom),
-                     1 if bn.track_running_stats else 0, 1 if st.pending == 'fwd' else 0, st.C, copies)
+                     1 if bn.track_running_stats else 0, 1 if st.pending == 'fwd' else 0, st.C, copies, st.count_ptr)
     st.pending = 'written'
     return fin
 
@@ -934,7 +988,7 @@ def bn_backward_coef(ctx, st, consumer_follows=True, limit=FIN_MAXC):
         P = _lib._ptr
         lptr = local.data_ptr() + 8 * off if local is not None else None
         bf = _lib.BnBFin(packed.data_ptr() + 8 * off, P(st.bn.weight), P(st.mean), P(st.invstd), P(wg), P(bg), P(cA), P(cB),
-                         P(cC), st.count, 1, 1, st.C, 1, lptr, 1.0 / max(1, ctx.world))
+                         P(cC), st.count, 1, 1, st.C, 1, lptr, 1.0 / max(1, ctx.world), st.count_ptr)
         if _FIN_ONLOAD and consumer_follows and st.C <= limit:
             return st.coef, bf
         ctx.L.hrf_bn_bwd_finalize_packed(bf, 1, packed.data_ptr() + 8 * off, lptr, ctx.stream)

@@ -100,6 +100,9 @@ class Trainer:
         self.sync_schedule = ctx.schedule_desc()
         if not grads_only:
             self.optimizer_step()
+        st = net.__dict__.get('_stage_stamps')
+        if st is not None:
+            st.take(ctx, 'step', 'step_end')
         return outs
 
     def step(self, x, mods, cots, grads_only=False):

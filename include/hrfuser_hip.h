@@ -53,6 +53,9 @@ typedef struct hrf_bn_fin {
   double count; float eps; float momentum; int update_running; int write; int C;
   int copies;                    /* replication of `stats`: 0 = HRF_STAT_COPIES; 1 = already folded (SyncBN: the packed,
                                     all-reduced moments of hrf_bn_pack) */
+  const double* count_ptr;       /* nullable: the sample count read from the DEVICE instead of `count` - SyncBN all-reduces
+                                    the ranks' row counts with the moments (hrf_bn_pack `rows`), so ranks with unequal
+                                    batches normalise by the true global count, as torch.nn.SyncBatchNorm does */
 } hrf_bn_fin_t;
 typedef struct hrf_bn_bfin {
   const double* gstats;
@@ -64,6 +67,7 @@ typedef struct hrf_bn_bfin {
   float pgrad_scale;             /* gstats_local == NULL: dgamma / dbeta += pgrad_scale * (value from gstats); 0 means 1.
                                     SyncBN without a rank-local copy: the all-reduced sums give the GLOBAL dgamma / dbeta,
                                     every rank adds 1/world of it and the gradient all-reduce restores the sum */
+  const double* count_ptr;       /* as in hrf_bn_fin_t */
 } hrf_bn_bfin_t;
 
 #ifdef __cplusplus
@@ -217,8 +221,10 @@ int hrf_bn_bwd_finalize(const double* gstats, const double* gstats_local, const 
  * `packed` (2*C doubles per layer, back to back) -> ONE all-reduce of `packed` by the host -> hrf_bn_finalize_packed /
  * hrf_bn_bwd_finalize_packed finalise all n layers from the packed sums (the `stats` / `gstats` / `write` fields of the
  * structs are ignored; packed_local = this rank's copy of `packed` taken before the all-reduce: parameter gradients use the
- * rank-local moments).  stats / C / fins / bfins are HOST arrays of n entries.                                          */
-int hrf_bn_pack(const double* const* stats, const int* C, int n, double* packed, void* stream);
+ * rank-local moments).  stats / C / fins / bfins are HOST arrays of n entries.  `rows` (nullable HOST array of n doubles):
+ * this rank's sample count of every layer, stored behind the sums at packed[sum_i 2*C_i + i] so that the SAME all-reduce
+ * yields the global counts (hrf_bn_fin_t.count_ptr points there): `packed` then holds sum_i 2*C_i + n doubles.            */
+int hrf_bn_pack(const double* const* stats, const int* C, int n, const double* rows, double* packed, void* stream);
 int hrf_bn_finalize_packed(const hrf_bn_fin_t* fins, int n, const double* packed, void* stream);
 int hrf_bn_bwd_finalize_packed(const hrf_bn_bfin_t* bfins, int n, const double* packed, const double* packed_local /* nullable: see pgrad_scale */, void* stream);
 
@@ -332,7 +338,10 @@ long hrf_wgrad_group_report(double* out, long cap_rows);
  * issued as it would have been, the launches of one call in their order.  The caller brackets MUTUALLY INDEPENDENT calls
  * only.  Results are identical to separate launches.  Per-thread state; begin / end must pair on one thread.
  * hrf_group_count(what): process-wide totals since load - 0 launches issued by hrf_group_end, 1 calls' launches they
- * carried, 2 hrf_group_end calls (measurement aid). */
+ * carried, 2 hrf_group_end calls (measurement aid); 3: the number of problems per launch the library was COMPILED for
+ * (HRF_GROUP_MAX).  The shipped build uses 1 - begin / end then only queue and re-issue - because on MI355X the merged
+ * launches measured slower than one HIP stream per sensor (csrc/hrf_group.h); -DHRF_GROUP_MAX=4 builds the
+ * multi-problem kernels (the CPU-emulator test build does). */
 int hrf_group_begin(void);
 int hrf_group_end(void* stream);
 long hrf_group_count(int what);
@@ -362,6 +371,12 @@ int hrf_fold_copies(const float* scratch, long copy_stride, const int* map, floa
 int hrf_adamw(float* p, const float* g, float* m, float* v, const float* wd_mask, long n, float lr,
               float beta1, float beta2, float eps, float weight_decay, const float* state,
               float grad_scale, void* stream);
+
+/* Measurement aid: when `stream` reaches this point one thread stores the GPU's constant-rate 100 MHz timestamp counter
+ * (wall_clock64) to *dst.  Unlike HIP events this can be timed INSIDE a replayed hipGraph: bench.py brackets the stages of
+ * the captured training step with it (stems, transitions, fusion_a/b/c, stage2-4 with the modality stages beside them;
+ * hrfuser_hrformer_based.py:535-607) for the per-stage roofline report. */
+int hrf_stamp(long long* dst, void* stream);
 
 /* hipMemsetAsync on `stream` (the per-step zeroing of the replicated accumulators). */
 int hrf_memset(void* ptr, int value, long bytes, void* stream);

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'hrfuser_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libhrfuser_emul.so')
-SOURCES = ['conv_engine.hip', 'lin_engine.hip', 'conv3_engine.hip', 'conv3w_engine.hip', 'dwconv.hip', 'attention.hip', 'attn_block.hip', 'pointwise.hip', 'group.hip']
+SOURCES = ['conv_engine.hip', 'lin_engine.hip', 'lin2_engine.hip', 'conv3_engine.hip', 'conv3w_engine.hip', 'dwconv.hip', 'attention.hip', 'attn_block.hip', 'pointwise.hip', 'group.hip']
 
 
 def build(force=False, sanitize=False):
@@ -23,6 +23,7 @@ def build(force=False, sanitize=False):
     for f in sorted(files):
         h.update(open(f, 'rb').read())
     h.update(b'asan' if sanitize else b'plain')
+    h.update(b'group4')
     stamp = LIB + '.stamp'
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
         return LIB
@@ -33,7 +34,7 @@ def build(force=False, sanitize=False):
         if not os.path.exists(sp):
             continue
         obj = os.path.join(OUT, src.replace('.hip', '.o').replace('.cpp', '.o'))
-        cmd = ['g++', '-x', 'c++', '-std=c++17', '-fPIC', '-DHRF_EMUL', '-ffp-contract=off', f'-I{HERE}', f'-I{CSRC}',
+        cmd = ['g++', '-x', 'c++', '-std=c++17', '-fPIC', '-DHRF_EMUL', '-DHRF_GROUP_MAX=4', '-ffp-contract=off', f'-I{HERE}', f'-I{CSRC}',
                '-c', sp, '-o', obj] + flags
         procs.append((src, subprocess.Popen(cmd)))
         objs.append(obj)

@@ -213,11 +213,15 @@ def _packed(C_list, backend):
         s[:, C:] += 2.0                                   # sum of squares > (sum)^2 / count
         stats.append((s * count / KC).reshape(-1).contiguous().to(dev))
         ref.append(stats[-1].view(KC, 2 * C).sum(0))
-    packed = torch.full((sum(2 * C for C in C_list),), float('nan'), dtype=torch.float64, device=dev)
+    tail = sum(2 * C for C in C_list)
+    packed = torch.full((tail + n,), float('nan'), dtype=torch.float64, device=dev)
     ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in stats])
     cs = (ctypes.c_int * n)(*C_list)
-    L.hrf_bn_pack(ptrs, cs, n, packed, _lib.stream_ptr())
-    assert r(packed, torch.cat(ref)) < 1e-12
+    rows = (ctypes.c_double * n)(*[count + 7.0 * i for i in range(n)])         # this rank's sample counts, behind the sums
+    L.hrf_bn_pack(ptrs, cs, n, rows, packed, _lib.stream_ptr())
+    assert r(packed[:tail], torch.cat(ref)) < 1e-12
+    assert packed[tail:].tolist() == [count + 7.0 * i for i in range(n)]
+    packed[tail:] = count                                     # (as if all-reduced: the layers below are finalised with `count`)
     # finalize every layer from the packed sums and compare with the stand-alone finalize on the replicated moments
     P = _lib._ptr
     off = 0
@@ -228,8 +232,10 @@ def _packed(C_list, backend):
         rm2, rv2 = rm.clone(), rv.clone()
         L.hrf_bn_finalize(st, gamma, beta, rm2, rv2, count, 1e-5, 0.1, 1, bufs['rscale'], bufs['rshift'], bufs['rmean'],
                           bufs['rinvstd'], C, _lib.stream_ptr())
+        # the host-side count is deliberately WRONG: the kernels must take the device-side count behind the sums (count_ptr)
+        li = C_list.index(C)
         fin = _lib.BnFin(None, P(gamma), P(beta), P(rm), P(rv), P(bufs['scale']), P(bufs['shift']), P(bufs['mean']),
-                         P(bufs['invstd']), count, 1e-5, 0.1, 1, 1, C)
+                         P(bufs['invstd']), 3.0, 1e-5, 0.1, 1, 1, C, 1, packed.data_ptr() + 8 * (tail + li))
         L.hrf_bn_finalize_packed(fin, 1, packed.data_ptr() + 8 * off, _lib.stream_ptr())
         for k in ('scale', 'shift', 'mean', 'invstd'):
             assert r(bufs[k], bufs['r' + k]) < 1e-6, (C, k)
@@ -240,7 +246,8 @@ def _packed(C_list, backend):
         dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
         dg2, db2 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
         L.hrf_bn_bwd_finalize(st, None, gamma, mean, invstd, count, 1, dg2, db2, c['rA'], c['rB'], c['rC'], C, _lib.stream_ptr())
-        bf = _lib.BnBFin(None, P(gamma), P(mean), P(invstd), P(dg), P(db), P(c['cA']), P(c['cB']), P(c['cC']), count, 1, 1, C, 1, None, 0.5)
+        bf = _lib.BnBFin(None, P(gamma), P(mean), P(invstd), P(dg), P(db), P(c['cA']), P(c['cB']), P(c['cC']), 3.0, 1, 1, C, 1, None, 0.5,
+                         packed.data_ptr() + 8 * (tail + li))
         L.hrf_bn_bwd_finalize_packed(bf, 1, packed.data_ptr() + 8 * off, None, _lib.stream_ptr())
         for k in 'ABC':
             assert r(c['c' + k], c['r' + k]) < 1e-6, (C, k)

@@ -1,6 +1,7 @@
 """Data-parallel logic on CPU: 2 ranks (gloo) each run the product tape/SyncBN/grad-exchange code
-on the kernel emulator with half of a batch; the result must equal ONE process on the whole batch
-(= the oracle on the concatenated batch): SyncBN statistics, summed/averaged gradients, AdamW."""
+on the kernel emulator with a part of a batch - UNEQUAL parts: one image on rank 0, two on rank 1, so the BatchNorm
+sample counts must travel with the moments (torch.nn.SyncBatchNorm all-gathers them) - and the result must equal ONE
+process on the whole batch (= the oracle on the concatenated batch): SyncBN statistics, summed/averaged gradients, AdamW."""
 import copy
 import os
 import sys
@@ -34,9 +35,9 @@ def _worker(rank, world, port, ret):
     net, orc, cfg = build_pair('t_nus', dev, edit=_short)           # SyncBN config
     net.train()
     enable_relu_probe(net)
-    B, (H, W) = 2, HW
+    B, (H, W) = 3, HW
     x, mods = O.seeded_inputs(B, H, W, [3, 3], seed=1)
-    sl = slice(rank, rank + 1)                          # one image per rank
+    sl = slice(0, 1) if rank == 0 else slice(1, 3)      # rank 0: one image, rank 1: two
     g = torch.Generator().manual_seed(5)
     shapes = [(B, H // 4 >> i, W // 4 >> i, c) for i, c in enumerate((18, 36, 72, 144))]
     cots = [torch.randn(s, generator=g) for s in shapes]
@@ -58,6 +59,7 @@ def _worker(rank, world, port, ret):
     neck.train()
     gm = torch.Generator().manual_seed(9)
     maps = [torch.randn(B, 18, 8, 16, generator=gm), torch.randn(B, 36, 4, 8, generator=gm)]
+    assert net.bn1.running_mean is not None
     ncots = [torch.randn(B, 8 >> i, 16 >> i, 32, generator=gm) for i in range(3)]
     ntr = Trainer(neck, lr=0.0, weight_decay=0.0, group=dist.group.WORLD, world_size=world)
     ntr.step(maps[0][sl], [maps[1][sl]], [c[sl] for c in ncots])
@@ -92,7 +94,7 @@ def test_two_rank_syncbn_and_grad_exchange_equal_single_process():
     # single-process reference on the WHOLE batch: the fp64 (and fp32) oracle with the ReLU decisions of the two ranks
     # pinned (each rank saw one image: their masks concatenate along the batch), so the gradient gate is the tight one
     _, orc, _ = build_pair('t_nus', torch.device('cpu'), edit=_short)
-    B, (H, W) = 2, HW
+    B, (H, W) = 3, HW
     x, mods = O.seeded_inputs(B, H, W, [3, 3], seed=1)
     g = torch.Generator().manual_seed(5)
     shapes = [(B, H // 4 >> i, W // 4 >> i, c) for i, c in enumerate((18, 36, 72, 144))]

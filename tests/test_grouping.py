@@ -44,9 +44,10 @@ def _queue_merge(backend):
     ys_g, outs, (x2, w2) = _two_convs(L, dev, True)
     c1 = [L.hrf_group_count(k) for k in range(3)]
     ys_s, _, _ = _two_convs(L, dev, False)
+    cap = L.hrf_group_count(3)                             # problems per launch of this build (product: 1, emulator tests: 4)
     assert c1[2] - c0[2] == 1                              # one hrf_group_end
     assert c1[1] - c0[1] == 4                              # four calls' launches ...
-    assert c1[0] - c0[0] == 2                              # ... in two launches: 3 merged + 1 alone
+    assert c1[0] - c0[0] == (2 if cap >= 3 else 4)         # ... in two launches (3 merged + 1 alone) when compiled for it
     for a, b in zip(ys_g, ys_s):
         assert torch.equal(a, b)                           # merging never changes arithmetic
     for (x, w, b, y) in outs:
@@ -102,7 +103,10 @@ def _lockstep_equals_serial(backend, tag, B, H, W):
     yc, gc, pc = _step(net, x, mods, dev, {'HRF_LOCKSTEP': '1', 'HRF_GROUP': '0'})
     merged, carried = c1[0] - c0[0], c1[1] - c0[1]
     print(f'[{tag}] merged launches {merged} carrying {carried} calls; serial pass issued {c2[0] - c1[0]} through the group path')
-    assert carried > merged > 0, (merged, carried)          # the sensor streams' equal layers really shared launches
+    if L.hrf_group_count(3) > 1:
+        assert carried > merged > 0, (merged, carried)      # the sensor streams' equal layers really shared launches
+    else:
+        assert carried == merged == 0                       # a build for one problem per launch never brackets
     assert c2[0] == c1[0]                                    # the serial schedule never brackets
     for a, b, c in zip(ya, yb, yc):
         assert torch.equal(a, b) and torch.equal(a, c)
