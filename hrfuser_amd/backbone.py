@@ -966,15 +966,16 @@ class _GraphedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(fctx, module, ent, anchor, *inputs):
-        fctx.hrf = (module, ent)
         fctx.set_materialize_grads(False)
-        return module._graph_forward(ent, inputs)
+        outs = module._graph_forward(ent, inputs)
+        fctx.hrf = (module, ent, ent.gen)                  # the engine generation of THIS replay
+        return outs
 
     @staticmethod
     def backward(fctx, *gouts):
-        module, ent = fctx.hrf
+        module, ent, gen = fctx.hrf
         fctx.hrf = None
-        return (None, None, None) + module._graph_backward(ent, gouts)
+        return (None, None, None) + module._graph_backward(ent, gouts, gen)
 
 
 class HipModule(nn.Module, EngineOwner):
@@ -1080,9 +1081,9 @@ class HipModule(nn.Module, EngineOwner):
         ent.gen = eng.gen
         return tuple(o.t.clone().permute(0, 3, 1, 2) for o in ent.outs)
 
-    def _graph_backward(self, ent, gouts):
+    def _graph_backward(self, ent, gouts, gen):
         eng = self._engine()
-        if ent.gen != getattr(eng, 'gen', ent.gen):
+        if gen != getattr(eng, 'gen', gen):
             raise _lib.HRFuserHipError(
                 'backward of a forward pass that is no longer the latest one of this module (the BatchNorm statistics slots '
                 'were overwritten by a later forward): run backward before the next forward of the same module')
@@ -1480,7 +1481,7 @@ class HRFuserHRFormerBased(HipModule):
         stages are enqueued on their own lanes first; the camera stage then runs from the main lane,
         each of its modules forking branch lanes from main (flat, never nested)."""
         M = self.num_fused_modalities
-        lanes = ctx.bundle_lanes(M, 'stages')
+        lanes = ctx.bundle_lanes(M, 'stages', cap=ctx.mod_lanes)
         mods = [None] * M
         ys = [None]
 
@@ -1489,7 +1490,10 @@ class HRFuserHRFormerBased(HipModule):
 
         def camera():
             ys[0] = self._run_stage(ctx, cam_stage, xs)
-        ctx.parallel(list(lanes) + [ctx.cur], [lambda k=k: mod_stage(k) for k in range(M)] + [camera])
+        if ctx.cam_first:          # (the camera stage is the long chain: its nodes first in issue / graph order)
+            ctx.parallel([ctx.cur] + list(lanes), [camera] + [lambda k=k: mod_stage(k) for k in range(M)])
+        else:
+            ctx.parallel(list(lanes) + [ctx.cur], [lambda k=k: mod_stage(k) for k in range(M)] + [camera])
         ctx.join(lanes)
         return ys[0], mods
 

@@ -468,6 +468,7 @@ __global__ __launch_bounds__(NTHR) void rowgemm_kernel(RgArgs a) {
   __syncthreads();
   read_frags(0, 0);
   HRF_WAIT_LDS();
+  __syncthreads();                                      // slot 0 is rewritten in step 0: every wave holds its fragments first
   // one step: MFMAs of step s on fragment set `set`, with the tile of step s+2 written into slot s%2 (its fragments
   // are in registers already) and the fragments of step s+1 fetched from the other slot half-way
   auto step = [&](int s, int set) {

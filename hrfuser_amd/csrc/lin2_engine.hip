@@ -20,6 +20,7 @@
 //     are guarded at the loads (no packed copies, no padding);
 //   * bias / residual rows, activation' of the producer, per-channel (sum, sum*.) moments and LayerNorm row statistics are
 //     applied to the accumulators (D[channel][pixel]: a lane owns 4 consecutive channels of one pixel).
+#include <type_traits>
 #include "hrf_common.h"
 #include "hrf_lin.h"
 #include "hrf_group.h"
@@ -37,9 +38,11 @@ constexpr int TBL = HRF_FIN_MAXC;          // widest contraction whose per-k tab
 #define L2_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define L2_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)      // lgkmcnt(0) only
 #endif
+// the pipeline stages are lambdas over ~100 live registers: an outlined call would pass them through memory
+#define L2_INLINE __attribute__((always_inline))
 
 __device__ float g_zero4l[4] = {0.f, 0.f, 0.f, 0.f};
-static int g_l2_knob[4] = {0, 0, 0, 0};    // 0: 1 = use this engine whenever the shape is supported, 2 = never (tests / A-B)
+static int g_l2_knob[4] = {0, 0, 0, 0};    // 0: 1 = use this engine whenever the shape is supported, 2 = never (tests / A-B); 1: forced WN
 
 __device__ __forceinline__ hrf_f4 l2_ld4(const float* p) {
 #ifdef HRF_EMUL
@@ -63,6 +66,21 @@ __device__ __forceinline__ hrf_f4 gl_ld4(const float* p, int nvalid) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) r[e] = *(e < nvalid ? p + e : g_zero4l);
   return r;
+}
+
+// row[idx .. idx+3] of a row of `len` >= 4 floats, elements at or beyond `len` read as 0 (idx may lie beyond the row): ONE
+// unconditional 16-byte load from a clamped index, then register selects - a load under a (per-lane) condition gets its own
+// dependent round trip, which is what a ragged K / N would cost in every step of the pipeline otherwise
+__device__ __forceinline__ hrf_f4 ld4_ragged(const float* row, int idx, int len) {
+  const int ic = idx > len - 4 ? len - 4 : idx;
+  const int d = idx - ic;                                // 0: aligned with the request; 1..3: shifted; >= 4: nothing valid
+  const hrf_f4 v = hrf_ld4(row + ic);
+  hrf_f4 o;
+  o[0] = d == 0 ? v[0] : (d == 1 ? v[1] : (d == 2 ? v[2] : (d == 3 ? v[3] : 0.f)));
+  o[1] = d == 0 ? v[1] : (d == 1 ? v[2] : (d == 2 ? v[3] : 0.f));
+  o[2] = d == 0 ? v[2] : (d == 1 ? v[3] : 0.f);
+  o[3] = d == 0 ? v[3] : 0.f;
+  return o;
 }
 
 // per-channel (sum v, sum v*w) over the pixels of a wave's tiles -> atomics into the block's replicated copy.
@@ -118,7 +136,8 @@ __global__ __launch_bounds__(NTHR) void lin2_fwd_kernel(HrfGroup<LinFwdArgs> grp
   HRF_DYN_SMEM(float, smem);                            // [2][SLOT] ring | [2][TBL] per-k tables | reduction scratch
   float* sTab = smem + 2 * SLOT;                        // scale | shift (BatchNorm affine or LayerNorm gamma / beta)
   float* sRed = sTab + (TBLS ? 2 * TBL : 0);            // [8 / WN][2][NB] moments, or [GROWS][WN] row sums
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: tile predicates become scalar branches
   const int i = lane & 15, q = lane >> 4;
   const int chg = wave % WN, rg = wave / WN;
   const long m0 = (long)blockIdx.x * GROWS;
@@ -142,28 +161,39 @@ __global__ __launch_bounds__(NTHR) void lin2_fwd_kernel(HrfGroup<LinFwdArgs> grp
 
   // staging: x tile = 128 rows x 4 float4 (one per thread); weight tile = NB rows x 4 float4
   const long xr = m0 + (tid >> 2) < a.M ? m0 + (tid >> 2) : a.M - 1;          // tail rows re-read the last row, never stored
-  const float* xsrc = a.x + xr * a.ldX + 4 * (tid & 3);
   const int xdst = (tid >> 2) * GLP + 4 * (tid & 3);
   float mean = 0.f, rstd = 1.f;
   if (TF == HRF_TF_LN) { mean = a.tf_rowstat[2 * xr]; rstd = a.tf_rowstat[2 * xr + 1]; }
-  const float* wsrc[NWV]; int wdst[NWV]; bool wrow[NWV];
+  const float* xrow = a.x + xr * a.ldX;
+  const float* wsrc[NWV]; int wdst[NWV]; float wmask[NWV];
 #pragma unroll
   for (int e = 0; e < NWV; ++e) {
     const int f = tid + e * NTHR, n = f >> 2;
-    wrow[e] = f < NB * 4 && n0 + n < a.N;
-    wsrc[e] = a.w + (long)(wrow[e] ? n0 + n : 0) * a.K + 4 * (f & 3);
+    const bool on = f < NB * 4 && n0 + n < a.N;
+    wmask[e] = on ? 1.f : 0.f;                           // rows beyond N: a valid row is read and multiplied by 0
+    wsrc[e] = a.w + (long)(on ? n0 + n : 0) * a.K;
     wdst[e] = f < NB * 4 ? (GROWS + n) * GLP + 4 * (f & 3) : -1;
   }
   hrf_f4 xpre, wpre[NWV];
   int kpre = 0;
-  auto load_tile = [&](int s) {
+  auto load_tile = [&](int s) L2_INLINE {
     const int kb = s * GK + 4 * (tid & 3);
     kpre = kb;
-    xpre = gl_ld4(xsrc + s * GK, a.K - kb);
+    if ((s + 1) * GK <= a.K) {                           // (uniform) whole step inside the rows: plain 16-byte loads
+      xpre = hrf_ld4(xrow + kb);
 #pragma unroll
-    for (int e = 0; e < NWV; ++e) wpre[e] = gl_ld4(wsrc[e] + s * GK, wrow[e] ? a.K - kb : 0);
+      for (int e = 0; e < NWV; ++e) wpre[e] = hrf_ld4(wsrc[e] + kb);
+    } else {
+      xpre = ld4_ragged(xrow, kb, a.K);
+#pragma unroll
+      for (int e = 0; e < NWV; ++e) wpre[e] = ld4_ragged(wsrc[e], kb, a.K);
+    }
+#pragma unroll
+    for (int e = 0; e < NWV; ++e)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wpre[e][r] *= wmask[e];
   };
-  auto store_tile = [&](int slot) {
+  auto store_tile = [&](int slot) L2_INLINE {
     float* d = smem + slot * SLOT;
     hrf_f4 v = xpre;
     if (TBLS) {
@@ -182,7 +212,7 @@ __global__ __launch_bounds__(NTHR) void lin2_fwd_kernel(HrfGroup<LinFwdArgs> grp
   hrf_f4 fa[2][WN], fb[2][4];
   const float* abase = smem + (rg * 16 * WN + i) * GLP + 4 * q;
   const float* bbase = smem + (GROWS + chg * 64 + i) * GLP + 4 * q;
-  auto read_frags = [&](int slot, int set) {
+  auto read_frags = [&](int slot, int set) L2_INLINE {
 #pragma unroll
     for (int rr = 0; rr < WN; ++rr) fa[set][rr] = l2_ld4(abase + slot * SLOT + rr * 16 * GLP);
 #pragma unroll
@@ -191,14 +221,27 @@ __global__ __launch_bounds__(NTHR) void lin2_fwd_kernel(HrfGroup<LinFwdArgs> grp
   bool tile_on[4];
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt) tile_on[tt] = n0 + chg * 64 + tt * 16 < a.N;
-  auto mma = [&](int set, int half) {
+  const bool all_on = tile_on[3];                       // (tiles switch off from the top: the common case is all four)
+  // ALL: every channel tile of this wave is inside N - the whole K loop is compiled twice, so that the common case carries
+  // no per-tile predicate (and no accumulator copies at the joins of a predicated version)
+  auto mma = [&](auto ALL, int set, int half) L2_INLINE {
+    if (decltype(ALL)::value) {
 #pragma unroll
-    for (int m = 2 * half; m < 2 * half + 2; ++m)
+      for (int m = 2 * half; m < 2 * half + 2; ++m)
 #pragma unroll
-      for (int rr = 0; rr < WN; ++rr)
+        for (int rr = 0; rr < WN; ++rr)
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-          if (tile_on[tt]) acc[rr][tt] = hrf_mfma16(fb[set][tt][m], fa[set][rr][m], acc[rr][tt]);
+          for (int tt = 0; tt < 4; ++tt) acc[rr][tt] = hrf_mfma16(fb[set][tt][m], fa[set][rr][m], acc[rr][tt]);
+    } else {
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        if (!tile_on[tt]) break;
+#pragma unroll
+        for (int m = 2 * half; m < 2 * half + 2; ++m)
+#pragma unroll
+          for (int rr = 0; rr < WN; ++rr) acc[rr][tt] = hrf_mfma16(fb[set][tt][m], fa[set][rr][m], acc[rr][tt]);
+      }
+    }
   };
 
   const int S = (a.K + GK - 1) / GK;
@@ -210,22 +253,26 @@ __global__ __launch_bounds__(NTHR) void lin2_fwd_kernel(HrfGroup<LinFwdArgs> grp
   __syncthreads();
   read_frags(0, 0);
   L2_WAIT_LDS();
-  auto step = [&](int s, int set) {
+  __syncthreads();                                      // slot 0 is rewritten in step 0: every wave holds its fragments first
+  auto step = [&](auto ALL, int s, int set) L2_INLINE {
     L2_SCHED_FENCE();
-    mma(set, 0);
+    mma(ALL, set, 0);
     L2_SCHED_FENCE();
     if (s + 2 < S) store_tile(s & 1);
     if (s + 3 < S) load_tile(s + 3);
     read_frags((s + 1) & 1, set ^ 1);          // complete since the previous barrier (stale but valid after the last step)
     L2_SCHED_FENCE();
-    mma(set, 1);
+    mma(ALL, set, 1);
     L2_SCHED_FENCE();
     __syncthreads();
   };
-  for (int s = 0; s < S; s += 2) {
-    step(s, 0);
-    if (s + 1 < S) step(s + 1, 1);
-  }
+  auto kloop = [&](auto ALL) L2_INLINE {
+    for (int s = 0; s < S; s += 2) {
+      step(ALL, s, 0);
+      if (s + 1 < S) step(ALL, s + 1, 1);
+    }
+  };
+  if (all_on) kloop(std::true_type{}); else kloop(std::false_type{});
 
   // ---- epilogue: acc[rr][tt][r] = y(row m0 + rg*16*WN + rr*16 + i, channel n0 + chg*64 + tt*16 + 4q + r)
   bool rowv[WN];
@@ -307,7 +354,8 @@ __global__ __launch_bounds__(NTHR) void lin2_bwd_data_kernel(HrfGroup<LinBwdData
   HRF_DYN_SMEM(float, smem);
   float* sTab = smem + 2 * SLOT;                        // cA | cB | cC
   float* sRed = sTab + (BNB ? 3 * TBL : 0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: tile predicates become scalar branches
   const int i = lane & 15, q = lane >> 4;
   const int chg = wave % WN, rg = wave / WN;
   const long m0 = (long)blockIdx.x * GROWS;
@@ -329,8 +377,8 @@ __global__ __launch_bounds__(NTHR) void lin2_bwd_data_kernel(HrfGroup<LinBwdData
     for (int tt = 0; tt < 4; ++tt) acc[rr][tt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
 
   const long xr = m0 + (tid >> 2) < a.M ? m0 + (tid >> 2) : a.M - 1;
-  const float* dsrc = a.dy + xr * a.ldD + a.doff + 4 * (tid & 3);
-  const float* ysrc = BNB ? a.yraw + xr * a.ldD + a.doff + 4 * (tid & 3) : nullptr;
+  const float* drow = a.dy + xr * a.ldD + a.doff;
+  const float* yrow = BNB ? a.yraw + xr * a.ldD + a.doff : nullptr;
   const int xdst = (tid >> 2) * GLP + 4 * (tid & 3);
   // weight staging: thread -> (kk = f & 15, n4 = f >> 4): a float4 of W[k][n .. n+3], written to LDS rows n .. n+3 at column kk
   int wkk[NWV], wn[NWV]; bool won[NWV];
@@ -342,19 +390,26 @@ __global__ __launch_bounds__(NTHR) void lin2_bwd_data_kernel(HrfGroup<LinBwdData
   }
   hrf_f4 dpre, ypre, wpre[NWV];
   int kpre = 0;
-  auto load_tile = [&](int s) {
+  auto load_tile = [&](int s) L2_INLINE {
     const int kb = s * GK + 4 * (tid & 3);
     kpre = kb;
-    dpre = gl_ld4(dsrc + s * GK, a.K - kb);
-    if (BNB) ypre = gl_ld4(ysrc + s * GK, a.K - kb);
+    if ((s + 1) * GK <= a.K) {                           // (uniform)
+      dpre = hrf_ld4(drow + kb);
+      if (BNB) ypre = hrf_ld4(yrow + kb);
+    } else {
+      dpre = ld4_ragged(drow, kb, a.K);
+      if (BNB) ypre = ld4_ragged(yrow, kb, a.K);
+    }
 #pragma unroll
     for (int e = 0; e < NWV; ++e) {
       const int k = s * GK + wkk[e];
-      const bool kv = won[e] && k < a.K;
-      wpre[e] = gl_ld4(a.w + (long)(kv ? k : 0) * a.N + n0 + wn[e], kv ? a.N - (n0 + wn[e]) : 0);
+      const float km = (won[e] && k < a.K) ? 1.f : 0.f;  // rows beyond K: row K-1 is read and multiplied by 0
+      wpre[e] = ld4_ragged(a.w + (long)(k < a.K ? k : a.K - 1) * a.N, n0 + wn[e], a.N);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wpre[e][r] *= km;
     }
   };
-  auto store_tile = [&](int slot) {
+  auto store_tile = [&](int slot) L2_INLINE {
     float* d = smem + slot * SLOT;
     hrf_f4 v = dpre;
     if (BNB) {
@@ -373,7 +428,7 @@ __global__ __launch_bounds__(NTHR) void lin2_bwd_data_kernel(HrfGroup<LinBwdData
   hrf_f4 fa[2][WN], fb[2][4];
   const float* abase = smem + (rg * 16 * WN + i) * GLP + 4 * q;
   const float* bbase = smem + (GROWS + chg * 64 + i) * GLP + 4 * q;
-  auto read_frags = [&](int slot, int set) {
+  auto read_frags = [&](int slot, int set) L2_INLINE {
 #pragma unroll
     for (int rr = 0; rr < WN; ++rr) fa[set][rr] = l2_ld4(abase + slot * SLOT + rr * 16 * GLP);
 #pragma unroll
@@ -382,14 +437,27 @@ __global__ __launch_bounds__(NTHR) void lin2_bwd_data_kernel(HrfGroup<LinBwdData
   bool tile_on[4];
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt) tile_on[tt] = n0 + chg * 64 + tt * 16 < a.N;
-  auto mma = [&](int set, int half) {
+  const bool all_on = tile_on[3];                       // (tiles switch off from the top: the common case is all four)
+  // ALL: every channel tile of this wave is inside N - the whole K loop is compiled twice, so that the common case carries
+  // no per-tile predicate (and no accumulator copies at the joins of a predicated version)
+  auto mma = [&](auto ALL, int set, int half) L2_INLINE {
+    if (decltype(ALL)::value) {
 #pragma unroll
-    for (int m = 2 * half; m < 2 * half + 2; ++m)
+      for (int m = 2 * half; m < 2 * half + 2; ++m)
 #pragma unroll
-      for (int rr = 0; rr < WN; ++rr)
+        for (int rr = 0; rr < WN; ++rr)
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-          if (tile_on[tt]) acc[rr][tt] = hrf_mfma16(fb[set][tt][m], fa[set][rr][m], acc[rr][tt]);
+          for (int tt = 0; tt < 4; ++tt) acc[rr][tt] = hrf_mfma16(fb[set][tt][m], fa[set][rr][m], acc[rr][tt]);
+    } else {
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        if (!tile_on[tt]) break;
+#pragma unroll
+        for (int m = 2 * half; m < 2 * half + 2; ++m)
+#pragma unroll
+          for (int rr = 0; rr < WN; ++rr) acc[rr][tt] = hrf_mfma16(fb[set][tt][m], fa[set][rr][m], acc[rr][tt]);
+      }
+    }
   };
 
   const int S = (a.K + GK - 1) / GK;
@@ -401,22 +469,26 @@ __global__ __launch_bounds__(NTHR) void lin2_bwd_data_kernel(HrfGroup<LinBwdData
   __syncthreads();
   read_frags(0, 0);
   L2_WAIT_LDS();
-  auto step = [&](int s, int set) {
+  __syncthreads();                                      // slot 0 is rewritten in step 0: every wave holds its fragments first
+  auto step = [&](auto ALL, int s, int set) L2_INLINE {
     L2_SCHED_FENCE();
-    mma(set, 0);
+    mma(ALL, set, 0);
     L2_SCHED_FENCE();
     if (s + 2 < S) store_tile(s & 1);
     if (s + 3 < S) load_tile(s + 3);
-    read_frags((s + 1) & 1, set ^ 1);
+    read_frags((s + 1) & 1, set ^ 1);          // complete since the previous barrier (stale but valid after the last step)
     L2_SCHED_FENCE();
-    mma(set, 1);
+    mma(ALL, set, 1);
     L2_SCHED_FENCE();
     __syncthreads();
   };
-  for (int s = 0; s < S; s += 2) {
-    step(s, 0);
-    if (s + 1 < S) step(s + 1, 1);
-  }
+  auto kloop = [&](auto ALL) L2_INLINE {
+    for (int s = 0; s < S; s += 2) {
+      step(ALL, s, 0);
+      if (s + 1 < S) step(ALL, s + 1, 1);
+    }
+  };
+  if (all_on) kloop(std::true_type{}); else kloop(std::false_type{});
 
   bool rowv[WN];
 #pragma unroll
@@ -462,6 +534,7 @@ __global__ __launch_bounds__(NTHR) void lin2_bwd_data_kernel(HrfGroup<LinBwdData
 }
 
 inline int pick_wn(long M, int N) {
+  if (g_l2_knob[1] == 1 || g_l2_knob[1] == 2 || g_l2_knob[1] == 4) return g_l2_knob[1];      // tests: force a block width
   const long mt = (M + GROWS - 1) / GROWS;
   if (N > 128 && mt * ((N + 255) / 256) >= 96) return 4;      // enough blocks to occupy the chip at one block per CU
   if (N > 64) return 2;
@@ -476,7 +549,10 @@ inline bool wide_enough(long M, int K, int N) {
   if (g_l2_knob[0] == 2) return false;
   if (K < 16 || N < 16 || M <= 0) return false;
   if (g_l2_knob[0] == 1) return true;
-  return (K < N ? K : N) >= 64 && M >= 1024;
+  // a block owns 128 rows: fewer than ~200 blocks cannot fill 256 CUs and the register-only kernels (64 rows per block, one
+  // wave per 16 rows) win (measured on HRFuser-B's 24x40 and 12x20 branches: 31.9 -> 90.6 us for 312 -> 936 at 1920 rows)
+  const long blocks = ((M + GROWS - 1) / GROWS) * ((N + 255) / 256);
+  return (K < N ? K : N) >= 64 && blocks >= 200;
 }
 
 template <class KERN>

@@ -327,7 +327,16 @@ class Ctx:
         # which sibling sets are bundled (A/B knob): stems, trans(itions), stages; keep_first: the finest camera branch
         # stays on the current lane so that it merges with the modality stages bundled there
         self.bundle_what = set(os.environ.get('HRF_BUNDLE_WHAT', 'stems,trans,stages').split(',')) if self.bundle else set()
-        self.keep_first = self.bundle and 'stages' in self.bundle_what and os.environ.get('HRF_KEEP_FIRST', '1') != '0'
+        # keep_first: the first sibling of a fork stays on the current lane (needed for merging with the bundled modality
+        # stages; on its own a lane-count measure: main + nb - 1 streams per HRModule instead of nb, see mod_lanes)
+        kf = os.environ.get('HRF_KEEP_FIRST')
+        self.keep_first = (self.bundle and 'stages' in self.bundle_what) if kf is None else kf != '0'
+        self.cam_first = os.environ.get('HRF_CAM_FIRST', '0') != '0'     # issue the camera stage before the modality stages
+        # the MI355X runtime drives 4 hardware queues; a step with more concurrently active HIP streams aliases two of them
+        # onto one queue, and a queue executes its streams' kernels in order: in stage 3 the camera's 72-channel branch sat
+        # behind a modality stream's six-block chain (rocprofv3 trace, profiles/r03_stage_trace.txt).  mod_lanes = HIP streams
+        # for the M modality stages that run beside a camera stage (0: one each)
+        self.mod_lanes = int(os.environ.get('HRF_MOD_LANES', '0') or 0)
         self._sweeper = None            # greenlet running the sweep (None: not inside parallel())
         self._strands = []              # live strands of the running sweep, all levels
         self._xlane = None
@@ -612,7 +621,7 @@ class Ctx:
             self.n_collectives += 1
 
     # ---- lanes ---------------------------------------------------------------------------------
-    def fork(self, n, keep_first=False):
+    def fork(self, n, keep_first=False, cap=0):
         """n sibling lanes that start after everything enqueued so far on the current lane.  keep_first: the first
         sibling stays on the current lane (its launches can then merge with equal-shape strands bundled on that lane)."""
         # lanes are always direct children of the main lane: nested stream forks crash hipGraph
@@ -633,6 +642,8 @@ class Ctx:
         first = [self.cur] if keep_first else []
         n -= len(first)
         m = n if _MAX_LANES <= 0 else min(n, _MAX_LANES)      # HRF_MAX_LANES: fewer streams than siblings
+        if cap > 0:
+            m = min(m, cap)                                   # siblings share streams on purpose (run one after the other)
         while len(self._free) < m:
             self._free.append(self.owner._lane_pool(grow=True))
         uniq = [self._free.pop() for _ in range(m)]
@@ -642,13 +653,13 @@ class Ctx:
             self.strand.tape.append(('F', self.cur, uniq))
         return first + [uniq[i % m] for i in range(n)]
 
-    def bundle_lanes(self, n, what='stems'):
+    def bundle_lanes(self, n, what='stems', cap=0):
         """Lanes for n strands of EQUAL shape (camera stem + modality stems, the modality stages beside the camera stage):
         all on the current lane when launch merging is on - their equal calls become one multi-problem launch, in order on
         one queue, no cross-queue edges - otherwise a stream each."""
         if self.bundle and what in self.bundle_what:
             return [self.cur] * n
-        return self.fork(n)
+        return self.fork(n, cap=cap)
 
     def join(self, kids):
         """The current lane continues after all sibling lanes have finished."""

@@ -202,6 +202,46 @@ def run_conv(case, backend):
     assert r(dw, wq.grad) < TOL and r(db, bq.grad) < TOL
 
 
+# the LDS-tiled row GEMM (csrc/lin2_engine.hip) serves wide 1x1 problems (min(Cin, Cout) >= 64, >= 1024 rows); the debug knob 28
+# forces it on the small shapes a CPU emulator run can afford, knob 29 forces the block width (64 / 128 / 256 channels)
+LIN2_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
+    (2, 9, 11, 18, 72, 1, 1, 4, True, False),       # LayerNorm on load, ragged K (18) and N (72)
+    (2, 9, 11, 72, 18, 1, 1, 3, True, True),        # BatchNorm + GELU finalised on load; act' epilogue + moments
+    (1, 13, 11, 78, 312, 1, 1, 4, True, True),      # HRFuser-B fc1 shape: K = 78 (tail of 14), N = 312 (two column blocks)
+    (1, 13, 11, 312, 78, 1, 1, 3, True, True),      # HRFuser-B fc3
+    (2, 7, 9, 144, 80, 1, 1, 0, False, False),
+    (1, 16, 9, 64, 256, 1, 1, 2, True, True),       # Bottleneck conv3 (ReLU input)
+    (1, 9, 16, 256, 64, 1, 1, 1, True, False),
+    (1, 5, 3, 78, 78, 1, 1, 4, False, True),        # fewer rows than one block
+]
+
+
+def run_lin2(case, wn, backend):
+    use_backend(backend)
+    L = _lib.lib()
+    L.hrf_debug_knob(28, 1)
+    L.hrf_debug_knob(29, wn)
+    try:
+        run_conv(case, backend)
+    finally:
+        L.hrf_debug_knob(28, 0)
+        L.hrf_debug_knob(29, 0)
+
+
+@pytest.mark.parametrize('wn', [1, 2, 4])
+@pytest.mark.parametrize('case', LIN2_CASES[:5])
+def test_lin2_emul(case, wn):
+    run_lin2(case, wn, 'emul')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wn', [0, 1, 2, 4])
+@pytest.mark.parametrize('case', LIN2_CASES + [(2, 96, 160, 78, 312, 1, 1, 4, True, True), (2, 96, 160, 312, 78, 1, 1, 3, True, True),
+                                               (2, 48, 80, 156, 468, 1, 1, 4, True, False), (2, 96, 160, 64, 256, 1, 1, 2, True, True)])
+def test_lin2_gpu(case, wn):
+    run_lin2(case, wn, 'hip')
+
+
 DW_CASES = [(2, 9, 11, 72, 1, 3, True, True, True), (2, 17, 35, 40, 1, 0, False, False, False), (2, 19, 21, 18, 1, 3, False, True, True),
             (2, 10, 13, 18, 2, 0, False, True, False), (2, 11, 15, 36, 2, 2, False, True, True),
             (1, 16, 32, 33, 2, 1, False, False, True)]
