@@ -256,27 +256,35 @@ class Engine:
         for key, need in plan.items():
             kind, p = key
             ent = pools.get(key)
-            if ent is None or ent[0].numel() != need:          # persistent buffers: refilled in place
-                ent = pools[key] = [torch.empty(need, device=self.device, dtype=torch.float32), 0]
+            if ent is None or ent.numel() != need:             # persistent buffers: refilled in place
+                ent = pools[key] = torch.empty(need, device=self.device, dtype=torch.float32)
             if kind == 'mask':
-                ent[0].bernoulli_(1.0 - p)
+                ent.bernoulli_(1.0 - p)
             else:
                 keep = 1.0 - p
-                ent[0].uniform_().add_(keep).floor_().div_(keep)
-            ent[1] = 0
-        self._rng_need = {}
+                ent.uniform_().add_(keep).floor_().div_(keep)
+        self._rng_calls = {}
 
     def _rng_take(self, kind, p, n, fresh):
+        """A slice of the step's pool that belongs to the CALL SITE (`rng_site`, set by the block right before it draws, and
+        the how-manieth draw of that site this step) - not to the position of the call in program order: the lock-step
+        scheduler interleaves sibling strands differently from the serial one (HRF_LOCKSTEP=0, HRF_SYNC_LANE_COMMS=1), and
+        the same seed must give every layer the same draws under either (bench.py sync_ab compares their gradients)."""
         key = (kind, float(p))
-        self._rng_need[key] = self._rng_need.get(key, 0) + n
+        calls = self.__dict__.setdefault('_rng_calls', {})
+        site = self.__dict__.get('rng_site')
+        k = calls.get((key, site), 0)
+        calls[(key, site)] = k + 1
+        slots = self.__dict__.setdefault('_rng_slots', {}).setdefault(key, {})
+        slot = slots.get((site, k))
+        if slot is None or slot[1] != n:
+            off = self._rng_plan.get(key, 0)
+            slot = slots[(site, k)] = (off, n)
+            self._rng_plan[key] = off + n
         ent = self._rng_pool.get(key)
-        if ent is not None and ent[1] + n <= ent[0].numel():
-            out = ent[0][ent[1]:ent[1] + n]
-            ent[1] += n
-        else:
-            out = fresh()                       # first training step (sizes unknown yet)
-        self._rng_plan[key] = max(self._rng_plan.get(key, 0), self._rng_need[key])
-        return out
+        if ent is not None and slot[0] + n <= ent.numel():
+            return ent[slot[0]:slot[0] + n]
+        return fresh()                          # first training step (sizes unknown yet)
 
     def dropout_mask(self, shape, p):
         n = 1
@@ -314,9 +322,7 @@ class Engine:
         if pre:
             self.pre_step(training)
         else:
-            for ent in self.__dict__.get('_rng_pool', {}).values():
-                ent[1] = 0
-            self._rng_need = {}
+            self._rng_calls = {}
         if self.arena_d.numel():
             R.gpu_zero_(self.arena_d)
         if self._bns and not (training and all(m.training for m in self._bns)):
@@ -533,6 +539,7 @@ class HRFormerBlock(nn.Module):
         if p > 0.0 and ctx.training and self.training:
             # mmcv DropPath: per-sample floor(keep + U[0,1)) / keep, drawn independently for the two residual paths
             eng = ctx.owner._engine()
+            eng.rng_site = id(self)
             s1, s2 = eng.droppath_scale(x.t.shape[0], p), eng.droppath_scale(x.t.shape[0], p)
         msa = self.attn.attn
         C = x.t.shape[-1]
@@ -591,6 +598,7 @@ class MultiWindowCrossAttention(nn.Module):
         if ctx.training and a.proj_drop.training and (p > 0 or drop_path_scale is not None):
             mask = None
             if p > 0:
+                ctx.owner._engine().rng_site = id(self)
                 mask = ctx.owner._engine().dropout_mask((B, H, W, C), p)
             drop = (mask, 1.0 / (1.0 - p) if p > 0 else 1.0, drop_path_scale)
         return R.linear_residual(ctx, o, a.out_proj, acc, res2=z, drop=drop)
@@ -619,6 +627,7 @@ class HRFuserFusionBlock(nn.Module):
         p = self.drop_path_prob
         if not (ctx.training and self.training) or p <= 0.0:
             return None
+        ctx.owner._engine().rng_site = id(self)
         return ctx.owner._engine().droppath_scale(B, p)
 
     def run(self, ctx, x, mods):
@@ -642,6 +651,7 @@ class HRFuserFusionBlock(nn.Module):
                 p = a.proj_drop.p
                 drop = None
                 if ctx.training and a.proj_drop.training and (p > 0 or dps is not None):
+                    ctx.owner._engine().rng_site = (id(self), k)
                     mask = ctx.owner._engine().dropout_mask(tuple(x.t.shape), p) if p > 0 else None
                     drop = (mask, 1.0 / (1.0 - p) if p > 0 else 1.0, dps)
                 acc, h1 = R.attn_block(ctx, (id(self), k), heads, x, z, self.norm1[k], self.norm2[k], (a.q_proj, 0),

@@ -113,3 +113,31 @@ def test_draw_statistics_emul():
 @pytest.mark.gpu
 def test_draw_statistics_gpu():
     _draw_stats(use_backend('hip'))
+
+
+def test_draws_belong_to_the_call_site_not_to_program_order():
+    """The lock-step scheduler and the serial one (HRF_LOCKSTEP=0 / HRF_SYNC_LANE_COMMS=1) reach the layers in different
+    orders; with one seed every layer must get the same draws under either (bench.py's sync_ab compares gradients)."""
+    dev = use_backend('emul')
+    blk = B.HRFuserFusionBlock(18, 18, 1, norm_cfg=NORM, transformer_norm_cfg=LN, num_fused_modalities=2)
+    eng = BlockHarness(blk, lambda k, b, x: b.run(k, x[0], x[1:])).to(dev)._engine()
+    eng.ready(dev)
+
+    def step(order, seed):
+        eng.begin_forward(True)                            # the pools were refilled from torch's generator just now
+        out = {}
+        for site in order:
+            eng.rng_site = site
+            out[site] = (eng.dropout_mask((2, 8, 8, 18), 0.1).clone(), eng.droppath_scale(2, 0.2).clone(), eng.droppath_scale(2, 0.2).clone())
+        return out
+
+    torch.manual_seed(1)
+    step(['a', 'b', 'c'], 1)                               # first step: fresh draws, slots assigned
+    torch.manual_seed(2)
+    r1 = step(['a', 'b', 'c'], 2)
+    torch.manual_seed(2)
+    r2 = step(['c', 'a', 'b'], 2)
+    for site in 'abc':
+        for u, v in zip(r1[site], r2[site]):
+            assert torch.equal(u, v)
+    assert not torch.equal(r1['a'][0], r1['b'][0])         # distinct slices of the pool
