@@ -203,7 +203,7 @@ def run_conv(case, backend):
 
 
 # the LDS-tiled row GEMM (csrc/lin2_engine.hip) serves wide 1x1 problems (min(Cin, Cout) >= 64, >= 1024 rows); the debug knob 28
-# forces it on the small shapes a CPU emulator run can afford, knob 29 forces the block width (64 / 128 / 256 channels)
+# forces it on the small shapes a CPU emulator run can afford, knob 29 forces the block width (1..4 = 80 / 160 / 256 / 320 channels)
 LIN2_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
     (2, 9, 11, 18, 72, 1, 1, 4, True, False),       # LayerNorm on load, ragged K (18) and N (72)
     (2, 9, 11, 72, 18, 1, 1, 3, True, True),        # BatchNorm + GELU finalised on load; act' epilogue + moments
@@ -228,14 +228,14 @@ def run_lin2(case, wn, backend):
         L.hrf_debug_knob(29, 0)
 
 
-@pytest.mark.parametrize('wn', [1, 2, 4])
+@pytest.mark.parametrize('wn', [1, 2, 3, 4])
 @pytest.mark.parametrize('case', LIN2_CASES[:5])
 def test_lin2_emul(case, wn):
     run_lin2(case, wn, 'emul')
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('wn', [0, 1, 2, 4])
+@pytest.mark.parametrize('wn', [0, 1, 2, 3, 4])
 @pytest.mark.parametrize('case', LIN2_CASES + [(2, 96, 160, 78, 312, 1, 1, 4, True, True), (2, 96, 160, 312, 78, 1, 1, 3, True, True),
                                                (2, 48, 80, 156, 468, 1, 1, 4, True, False), (2, 96, 160, 64, 256, 1, 1, 2, True, True)])
 def test_lin2_gpu(case, wn):
