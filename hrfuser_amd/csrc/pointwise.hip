@@ -156,7 +156,11 @@ struct LnBwdArgs {
   float* dbeta;
   long copy_stride;
 };
-template <int NCH>
+// LPR lanes per row (16: rows of up to 80 channels, 16 rows per pass; 64: wider rows, 4 rows per pass - at 312 / 624 channels the
+// 16-lane form had 60 / 120 dword loads per lane and 60 resp. 15 blocks on the 24x40 and 12x20 grids of HRFuser-B: 20 - 37 us for
+// 2 - 7 MB), NCH channels per lane.  The parameter gradients of a block meet through wave shuffles and plain LDS stores (the
+// first version merged its 16 row slots with same-address LDS atomics).
+template <int NCH, int LPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(HrfGroup<LnBwdArgs> grp) {
   const LnBwdArgs& pa_ = grp.sel();
   const float* da = pa_.da;
@@ -170,22 +174,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(HrfGroup<LnBwdArgs> grp) {
   float* dgamma = pa_.dgamma;
   float* dbeta = pa_.dbeta;
   long copy_stride = pa_.copy_stride;
-  __shared__ float sacc[2 * 16 * NCH];
-  for (int i = threadIdx.x; i < 2 * 16 * NCH; i += 256) sacc[i] = 0.f;
-  const int sub = threadIdx.x & 15;
+  constexpr int RPB = 256 / LPR, CW = LPR * NCH;
+  __shared__ float sacc[4 * 2 * CW];
+  const int sub = threadIdx.x % LPR, slot = threadIdx.x / LPR, wave = threadIdx.x >> 6;
   float gam[NCH], ag[NCH], ab[NCH];
   bool cv[NCH];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
-    const int c = sub + 16 * k;
+    const int c = sub + LPR * k;
     cv[k] = c < C;
     gam[k] = gamma[cv[k] ? c : 0];
     ag[k] = 0.f; ab[k] = 0.f;
   }
-  const int nrb = (rows + 15) / 16;
+  const int nrb = (rows + RPB - 1) / RPB;
   const float invC = 1.0f / (float)C;
   for (int rbk = blockIdx.x; rbk < nrb; rbk += gridDim.x) {
-    const int row = rbk * 16 + (threadIdx.x >> 4);
+    const int row = rbk * RPB + slot;
     const bool rv = row < rows;
     const int rc = rv ? row : 0;
     const long base = (long)rc * C;
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(HrfGroup<LnBwdArgs> grp) {
     float d[NCH], xh[NCH], pv[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      const long idx = (rv && cv[k]) ? base + sub + 16 * k : 0;
+      const long idx = (rv && cv[k]) ? base + sub + LPR * k : 0;
       d[k] = da[idx];
       xh[k] = x[idx];
       pv[k] = accumulate ? dx[idx] : 0.f;
@@ -207,28 +211,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(HrfGroup<LnBwdArgs> grp) {
       const float g = d[k] * gam[k];
       s1 += g; s2 = fmaf(g, xh[k], s2);
     }
-    s1 += __shfl_xor(s1, 8); s1 += __shfl_xor(s1, 4); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 1);
-    s2 += __shfl_xor(s2, 8); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 1);
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     const float m1 = s1 * invC, m2 = s2 * invC;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const float v = rstd * (d[k] * gam[k] - m1 - xh[k] * m2);
-      if (rv && cv[k]) dx[base + sub + 16 * k] = pv[k] + v;
+      if (rv && cv[k]) dx[base + sub + LPR * k] = pv[k] + v;
       ag[k] = fmaf(d[k], xh[k], ag[k]);
       ab[k] += d[k];
     }
   }
-  __syncthreads();
+  // row slots of one wave (LPR = 16: lanes sub, sub + 16, sub + 32, sub + 48), then the four waves through LDS
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
-    hrf_atomic_add(&sacc[sub + 16 * k], ag[k]);
-    hrf_atomic_add(&sacc[16 * NCH + sub + 16 * k], ab[k]);
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) { ag[k] += __shfl_xor(ag[k], o); ab[k] += __shfl_xor(ab[k], o); }
+    if ((threadIdx.x & 63) < LPR) {
+      sacc[(wave * 2 + 0) * CW + sub + LPR * k] = ag[k];
+      sacc[(wave * 2 + 1) * CW + sub + LPR * k] = ab[k];
+    }
   }
   __syncthreads();
   const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * copy_stride;
   for (int i = threadIdx.x; i < C; i += 256) {
-    hrf_atomic_add(&dgamma[cp + i], sacc[i]);
-    hrf_atomic_add(&dbeta[cp + i], sacc[16 * NCH + i]);
+    hrf_atomic_add(&dgamma[cp + i], (sacc[i] + sacc[2 * CW + i]) + (sacc[4 * CW + i] + sacc[6 * CW + i]));
+    hrf_atomic_add(&dbeta[cp + i], (sacc[CW + i] + sacc[3 * CW + i]) + (sacc[5 * CW + i] + sacc[7 * CW + i]));
   }
 }
 
@@ -921,13 +929,16 @@ extern "C" int hrf_ln_bwd(const float* da, const float* x, const float* rowstat,
   HRF_GROUP_CALL();
   if (rows <= 0) return HRF_OK;
   if (C > 640) return HRF_ERR_ARG;
-  int grid = hrf_cdiv(hrf_cdiv(rows, 16), g_pw_knob[0] > 0 ? g_pw_knob[0] : 2);
+  const int lpr = C > 80 ? 64 : 16, nch = hrf_cdiv(C, lpr);
+  const int nrb = hrf_cdiv(rows, 256 / lpr);
+  // passes per block: ~640 blocks at most - every block ends with 2*C global atomics, and at 1 920 blocks those were the
+  // kernel (156 channels x 7 680 rows: 12.9 us at 480 blocks, 18.2 us at 1 920)
+  int grid = hrf_cdiv(nrb, g_pw_knob[0] > 0 ? g_pw_knob[0] : (nrb + 639) / 640);
   if (grid > 2048) grid = 2048;
-  const int nch = hrf_cdiv(C, 16);
-#define HRF_LNB(N_) HRF_LAUNCH_G(ln_bwd_kernel<N_>, dim3(grid), dim3(256), 0, stream, \
-                                 (LnBwdArgs{da, x, rowstat, gamma, rows, C, dx, accumulate, dgamma, dbeta, copy_stride}))
-  if (nch <= 2) { HRF_LNB(2); } else if (nch <= 3) { HRF_LNB(3); } else if (nch <= 5) { HRF_LNB(5); }
-  else if (nch <= 10) { HRF_LNB(10); } else if (nch <= 20) { HRF_LNB(20); } else { HRF_LNB(40); }
+#define HRF_LNB(N_, L_) HRF_LAUNCH_G((ln_bwd_kernel<N_, L_>), dim3(grid), dim3(256), 0, stream, \
+                                     (LnBwdArgs{da, x, rowstat, gamma, rows, C, dx, accumulate, dgamma, dbeta, copy_stride}))
+  if (lpr == 16) { if (nch <= 2) { HRF_LNB(2, 16); } else if (nch <= 3) { HRF_LNB(3, 16); } else { HRF_LNB(5, 16); } }
+  else if (nch <= 3) { HRF_LNB(3, 64); } else if (nch <= 5) { HRF_LNB(5, 64); } else { HRF_LNB(10, 64); }
   return hrf_check_launch();
 }
 
