@@ -25,17 +25,30 @@ WIN = 7
 
 # ----------------------------------------------------------------------------- norm factories
 def build_bn(norm_cfg, c):
-    """mmcv.build_norm_layer subset for norm_cfg type BN / SyncBN (SyncBN = BN + RCCL stat exchange,
-    decided at run time by the engine's process group, so the module class is the same)."""
+    """mmcv.build_norm_layer subset for norm_cfg type BN / SyncBN (SyncBN = BN + RCCL stat exchange, decided at run time by
+    the engine's process group, so the module class is the same) and GN (nn.GroupNorm(num_groups, c): per-sample statistics,
+    no exchange; runtime.gn_forward)."""
     cfg = dict(norm_cfg or dict(type='BN'))
     kind = cfg.pop('type')
-    if kind not in ('BN', 'SyncBN'):
+    if kind not in ('BN', 'SyncBN', 'GN'):
         raise KeyError(f'unsupported norm_cfg type {kind}')
     requires_grad = cfg.pop('requires_grad', True)
-    bn = nn.BatchNorm2d(c, eps=cfg.get('eps', 1e-5), momentum=cfg.get('momentum', 0.1))
+    if kind == 'GN':
+        if 'num_groups' not in cfg:
+            raise AssertionError('norm_cfg of type GN needs num_groups')          # mmcv: assert 'num_groups' in cfg_
+        bn = nn.GroupNorm(cfg['num_groups'], c, eps=cfg.get('eps', 1e-5))
+    else:
+        bn = nn.BatchNorm2d(c, eps=cfg.get('eps', 1e-5), momentum=cfg.get('momentum', 0.1))
     for p in bn.parameters():
         p.requires_grad_(requires_grad)
     return bn
+
+
+def norm_name(norm_cfg, postfix):
+    """The attribute name mmcv.build_norm_layer gives a postfixed norm layer (abbreviation + postfix): state-dict keys of
+    the stems and the residual blocks follow the norm type (hrnet.py:338-360, resnet.py:34-49,161-206)."""
+    kind = dict(norm_cfg or dict(type='BN')).get('type', 'BN')
+    return ('gn' if kind == 'GN' else 'bn') + str(postfix)
 
 
 def build_ln(cfg, c):
@@ -422,18 +435,20 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, norm_cfg, downsample=None):
         super().__init__()
+        self._nn = [norm_name(norm_cfg, k) for k in (1, 2, 3)]
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = build_bn(norm_cfg, planes)
+        self.add_module(self._nn[0], build_bn(norm_cfg, planes))
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = build_bn(norm_cfg, planes)
+        self.add_module(self._nn[1], build_bn(norm_cfg, planes))
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = build_bn(norm_cfg, planes * 4)
+        self.add_module(self._nn[2], build_bn(norm_cfg, planes * 4))
         self.downsample = downsample
 
     def run(self, ctx, x):
-        y = R.conv_bn(ctx, x, self.conv1, self.bn1, R.TF_RELU)
-        y = R.conv_bn(ctx, y, self.conv2, self.bn2, R.TF_RELU)
-        y = R.conv_bn(ctx, y, self.conv3, self.bn3, R.TF_AFFINE)
+        n1, n2, n3 = (getattr(self, k) for k in self._nn)
+        y = R.conv_bn(ctx, x, self.conv1, n1, R.TF_RELU)
+        y = R.conv_bn(ctx, y, self.conv2, n2, R.TF_RELU)
+        y = R.conv_bn(ctx, y, self.conv3, n3, R.TF_AFFINE)
         if self.downsample is not None:
             idt = R.conv_bn(ctx, x, self.downsample[0], self.downsample[1], R.TF_AFFINE)
             return R.materialize(ctx, y, R.ACT_RELU, lazy2=idt)
@@ -448,15 +463,16 @@ class BasicBlock(nn.Module):
         super().__init__()
         if downsample is not None or inplanes != planes:
             raise NotImplementedError('BasicBlock with a downsample path is unused by the HRNet branches')
+        self._nn = [norm_name(norm_cfg, k) for k in (1, 2)]
         self.conv1 = nn.Conv2d(inplanes, planes, 3, 1, 1, bias=False)
-        self.bn1 = build_bn(norm_cfg, planes)
+        self.add_module(self._nn[0], build_bn(norm_cfg, planes))
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = build_bn(norm_cfg, planes)
+        self.add_module(self._nn[1], build_bn(norm_cfg, planes))
         self.downsample = None
 
     def run(self, ctx, x):
-        y = R.conv_bn(ctx, x, self.conv1, self.bn1, R.TF_RELU)
-        y = R.conv_bn(ctx, y, self.conv2, self.bn2, R.TF_AFFINE)
+        y = R.conv_bn(ctx, x, self.conv1, getattr(self, self._nn[0]), R.TF_RELU)
+        y = R.conv_bn(ctx, y, self.conv2, getattr(self, self._nn[1]), R.TF_AFFINE)
         return R.materialize(ctx, y, R.ACT_RELU, res=x)
 
 
@@ -543,7 +559,7 @@ class HRFormerBlock(nn.Module):
             s1, s2 = eng.droppath_scale(x.t.shape[0], p), eng.droppath_scale(x.t.shape[0], p)
         msa = self.attn.attn
         C = x.t.shape[-1]
-        if R.attn_block_ok(ctx, C, msa.num_heads) and self.ffn.layers[0].weight.shape[0] == 4 * C:
+        if R.attn_block_ok(ctx, C, msa.num_heads) and self.ffn.layers[0].weight.shape[0] == 4 * C and not R.is_gn(self.ffn.layers[1]):
             # one launch: norm1 -> qkv -> window attention -> out_proj -> residual -> norm2 -> CrossFFN 1x1 expansion
             x, h1 = R.attn_block(ctx, id(self), msa.num_heads, x, x, self.norm1, self.norm1, (msa.qkv, 0), (msa.qkv, C),
                                  (msa.qkv, 2 * C), msa.relative_position_bias_table, msa.out_proj, x,
@@ -640,7 +656,7 @@ class HRFuserFusionBlock(nn.Module):
         M = self.num_fused_modalities
         C = x.t.shape[-1]
         heads = self.attn[0].attn.num_heads
-        if R.attn_block_ok(ctx, C, heads) and self.ffn.layers[0].weight.shape[0] == 4 * C:
+        if R.attn_block_ok(ctx, C, heads) and self.ffn.layers[0].weight.shape[0] == 4 * C and not R.is_gn(self.ffn.layers[1]):
             # one launch per modality: norm1[k] / norm2[k] -> q / k / v -> window cross-attention -> out_proj -> Dropout ->
             # DropPath -> + z_k + running sum; the last one also runs norm3 and the CrossFFN 1x1 expansion
             h1 = None
@@ -924,7 +940,7 @@ def default_or_pretrained_init(module):
             nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
             if m.bias is not None:
                 nn.init.constant_(m.bias, 0)
-        elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+        elif isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.GroupNorm)):      # hrnet.py:311-316
             nn.init.constant_(m.weight, 1)
             nn.init.constant_(m.bias, 0)
 
@@ -1210,9 +1226,10 @@ class HRFuserHRFormerBased(HipModule):
 
         # camera stem + stage 1 (hrnet.py:337-371)
         self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)
-        self.bn1 = build_bn(ncfg, 64)
+        self._stem_nn = [norm_name(ncfg, 1), norm_name(ncfg, 2)]      # 'bn1' / 'bn2', or 'gn1' / 'gn2' (hrnet.py:338-360)
+        self.add_module(self._stem_nn[0], build_bn(ncfg, 64))
         self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
-        self.bn2 = build_bn(ncfg, 64)
+        self.add_module(self._stem_nn[1], build_bn(ncfg, 64))
         self.stage1_cfg = extra['stage1']
         blk = self.blocks_dict[self.stage1_cfg['block']]
         if blk is not Bottleneck:
@@ -1426,7 +1443,7 @@ class HRFuserHRFormerBased(HipModule):
         cam = [None]
 
         def cam_stem():
-            cam[0] = self._stem(ctx, srcs[0], self.conv1, self.bn1, self.conv2, self.bn2, self.layer1)
+            cam[0] = self._stem(ctx, srcs[0], self.conv1, getattr(self, self._stem_nn[0]), self.conv2, getattr(self, self._stem_nn[1]), self.layer1)
 
         def mod_stem(k):
             mods[k] = self._stem(ctx, srcs[1 + k], self.conv_a[k], self.norm_a[k], self.conv_b[k], self.norm_b[k],
@@ -1573,9 +1590,10 @@ class HRFormer(HipModule):
         self.norm_eval, self.with_cp = norm_eval, with_cp
         ncfg = norm_cfg
         self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)                                   # hrnet.py:337-371
-        self.bn1 = build_bn(ncfg, 64)
+        self._stem_nn = [norm_name(ncfg, 1), norm_name(ncfg, 2)]      # 'bn1' / 'bn2', or 'gn1' / 'gn2' (hrnet.py:338-360)
+        self.add_module(self._stem_nn[0], build_bn(ncfg, 64))
         self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
-        self.bn2 = build_bn(ncfg, 64)
+        self.add_module(self._stem_nn[1], build_bn(ncfg, 64))
         self.stage1_cfg = extra['stage1']
         if self.blocks_dict[self.stage1_cfg['block']] is not Bottleneck:
             raise NotImplementedError('stage1 block must be BOTTLENECK')
@@ -1622,7 +1640,7 @@ class HRFormer(HipModule):
         return xs
 
     def _run(self, ctx, srcs):
-        x = self._stem(ctx, srcs[0], self.conv1, self.bn1, self.conv2, self.bn2, self.layer1)
+        x = self._stem(ctx, srcs[0], self.conv1, getattr(self, self._stem_nn[0]), self.conv2, getattr(self, self._stem_nn[1]), self.layer1)
         ys = self._run_stage(ctx, self.stage2, self._transition(ctx, self.transition1, x, True))
         ys = self._run_stage(ctx, self.stage3, self._transition(ctx, self.transition2, ys, False))
         return self._run_stage(ctx, self.stage4, self._transition(ctx, self.transition3, ys, False))

@@ -240,6 +240,119 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(HrfGroup<LnBwdArgs> grp) {
   }
 }
 
+// ------------------------------------------------------------------------------- GroupNorm (norm_cfg type 'GN')
+// mmcv build_norm_layer(dict(type='GN', num_groups=G), C) -> nn.GroupNorm (hrnet.py:338-339, resnet.py:161-164,
+// hrformer.py:269): statistics per (sample, group) over H*W*(C/G) elements - no cross-sample and no cross-rank exchange.
+// No reference config uses it, so it gets a plain three-launch form per direction instead of the on-load machinery of
+// BatchNorm: (1) per-(sample, channel) moments with the reduction structure of act_bwd_kernel (a thread keeps one channel),
+// fp64 atomics into [B][2][C]; (2) every block of the apply kernel folds the C/G channel moments of its sample's groups
+// in its prologue and normalises its chunk of pixels.  The output is the PRE-activation value gamma*xhat + beta; the
+// consumers apply ReLU / GELU on load through a unit affine (runtime.conv_bn).
+__global__ __launch_bounds__(256) void gn_moments_kernel(const float* v, const float* w, long rows_per_sample, int C,
+                                                         double* out, long chunk) {
+  HRF_DYN_SMEM(float, sacc);                              // [2][C]
+  const int n = blockIdx.y;
+  const long p0 = (long)blockIdx.x * chunk, p1 = min(rows_per_sample, p0 + chunk);
+  const float* vb = v + (long)n * rows_per_sample * C;
+  const float* wb = w != nullptr ? w + (long)n * rows_per_sample * C : vb;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sacc[i] = 0.f;
+  __syncthreads();
+  if (C <= 256) {
+    const int R = 256 / C, c = threadIdx.x % C, r0 = threadIdx.x / C;
+    if (r0 < R) {
+      float s1 = 0.f, s2 = 0.f;
+      for (long p = p0 + r0; p < p1; p += R) { const float a = vb[p * C + c]; s1 += a; s2 = fmaf(a, wb[p * C + c], s2); }
+      hrf_atomic_add(&sacc[c], s1);
+      hrf_atomic_add(&sacc[C + c], s2);
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s1 = 0.f, s2 = 0.f;
+      for (long p = p0; p < p1; ++p) { const float a = vb[p * C + c]; s1 += a; s2 = fmaf(a, wb[p * C + c], s2); }
+      sacc[c] = s1; sacc[C + c] = s2;
+    }
+  }
+  __syncthreads();
+  double* o = out + (long)n * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) hrf_atomic_add(&o[i], (double)sacc[i]);
+}
+
+// (mean, rstd) of group g of this block's sample from the per-channel moments -> sStat[2*g], sStat[2*g+1]
+__device__ __forceinline__ void gn_group_stats(const double* mom, int C, int G, long rows_per_sample, float eps, float* sStat) {
+  const int cg = C / G;
+  const double inv = 1.0 / ((double)rows_per_sample * (double)cg);
+  for (int g = threadIdx.x; g < G; g += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < cg; ++k) { s1 += mom[g * cg + k]; s2 += mom[C + g * cg + k]; }
+    const double mean = s1 * inv;
+    double var = s2 * inv - mean * mean;
+    if (var < 0.0) var = 0.0;
+    sStat[2 * g] = (float)mean;
+    sStat[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* raw, const double* mom, const float* gamma, const float* beta,
+                                                       float eps, long rows_per_sample, int C, int G, float* y, float* stat, long chunk) {
+  HRF_DYN_SMEM(float, sStat);                             // [G][2]
+  const int n = blockIdx.y;
+  gn_group_stats(mom + (long)n * 2 * C, C, G, rows_per_sample, eps, sStat);
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < 2 * G; i += 256) stat[(long)n * 2 * G + i] = sStat[i];
+  const int cg = C / G;
+  const long e0 = (long)blockIdx.x * chunk * C, e1 = min(rows_per_sample, ((long)blockIdx.x + 1) * chunk) * C;
+  const long base = (long)n * rows_per_sample * C;
+  for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+    const int c = (int)(e % C), g = c / cg;
+    y[base + e] = fmaf((raw[base + e] - sStat[2 * g]) * sStat[2 * g + 1], gamma[c], beta[c]);
+  }
+}
+
+// draw = rstd * (du*gamma - (S1 + xhat*S2) / m),  S1 = sum_group du*gamma,  S2 = sum_group du*gamma*xhat,  m = H*W*C/G;
+// gmom = per-(sample, channel) (sum du, sum du*raw).  Block (0, 0) adds the parameter gradients of all samples.
+__global__ __launch_bounds__(256) void gn_bwd_kernel(const float* du, const float* raw, const float* stat, const double* gmom,
+                                                     const float* gamma, int B, long rows_per_sample, int C, int G, float* draw,
+                                                     float* dgamma, float* dbeta, long chunk) {
+  HRF_DYN_SMEM(float, sS);                                // [G][4]: mean, rstd, S1/m, S2/m
+  const int n = blockIdx.y, cg = C / G;
+  const double* gm = gmom + (long)n * 2 * C;
+  const double invm = 1.0 / ((double)rows_per_sample * (double)cg);
+  for (int g = threadIdx.x; g < G; g += 256) {
+    const double mean = stat[(long)n * 2 * G + 2 * g], rstd = stat[(long)n * 2 * G + 2 * g + 1];
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < cg; ++k) {
+      const int c = g * cg + k;
+      const double a = gm[c], b = gm[C + c], ga = gamma[c];
+      s1 += ga * a;
+      s2 += ga * rstd * (b - mean * a);
+    }
+    sS[4 * g] = (float)mean; sS[4 * g + 1] = (float)rstd; sS[4 * g + 2] = (float)(s1 * invm); sS[4 * g + 3] = (float)(s2 * invm);
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && n == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int g = c / cg;
+      double dg = 0.0, db = 0.0;
+      for (int b = 0; b < B; ++b) {
+        const double mean = stat[(long)b * 2 * G + 2 * g], rstd = stat[(long)b * 2 * G + 2 * g + 1];
+        const double a = gmom[(long)b * 2 * C + c], bb = gmom[(long)b * 2 * C + C + c];
+        dg += rstd * (bb - mean * a);
+        db += a;
+      }
+      if (dgamma != nullptr) dgamma[c] += (float)dg;
+      if (dbeta != nullptr) dbeta[c] += (float)db;
+    }
+  }
+  const long e0 = (long)blockIdx.x * chunk * C, e1 = min(rows_per_sample, ((long)blockIdx.x + 1) * chunk) * C;
+  const long base = (long)n * rows_per_sample * C;
+  for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+    const int c = (int)(e % C), g = c / cg;
+    const float xh = (raw[base + e] - sS[4 * g]) * sS[4 * g + 1];
+    draw[base + e] = sS[4 * g + 1] * (du[base + e] * gamma[c] - sS[4 * g + 2] - xh * sS[4 * g + 3]);
+  }
+}
+
 // ------------------------------------------------------------------------------- BN apply + act + residual
 // act_first=1: out = res + rowscale*act(sc1*y1+sh1)            (CrossFFN tail: x + GELU(BN(h3)))
 // act_first=0: out = act(sc1*y1+sh1 [+ res] [+ sc2*y2+sh2])    (Bottleneck tail / transition ReLU)
@@ -939,6 +1052,41 @@ extern "C" int hrf_ln_bwd(const float* da, const float* x, const float* rowstat,
                                      (LnBwdArgs{da, x, rowstat, gamma, rows, C, dx, accumulate, dgamma, dbeta, copy_stride}))
   if (lpr == 16) { if (nch <= 2) { HRF_LNB(2, 16); } else if (nch <= 3) { HRF_LNB(3, 16); } else { HRF_LNB(5, 16); } }
   else if (nch <= 3) { HRF_LNB(3, 64); } else if (nch <= 5) { HRF_LNB(5, 64); } else { HRF_LNB(10, 64); }
+  return hrf_check_launch();
+}
+
+static long gn_chunk(long rows_per_sample, int B) {
+  // ~1024 blocks per launch, at least 16 pixels per block
+  long chunks = 1024 / (B > 0 ? B : 1);
+  if (chunks < 1) chunks = 1;
+  long chunk = (rows_per_sample + chunks - 1) / chunks;
+  return chunk < 16 ? 16 : chunk;
+}
+extern "C" int hrf_gn_moments(const float* v, const float* w, int B, long rows_per_sample, int C, double* out, void* stream) {
+  if (B <= 0 || rows_per_sample <= 0 || C <= 0) return HRF_OK;
+  if (v == nullptr || out == nullptr || C > 4096) return HRF_ERR_ARG;
+  const long chunk = gn_chunk(rows_per_sample, B);
+  HRF_LAUNCH(gn_moments_kernel, dim3(hrf_cdiv(rows_per_sample, chunk), B), dim3(256), (unsigned)(2 * C * sizeof(float)), stream,
+             v, w, rows_per_sample, C, out, chunk);
+  return hrf_check_launch();
+}
+extern "C" int hrf_gn_apply(const float* raw, const double* mom, const float* gamma, const float* beta, float eps, int B,
+                            long rows_per_sample, int C, int G, float* y, float* stat, void* stream) {
+  if (B <= 0 || rows_per_sample <= 0 || C <= 0) return HRF_OK;
+  if (G <= 0 || C % G != 0 || raw == nullptr || mom == nullptr || y == nullptr || stat == nullptr || G > 4096) return HRF_ERR_ARG;
+  const long chunk = gn_chunk(rows_per_sample, B);
+  HRF_LAUNCH(gn_apply_kernel, dim3(hrf_cdiv(rows_per_sample, chunk), B), dim3(256), (unsigned)(2 * G * sizeof(float)), stream,
+             raw, mom, gamma, beta, eps, rows_per_sample, C, G, y, stat, chunk);
+  return hrf_check_launch();
+}
+extern "C" int hrf_gn_bwd(const float* du, const float* raw, const float* stat, const double* gmom, const float* gamma, int B,
+                          long rows_per_sample, int C, int G, float* draw, float* dgamma, float* dbeta, void* stream) {
+  if (B <= 0 || rows_per_sample <= 0 || C <= 0) return HRF_OK;
+  if (G <= 0 || C % G != 0 || du == nullptr || raw == nullptr || stat == nullptr || gmom == nullptr || draw == nullptr || G > 4096)
+    return HRF_ERR_ARG;
+  const long chunk = gn_chunk(rows_per_sample, B);
+  HRF_LAUNCH(gn_bwd_kernel, dim3(hrf_cdiv(rows_per_sample, chunk), B), dim3(256), (unsigned)(4 * G * sizeof(float)), stream,
+             du, raw, stat, gmom, gamma, B, rows_per_sample, C, G, draw, dgamma, dbeta, chunk);
   return hrf_check_launch();
 }
 

@@ -145,7 +145,8 @@ class Act:
 class BNState:
     """One BatchNorm application: raw conv output + the per-channel vectors around it."""
     __slots__ = ('bn', 'C', 'raw', 'count', 'scale', 'shift', 'mean', 'invstd', 'stats', 'gstats',
-                 'coef', 'du', 'train', 'pending', 'lane', 'bx_done', 'packed', 'bpacked', 'count_ptr')
+                 'coef', 'du', 'train', 'pending', 'lane', 'bx_done', 'packed', 'bpacked', 'count_ptr',
+                 'gn_raw', 'gn_stat')          # GroupNorm (gn_forward): the raw convolution output and its (mean, rstd) table
 
 
 class Lazy:
@@ -1081,6 +1082,64 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
             tf, sc, sh, rowstat, weight.grad, bgrad, ctx.stream), cost=cost)
 
 
+# ----------------------------------------------------------------------------- GroupNorm (norm_cfg type 'GN')
+def is_gn(norm):
+    return isinstance(norm, torch.nn.GroupNorm)
+
+
+_GN_CONST = {}
+
+
+def _gn_unit_affine(C, device):
+    """(ones, zeros) of C floats: the consumers of a GroupNorm output apply their activation through the on-load affine of
+    the BatchNorm machinery with scale 1 / shift 0."""
+    key = (str(device), C)
+    if key not in _GN_CONST:
+        _GN_CONST[key] = (torch.ones(C, device=device), torch.zeros(C, device=device))
+    return _GN_CONST[key]
+
+
+def gn_forward(ctx, gn, raw):
+    """GroupNorm of a raw convolution output (hrf_gn_moments -> hrf_gn_apply) -> a BNState whose `raw` is the NORMALISED
+    pre-activation value gamma*xhat + beta with a unit affine and frozen statistics: every consumer kernel (conv / dw /
+    materialize / fuse_sum loaders and their backward epilogues) works on it unchanged, and the gradient they leave in
+    st.du is the gradient with respect to the GroupNorm output (gn_backward)."""
+    L, s = ctx.L, ctx.stream
+    B, H, W, C = raw.shape
+    G = gn.num_groups
+    mom = _keep(torch.zeros(B * 2 * C, device=raw.device, dtype=torch.float64))
+    L.hrf_gn_moments(raw, None, B, H * W, C, mom, s)
+    y = _new_like(raw)
+    stat = _new((B, G, 2), raw.device)
+    L.hrf_gn_apply(raw, mom, gn.weight, gn.bias, float(gn.eps), B, H * W, C, G, y, stat, s)
+    st = BNState()
+    st.bn, st.C, st.raw, st.du, st.coef, st.pending, st.lane, st.bx_done = gn, C, y, None, None, None, None, True
+    st.packed = st.bpacked = None
+    st.count_ptr = None
+    st.train = False
+    st.stats = None
+    st.gstats = _keep(torch.zeros(_lib.STAT_COPIES * 2 * C, device=raw.device, dtype=torch.float64))   # consumers' moments: unused
+    st.scale, st.shift = _gn_unit_affine(C, raw.device)
+    st.mean = st.invstd = None
+    st.count = float(B * H * W)
+    st.gn_raw, st.gn_stat = raw, stat
+    return st
+
+
+def gn_backward(ctx, st):
+    """-> gradient with respect to the raw convolution output (the parameter gradients are added in the same launch)."""
+    L, s = ctx.L, ctx.stream
+    gn, raw = st.bn, st.gn_raw
+    B, H, W, C = raw.shape
+    gmom = _keep(torch.zeros(B * 2 * C, device=raw.device, dtype=torch.float64))
+    L.hrf_gn_moments(st.du, raw, B, H * W, C, gmom, s)
+    draw = _new_like(raw)
+    wg = gn.weight.grad if gn.weight.requires_grad else None
+    bg = gn.bias.grad if gn.bias.requires_grad else None
+    L.hrf_gn_bwd(st.du, raw, st.gn_stat, gmom, gn.weight, B, H * W, C, gn.num_groups, draw, wg, bg, s)
+    return draw
+
+
 def conv_bn(ctx, src, conv, bn, mode):
     """conv (k=1|3, dense) + BatchNorm (+ReLU/GELU) -> Lazy.  mode: TF_AFFINE / TF_RELU / TF_GELU."""
     L, s = ctx.L, ctx.stream
@@ -1089,6 +1148,20 @@ def conv_bn(ctx, src, conv, bn, mode):
     Cout, KH, stride = w.shape[0], w.shape[2], conv.stride[0]
     Ho, Wo = _conv_out_hw(H, W, KH, stride)
     y = _new((B, Ho, Wo, Cout), x.device)
+    if is_gn(bn):
+        L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
+                       tf, sc, sh, rowstat, None, _src_fin(ctx, src), None, 0.0, s)
+        gst = gn_forward(ctx, bn, y)
+        gout = Lazy(gst, mode)
+        if ctx.probe is not None and mode == TF_RELU:
+            ctx.probe.append(('lazy', gst))
+
+        def gbwd():
+            draw = gn_backward(ctx, gst)
+            _conv_backward(ctx, src, w, b, KH, stride, Cout, draw, Cout, 0, None, None)
+            gst.du = None
+        ctx.push(gbwd)
+        return gout
     slot = ctx.owner._bn_slot(bn)
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None
@@ -1347,6 +1420,34 @@ def dwconv_bn(ctx, src, conv, bn, mode):
     stride = conv.stride[0]
     Ho, Wo = _conv_out_hw(H, W, 3, stride)
     y = _new((B, Ho, Wo, C), x.device)
+    if is_gn(bn):
+        L.hrf_dwconv_fwd(x, B, H, W, C, w, b, stride, tf, sc, sh, y, None, _src_fin(ctx, src, 1 << 30), s)
+        gst = gn_forward(ctx, bn, y)
+        gout = Lazy(gst, mode)
+        if ctx.probe is not None and mode == TF_RELU:
+            ctx.probe.append(('lazy', gst))
+
+        def gbwd():
+            draw = gn_backward(ctx, gst)
+            if isinstance(src, Lazy):
+                ps = src.st
+                ps.du = _new_like(ps.raw)
+                L.hrf_dwconv_bwd_data(draw, None, None, None, None, None, w, stride, B, H, W, C, ps.du, 0, 1, ps.raw,
+                                      ps.scale, ps.shift, _TF2ACT[src.mode], ps.gstats, s)
+            elif src.needs_grad:
+                g, acc = src.grad_target()
+                L.hrf_dwconv_bwd_data(draw, None, None, None, None, None, w, stride, B, H, W, C, g, acc, 0, None, None,
+                                      None, 0, None, s)
+            if w.requires_grad:
+                eng = ctx.owner._engine()
+                wacc, cs = eng.grad_acc(w)
+                bacc = eng.grad_acc(b)[0] if b is not None else None
+                ctx.side_launch(lambda: L.hrf_dwconv_bwd_weight(
+                    draw, None, None, None, None, x, B, H, W, C, stride, tf, sc, sh, wacc, bacc, cs, ctx.stream),
+                    cost=4.0 * B * H * W * C * (1.0 + 2.0 / (stride * stride)))
+            gst.du = None
+        ctx.push(gbwd)
+        return gout
     slot = ctx.owner._bn_slot(bn)
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None

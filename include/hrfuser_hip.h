@@ -228,6 +228,20 @@ int hrf_bn_pack(const double* const* stats, const int* C, int n, const double* r
 int hrf_bn_finalize_packed(const hrf_bn_fin_t* fins, int n, const double* packed, void* stream);
 int hrf_bn_bwd_finalize_packed(const hrf_bn_bfin_t* bfins, int n, const double* packed, const double* packed_local /* nullable: see pgrad_scale */, void* stream);
 
+/* ---- GroupNorm (norm_cfg = dict(type='GN', num_groups=G): build_norm_layer at hrnet.py:338-339,438,459,476,
+ * resnet.py:34-35,161-164, hrformer.py:269,278,281,518,542,552 -> nn.GroupNorm / F.group_norm).  Per-(sample, group)
+ * statistics, no exchange between samples or ranks.  Three launches per direction:
+ *   hrf_gn_moments  out[b][0][c] += sum_p v, out[b][1][c] += sum_p v*w (w NULL: v*v) over the rows_per_sample pixels of
+ *                   sample b; `out` ([B][2][C] doubles) must be zero.  Forward: v = raw conv output; backward: v = du, w = raw.
+ *   hrf_gn_apply    y = gamma*(raw - mean)*rstd + beta with (mean, rstd) of every (sample, group) folded from `mom`,
+ *                   also stored in stat[b][g][2] for the backward.
+ *   hrf_gn_bwd      draw = rstd*(du*gamma - mean_group(du*gamma) - xhat*mean_group(du*gamma*xhat)); dgamma += , dbeta += . */
+int hrf_gn_moments(const float* v, const float* w, int B, long rows_per_sample, int C, double* out, void* stream);
+int hrf_gn_apply(const float* raw, const double* mom, const float* gamma, const float* beta, float eps, int B,
+                 long rows_per_sample, int C, int G, float* y, float* stat, void* stream);
+int hrf_gn_bwd(const float* du, const float* raw, const float* stat, const double* gmom, const float* gamma, int B,
+               long rows_per_sample, int C, int G, float* draw, float* dgamma, float* dbeta, void* stream);
+
 /* ---- LayerNorm over channels (F.layer_norm: hrformer.py:343,351; hrfuser_hrformer_based.py:279-291) */
 int hrf_ln_stats(const float* x, int rows, int C, float eps, float* rowstat, void* stream);
 int hrf_ln_bwd(const float* da, const float* x, const float* rowstat, const float* gamma, int rows, int C,

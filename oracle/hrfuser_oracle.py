@@ -35,14 +35,24 @@ WIN = 7
 
 # ----------------------------------------------------------------------------- helpers
 def make_bn(norm_cfg, c):
+    """mmcv.cnn.build_norm_layer for the norm types the path accepts: BN / SyncBN -> nn.BatchNorm2d, GN ->
+    nn.GroupNorm(num_groups, c) (hrnet.py:338-339, resnet.py:161-164, hrformer.py:269); eps defaults to 1e-5."""
     cfg = dict(norm_cfg or dict(type='BN'))
     kind = cfg.pop('type')
-    assert kind in ('BN', 'SyncBN'), kind
+    assert kind in ('BN', 'SyncBN', 'GN'), kind
     requires_grad = cfg.pop('requires_grad', True)
-    bn = nn.BatchNorm2d(c, eps=cfg.get('eps', 1e-5), momentum=cfg.get('momentum', 0.1))
+    if kind == 'GN':
+        bn = nn.GroupNorm(cfg['num_groups'], c, eps=cfg.get('eps', 1e-5))
+    else:
+        bn = nn.BatchNorm2d(c, eps=cfg.get('eps', 1e-5), momentum=cfg.get('momentum', 0.1))
     for p in bn.parameters():
         p.requires_grad_(requires_grad)
     return bn
+
+
+def norm_name(norm_cfg, postfix):
+    """attribute name of a postfixed norm layer: mmcv's abbreviation of the norm type + postfix ('bn1' / 'gn1')"""
+    return ('gn' if dict(norm_cfg or dict(type='BN')).get('type') == 'GN' else 'bn') + str(postfix)
 
 
 def make_ln(ln_cfg, c):
@@ -252,19 +262,21 @@ class Bottleneck(nn.Module):
 
     def __init__(self, cin, planes, norm_cfg, downsample=None):
         super().__init__()
+        self._nn = [norm_name(norm_cfg, k) for k in (1, 2, 3)]
         self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
-        self.bn1 = make_bn(norm_cfg, planes)
+        self.add_module(self._nn[0], make_bn(norm_cfg, planes))
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = make_bn(norm_cfg, planes)
+        self.add_module(self._nn[1], make_bn(norm_cfg, planes))
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = make_bn(norm_cfg, planes * 4)
+        self.add_module(self._nn[2], make_bn(norm_cfg, planes * 4))
         self.downsample = downsample
 
     def forward(self, x):
+        n1, n2, n3 = (getattr(self, k) for k in self._nn)
         idt = x if self.downsample is None else self.downsample(x)
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = F.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
+        y = F.relu(n1(self.conv1(x)))
+        y = F.relu(n2(self.conv2(y)))
+        y = n3(self.conv3(y))
         return F.relu(y + idt)
 
 
@@ -376,9 +388,10 @@ class HRFuserOracle(nn.Module):
         self.pre_neck_fusion = bool(extra.get('LidarStageD'))       # hrfuser_hrformer_based.py:364-366
         # camera stem + stage1 (hrnet.py:337-371)
         self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)
-        self.bn1 = make_bn(ncfg, 64)
+        self._stem_nn = [norm_name(ncfg, 1), norm_name(ncfg, 2)]
+        self.add_module(self._stem_nn[0], make_bn(ncfg, 64))
         self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
-        self.bn2 = make_bn(ncfg, 64)
+        self.add_module(self._stem_nn[1], make_bn(ncfg, 64))
         s1 = extra['stage1']
         assert s1['block'] == 'BOTTLENECK'
         self.layer1 = make_bottleneck_layer(64, s1['num_channels'][0], s1['num_blocks'][0], ncfg)
@@ -448,8 +461,8 @@ class HRFuserOracle(nn.Module):
     def forward(self, x, x_mod):
         if self.M != len(x_mod):
             raise Exception('num_fused_modalities does not fit the given input length')
-        x = F.relu(self.bn1(self.conv1(x)))
-        x = self.layer1(F.relu(self.bn2(self.conv2(x))))
+        x = F.relu(getattr(self, self._stem_nn[0])(self.conv1(x)))
+        x = self.layer1(F.relu(getattr(self, self._stem_nn[1])(self.conv2(x))))
         mods = []
         for k in range(self.M):
             m = F.relu(self.norm_a[k](self.conv_a[k](x_mod[k])))
@@ -507,16 +520,17 @@ class BasicBlock(nn.Module):
 
     def __init__(self, cin, planes, norm_cfg, downsample=None):
         super().__init__()
+        self._nn = [norm_name(norm_cfg, k) for k in (1, 2)]
         self.conv1 = nn.Conv2d(cin, planes, 3, 1, 1, bias=False)
-        self.bn1 = make_bn(norm_cfg, planes)
+        self.add_module(self._nn[0], make_bn(norm_cfg, planes))
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = make_bn(norm_cfg, planes)
+        self.add_module(self._nn[1], make_bn(norm_cfg, planes))
         self.downsample = downsample
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        y = F.relu(self.bn1(self.conv1(x)))
-        return F.relu(self.bn2(self.conv2(y)) + idt)
+        y = F.relu(getattr(self, self._nn[0])(self.conv1(x)))
+        return F.relu(getattr(self, self._nn[1])(self.conv2(y)) + idt)
 
 
 class HRNetModule(nn.Module):
@@ -602,9 +616,10 @@ class HRFormerOracle(nn.Module):
         dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
         cuts = [0, depths[0], depths[0] + depths[1], sum(depths)]
         self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)
-        self.bn1 = make_bn(ncfg, 64)
+        self._stem_nn = [norm_name(ncfg, 1), norm_name(ncfg, 2)]
+        self.add_module(self._stem_nn[0], make_bn(ncfg, 64))
         self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
-        self.bn2 = make_bn(ncfg, 64)
+        self.add_module(self._stem_nn[1], make_bn(ncfg, 64))
         s1 = extra['stage1']
         assert s1['block'] == 'BOTTLENECK'
         self.layer1 = make_bottleneck_layer(64, s1['num_channels'][0], s1['num_blocks'][0], ncfg)
@@ -631,8 +646,8 @@ class HRFormerOracle(nn.Module):
         return self
 
     def forward(self, x):                                                   # hrnet.py:552-586
-        x = F.relu(self.bn1(self.conv1(x)))
-        x = self.layer1(F.relu(self.bn2(self.conv2(x))))
+        x = F.relu(getattr(self, self._stem_nn[0])(self.conv1(x)))
+        x = self.layer1(F.relu(getattr(self, self._stem_nn[1])(self.conv2(x))))
         xs = [t(x) if t is not None else x for t in self.transition1]
         ys = HRFuserOracle._run(self.stage2, xs)
         xs = [t(ys[-1]) if t is not None else ys[i] for i, t in enumerate(self.transition2)]

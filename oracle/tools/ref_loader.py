@@ -87,7 +87,11 @@ def _build_norm_layer(cfg, num_features, postfix=''):
     requires_grad = c.pop('requires_grad', True)
     c.setdefault('eps', 1e-5)
     cls, abbr = _NORMS[kind]
-    layer = cls(num_features, **c)
+    if kind == 'GN':
+        assert 'num_groups' in c                          # mmcv: layer = norm_layer(num_channels=num_features, **cfg_)
+        layer = cls(num_channels=num_features, **c)
+    else:
+        layer = cls(num_features, **c)
     for p in layer.parameters():
         p.requires_grad_(requires_grad)
     return abbr + str(postfix), layer
