@@ -170,7 +170,10 @@ template <int N, int PW, int NT>
 __device__ __forceinline__ void wave_gemm_tl(const float* sW, int K, const float* brow, int lane, hrf_f4* acc) {
   const int i = lane & 15, q = lane >> 4;
   constexpr int NS = (N + 15) / 16;
-#pragma unroll 2
+#ifndef HRF_TL_UNROLL
+#define HRF_TL_UNROLL 2
+#endif
+#pragma unroll HRF_TL_UNROLL
   for (int s = 0; s < NS; ++s) {
     const int nbase = 16 * s + 4 * q;
 #pragma unroll
@@ -481,7 +484,13 @@ __device__ __forceinline__ void wave_tgemm(const float* sA, int pitchA, int n0, 
                                            int K, const float* gam, const float* bet, const float* realf, int lane, hrf_f4* acc) {
   const int i = lane & 15, q = lane >> 4;
   const bool nv = n0 + i < N;
-#pragma unroll 1
+// (rolled, every token step was a dependent LDS round trip in front of its MFMAs: 13 steps x ~150 cycles per call, four calls
+// per wave; unrolled by 4 the workgroup's program went 50.0 -> 46.3 us at 18 channels, 72.2 -> 64.6 us at 36 - a full unroll
+// adds nothing: tools/time_ab_phases.py)
+#ifndef HRF_TG_UNROLL
+#define HRF_TG_UNROLL 4
+#endif
+#pragma unroll HRF_TG_UNROLL
   for (int tt = 0; tt < 13; ++tt) {
     const int tok = 4 * tt + q;
     const bool tv = tok < NTOK;

@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT)
 import hrfuser_amd.backbone as B
 import hrfuser_amd.runtime as R
 from hrfuser_amd import _lib
+if os.environ.get('HRF_TIMING_LIB'):
+    _lib.LIB_PATH = os.environ['HRF_TIMING_LIB']
 from hrfuser_amd.testing import BlockHarness
 NORM = dict(type='BN', requires_grad=True, momentum=0.1); LN = dict(type='LN', eps=1e-6)
 dev = torch.device('cuda:0')
