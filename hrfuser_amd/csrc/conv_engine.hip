@@ -576,8 +576,19 @@ constexpr int WNW = 8;     // waves per block (512 threads)
 // fragment load its own (ci, tap): 64 cache-line lookups per wave instruction, which is what the 3x3 problems spent
 // their time on), every dY fragment is reused by the 9 taps, and a block's output is 144 CONTIGUOUS floats per output
 // channel (16 ci x 9 taps in OIHW order), written by a transposing final pass.
+// phase stamps of one workgroup (wave 0) for tools/time_wgrad_phases.py: compiled in only with -DHRF_WG_TIMING
+#if defined(HRF_WG_TIMING) && !defined(HRF_EMUL)
+__device__ long long g_wg_t[16];
+#define WG_T(k) do { if (blockIdx.x == 17 && threadIdx.x == 0) g_wg_t[k] = wall_clock64(); } while (0)
+extern "C" int hrf_wgrad_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_t), sizeof(long long) * 16) == hipSuccess ? HRF_OK : HRF_ERR_LAUNCH;
+}
+#else
+#define WG_T(k)
+#endif
 template <int MT, int NT, bool BNB, int ACT, int TAPM>
 __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_args) {
+  WG_T(0);
   constexpr bool TAP = TAPM != 0, TAPB = TAPM == 2;
   static_assert(!TAPB || NT == 9, "tap-blocked: one tile per tap");
   int prob = 0;
@@ -634,6 +645,7 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
 
+  WG_T(1);
   // wave w owns k-steps w, w+WNW, ... of the block's chunk: neighbouring waves read neighbouring rows
 #pragma unroll 1
   for (int p0 = pbeg + 4 * wave; p0 < pend; p0 += 4 * WNW * WU) {
@@ -708,6 +720,7 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
   // of its words BEFORE it stores any: a ld/add/st per element is a chain of dependent LDS round trips (the compiler
   // must assume that a store aliases the next load) - that chain, not the reduction, was the duration of this kernel
   // (~20 us for every problem size; tools/bench_wgrad.py).
+  WG_T(2);
   constexpr int WPR = WNW / NREG;                            // waves per merge region
   hrf_f4* S = reinterpret_cast<hrf_f4*>(sAcc) + (wave / WPR) * (MT * NT * 64);
   if (wave % WPR == 0) {
@@ -737,6 +750,7 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
     }
     __syncthreads();
   }
+  WG_T(3);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     float bsm = bsum[i];
@@ -769,7 +783,9 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
       }
     }
   }
+  WG_T(4);
   __syncthreads();
+  WG_T(5);
   if (a.dbias != nullptr && by == 0 && tid < MT * 16 && m0 + tid < a.Cout) {
     float t = 0.f;
 #pragma unroll

@@ -628,7 +628,9 @@ inline bool wide_enough(long M, int K, int N) {
   const long blocks = ((M + GROWS - 1) / GROWS) * ((N + tile_nb(id) - 1) / tile_nb(id));
   // (measured on HRFuser-B, tools/time_lin2_phases.py: a step of this pipeline costs ~0.7 us on top of its MFMAs, so the 120 ... 240
   // blocks of the 48x80 branch lose to lin_engine.hip - 44.7 -> 61 us for 624 -> 156 - while the 480+ of the 96x160 branch win)
-  const long minb = g_l2_knob[2] > 0 ? g_l2_knob[2] : 400;
+  // (the 48x80 branch wins here only in its "expand" form - K = 156 -> N = 624: few steps, wide blocks: 42.2 -> 36.2 us forward,
+  // 53.9 -> 41.9 us for the data gradient of fc3)
+  const long minb = g_l2_knob[2] > 0 ? g_l2_knob[2] : ((K <= 160 && N >= 320) ? 200 : 400);
   return (K < N ? K : N) >= 64 && blocks >= minb;
 }
 
