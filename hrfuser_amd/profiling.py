@@ -382,16 +382,19 @@ def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None):
     """Roofline entry of the kernel FAMILY with the largest time per step (isolated per-launch durations).  `achieved` =
     the family's algorithmic bytes (or flops) per launch / its average launch duration; `dominant_shape` = its heaviest
     single (entry point, shape).  `traffic` = PMC-measured fabric bytes per launch of that shape when
-    <profiles_dir>/r02_hbm_traffic.json holds it (a SEPARATE `rocprofv3 --pmc` run; the source is stated), else null."""
+    <profiles_dir>/r03_hbm_traffic.json (else r02_) holds it (a SEPARATE `rocprofv3 --pmc` run; the source is stated), else null."""
     key = max(table, key=lambda k: table[k][1])
     row = _row(key, table[key], peak_f, peak_b)
     row['selection'] = 'kernel family with the largest summed isolated launch time per training step'
-    traffic = {}
-    tpath = os.path.join(profiles_dir, 'r02_hbm_traffic.json') if profiles_dir else None
-    if tpath and os.path.exists(tpath):
-        import json
-        with open(tpath) as fh:
-            traffic = json.load(fh).get('shapes', {})
+    traffic, tname = {}, None
+    for cand in ('r03_hbm_traffic.json', 'r02_hbm_traffic.json'):          # the newest committed PMC pass
+        tpath = os.path.join(profiles_dir, cand) if profiles_dir else None
+        if tpath and os.path.exists(tpath):
+            import json
+            with open(tpath) as fh:
+                traffic = json.load(fh).get('shapes', {})
+            tname = cand
+            break
     sigs = [r for r in getattr(profile_step, 'last_signatures', []) if r['kernel'] == key]
     if sigs:
         top = sigs[0]
@@ -406,8 +409,8 @@ def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None):
         t = traffic.get(top['shape'])
         if t is not None:
             row['traffic'] = t['bytes_per_launch']
-            row['traffic_source'] = (f'profiles/r02_hbm_traffic.json[{top["shape"]}]: 2 x FETCH_SIZE + WRITE_SIZE of that launch from a '
-                                     'separate rocprofv3 --pmc run (tools/prof_r02.sh); NOT measured in this bench run')
+            row['traffic_source'] = (f'profiles/{tname}[{top["shape"]}]: 2 x FETCH_SIZE + WRITE_SIZE of that launch from a '
+                                     f'separate rocprofv3 --pmc run (tools/prof_{tname[:3]}.sh); NOT measured in this bench run')
     # the next families, for context
     others = sorted(table.items(), key=lambda kv: -kv[1][1])[1:6]
     row['next_families'] = [{k2: _row(k, t, peak_f, peak_b)[k2] for k2 in ('kernel', 'bound', 'frac', 'launches_per_step', 'time_per_step_ms')}

@@ -44,7 +44,19 @@ hn = BlockHarness(blk, lambda ctx, b, xs: b.run(ctx, xs[0])).to(dev)
 hn.train()
 xb = torch.randn(B, 18, H, W, device=dev, requires_grad=True)
 gb = torch.randn(B, 18, H, W, device=dev)
+# HRFuser-B's CrossFFN GEMMs at the 96x160 branch (round 3: the LDS-tiled lin2 engine): fc1 forward 78 -> 312 with LayerNorm on load
+# and BatchNorm moments, the fc3 data gradient (K = 78 -> N = 312: BatchNorm backward on load, GELU' epilogue, moments), the
+# fc1 weight gradient 312 x 78
+bx78, bw1, by312 = R(B, H, W, 78), R(312, 78, 1, 1) * 0.05, R(B, H, W, 312)
+brs, bg78 = R(P, 2), R(78)
+bst312 = torch.zeros(32 * 312, dtype=torch.float64, device=dev)
+bdy78, byr78, bw3, bdx312, bxr312 = R(B, H, W, 78), R(B, H, W, 78), R(78, 312, 1, 1) * 0.05, R(B, H, W, 312), R(B, H, W, 312)
+bc78, bs312 = [R(78) for _ in range(3)], R(312)
+bdw1, bdy312, byr312, bc312 = torch.zeros(312, 78, device=dev), R(B, H, W, 312), R(B, H, W, 312), [R(312) for _ in range(3)]
 for it in range(4):
+    L.hrf_conv_fwd(bx78, H * W * 78, W * 78, 78, 1, B, H, W, 78, bw1, None, 1, 1, 312, by312, 312, 0, None, None, 0, 4, bg78, bg78, brs, bst312, None, None, 0.0, sp())
+    L.hrf_conv_bwd_data(bdy78, 78, 0, byr78, *bc78, None, bw3, 1, 1, 78, B, H, W, 312, bdx312, H * W * 312, W * 312, 312, 1, 0, 1, bxr312, 312, bs312, bs312, 2, bst312, sp())
+    L.hrf_conv_bwd_weight(bdy312, 312, 0, byr312, *bc312, bx78, H * W * 78, W * 78, 78, 1, B, H, W, 78, 1, 1, 312, 4, bg78, bg78, brs, bdw1, None, sp())
     L.hrf_conv_bwd_weight(dy18, 18, 0, yr18, *c18, x72, H * W * 72, W * 72, 72, 1, B, H, W, 72, 1, 1, 18, 3, s72, s72, None, dw3, None, sp())
     L.hrf_conv_bwd_weight(dy, Cout, 0, yr, cA, cB, cC, x, H * W * Cin, W * Cin, Cin, 1, B, H, W, Cin, 3, 1, Cout, 2, sc, sh, None, dw, None, sp())
     L.hrf_conv_fwd(x, H * W * Cin, W * Cin, Cin, 1, B, H, W, Cin, w, None, 3, 1, Cout, y, Cout, 0, None, None, 0, 2, sc, sh, None, st, None, None, 0.0, sp())
