@@ -1,7 +1,13 @@
-# A/B on ONE box: step time and finalize-on-load cost with 16 vs 8 replicated accumulator copies (rebuilds in place)
-cd $GRAFT_REPO_ROOT
+# A/B on ONE box: step time and finalize-on-load cost with 16 vs 8 replicated accumulator copies.  Runs on the gpurun box's
+# scratch copy of the tree only; the tracked header and the shipped library are restored on every exit path.
+set -eu
+cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the scratch copy of the tree)}"
+H=include/hrfuser_hip.h
+cp $H /tmp/ab_copies_orig.h
+restore() { cp /tmp/ab_copies_orig.h $H; python -c "from hrfuser_amd import build_ext; build_ext.build()" > /dev/null 2>&1 || true; }
+trap restore EXIT
 for n in ${COPIES_LIST:-16 8}; do
-  sed -i "s/^#define HRF_STAT_COPIES .*/#define HRF_STAT_COPIES $n/" include/hrfuser_hip.h
+  sed -i "s/^#define HRF_STAT_COPIES .*/#define HRF_STAT_COPIES $n/" $H
   python -c "from hrfuser_amd import build_ext; build_ext.build()" > /dev/null 2>&1
   echo "== copies $n"
   python tools/bench_fin.py 2>&1 | tail -5

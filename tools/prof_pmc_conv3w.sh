@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_conv3w; rm -rf $OUT; mkdir -p $OUT; cd /tmp
+cd "${GRAFT_REPO_ROOT:?run through gpurun}"; export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_conv3w; rm -rf $OUT; mkdir -p $OUT; cd /tmp
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $grp | tr ' ' '_')
   timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -o p -- python3 $GRAFT_REPO_ROOT/tools/pmc_conv3w.py > $OUT/$tag.log 2>&1; echo "$grp rc=$?"

@@ -1,11 +1,11 @@
 # round 2: SQ counters (MFMA busy, LDS conflicts, waves) of the hot kernels at their branch-0 shapes (tools/pmc_kernels.py),
 # one rocprofv3 --pmc pass per counter group, --kernel-trace only
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq_r02; rm -rf $OUT; mkdir -p $OUT; cd /tmp
+cd "${GRAFT_REPO_ROOT:?run through gpurun}"; export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq_r02; rm -rf $OUT; mkdir -p $OUT; cd /tmp
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU"; do
   tag=$(echo $grp | tr ' ' '_')
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -o p -- python3 $GRAFT_REPO_ROOT/tools/pmc_kernels.py > $OUT/$tag.log 2>&1; echo "$grp rc=$?"
 done
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 python3 - <<'PY'
 import csv,glob,collections,json,shutil,os,re
 OUT='gpurun_out/pmc_sq_r02'

@@ -1,5 +1,5 @@
 # round-2 profiles: kernel trace + stats of the bench command, PMC fabric traffic of the hot kernels (separate passes)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02
 rm -rf $OUT; mkdir -p $OUT
@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r02 -- pyt
 echo trace rc=$?
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 $GRAFT_REPO_ROOT/tools/pmc_kernels.py > $OUT/pmc_fetch.log 2>&1; echo fetch rc=$?
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 $GRAFT_REPO_ROOT/tools/pmc_kernels.py > $OUT/pmc_write.log 2>&1; echo write rc=$?
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 python3 - <<'PY'
 import csv,glob,collections,os,json,re,shutil
 OUT='gpurun_out/prof_r02'
