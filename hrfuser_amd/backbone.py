@@ -687,6 +687,7 @@ class HRFuserFusionBlock(nn.Module):
                              rowscale=self._droppath_scale(ctx, B, dev))
 
 
+_CAM_LANES = int(os.environ.get('HRF_CAM_LANES', '0') or 0)      # 0: one stream per camera branch (A/B knob)
 _FORK_EXCHANGE = os.environ.get('HRF_FORK_EXCHANGE', '1') != '0'   # exchange chains on sibling lanes (0: serial)
 
 
@@ -746,7 +747,15 @@ class HRFomerModule(nn.Module):
         xs = list(xs)
         # parallel branches (hrnet.py:189-190); with launch merging the finest branch stays on the current lane, where the
         # modality stages run as well: equal calls of the three sensor streams become one multi-problem launch
-        lanes = ctx.fork(nb, keep_first=ctx.keep_first)
+        cap = ctx.__dict__.get('branch_lane_cap', 0)
+        if cap and nb > cap:
+            # beside the modality stages the runtime's 4 hardware queues are oversubscribed (camera branches + M streams) and
+            # two streams aliased onto one queue run in order: the coarse ("thin") branches share ONE stream on purpose
+            # instead - branch i runs on lane min(i, cap - 1) - so that no thin chain queues behind a fat one
+            base = ctx.fork(cap, keep_first=ctx.keep_first)
+            lanes = [base[min(i, cap - 1)] for i in range(nb)]
+        else:
+            lanes = ctx.fork(nb, keep_first=ctx.keep_first)
 
         def branch(i):
             for blk in self.branches[i]:
@@ -1516,7 +1525,11 @@ class HRFuserHRFormerBased(HipModule):
             mods[k] = self._run_stage(ctx, mod_stages[k], [m0[k]])[0]
 
         def camera():
-            ys[0] = self._run_stage(ctx, cam_stage, xs)
+            ctx.branch_lane_cap = _CAM_LANES          # streams for the camera stage's branches while M modality stages run beside it
+            try:
+                ys[0] = self._run_stage(ctx, cam_stage, xs)
+            finally:
+                ctx.branch_lane_cap = 0
         if ctx.cam_first:          # (the camera stage is the long chain: its nodes first in issue / graph order)
             ctx.parallel([ctx.cur] + list(lanes), [camera] + [lambda k=k: mod_stage(k) for k in range(M)])
         else:
