@@ -116,6 +116,8 @@ CONV_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
     (1, 18, 35, 64, 64, 3, 2, 2, True, True),      # stride-2 backward: parity-class kernel, ragged tiles
     (1, 70, 66, 64, 256, 1, 1, 2, True, True),     # wide 1x1 on the LDS-tiled engine (M >= 4096)
     (1, 66, 70, 256, 64, 1, 1, 1, True, False),      # M >= 128*.. exercises the BM=128 tile on GPU sizes
+    (2, 5, 6, 288, 72, 1, 1, 3, True, True),         # few rows, deep contraction (HRFuser-B's coarse branches in miniature)
+    (1, 6, 7, 330, 300, 1, 1, 4, True, False),       # deep in both directions, ragged K and N
 ]
 
 
