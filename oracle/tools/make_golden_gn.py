@@ -5,7 +5,8 @@ backbone with GN(2 groups) in place of BN, checks oracle.HRFuserOracle BIT-EXACT
 ref_loader (state-dict keys - the postfixed layers become gn1 / gn2 / gn3 -, eval and train outputs, input and parameter
 gradients) and writes
   tests/golden/hrfuser_gn_cfg.json   the backbone kwargs + state manifest (data)
-  tests/golden/hrfuser_gn.npz        reference outputs at 2x64x96 and fp64-free gradient digests."""
+  tests/golden/hrfuser_gn.npz        reference outputs at 2x64x96 and fp64-free gradient digests,
+and the same for the convolutional sibling HRFuserHRNetBased (BasicBlock trunk): tests/golden/hrfuser_hrnet_gn{_cfg.json,.npz}."""
 import copy
 import json
 import os
@@ -28,12 +29,32 @@ def make_cfg():
     return cfg
 
 
-def main():
-    cfg = make_cfg()
-    ref = R.build_reference(copy.deepcopy(cfg))
+def make_hrnet_cfg():
+    """the convolutional sibling (BasicBlock trunk: resnet.py:34-49 names its norms <abbr>1 / <abbr>2) with GN"""
+    from make_golden_hrnet_based import make_cfg as hrnet_cfg
+    cfg = hrnet_cfg()
+    cfg['norm_cfg'] = dict(type='GN', num_groups=2, requires_grad=True)
+    return cfg
+
+
+def build_pair(cfg):
+    R.install()
     kw = copy.deepcopy(cfg)
-    kw.pop('type')
-    orc = O.HRFuserOracle(**kw)
+    kind = kw.pop('type')
+    if kind == 'HRFuserHRNetBased':
+        import importlib
+        mod = importlib.import_module('mmdet.models.backbones.hrfuser_hrnet_based')
+        return mod.HRFuserHRNetBased(**copy.deepcopy(kw)), O.HRFuserHRNetOracle(**copy.deepcopy(kw))
+    return R.build_reference(copy.deepcopy(cfg)), O.HRFuserOracle(**kw)
+
+
+def main():
+    one(make_cfg(), 'hrfuser_gn')
+    one(make_hrnet_cfg(), 'hrfuser_hrnet_gn')
+
+
+def one(cfg, stem):
+    ref, orc = build_pair(cfg)
     assert list(ref.state_dict().keys()) == list(orc.state_dict().keys()), set(ref.state_dict()) ^ set(orc.state_dict())
     assert any('.gn1.' in k for k in ref.state_dict()) and not any('.bn1.' in k for k in ref.state_dict())
     O.seeded_fill_(ref, 0)
@@ -69,11 +90,11 @@ def main():
         orc.zero_grad(set_to_none=True)
         print('mode', mode, 'oracle == reference bit for bit', [tuple(t.shape) for t in ya])
     manifest = [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in ref.state_dict().items()]
-    with open(os.path.join(OUT, 'hrfuser_gn_cfg.json'), 'w') as fh:
+    with open(os.path.join(OUT, stem + '_cfg.json'), 'w') as fh:
         json.dump({'cfg': json.loads(json.dumps(cfg, default=lambda o: list(o))), 'n_params': sum(p.numel() for p in ref.parameters()),
                    'entries': manifest}, fh, indent=1, sort_keys=True)
-    np.savez_compressed(os.path.join(OUT, 'hrfuser_gn.npz'), **arrays)
-    print('written', len(arrays), 'arrays;', len(manifest), 'state entries')
+    np.savez_compressed(os.path.join(OUT, stem + '.npz'), **arrays)
+    print(stem, 'written', len(arrays), 'arrays;', len(manifest), 'state entries')
 
 
 if __name__ == '__main__':

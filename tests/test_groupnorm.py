@@ -19,17 +19,20 @@ from helpers import (ROOT, PinnedReLU, disable_stochastic, enable_relu_probe, re
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 
-def _cfg():
-    with open(os.path.join(GOLD, 'hrfuser_gn_cfg.json')) as fh:
+STEMS = ['hrfuser_gn', 'hrfuser_hrnet_gn']      # HRFuserHRFormerBased (Bottleneck stems, transformer stages) / HRFuserHRNetBased (BasicBlock trunk)
+
+
+def _cfg(stem):
+    with open(os.path.join(GOLD, stem + '_cfg.json')) as fh:
         return json.load(fh)
 
 
-def _pair(dev):
+def _pair(dev, stem='hrfuser_gn'):
     from hrfuser_amd import build_backbone
-    meta = _cfg()
+    meta = _cfg(stem)
     kw = copy.deepcopy(meta['cfg'])
-    kw.pop('type')
-    orc = O.HRFuserOracle(**kw)
+    kind = kw.pop('type')
+    orc = (O.HRFuserHRNetOracle if kind == 'HRFuserHRNetBased' else O.HRFuserOracle)(**kw)
     O.seeded_fill_(orc, 0)
     net = build_backbone(copy.deepcopy(meta['cfg']))
     net.load_state_dict(orc.state_dict())
@@ -38,15 +41,18 @@ def _pair(dev):
     return net, orc, meta
 
 
-def test_oracle_matches_reference_golden_and_manifest():
-    net, orc, meta = _pair(torch.device('cpu'))
+@pytest.mark.parametrize('stem', STEMS)
+def test_oracle_matches_reference_golden_and_manifest(stem):
+    net, orc, meta = _pair(torch.device('cpu'), stem)
     sd = net.state_dict()
     assert list(sd.keys()) == [e[0] for e in meta['entries']] == list(orc.state_dict().keys())
     assert 'gn1.weight' in sd and 'layer1.0.gn3.weight' in sd and not any('.bn' in k or k.startswith('bn') for k in sd)
+    if stem == 'hrfuser_hrnet_gn':
+        assert any(k.endswith('branches.0.0.gn2.weight') for k in sd)          # BasicBlock norms (resnet.py:34-49)
     assert sum(p.numel() for p in net.parameters()) == meta['n_params']
     for k, shape, dt in meta['entries']:
         assert list(sd[k].shape) == shape and str(sd[k].dtype) == 'torch.' + dt, k
-    gold = np.load(os.path.join(GOLD, 'hrfuser_gn.npz'))
+    gold = np.load(os.path.join(GOLD, stem + '.npz'))
     x, mods = O.seeded_inputs(2, 64, 96, [3, 3], seed=1)
     for mode in ('eval', 'train'):
         orc.train(mode == 'train')
@@ -110,9 +116,9 @@ def test_gn_kernels_gpu():
     _kernels('hip')
 
 
-def _run(train, backend):
+def _run(train, backend, stem='hrfuser_gn'):
     dev = use_backend(backend)
-    net, orc, meta = _pair(dev)
+    net, orc, meta = _pair(dev, stem)
     net.train(train)
     orc.train(train)
     B, H, W = (2, 64, 96) if backend == 'hip' else (1, 32, 32)
@@ -121,7 +127,7 @@ def _run(train, backend):
     enable_relu_probe(net)
     ya = net(xa, [m.to(dev) for m in mods])
     if backend == 'hip':
-        gold = np.load(os.path.join(GOLD, 'hrfuser_gn.npz'))
+        gold = np.load(os.path.join(GOLD, stem + '.npz'))
         for i, y in enumerate(ya):
             assert relmax(y, torch.as_tensor(gold[f'B2_64x96/{"train" if train else "eval"}/out{i}'])) < 1e-3
     masks = relu_masks(net)
@@ -141,7 +147,7 @@ def _run(train, backend):
     sum((t * c.to(dev)).sum() for t, c in zip(ya, cots)).backward()
     e, e_ref = rel_l2(xa.grad, xb.grad), rel_l2(refs[1][2].grad, xb.grad)
     assert e <= max(1e-3, 3 * e_ref), (e, e_ref)
-    tight_grad_gate(net.named_parameters(), o64.named_parameters(), refs[1][0].named_parameters(), 1e-3, f'groupnorm train={train}')
+    tight_grad_gate(net.named_parameters(), o64.named_parameters(), refs[1][0].named_parameters(), 1e-3, f'groupnorm {stem} train={train}')
 
 
 @pytest.mark.parametrize('train', [False, True])
@@ -149,7 +155,12 @@ def test_groupnorm_backbone_emul(train):
     _run(train, 'emul')
 
 
+def test_groupnorm_hrnet_based_emul():
+    _run(True, 'emul', 'hrfuser_hrnet_gn')
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize('stem', STEMS)
 @pytest.mark.parametrize('train', [False, True])
-def test_groupnorm_backbone_gpu(train):
-    _run(train, 'hip')
+def test_groupnorm_backbone_gpu(train, stem):
+    _run(train, 'hip', stem)
