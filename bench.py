@@ -60,7 +60,7 @@ def parse(argv=None):
     ap.add_argument('--dump-kernels', default='', help='write the per-kernel table (JSON) to this path')
     ap.add_argument('--no-sync-ab', action='store_true', help='N > 1: skip the A/B of the per-lane-communicator SyncBN schedule')
     ap.add_argument('--sync-ab-child', action='store_true', help=argparse.SUPPRESS)     # internal: the A/B child job
-    ap.add_argument('--sync-ab-timeout', type=float, default=420.0)
+    ap.add_argument('--sync-ab-timeout', type=float, default=300.0)
     ap.add_argument('--backend', default=os.environ.get('HRF_BENCH_BACKEND', 'nccl'),
                     help="torch.distributed backend: 'nccl' (= RCCL, the product path) | 'gloo' (flow tests of the N > 1 path on a "
                          "box with fewer GPUs than ranks: the ranks share GPU 0, eager launches)")
