@@ -686,6 +686,7 @@ int hrf_lin2_fwd_launch(const LinFwdArgs& a, void* stream) {
   // LayerNorm row statistics of the output are emitted by the register-only kernels (one wave holds whole rows there); the
   // caller's fallback serves such launches (out_proj + residual followed by a LayerNorm: N = the block width, K = N)
   if (a.ln_out != nullptr && g_l2_knob[0] != 1) return -1;
+  if ((long)a.M * a.ldX >= (1L << 32)) return -1;         // operand rows are addressed through 32-bit element offsets
   // the on-load finalize of a BatchNorm is limited to HRF_FIN_MAXC channels; beyond it scale / shift arrive as arrays
   if (a.tf_mode != HRF_TF_NONE && a.tf_mode != HRF_TF_LN && a.fin.stats != nullptr && a.K > HRF_FIN_MAXC) return -1;
   const int id = pick_tile(a.N);
@@ -700,6 +701,7 @@ bool hrf_lin2_fwd_emits_ln(const LinFwdArgs&) { return false; }
 int hrf_lin2_bwd_data_launch(const LinBwdDataArgs& a, void* stream) {
   if (!wide_enough(a.M, a.K, a.N)) return -1;
   if (a.cA != nullptr && a.bfin.gstats != nullptr && a.K > HRF_FIN_MAXC) return -1;
+  if ((long)a.M * a.ldD + a.doff >= (1L << 32)) return -1;   // 32-bit element offsets (see the forward)
   const int id = pick_tile(a.N);
   switch (id) {
     case 1: return launch_bwd_b<TileA>(a, id, stream);
