@@ -283,6 +283,18 @@ _REGIONS = [('stems', ('stem_cam', 'layer1_cam', 'stem_mod', 'layer_a_mod')), ('
             ('stage3+stage_c', ('stage3', 'stage_c')), ('fusion_c', ('fusion_c',)), ('stage4', ('stage4',))]
 
 
+def _stage_pmc(tag):
+    """stage name -> {'MB': ...} of the committed per-stage PMC pass (HRFuser-T nus only), or None"""
+    if tag.replace('_bn', '') != 't_nus':
+        return None
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r03_stage_hbm_traffic.json')
+    if not os.path.exists(path):
+        return None
+    import json
+    with open(path) as fh:
+        return json.load(fh).get('stages')
+
+
 def stage_table(trainer, x, mods, cots, tag, peak_f, peak_b, replays=10):
     """Per-stage durations of the CAPTURED training step and their roofline fractions (north star: "achieved fraction of
     HBM and MFMA roofline reported per stage").  The step is captured once more with GPU timestamps at the stage boundaries
@@ -338,10 +350,28 @@ def stage_table(trainer, x, mods, cots, tag, peak_f, peak_b, replays=10):
         bf, bb = frac(g, mb, b_us)
         rows.append({'name': reg, 'fwd_ms': round(f_us / 1e3, 4), 'bwd_ms': round(b_us / 1e3, 4), 'fwd_gflop': round(B * g, 2),
                      'fwd_eager_MB': round(B * mb, 1), 'fwd_flops_frac': ff, 'fwd_bytes_frac': fb, 'bwd_flops_frac': bf, 'bwd_bytes_frac': bb})
+    # MEASURED fabric traffic per stage (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one eager single-stream step, cut at the same
+    # stamps: tools/pmc_stages.py -> profiles/r03_stage_hbm_traffic.json; a separate run - the source is stated)
+    pmc = _stage_pmc(tag)
+    if pmc is not None:
+        for row in rows:
+            keys = [k for k in order if k == row['name'] or (row['name'] == 'transitions' and k.startswith('transitions_'))]
+            fmb = sum(pmc.get('fwd ' + k, {}).get('MB', 0.0) for k in keys)
+            bmb = sum(pmc.get('bwd ' + k, {}).get('MB', 0.0) for k in keys)
+            row['fwd_pmc_MB'], row['bwd_pmc_MB_incl_weight_gradients'] = round(fmb, 1), round(bmb, 1)
+            row['fwd_pmc_hbm_frac'] = round(fmb * 1e6 / (row['fwd_ms'] * 1e-3) / peak_b, 4) if row['fwd_ms'] else None
     wf, wb = frac(tot_g, tot_mb, wg)
     rows.append({'name': 'weight_gradients (deferred phase, all stages)', 'fwd_ms': None, 'bwd_ms': round(wg / 1e3, 4),
                  'fwd_gflop': round(B * tot_g, 2), 'fwd_eager_MB': round(B * tot_mb, 1), 'bwd_flops_frac': wf, 'bwd_bytes_frac': wb})
-    out = {'stages': rows, 'turnaround_ms': round(turn / 1e3, 4),
+    step_pmc = None
+    if pmc is not None:
+        tot = sum(v.get('MB', 0.0) for v in pmc.values())
+        step_ms = (end if end is not None else t[('bwd', 'weight_gradients')]) / 1e3
+        step_pmc = {'MB': round(tot, 1), 'hbm_frac': round(tot * 1e6 / (step_ms * 1e-3) / peak_b, 4),
+                    'source': 'profiles/r03_stage_hbm_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of every dispatch of ONE eager single-stream '
+                              'step from separate rocprofv3 --pmc passes (tools/pmc_stages.py), cut at the stage stamps; NOT measured in this '
+                              'bench run; backward rows include the weight gradients of the stage (issued inline in that step)'}
+    out = {'stages': rows, 'step_pmc_traffic': step_pmc, 'turnaround_ms': round(turn / 1e3, 4),
            'grad_exchange_adamw_ms': round((end - t[('bwd', 'weight_gradients')]) / 1e3, 4) if end is not None else None,
            'step_ms_with_stamps': round((end if end is not None else t[('bwd', 'weight_gradients')]) / 1e3, 4),
            'timer': f'hrf_stamp (100 MHz GPU counter) at the stage boundaries of the captured step, median of {replays} replays; '
