@@ -289,10 +289,10 @@ class Engine:
         k = calls.get((key, site), 0)
         calls[(key, site)] = k + 1
         slots = self.__dict__.setdefault('_rng_slots', {}).setdefault(key, {})
-        slot = slots.get((site, k))
-        if slot is None or slot[1] != n:
+        slot = slots.get((site, k, n))                   # keyed by the size too: a shape that comes back re-uses its span
+        if slot is None:                                 # (alternating input shapes used to grow the pools without bound)
             off = self._rng_plan.get(key, 0)
-            slot = slots[(site, k)] = (off, n)
+            slot = slots[(site, k, n)] = (off, n)
             self._rng_plan[key] = off + n
         ent = self._rng_pool.get(key)
         if ent is not None and slot[0] + n <= ent.numel():
@@ -993,7 +993,8 @@ def fctx_module_input_grad(src):
 class _GraphEntry:
     """One captured (shape, mode) instance of a module: static input / cotangent buffers, the forward hipGraph, the tape of the
     capture-time forward and - from the first backward on - the backward hipGraph replaying that tape's launches."""
-    __slots__ = ('fwd', 'bwd', 'ins', 'ctx', 'outs', 'srcs', 'gouts', 'keep', 'gen', 'calls', 'needs', 'failed', 'ctx_record')
+    __slots__ = ('fwd', 'bwd', 'ins', 'ctx', 'outs', 'srcs', 'gouts', 'keep', 'gen', 'calls', 'needs', 'failed', 'ctx_record',
+                 'refs')          # engine-owned buffers whose raw pointers the captured launches carry (see _pin_engine_buffers)
 
 
 class _GraphedFn(torch.autograd.Function):
@@ -1091,12 +1092,26 @@ class HipModule(nn.Module, EngineOwner):
             return None
         return ent
 
+    @staticmethod
+    def _pin_engine_buffers(ent, eng):
+        """The captured launches carry RAW pointers into buffers the engine allocates outside the capture and REBINDS when
+        another input signature comes along: the slot arena / segment table / index map of hrf_fold_slots and the fused
+        attention backward (Engine.fs_tables), and the Dropout / DropPath pools (Engine._rng_begin).  The entry keeps every
+        such tensor alive for as long as it exists, so a later eager step or a second captured signature can rebind the
+        engine's attributes (new tensors) without the replays of THIS entry reading freed or reused memory."""
+        ent.refs = getattr(ent, 'refs', None) or []
+        for t in (eng.fs_arena, getattr(eng, 'fs_seg', None), getattr(eng, 'fs_map', None), eng.ps_scratch, eng.ps_map):
+            if t is not None:
+                ent.refs.append(t)
+        ent.refs.extend(eng.__dict__.get('_rng_pool', {}).values())
+
     def _graph_forward(self, ent, inputs):
         eng = self._engine()
         if ent.fwd is None:
             ent.ins = [torch.empty_like(t) for t in inputs]
             ent.needs = [bool(t.requires_grad) for t in inputs]
             ent.keep = []
+            ent.refs = []
         for d, t in zip(ent.ins, inputs):
             d.copy_(t)
         if ent.fwd is None:
@@ -1111,6 +1126,7 @@ class HipModule(nn.Module, EngineOwner):
                 eng.keep = saved
             ent.fwd = g
             ent.gouts = None
+            self._pin_engine_buffers(ent, eng)
         ent.fwd.replay()
         eng.gen = getattr(eng, 'gen', 0) + 1                 # a replay overwrites the BatchNorm slots like any forward
         ent.gen = eng.gen
@@ -1130,6 +1146,9 @@ class HipModule(nn.Module, EngineOwner):
             else:
                 d.copy_(g.permute(0, 2, 3, 1))
         if ent.bwd is None:
+            # this entry gets tables (and an arena) of its OWN: the engine's current ones may be shared with another
+            # signature's replays, and fs_tables re-uses an arena that is large enough
+            eng.fs_sig, eng.fs_arena = None, None
             eng.fs_tables(tuple(eng.fs_step))                # (host-to-device table copies: not inside the capture)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -1145,6 +1164,8 @@ class HipModule(nn.Module, EngineOwner):
             finally:
                 eng.keep = saved
             ent.bwd = g
+            self._pin_engine_buffers(ent, eng)
+            eng.fs_sig = None                                # the next eager backward builds its own tables
         ent.bwd.replay()
         return tuple((fctx_module_input_grad(s).clone() if (s.needs_grad and s.grad is not None) else None) for s in ent.srcs)
 

@@ -42,6 +42,11 @@ _XHUB = os.environ.get('HRF_XHUB', '0') != '0'
 _LANE_COMMS = os.environ.get('HRF_SYNC_LANE_COMMS', '0') == '1'
 
 
+def _p2p_mode_id():
+    """0: collectives through the communicator; 1: the peer-to-peer SyncBN exchange (HRF_SYNC_P2P=1)."""
+    return 1 if os.environ.get('HRF_SYNC_P2P', '0') == '1' else 0
+
+
 def set_lane_comms(on):
     """Switch the SyncBN schedule of the NEXT forward passes of this process (bench.py's sync_ab child compares the two
     schedules in one process).  Every rank must make the same choice."""
@@ -56,8 +61,12 @@ def lane_comms():
 def sync_schedule_fingerprint():
     """What decides the ORDER and NUMBER of SyncBN collectives a rank issues: ranks that disagree on any of these would
     hang or reduce mismatched buffers."""
-    return [1 if _greenlet is not None else 0, 0 if os.environ.get('HRF_SYNC_BATCH', '1') == '0' else 1,
-            1 if _XHUB else 0, 1 if _LANE_COMMS else 0, 1 if _FIN_ONLOAD else 0, _lib.STAT_COPIES]
+    lockstep = os.environ.get('HRF_LOCKSTEP', '1') != '0'
+    batch = os.environ.get('HRF_SYNC_BATCH', '1') != '0'
+    # the EFFECTIVE batching decision of Ctx.__init__ (sync_batch) rides along: HRF_LOCKSTEP=0 alone turns it off (ADVICE r3)
+    eff = 1 if (_greenlet is not None and lockstep and batch and not _LANE_COMMS) else 0
+    return [1 if _greenlet is not None else 0, 1 if batch else 0, 1 if _XHUB else 0, 1 if _LANE_COMMS else 0,
+            1 if _FIN_ONLOAD else 0, _lib.STAT_COPIES, 1 if lockstep else 0, eff, _p2p_mode_id()]
 
 
 def check_sync_schedule(group, world):
@@ -79,7 +88,7 @@ def check_sync_schedule(group, world):
     if not bool((lo == hi).all()):
         raise _lib.HRFuserHipError(
             f'SyncBN: the ranks disagree on the exchange schedule (greenlet, HRF_SYNC_BATCH, HRF_XHUB, HRF_SYNC_LANE_COMMS, '
-            f'HRF_FIN_ONLOAD, HRF_STAT_COPIES): min {lo.tolist()} max {hi.tolist()}, this rank {fp.tolist()}')
+            f'HRF_FIN_ONLOAD, HRF_STAT_COPIES, HRF_LOCKSTEP, effective batching, HRF_SYNC_P2P): min {lo.tolist()} max {hi.tolist()}, this rank {fp.tolist()}')
 FIN_MAXC = _lib.FIN_MAXC
 LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
 _MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
@@ -145,7 +154,7 @@ class Act:
 class BNState:
     """One BatchNorm application: raw conv output + the per-channel vectors around it."""
     __slots__ = ('bn', 'C', 'raw', 'count', 'scale', 'shift', 'mean', 'invstd', 'stats', 'gstats',
-                 'coef', 'du', 'train', 'pending', 'lane', 'bx_done', 'packed', 'bpacked', 'count_ptr',
+                 'coef', 'du', 'train', 'pending', 'lane', 'bx_done', 'packed', 'bpacked', 'count_ptr', 'fin_lane',
                  'gn_raw', 'gn_stat')          # GroupNorm (gn_forward): the raw convolution output and its (mean, rstd) table
 
 
@@ -918,6 +927,7 @@ def bn_forward(ctx, bn, raw, stats):
     st.bn, st.C, st.raw, st.du, st.coef, st.pending, st.lane, st.bx_done = bn, C, raw, None, None, None, None, False
     st.packed = st.bpacked = None
     st.count_ptr = None
+    st.fin_lane = None
     slot = ctx.owner._bn_slot(bn)
     st.train = bool(ctx.training and bn.training)
     if st.train:
@@ -938,20 +948,22 @@ def bn_forward(ctx, bn, raw, stats):
     return st
 
 
-def _finalize_now(ctx, st):
+def _finalize_now(ctx, st, update_running=True):
     bn = st.bn
     mom = bn.momentum if bn.momentum is not None else 0.1
+    track = 1 if (bn.track_running_stats and update_running) else 0
     if st.packed is not None:                           # SyncBN: the folded, all-reduced sums
         P = _lib._ptr
         fin = _lib.BnFin(None, P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var), P(st.scale), P(st.shift),
-                         P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom), 1 if bn.track_running_stats else 0, 1, st.C,
+                         P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom), track, 1, st.C,
                          1, st.count_ptr)
         ctx.L.hrf_bn_finalize_packed(fin, 1, st.packed[0].data_ptr() + 8 * st.packed[1], ctx.stream)
     else:
         ctx.L.hrf_bn_finalize(st.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, st.count,
-                              float(bn.eps), float(mom), 1 if bn.track_running_stats else 0,
+                              float(bn.eps), float(mom), track,
                               st.scale, st.shift, st.mean, st.invstd, st.C, ctx.stream)
     st.pending = None
+    st.fin_lane = ctx.cur
 
 
 def take_fin(ctx, st, limit=FIN_MAXC):
@@ -966,6 +978,12 @@ def take_fin(ctx, st, limit=FIN_MAXC):
         # momentum update twice in one step
         if st.pending == 'fwd':
             _finalize_now(ctx, st)
+        elif st.fin_lane is not None and st.fin_lane is not ctx.cur:
+            # ... but only a consumer that is stream-ordered behind the writer may rely on that: on a SIBLING lane (forked after
+            # the producer, no join in between) the writer's kernel may not have run yet.  Finalise again on this lane without
+            # touching the running statistics: both launches store identical scale / shift / mean / invstd
+            _finalize_now(ctx, st, update_running=False)
+            st.pending = 'written'
         else:
             st.pending = None
         return None
@@ -977,6 +995,7 @@ def take_fin(ctx, st, limit=FIN_MAXC):
                      P(st.scale), P(st.shift), P(st.mean), P(st.invstd), st.count, float(bn.eps), float(mom),
                      1 if bn.track_running_stats else 0, 1 if st.pending == 'fwd' else 0, st.C, copies, st.count_ptr)
     st.pending = 'written'
+    st.fin_lane = ctx.cur
     return fin
 
 
@@ -995,6 +1014,11 @@ def bn_backward_coef(ctx, st, consumer_follows=True, limit=FIN_MAXC):
     wg = st.bn.weight.grad if st.bn.weight.requires_grad else None
     bg = st.bn.bias.grad if st.bn.bias.requires_grad else None
     coll = st.train and _collectives(ctx)
+    if coll and not st.bx_done:
+        # a tape entry that was pushed without `sync=`: exchange now, through the same packed route as everybody else, so that
+        # EVERY SyncBN backward normalises by the all-reduced sample count (st.count_ptr) - the stand-alone
+        # hrf_bn_bwd_finalize below only knows rows x world
+        ctx.flush_bwd([st], [ctx.cur])
     if coll and st.bx_done:                             # exchanged by run_backward's batch (Ctx.flush_bwd): packed sums
         packed, local, off = st.bpacked
         P = _lib._ptr
@@ -1116,6 +1140,7 @@ def gn_forward(ctx, gn, raw):
     st.bn, st.C, st.raw, st.du, st.coef, st.pending, st.lane, st.bx_done = gn, C, y, None, None, None, None, True
     st.packed = st.bpacked = None
     st.count_ptr = None
+    st.fin_lane = None
     st.train = False
     st.stats = None
     st.gstats = _keep(torch.zeros(_lib.STAT_COPIES * 2 * C, device=raw.device, dtype=torch.float64))   # consumers' moments: unused
