@@ -549,24 +549,31 @@ class HRFormerBlock(nn.Module):
         self.ffn = CrossFFN(in_channels, int(in_channels * mlp_ratio), out_channels, norm_cfg)
         self.drop_path_prob = float(drop_path)
 
-    def run(self, ctx, x):
+    def run(self, ctx, x, defer=False):
+        """defer: the caller hands the result to another HRFormerBlock (the next block of the branch, or of the next
+        single-branch module): the CrossFFN tail may then stay lazy (R.LazyTail) - the next block's fused attention launch
+        forms the rows on load, no hrf_affine_act_res / hrf_act_bwd launch for this block."""
         p = self.drop_path_prob
         s1 = s2 = None
         if p > 0.0 and ctx.training and self.training:
             # mmcv DropPath: per-sample floor(keep + U[0,1)) / keep, drawn independently for the two residual paths
             eng = ctx.owner._engine()
             eng.rng_site = id(self)
-            s1, s2 = eng.droppath_scale(x.t.shape[0], p), eng.droppath_scale(x.t.shape[0], p)
+            s1, s2 = eng.droppath_scale(x.shape[0], p), eng.droppath_scale(x.shape[0], p)
         msa = self.attn.attn
-        C = x.t.shape[-1]
+        C = x.shape[-1]
         if R.attn_block_ok(ctx, C, msa.num_heads) and self.ffn.layers[0].weight.shape[0] == 4 * C and not R.is_gn(self.ffn.layers[1]):
             # one launch: norm1 -> qkv -> window attention -> out_proj -> residual -> norm2 -> CrossFFN 1x1 expansion
+            # (x may be the previous block's lazy tail: the launch forms it on load)
             x, h1 = R.attn_block(ctx, id(self), msa.num_heads, x, x, self.norm1, self.norm1, (msa.qkv, 0), (msa.qkv, C),
                                  (msa.qkv, 2 * C), msa.relative_position_bias_table, msa.out_proj, x,
                                  drop=None if s1 is None else (None, 1.0, s1),
                                  ffn=(self.norm2, self.ffn.layers[0], self.ffn.layers[1]))
             tail = self.ffn.run_tail(ctx, h1)
+            if defer and R.tail_onload():
+                return R.LazyTail(x, tail, s2)
             return R.materialize(ctx, tail, R.ACT_GELU, res=x, act_first=True, rowscale=s2)
+        x = R.force(ctx, x)
         x = self.attn.run(ctx, x, self.norm1, drop=None if s1 is None else (None, 1.0, s1))
         tail = self.ffn.run(ctx, R.ln_input(ctx, x, self.norm2))
         return R.materialize(ctx, tail, R.ACT_GELU, res=x, act_first=True, rowscale=s2)
@@ -689,6 +696,7 @@ class HRFuserFusionBlock(nn.Module):
 
 _CAM_LANES = int(os.environ.get('HRF_CAM_LANES', '0') or 0)      # 0: one stream per camera branch (A/B knob)
 _FORK_EXCHANGE = os.environ.get('HRF_FORK_EXCHANGE', '1') != '0'   # exchange chains on sibling lanes (0: serial)
+_BRANCH_ORDER = os.environ.get('HRF_BRANCH_ORDER', '')
 
 
 class HRFomerModule(nn.Module):
@@ -742,7 +750,9 @@ class HRFomerModule(nn.Module):
                 rows.append(nn.ModuleList(row))
             self.fuse_layers = nn.ModuleList(rows)
 
-    def run(self, ctx, xs):
+    def run(self, ctx, xs, defer_out=False):
+        """defer_out (single-branch modules only): the output feeds the first block of the NEXT module of the stage and may
+        stay a lazy CrossFFN tail."""
         nb = self.num_branches
         xs = list(xs)
         # parallel branches (hrnet.py:189-190); with launch merging the finest branch stays on the current lane, where the
@@ -758,9 +768,17 @@ class HRFomerModule(nn.Module):
             lanes = ctx.fork(nb, keep_first=ctx.keep_first)
 
         def branch(i):
-            for blk in self.branches[i]:
-                xs[i] = blk.run(ctx, xs[i])
-        ctx.parallel(lanes, [lambda i=i: branch(i) for i in range(nb)])
+            blocks = list(self.branches[i])
+            for b, blk in enumerate(blocks):
+                last = b == len(blocks) - 1
+                if isinstance(blk, HRFormerBlock):
+                    xs[i] = blk.run(ctx, xs[i], defer=(not last) or (nb == 1 and defer_out))
+                else:
+                    xs[i] = blk.run(ctx, R.force(ctx, xs[i]))
+        order = list(range(nb))
+        if _BRANCH_ORDER == 'rev':
+            order.reverse()                              # (experiment: which lane of a fork starts late - the last one, or the coarse one?)
+        ctx.parallel([lanes[i] for i in order], [lambda i=i: branch(i) for i in order])
         ctx.join(lanes)
         if nb == 1:
             return [xs[0]]
@@ -1031,6 +1049,10 @@ class HipModule(nn.Module, EngineOwner):
         st = self.__dict__.get('_stage_stamps')
         if st is not None:
             st.reset()
+        ls = self.__dict__.get('_lane_stamps')
+        if ls is not None:
+            ls.reset()
+            ls.nfork = 0
         with torch.no_grad():
             srcs = self._wrap_inputs(inputs)
             if needs is not None:                       # static graph inputs: the flags of the caller's tensors
@@ -1050,6 +1072,14 @@ class HipModule(nn.Module, EngineOwner):
             return None
         dev = next(self.parameters()).device
         st = self.__dict__['_stage_stamps'] = R.StageStamps(dev)
+        return st
+
+    def enable_lane_stamps(self, on=True, cap=8192):
+        """Measurement aid (tools/lane_stamps.py): GPU timestamps at every fork / join of the lanes (runtime.Ctx._lane_stamp)."""
+        if not on:
+            self.__dict__.pop('_lane_stamps', None)
+            return None
+        st = self.__dict__['_lane_stamps'] = R.StageStamps(next(self.parameters()).device, cap)
         return st
 
     # ---- captured graphs at the module boundary -----------------------------------------------------------------------
@@ -1462,8 +1492,13 @@ class HRFuserHRFormerBased(HipModule):
 
     @staticmethod
     def _run_stage(ctx, stage, xs):
-        for mod in stage:
-            xs = mod.run(ctx, xs)
+        mods = list(stage)
+        for k, mod in enumerate(mods):
+            if isinstance(mod, HRFomerModule) and mod.num_branches == 1 and k + 1 < len(mods) and \
+                    isinstance(mods[k + 1], HRFomerModule) and mods[k + 1].num_branches == 1:
+                xs = mod.run(ctx, xs, defer_out=True)       # single-branch stage (LidarStageB / C): the chain continues
+            else:
+                xs = mod.run(ctx, xs)
         return xs
 
     def _run(self, ctx, srcs):

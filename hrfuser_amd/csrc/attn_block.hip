@@ -88,9 +88,13 @@ __device__ __forceinline__ void acc_bias(const float* bias, int n0, int N, int l
 
 // Stage the 49 rows of a window (zeros for tokens outside the image and for rows 49..63) and LayerNorm them in place.
 // Four lanes cooperate on one token; all global loads of a thread are issued before its first LDS store.
+// `tail` (uniform): the rows are FORMED here - x = x[.] + rs * GELU(sTs[c] * traw[.] + sTs[C + c]), the CrossFFN tail of the
+// preceding block (hrformer.py:371-372) - and written to xout for the residual add of this launch and for the backward.
 template <int C>
 __device__ __forceinline__ void stage_ln_rows(const hrf_attn_block_t& a, const float* x, const float* gam, const float* bet,
-                                              int b, int wy, int wx, float* sX, const int* sPix) {
+                                              int b, int wy, int wx, float* sX, const int* sPix,
+                                              const float* traw = nullptr, const float* sTs = nullptr, float rs = 1.f,
+                                              float* xout = nullptr) {
   constexpr int PC = C + 1;
   constexpr int NE = (NTOK * C + 255) / 256;
   float v[NE];
@@ -102,6 +106,27 @@ __device__ __forceinline__ void stage_ln_rows(const hrf_attn_block_t& a, const f
     const int pix = sPix[j];
     const float x0 = x[(long)(pix >= 0 ? pix : 0) * C + c];
     v[u] = pix >= 0 ? x0 : 0.f;
+  }
+  if (traw != nullptr) {                                            // (uniform)
+    float rw[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      const int ec = e < NTOK * C ? e : 0;
+      const int j = ec / C, c = ec - j * C;
+      const int pix = sPix[j];
+      rw[u] = traw[(long)(pix >= 0 ? pix : 0) * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      const int ec = e < NTOK * C ? e : 0;
+      const int j = ec / C, c = ec - j * C;
+      const int pix = sPix[j];
+      const float xv = v[u] + rs * hrf_gelu(fmaf(rw[u], sTs[c], sTs[C + c]));
+      v[u] = pix >= 0 ? xv : 0.f;
+      if (e < NTOK * C && pix >= 0) xout[(long)pix * C + c] = xv;
+    }
   }
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
@@ -191,9 +216,15 @@ __device__ __forceinline__ void wave_gemm_tl(const float* sW, int K, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------- forward
+struct AbFwdArgs {
+  hrf_attn_block_t a;
+  hrf_bn_fin_t fin;     // BatchNorm of the preceding block's CrossFFN tail finalised on load (stats != null)
+};
+
 template <int C, int HEADS>
-__global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<hrf_attn_block_t> grp) {
-  const hrf_attn_block_t& a = grp.sel();
+__global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<AbFwdArgs> grp) {
+  const hrf_attn_block_t& a = grp.sel().a;
+  const hrf_bn_fin_t& tfin = grp.sel().fin;
   constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16, PW = (C + 3) & ~3;
   constexpr int KSD = (D + 3) / 4, DT = (D + 15) / 16;
   constexpr int TILE = 64 * PC;
@@ -211,11 +242,17 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<hrf_attn_b
   float* sT = sV + TILE + 32;             // [HEADS][176] relative position bias of every head
   float* sStat = sK;                      // [4][2][4C] BatchNorm moments of h1 per wave: aliases K / V once attention is done
   __shared__ int sPix[64];
+  __shared__ float sTs[2 * C];            // scale | shift of the tail's BatchNorm
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 15, q = lane >> 4;
   const int win = blockIdx.x;
   const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
+  const bool tail = a.tail_raw != nullptr;
   if (tid < 64) sPix[tid] = tid < NTOK ? ab_tok_pixel(a, b, wy, wx, tid) : -1;
+  if (tail) {
+    if (tfin.stats != nullptr) hrf_bn_fin_onload(tfin, sTs, sTs + C, tid, 256, blockIdx.x == 0);
+    else for (int e = tid; e < C; e += 256) { sTs[e] = a.tail_scale[e]; sTs[C + e] = a.tail_shift[e]; }
+  }
   for (int e = tid; e < 64 * PC; e += 256) sX[e] = 0.f;
   for (int e = tid; e < HEADS * 176; e += 256) {
     const int h = e / 176, k = e - h * 176;
@@ -234,7 +271,9 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<hrf_attn_b
   const int tok0 = 16 * wave;
 
   // ---- projections: q from the query source, k / v from the key-value source (the same rows for self-attention)
-  stage_ln_rows<C>(a, a.xq, a.lnq_g, a.lnq_b, b, wy, wx, sX, sPix);
+  if (tail) stage_ln_rows<C>(a, a.tail_res, a.lnq_g, a.lnq_b, b, wy, wx, sX, sPix, a.tail_raw, sTs,
+                             a.tail_rowscale != nullptr ? a.tail_rowscale[b] : 1.f, a.x_out);
+  else stage_ln_rows<C>(a, a.xq, a.lnq_g, a.lnq_b, b, wy, wx, sX, sPix);
   __syncthreads();
   {
     hrf_f4 acc[CT];
@@ -432,7 +471,9 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<hrf_attn_b
 }
 
 template <int C, int HEADS>
-int launch_fwd(const hrf_attn_block_t& a, int nwin, void* stream) {
+int launch_fwd(const hrf_attn_block_t& a0, const hrf_bn_fin_t& fin, int nwin, void* stream) {
+  AbFwdArgs a;
+  a.a = a0; a.fin = fin;
   constexpr size_t smem = ((size_t)(C <= 36 ? 8 * C * ((C + 3) & ~3) : 0) + 4 * 64 * (C + 1) + 32 + HEADS * 176) * sizeof(float);
 #ifndef HRF_EMUL
   static bool once = false;
@@ -636,11 +677,13 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
   __shared__ float sGam[3][C], sBet[3][C];                 // LN_2, LN_q, LN_kv affine parameters
   __shared__ float sPar[4][3][2 * C];                      // per wave: (sum dn*xhat | sum dn) of LN_2, LN_q, LN_kv
   __shared__ float sCo[3 * (4 * C)];                       // BatchNorm-backward coefficients of h1 (cA | cB | cC)
+  __shared__ float sTs[2 * C];                             // scale | shift of the preceding block's tail BatchNorm
+  __shared__ float sTst[4][2 * C];                         // per wave: (sum tail_du | sum tail_du * tail_raw)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 15, q = lane >> 4;
   const int win = blockIdx.x;
   const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
-  const bool cross = a.xkv != a.xq, ffn = a.w1 != nullptr;
+  const bool cross = a.xkv != a.xq, ffn = a.w1 != nullptr, tail = a.tail_raw != nullptr;
   float* slot = a.pslot + (long)blockIdx.x * a.slot_stride;
   if (tid < 64) {
     const int px = tid < NTOK ? ab_tok_pixel(a, b, wy, wx, tid) : -1;
@@ -675,6 +718,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
     sGam[2][e] = a.lnkv_g[e]; sBet[2][e] = a.lnkv_b[e];
   }
   for (int e = tid; e < 4 * 3 * 2 * C; e += 256) (&sPar[0][0][0])[e] = 0.f;
+  if (tail) for (int e = tid; e < C; e += 256) { sTs[e] = a.tail_scale[e]; sTs[C + e] = a.tail_shift[e]; }
   if (ffn) {
     if (bf.gstats != nullptr) hrf_bn_bfin_onload(bf, sCo, sCo + N1, sCo + 2 * N1, tid, 256, blockIdx.x == 0);
     else for (int e = tid; e < N1; e += 256) { sCo[e] = a.cA1[e]; sCo[N1 + e] = a.cB1[e]; sCo[2 * N1 + e] = a.cC1[e]; }
@@ -1022,6 +1066,14 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
   AB_T(7);
   // ---- d LN outputs = dq Wq (+ dk Wk + dv Wv), LayerNorm backward, output gradients
   {
+    hrf_f4 tr[CT];                                                  // raw rows of the preceding block's tail (u = sc*raw + sh)
+    if (tail) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int nb = 16 * t + 4 * q;
+        tr[t] = ld_sel(16 * (t + 1) <= C, a.tail_raw, pc * C + nb, tokv ? C - nb : 0);
+      }
+    }
     hrf_f4 dn[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
@@ -1039,9 +1091,27 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
         for (int r = 0; r < 4; ++r) {
           if (nb + r < C) {
             float v = dn[t][r] + (a.dq_add_res ? gx[t][r] : 0.f);
+            dn[t][r] = v;                                           // dx of this launch alone (the tail below needs it)
             if (a.dq_acc) v += a.dq[pc * C + nb + r];
             a.dq[pc * C + nb + r] = v;
           }
+        }
+      }
+    }
+    if (tail) {
+      // x = tail_res + rs * GELU(u): tail_du = dx * rs * GELU'(u) and its BatchNorm moments (what hrf_act_bwd computed)
+      const float rs = a.tail_rowscale != nullptr ? a.tail_rowscale[b] : 1.f;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int nb = 16 * t + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ch = nb + r < C ? nb + r : 0;
+          const float rw = tr[t][r];
+          const float du = (tokv && nb + r < C) ? dn[t][r] * rs * hrf_gelu_grad(fmaf(rw, sTs[ch], sTs[C + ch])) : 0.f;
+          if (tokv && nb + r < C) a.tail_du[pc * C + nb + r] = du;
+          const float m1 = hrf_row16_sum(du), m2 = hrf_row16_sum(du * rw);
+          if (i == 0 && nb + r < C) { sTst[wave][nb + r] = m1; sTst[wave][C + nb + r] = m2; }
         }
       }
     }
@@ -1114,6 +1184,11 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
   }
   __syncthreads();
   AB_T(9);
+  if (tail) {
+    double* st = a.tail_gstats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
+    for (int e = tid; e < 2 * C; e += 256)
+      hrf_atomic_add(&st[e], (double)((sTst[0][e] + sTst[1][e]) + (sTst[2][e] + sTst[3][e])));
+  }
   // LayerNorm parameter gradients: sum of the four waves' partials
   for (int e = tid; e < 3 * 2 * C; e += 256) {
     const int ln = e / (2 * C), k = e - ln * 2 * C;
@@ -1207,6 +1282,8 @@ extern "C" int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream) {
   if (a.xq == nullptr || a.xkv == nullptr || a.gout == nullptr || a.pslot == nullptr || a.ds_plane == nullptr) return HRF_ERR_ARG;
   if (a.w1 != nullptr && (a.hidden != 4 * a.C || a.h1 == nullptr || a.du1 == nullptr || a.out == nullptr ||
                           (a.bfin1 == nullptr && a.cA1 == nullptr))) return HRF_ERR_ARG;
+  if (a.tail_raw != nullptr && (a.xkv != a.xq || a.dq == nullptr || !a.dq_add_res || a.tail_du == nullptr ||
+                                a.tail_gstats == nullptr || a.tail_scale == nullptr || a.tail_shift == nullptr)) return HRF_ERR_ARG;
   hrf_bn_bfin_t bf{};
   if (a.w1 != nullptr && a.bfin1 != nullptr) {
     bf = *a.bfin1;
@@ -1239,13 +1316,24 @@ extern "C" int hrf_attn_block_fwd(const hrf_attn_block_t* p, void* stream) {
   hrf_attn_block_t a = *p;
   if (a.xq == nullptr || a.xkv == nullptr || a.res == nullptr || a.out == nullptr) return HRF_ERR_ARG;
   if (a.w1 != nullptr && (a.hidden != 4 * a.C || a.h1 == nullptr)) return HRF_ERR_ARG;
+  hrf_bn_fin_t fin{};
+  if (a.tail_raw != nullptr) {
+    // the rows are formed by this launch: self-attention on the buffer it writes them to
+    if (a.tail_res == nullptr || a.x_out == nullptr || a.xq != a.x_out || a.xkv != a.x_out || a.res != a.x_out ||
+        a.res2 != nullptr) return HRF_ERR_ARG;
+    if (a.tail_fin != nullptr) {
+      fin = *a.tail_fin;
+      if (fin.C != a.C || fin.stats == nullptr) return HRF_ERR_ARG;
+    } else if (a.tail_scale == nullptr || a.tail_shift == nullptr) return HRF_ERR_ARG;
+  }
+  a.tail_fin = nullptr;
   ab_geometry(a);
   const int nwin = a.B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
   switch (a.heads) {
-    case 1: return launch_fwd<18, 1>(a, nwin, stream);
-    case 2: return launch_fwd<36, 2>(a, nwin, stream);
-    case 4: return launch_fwd<72, 4>(a, nwin, stream);
-    default: return launch_fwd<144, 8>(a, nwin, stream);
+    case 1: return launch_fwd<18, 1>(a, fin, nwin, stream);
+    case 2: return launch_fwd<36, 2>(a, fin, nwin, stream);
+    case 4: return launch_fwd<72, 4>(a, fin, nwin, stream);
+    default: return launch_fwd<144, 8>(a, fin, nwin, stream);
   }
 }

@@ -92,6 +92,7 @@ def check_sync_schedule(group, world):
 FIN_MAXC = _lib.FIN_MAXC
 LN_EPS = 1e-6            # eps of every transformer LayerNorm of the reference configs (transformer_norm_cfg)
 _MAX_LANES = int(os.environ.get('HRF_MAX_LANES', '0'))
+_FORK_ANCHOR = os.environ.get('HRF_FORK_ANCHOR', '0') == '1'
 
 
 def force_collectives():
@@ -187,6 +188,37 @@ class LNIn:
         return self.act.t.shape
 
 
+class LazyTail:
+    """res + rowscale * GELU(BN(raw)) - the CrossFFN tail of a transformer block (hrformer.py:371-372) - NOT materialised:
+    the fused attention launch of the NEXT block of the chain forms the rows while it stages its window (attn_block(xq =
+    LazyTail)), and its backward launch emits the tail's du and BatchNorm moments.  force() materialises it for any other
+    consumer."""
+    __slots__ = ('res', 'lazy', 'rowscale')
+
+    def __init__(self, res, lazy, rowscale=None):
+        self.res, self.lazy, self.rowscale = res, lazy, rowscale
+
+    @property
+    def shape(self):
+        return self.res.t.shape
+
+    def force(self, ctx):
+        return materialize(ctx, self.lazy, ACT_GELU, res=self.res, act_first=True, rowscale=self.rowscale)
+
+
+def force(ctx, x):
+    """-> an Act: materialises a LazyTail, passes everything else through."""
+    return x.force(ctx) if isinstance(x, LazyTail) else x
+
+
+# the CrossFFN tail of a block formed on load by the next block's fused attention launch (HRF_TAIL_ONLOAD=0: materialised)
+_TAIL_ONLOAD = os.environ.get('HRF_TAIL_ONLOAD', '1') != '0'
+
+
+def tail_onload():
+    return _TAIL_ONLOAD
+
+
 class RawInput:
     """A network input in its native NCHW layout (read through element strides by the stem conv)."""
     __slots__ = ('t', 'grad', 'needs_grad', 'nhwc')
@@ -213,12 +245,12 @@ class StageStamps:
     def reset(self):
         self.marks = []
 
-    def take(self, ctx, direction, name):
+    def take(self, ctx, direction, name, stream=None):
         i = len(self.marks)
         if i >= self.buf.numel():
             return
         self.marks.append((direction, name))
-        ctx.lib.hrf_stamp(self.buf.data_ptr() + 8 * i, ctx.stream)
+        ctx.lib.hrf_stamp(self.buf.data_ptr() + 8 * i, ctx.stream if stream is None else stream)
 
     def read(self):
         """-> [(direction, name, microseconds since the first stamp)]"""
@@ -370,6 +402,7 @@ class Ctx:
         """End of stage `name` in the forward pass (root level, main lane).  With stage stamps enabled on the owner
         (HipModule.enable_stage_stamps) a GPU timestamp is taken here and again when the backward pass comes back to this
         point (= the start of that stage's backward)."""
+        self.owner.__dict__['_stage_tag'] = name
         st = self.owner.__dict__.get('_stage_stamps')
         if st is None or self.strand is not self.root:
             return
@@ -659,9 +692,39 @@ class Ctx:
         uniq = [self._free.pop() for _ in range(m)]
         for k in uniq:
             k.stream.wait_stream(self.cur.stream)
+        self._fork_anchor(self.cur)
+        self._lane_stamp('fork', self.cur, uniq)
         if self.record and uniq:
             self.strand.tape.append(('F', self.cur, uniq))
         return first + [uniq[i % m] for i in range(n)]
+
+    def _lane_stamp(self, what, parent, lanes):
+        """Measurement aid (HipModule.enable_lane_stamps; tools/lane_stamps.py): a GPU timestamp on the parent lane and on
+        every sibling lane at each fork (= when the lane really starts) and join (= when it is done) - the un-profiled truth
+        about lane start offsets (rocprofv3's packet interception paces the queues itself)."""
+        st = self.owner.__dict__.get('_lane_stamps')
+        if st is None or not self.multi:
+            return
+        k = st.__dict__.setdefault('nfork', 0)
+        if what == 'fork':
+            st.nfork = k = k + 1
+        tag = self.owner.__dict__.get('_stage_tag', '')
+        st.take(self, what, (k, 'parent', tag), parent.ptr)
+        for i, l in enumerate(lanes):
+            if l.stream is not None:
+                st.take(self, what, (k, i, tag), l.ptr)
+
+    def _fork_anchor(self, parent):
+        """EXPERIMENT (HRF_FORK_ANCHOR=1): one trivial kernel on the PARENT lane right after a fork.  The ROCm graph executor
+        gives the first child of a node the node's own stream and resolves a cross-stream dependency through a marker at the
+        TAIL of the source stream at enqueue time - so without it the first sibling's whole chain sits between the fork
+        point and the markers the other siblings wait for (they started 100-200 us late in the rocprofv3 timeline)."""
+        if not _FORK_ANCHOR or not self.multi or parent.stream is None:
+            return
+        buf = self.owner.__dict__.get('_fork_scratch')
+        if buf is None:
+            buf = self.owner.__dict__['_fork_scratch'] = torch.zeros(8, dtype=torch.int64, device=torch.device('cuda', torch.cuda.current_device()))
+        self.lib.hrf_stamp(buf.data_ptr(), parent.ptr)
 
     def bundle_lanes(self, n, what='stems', cap=0):
         """Lanes for n strands of EQUAL shape (camera stem + modality stems, the modality stages beside the camera stage):
@@ -682,6 +745,7 @@ class Ctx:
             return
         if not self.multi:
             return
+        self._lane_stamp('join', self.cur, kids)
         for k in kids:
             self.cur.stream.wait_stream(k.stream)
         if self.record:
@@ -744,7 +808,12 @@ class Ctx:
                 for k in e[2]:
                     if self.multi and k.stream is not None:
                         k.stream.wait_stream(e[1].stream)
+                if self.multi and e[2] and e[2][0].stream is not None:
+                    self._fork_anchor(e[1])
+                    self._lane_stamp('fork', e[1], e[2])
             elif e[0] == 'F':                   # reverse of a fork = join
+                if self.multi and e[2] and e[2][0].stream is not None:
+                    self._lane_stamp('join', e[1], e[2])
                 for k in e[2]:
                     if self.multi and k.stream is not None:
                         e[1].stream.wait_stream(k.stream)
@@ -1339,6 +1408,12 @@ def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, r
     self-attention.  The residual conventions are the reference's: self-attention res is xq; cross-attention res is
     the running sum and res2 the modality map that is also the key/value source."""
     L, s = ctx.L, ctx.stream
+    tail = None
+    if isinstance(xq, LazyTail):
+        # the block input is the previous block's CrossFFN tail: this launch forms the rows and writes them to `xin`
+        tail = xq
+        assert xkv is tail and res is tail and res2 is None, 'a lazy CrossFFN tail feeds self-attention blocks only'
+        xq = xkv = res = Act(_new_like(tail.res.t))
     B, H, W, C = xq.t.shape
     cross = xkv is not xq
     assert res2 is None or res2 is xkv
@@ -1373,9 +1448,19 @@ def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, r
         if ffn is not None:
             a.ln2_g, a.ln2_b, a.out_eps = P(ln2.weight), P(ln2.bias), float(ln2.eps)
             a.w1, a.b1, a.h1, a.stats1, a.hidden = P(conv1.weight), P(conv1.bias), P(h1raw), P(stats), N1
+        if tail is not None:
+            ts = tail.lazy.st
+            a.tail_res, a.tail_raw, a.tail_scale, a.tail_shift = P(tail.res.t), P(ts.raw), P(ts.scale), P(ts.shift)
+            a.tail_rowscale, a.x_out = P(tail.rowscale), P(xq.t)
         return a
 
-    L.hrf_attn_block_fwd(fill(), s)
+    a0 = fill()
+    if tail is not None:
+        tfin = take_fin(ctx, tail.lazy.st)
+        if tfin is not None:
+            a0._keep_fin = tfin                         # the struct holds a raw pointer to it
+            a0.tail_fin = ctypes.addressof(tfin)
+    L.hrf_attn_block_fwd(a0, s)
     h1 = None
     if ffn is not None:
         st = bn_forward(ctx, bn1, h1raw, stats)
@@ -1418,6 +1503,13 @@ def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, r
             if xq.needs_grad:
                 g, acc = xq.grad_target()
                 a.dq, a.dq_acc, a.dq_add_res = P(g), acc, 1 if res_is_q else 0
+        elif tail is not None:
+            # dx of this block IS the gradient of the tail's residual stream; the launch also emits the tail's du and moments
+            ts = tail.lazy.st
+            g, acc = tail.res.grad_target()
+            a.dq, a.dq_acc, a.dq_add_res = P(g), acc, 1
+            ts.du = _new_like(ts.raw)
+            a.tail_du, a.tail_gstats = P(ts.du), P(ts.gstats)
         elif xq.needs_grad:
             assert res is xq
             g, acc = xq.grad_target()

@@ -188,6 +188,16 @@ typedef struct hrf_attn_block {
   const float* gout; const float* du1; const float* cA1; const float* cB1; const float* cC1; const hrf_bn_bfin_t* bfin1;
   float* dres; int dres_acc; float* dq; int dq_acc; int dq_add_res; float* dkv; int dkv_acc; int dkv_add_res;
   float* pslot; long slot_stride; float* ds_plane;
+  /* CrossFFN tail of the PRECEDING block formed on load (hrformer.py:371-372 x = x' + DropPath(GELU(BN3(fc3(.)))), self-
+   * attention only, tail_raw != NULL): the block input rows are x = tail_res + tail_rowscale[b] * GELU(tail_scale *
+   * tail_raw + tail_shift) (tail_fin: scale / shift derived on load from the producer's moments, as hrf_conv_fwd's fin).
+   * forward : every workgroup forms the rows of its window and WRITES them to x_out (== xq == xkv == res: the block's
+   *           residual and, in the backward, its recomputation source).
+   * backward: with dx = the block-input gradient (what dq receives; dq_add_res = 1): tail_du = dx * rowscale * GELU'(u),
+   *           tail_gstats [HRF_STAT_COPIES][2*C] += (sum tail_du, sum tail_du * tail_raw): the hrf_act_bwd launch of the
+   *           preceding block's BatchNorm is gone; tail_scale / tail_shift must be in memory (published by the forward). */
+  const float* tail_res; const float* tail_raw; const float* tail_scale; const float* tail_shift; const float* tail_rowscale;
+  const hrf_bn_fin_t* tail_fin; float* x_out; float* tail_du; double* tail_gstats;
   int off_w1, off_b1, off_g2, off_bt2, off_wo, off_bo, off_wq, off_bq, off_wk, off_bk, off_wv, off_bv;
   int off_gq, off_btq, off_gkv, off_btkv, off_rpb;
   int nWh, nWw, pt, pl; float scale;

@@ -37,7 +37,9 @@ def _reference(blk, x, xkv, res2, cross, with_ffn):
     return out, h1
 
 
-def _run(C, heads, B, H, W, cross, with_ffn, backward, backend):
+def _run(C, heads, B, H, W, cross, with_ffn, backward, backend, tail=False):
+    """tail: the block input is formed on load, x = tail_res + rowscale[b] * GELU(scale * tail_raw + shift) (the CrossFFN tail
+    of the preceding block, hrformer.py:371-372); the backward also emits tail_du and the tail BatchNorm's moments."""
     dev = use_backend(backend)
     L = _lib.lib()
     if cross:
@@ -49,13 +51,22 @@ def _run(C, heads, B, H, W, cross, with_ffn, backward, backend):
     O.seeded_fill_(blk, 5)
     blk = blk.double()
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(B, C, H, W, generator=g).double().requires_grad_(True)
+    if tail:
+        assert not cross
+        t_res = torch.randn(B, C, H, W, generator=g).double().requires_grad_(True)
+        t_raw = torch.randn(B, C, H, W, generator=g).double()
+        t_sc, t_sh = (torch.rand(C, generator=g) + 0.5).double(), torch.randn(C, generator=g).double()
+        t_rs = torch.tensor([1.25, 0.0, 1.25][:B] + [1.25] * max(0, B - 3)).double()
+        t_u = (t_raw * t_sc.view(1, C, 1, 1) + t_sh.view(1, C, 1, 1)).requires_grad_(True)
+        x = t_res + t_rs.view(B, 1, 1, 1) * torch.nn.functional.gelu(t_u)
+    else:
+        x = torch.randn(B, C, H, W, generator=g).double().requires_grad_(True)
     xkv = torch.randn(B, C, H, W, generator=g).double().requires_grad_(True) if cross else x
     out_ref, h1_ref = _reference(blk, x, xkv, True, cross, with_ffn)
 
     f32 = lambda t: t.detach().float().contiguous().to(dev)
     rows = lambda t: f32(t.permute(0, 2, 3, 1).reshape(B * H * W, C))
-    xq_d = rows(x)
+    xq_d = rows(x) if not tail else torch.full((B * H * W, C), float('nan'), device=dev)     # tail: written by the launch
     xkv_d = rows(xkv) if cross else xq_d
     P = _lib._ptr
     keep = []
@@ -81,6 +92,9 @@ def _run(C, heads, B, H, W, cross, with_ffn, backward, backend):
     a.rpb, a.wo, a.bo = P(rpb), P(wo), P(bo)
     a.res, a.res2 = P(xq_d), (P(xkv_d) if cross else None)
     a.mask, a.mscale, a.rowscale, a.rows_per_sample = None, 1.0, None, H * W
+    if tail:
+        tres_d, traw_d, tsc_d, tsh_d, trs_d = rows(t_res), rows(t_raw), dp(t_sc), dp(t_sh), dp(t_rs)
+        a.tail_res, a.tail_raw, a.tail_scale, a.tail_shift, a.tail_rowscale, a.x_out = P(tres_d), P(traw_d), P(tsc_d), P(tsh_d), P(trs_d), P(xq_d)
     out = torch.full((B * H * W, C), float('nan'), device=dev)
     a.out = P(out)
     N1 = 4 * C
@@ -94,6 +108,8 @@ def _run(C, heads, B, H, W, cross, with_ffn, backward, backend):
         a.w1, a.b1, a.h1, a.stats1, a.hidden = P(w1), P(b1), P(h1), P(stats), N1
     L.hrf_attn_block_fwd(a, _lib.stream_ptr())
     assert r(out.reshape(B, H * W, C), out_ref) < 2e-5
+    if tail:
+        assert r(xq_d.reshape(B, H, W, C).permute(0, 3, 1, 2), x) < 1e-5        # the formed rows, written for the backward
     if with_ffn:
         assert r(h1.reshape(B, H * W, N1), h1_ref) < 2e-5
         st = stats.view(KC, 2, N1).sum(0)
@@ -125,6 +141,10 @@ def _run(C, heads, B, H, W, cross, with_ffn, backward, backend):
         a.du1, a.cA1, a.cB1, a.cC1 = P(du1_d), P(cA), P(cB), P(cC)
     dq = torch.full((B * H * W, C), float('nan'), device=dev)
     a.dq, a.dq_acc = P(dq), 0
+    if tail:
+        tdu = torch.full((B * H * W, C), float('nan'), device=dev)
+        tgs = torch.zeros(KC * 2 * C, dtype=torch.float64, device=dev)
+        a.tail_du, a.tail_gstats = P(tdu), P(tgs)
     if cross:
         dkv = torch.full((B * H * W, C), float('nan'), device=dev)
         a.dkv, a.dkv_acc, a.dkv_add_res = P(dkv), 0, 1
@@ -135,7 +155,15 @@ def _run(C, heads, B, H, W, cross, with_ffn, backward, backend):
     for n in ('w1', 'b1', 'g2', 'bt2', 'wo', 'bo', 'wq', 'bq', 'wk', 'bk', 'wv', 'bv', 'gq', 'btq', 'gkv', 'btkv', 'rpb'):
         setattr(a, 'off_' + n, offs.get(n, -1))
     L.hrf_attn_block_bwd(a, _lib.stream_ptr())
-    assert r(dq.reshape(B, H, W, C).permute(0, 3, 1, 2), x.grad) < 5e-5
+    if tail:
+        assert r(dq.reshape(B, H, W, C).permute(0, 3, 1, 2), t_res.grad) < 5e-5
+        du_ref = t_u.grad.permute(0, 2, 3, 1).reshape(-1, C)
+        assert r(tdu, du_ref) < 5e-5
+        gs = tgs.view(KC, 2, C).sum(0)
+        raw_rows = t_raw.permute(0, 2, 3, 1).reshape(-1, C)
+        assert r(gs[0], du_ref.sum(0)) < 1e-4 and r(gs[1], (du_ref * raw_rows).sum(0)) < 1e-4
+    else:
+        assert r(dq.reshape(B, H, W, C).permute(0, 3, 1, 2), x.grad) < 5e-5
     if cross:
         assert r(dkv.reshape(B, H, W, C).permute(0, 3, 1, 2), xkv.grad) < 5e-5
 
@@ -191,6 +219,19 @@ def test_attn_block_abi_emul(case, cross):
 @pytest.mark.parametrize('case', EDGE)
 def test_attn_block_abi_gpu(case, cross, with_ffn):
     _run(*case, cross, with_ffn, True, 'hip')
+
+
+@pytest.mark.parametrize('case', [EDGE[1], EDGE[2]])
+def test_attn_block_tail_abi_emul(case):
+    _run(*case, False, True, True, 'emul', tail=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('with_ffn', [False, True])
+@pytest.mark.parametrize('case', EDGE)
+def test_attn_block_tail_abi_gpu(case, with_ffn):
+    """the preceding block's CrossFFN tail formed on load (forward) / its du + BatchNorm moments emitted (backward)"""
+    _run(*case, False, with_ffn, True, 'hip', tail=True)
 
 
 @pytest.mark.gpu
