@@ -167,21 +167,35 @@ def run_ranks(argv, gpus, env=None, timeout=None):
     return rc, line, '\n'.join(rest[-15:])
 
 
-def run_sync_ab(argv, gpus, timeout):
-    """A/B of the SyncBN schedule with one RCCL communicator per lane (HRF_SYNC_LANE_COMMS=1) in a FRESH child job
-    with a timeout: the child first checks that one step's gradient arena equals the main-lane schedule's (rel-L2 < 1e-6),
-    then times the captured step.  Reported beside the headline, never as the headline; a hang or failure is text."""
+_AB_ARMS = {
+    'lane_comms': ('one communicator per lane (HRF_SYNC_LANE_COMMS=1)', {'HRF_SYNC_LANE_COMMS': '1', 'HRF_SYNC_P2P': '0'}),
+    'p2p': ('peer-to-peer exchange through IPC inboxes, no communicator (HRF_SYNC_P2P=1)', {'HRF_SYNC_AB_MODE': 'p2p'}),
+}
+
+
+def _run_ab_arm(arm, argv, gpus, timeout):
+    name, extra = _AB_ARMS[arm]
     env = dict(os.environ)
-    env['HRF_SYNC_LANE_COMMS'] = '1'
+    env.update(extra)
     env.pop('HRF_FORCE_COLLECTIVES', None)
     t0 = time.time()
     rc, line, rest = run_ranks(list(argv) + ['--sync-ab-child'], gpus, env=env, timeout=timeout)
     if rc is None:
-        return {'schedule': 'one communicator per lane (HRF_SYNC_LANE_COMMS=1)', 'error': f'no result within {timeout:.0f} s (child process group killed)'}
+        return {'schedule': name, 'error': f'no result within {timeout:.0f} s (child process group killed)'}
     if line is None or 'sync_ab' not in line:
-        return {'schedule': 'one communicator per lane (HRF_SYNC_LANE_COMMS=1)', 'error': f'child exited with {rc} and no result: {rest[-400:]}'}
+        return {'schedule': name, 'error': f'child exited with {rc} and no result: {rest[-400:]}'}
     res = line['sync_ab']
     res['wall_s'] = round(time.time() - t0, 1)
+    return res
+
+
+def run_sync_ab(argv, gpus, timeout):
+    """A/B of the SyncBN schedules that need no hop to the main lane, each in a FRESH child job with a timeout:
+    one RCCL communicator per lane (HRF_SYNC_LANE_COMMS=1), and the peer-to-peer exchange through IPC inboxes
+    (HRF_SYNC_P2P=1).  A child first checks that one step's gradient arena equals the main-lane schedule's (rel-L2 < 1e-6),
+    then times the captured step.  Reported beside the headline, never as the headline; a hang or failure is text."""
+    res = _run_ab_arm('lane_comms', argv, gpus, timeout)
+    res['p2p'] = _run_ab_arm('p2p', argv, gpus, timeout)
     return res
 
 
@@ -325,29 +339,38 @@ def leave(world, force_coll):
 
 
 def sync_ab_child(args):
-    """The A/B job of run_sync_ab (HRF_SYNC_LANE_COMMS=1 in the environment, N ranks): gradient equivalence of the two
-    SyncBN schedules on one eager step each, then the captured step of the per-lane-communicator schedule, timed like the
-    headline.  Rank 0 prints {"sync_ab": {...}}."""
+    """One arm of run_sync_ab (N ranks): gradient equivalence of the arm's SyncBN schedule with the main-lane one on one eager
+    step each, then the captured step of the arm, timed like the headline.  Rank 0 prints {"sync_ab": {...}}."""
     from hrfuser_amd import runtime as R
+    p2p_arm = os.environ.get('HRF_SYNC_AB_MODE') == 'p2p'
     rank, world, dev, group, force_coll = init_ranks(args)
     tag, cfg, stf, H, W, mc, net, B, x, mods, cots, trainer = build_workload(args, rank, world, dev, group, force_coll)
-    res = {'schedule': 'one communicator per lane, unbatched (HRF_SYNC_LANE_COMMS=1)'}
+    res = {'schedule': _AB_ARMS['p2p' if p2p_arm else 'lane_comms'][0]}
     try:
         eng = net._engine()
-        R.set_lane_comms(False)
+
+        def select(on):
+            if p2p_arm:
+                os.environ['HRF_SYNC_P2P'] = '1' if on else '0'      # read when a forward starts (hrfuser_amd/p2p.py)
+            else:
+                R.set_lane_comms(on)
+        select(False)
         trainer.step(x, mods, cots)                               # sizes of the random pools are known after one step
         torch.cuda.synchronize()
 
-        def grads(lane):
-            R.set_lane_comms(lane)
+        def grads(on):
+            select(on)
             torch.manual_seed(777)                                # the same Dropout / DropPath draws for both schedules
             trainer.step(x, mods, cots, grads_only=True)
+            trainer.check()
             torch.cuda.synchronize()
-            return eng.flat_g.clone(), trainer.collectives_per_step
-        g_main, n_main = grads(False)
-        g_lane, n_lane = grads(True)
-        err = float((g_lane.double() - g_main.double()).norm() / g_main.double().norm().clamp_min(1e-300))
-        res.update({'grad_rel_l2_vs_main_lane': err, 'collectives_per_step': n_lane, 'main_lane_collectives_per_step': n_main})
+            return eng.flat_g.clone(), trainer.collectives_per_step, getattr(trainer, 'p2p_exchanges_per_step', 0)
+        g_main, n_main, _ = grads(False)
+        g_arm, n_arm, n_px = grads(True)
+        err = float((g_arm.double() - g_main.double()).norm() / g_main.double().norm().clamp_min(1e-300))
+        res.update({'grad_rel_l2_vs_main_lane': err, 'collectives_per_step': n_arm, 'main_lane_collectives_per_step': n_main})
+        if p2p_arm:
+            res['p2p_exchanges_per_step'] = n_px
         if not (err < 1e-6):
             raise RuntimeError(f'gradient arena differs from the main-lane schedule: rel-L2 {err:.3e}')
         use_graph = not args.no_graph and args.backend == 'nccl'
@@ -355,8 +378,23 @@ def sync_ab_child(args):
             trainer.capture(x, mods, cots)
         run = trainer.replay if use_graph else (lambda: trainer.step(x, mods, cots))
         dt, per = time_steps(args, run, world, dev)
+        trainer.check()
         res.update({'ms_per_step': round(dt / args.steps * 1e3, 4), 'images_per_sec': round(B * world * args.steps / dt, 3),
                     'launch': 'hipGraph replay' if use_graph else 'eager', 'finite': bool(torch.isfinite(eng.flat_p).all())})
+        if p2p_arm:
+            # ... and the collective main-lane schedule timed the same way in the same job: the baseline of the comparison
+            # when the headline itself ran on the peer-to-peer exchange
+            try:
+                select(False)
+                trainer.step(x, mods, cots)
+                torch.cuda.synchronize()
+                if use_graph:
+                    trainer.capture(x, mods, cots)
+                run = trainer.replay if use_graph else (lambda: trainer.step(x, mods, cots))
+                dt, per = time_steps(args, run, world, dev)
+                res['main_lane_ms_per_step'] = round(dt / args.steps * 1e3, 4)
+            except Exception as e:
+                res['main_lane_error'] = f'{type(e).__name__}: {str(e)[:200]}'
     except Exception as e:
         res['error'] = f'{type(e).__name__}: {str(e)[:300]}'
     if rank == 0:
@@ -542,6 +580,7 @@ def main(argv=None):
                        'global_batch': B * world, 'parallelism': f'dp{world}',
                        'launch': 'hipGraph replay' if use_graph else 'eager',
                        'collectives_per_step': trainer.collectives_per_step,
+                       'p2p_exchanges_per_step': getattr(trainer, 'p2p_exchanges_per_step', 0),
                        'sync_schedule': getattr(trainer, 'sync_schedule', None) if (world > 1 or force_coll) else None,
                        'backend': ('RCCL (torch.distributed nccl)' if args.backend == 'nccl' else args.backend + ' (flow test, ranks share GPU 0)') if (world > 1 or force_coll) else None,
                        'exchange_lanes_hist': {f'{k[0]}{"m" if k[1] else ""}': v for k, v in sorted(getattr(trainer, 'exchange_hist', {}).items())}},

@@ -34,6 +34,13 @@ def struct_from_header(tag, path=HEADER):
         decl = ' '.join(decl.split())
         if not decl:
             continue
+        arr = re.search(r'(\w+)\[(\w+)\]$', decl)
+        if arr:                                        # fixed-size array field (extent: a number or a #define of the header)
+            ext = int(arr.group(2)) if arr.group(2).isdigit() else _header_int(arr.group(2), 0)
+            base = decl.split(' ', 1)[0]
+            el = ctypes.c_void_p if '*' in decl else {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'double': ctypes.c_double}[base]
+            fields.append((arr.group(1), el * ext))
+            continue
         if '*' in decl:
             ct, names = ctypes.c_void_p, [re.findall(r'(\w+)$', decl)[0]]
         else:
@@ -47,6 +54,7 @@ def struct_from_header(tag, path=HEADER):
 BnFin = struct_from_header('hrf_bn_fin')            # BatchNorm of a consumer's input finalised on load
 BnBFin = struct_from_header('hrf_bn_bfin')          # BatchNorm-backward coefficients derived on load
 AttnBlock = struct_from_header('hrf_attn_block')    # fused window-attention block (csrc/attn_block.hip)
+P2p = struct_from_header('hrf_p2p')                 # peer-to-peer SyncBN exchange context (csrc/p2p_exchange.hip)
 
 
 def _ptr(t):

@@ -189,6 +189,49 @@ class Engine:
                 m.num_batches_tracked = self.nbt_flat[i]          # 0-dim view: one add_ per step updates all
         self.device = device
 
+    # ---- peer-to-peer SyncBN exchange (hrfuser_amd/p2p.py; HRF_SYNC_P2P=1 on every rank)
+    def p2p_context(self, group, world):
+        """The exchange context of this engine for (group, world), built at the first training forward that needs it - a
+        COLLECTIVE operation (IPC handles are all-gathered over `group`, a handshake runs): every rank gets here at the same
+        point of its program.  None: collectives go through the communicator (HRF_SYNC_P2P=0, a one-rank group in auto mode,
+        or a failed handshake in auto mode - decided by ALL ranks together, with a warning)."""
+        from . import p2p
+        if group is None or not p2p.wanted(world):
+            return None
+        cur = self.__dict__.get('_p2p')
+        if cur is not None and cur[0] is group and cur[1] == world and cur[3] == p2p.mode():
+            return cur[2]
+        if cur is not None and cur[2] is not None:
+            cur[2].close()
+        import torch.distributed as dist
+        rank = dist.get_rank(group) if world > 1 else 0
+        strict = p2p.mode() == 'on'
+        ctx, why = None, ''
+        try:
+            ctx = p2p.P2PExchange(self.root._lib_handle(), self._bns, group, world, rank, self.device)
+            if world > 1:
+                ctx.handshake()
+        except Exception as e:                                    # (no IPC on this driver, a peer on another node, a time-out ...)
+            if strict or world == 1:
+                raise
+            why = f'{type(e).__name__}: {str(e)[:200]}'
+            if ctx is not None:
+                ctx.close()
+            ctx = None
+        if world > 1 and not strict:
+            # every rank takes the SAME schedule: one failure sends all of them back to the communicator
+            dev = self.device if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+            ok = torch.tensor([1 if ctx is not None else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok) == 0:
+                if ctx is not None:
+                    ctx.close()
+                ctx = None
+                warnings.warn('SyncBN: the peer-to-peer exchange is not available on every rank'
+                              + (f' (this rank: {why})' if why else '') + '; using the collective schedule (HRF_SYNC_P2P=0 silences this)')
+        self.__dict__['_p2p'] = (group, world, ctx, p2p.mode())
+        return ctx
+
     def grad_acc(self, p):
         """-> (accumulator tensor, copy_stride) for a parameter gradient written by many blocks."""
         o = self.pslot.get(id(p))
@@ -338,6 +381,10 @@ class Engine:
             self._rng_calls = {}
         if self.arena_d.numel():
             R.gpu_zero_(self.arena_d)
+        if training and self.root.sync_group is not None and (self.root.sync_world > 1 or R.force_collectives()):
+            px = self.p2p_context(self.root.sync_group, self.root.sync_world)
+            if px is not None:
+                px.tick(_lib.stream_ptr())            # the step generation the exchanges of this forward / backward carry
         if self._bns and not (training and all(m.training for m in self._bns)):
             self.refresh_eval_affine()
 

@@ -1,0 +1,163 @@
+"""Peer-to-peer SyncBN exchange (csrc/p2p_exchange.hip): the host side - inbox allocation, IPC handle exchange, slot table.
+
+What the reference gets from torch.nn.SyncBatchNorm (norm_cfg type SyncBN, configs/_base_/models/
+cascade_rcnn_hrfuser_fpn_nus_clr_fusion.py:2; wrapped by MMDistributedDataParallel, mmdet/apis/train.py:113-121) is, per
+BatchNorm layer and direction, an exchange of 2*C moments + a sample count between the ranks.  With RCCL those are
+collectives of one communicator that must run in one order on every rank (the lanes hop to the main lane for each);
+here every layer owns a slot in an inbox every rank exposes to its peers and an exchange is ONE launch on the lane that needs
+it (include/hrfuser_hip.h: hrf_p2p_exchange).  HRF_SYNC_P2P (the same on every rank: part of the schedule fingerprint): unset
+= auto (groups of more than one rank use it after a collective handshake and fall back TOGETHER to the communicator schedule
+if any rank cannot), 1 = on, 0 = off.  The communicator schedule stays the fallback and the parity reference
+(bench.py sync_ab times both), and the gradient all-reduce at the end of a step stays a collective.
+
+Nothing here computes: allocation, `torch.distributed` object all-gather of the 64-byte IPC handles, pointer tables.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+
+
+def mode():
+    """HRF_SYNC_P2P: '1' = on (a failure to set it up raises), '0' = off (collectives through the communicator), unset /
+    'auto' = on for a group of more than one rank AFTER a collective handshake (IPC mapping + a few verified test exchanges
+    with a short time-out); any rank failing it sends every rank back to the communicator schedule with a warning."""
+    v = os.environ.get('HRF_SYNC_P2P', 'auto').strip().lower()
+    return {'1': 'on', 'on': 'on', '0': 'off', 'off': 'off'}.get(v, 'auto')
+
+
+def wanted(world):
+    m = mode()
+    return m == 'on' or (m == 'auto' and world > 1)
+
+
+class P2PExchange:
+    """Inbox of this rank + the mapped inboxes of its peers + the static slot of every BatchNorm (layer, direction)."""
+
+    def __init__(self, lib, bns, group, world, rank, device, timeout_s=None):
+        self.lib, self.world, self.rank, self.device = lib, int(world), int(rank), device
+        if not (1 <= self.world <= 8):
+            raise _lib.HRFuserHipError(f'peer-to-peer SyncBN exchange: 1..8 ranks of one node, got {world}')
+        off = 0
+        self.slots = {}
+        for i, m in enumerate(bns):
+            C = m.num_features
+            self.slots[id(m)] = ((off, 2 * i), (off + 2 * C + 1, 2 * i + 1))       # (slot_off, slot_id) forward, backward
+            off += 2 * (2 * C + 1)
+        self.test_slot = (off, 2 * len(bns))                                       # one more slot (C = 1): the handshake
+        off += 3
+        self.slot_doubles, self.nslots = off, 2 * len(bns) + 1
+        self.data_bytes = self.world * 2 * self.slot_doubles * 8
+        self.bytes = self.data_bytes + self.world * 2 * self.nslots * 8
+        base = ctypes.c_void_p()
+        handle = (ctypes.c_char * 64)()
+        need_ipc = self.world > 1
+        lib.hrf_p2p_alloc(self.bytes, ctypes.addressof(base), ctypes.addressof(handle) if need_ipc else None)
+        self.base = base.value
+        self.peers = [None] * self.world
+        self.peers[self.rank] = self.base
+        self.opened = []
+        if need_ipc:
+            import torch.distributed as dist
+            mine = (bytes(handle.raw), os.getpid(), self.bytes)
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine, group=group)
+            for p, (h, pid, nbytes) in enumerate(everyone):
+                if p == self.rank:
+                    continue
+                if nbytes != self.bytes:
+                    raise _lib.HRFuserHipError(f'peer-to-peer SyncBN exchange: rank {p} built a different slot table '
+                                               f'({nbytes} vs {self.bytes} bytes) - the ranks do not run the same model')
+                if pid == os.getpid():
+                    raise _lib.HRFuserHipError('peer-to-peer SyncBN exchange: two ranks in one process')
+                q = ctypes.c_void_p()
+                hb = (ctypes.c_char * 64).from_buffer_copy(h)
+                lib.hrf_p2p_open(ctypes.addressof(hb), ctypes.addressof(q))
+                self.peers[p] = q.value
+                self.opened.append(q.value)
+        self.gen = torch.zeros(1, dtype=torch.int64, device=device)
+        self.err = torch.zeros(1, dtype=torch.int64, device=device)
+        t = float(os.environ.get('HRF_P2P_TIMEOUT_S', '20')) if timeout_s is None else float(timeout_s)
+        c = _lib.P2p()
+        c.world, c.rank = self.world, self.rank
+        for p in range(self.world):
+            c.inbox[p] = self.peers[p]
+            c.flags[p] = self.peers[p] + self.data_bytes
+        c.slot_doubles, c.nslots = self.slot_doubles, self.nslots
+        c.gen, c.err = self.gen.data_ptr(), self.err.data_ptr()
+        c.timeout_ticks = int(t * 1e8)
+        self.ctx = c
+        self.exchanges = 0
+        if need_ipc:
+            import torch.distributed as dist
+            dist.barrier(group=group)                 # nobody pushes into an inbox that is not mapped everywhere yet
+
+    def handshake(self, rounds=6, timeout_s=5.0):
+        """A few verified test exchanges on the reserved slot (both parities, a short time-out): every rank contributes
+        (rank + 1) * generation per moment copy and must read back the sum over the ranks.  Raises on a time-out or a wrong
+        value - before the first real exchange depends on the mapping."""
+        keep = self.ctx.timeout_ticks
+        self.ctx.timeout_ticks = int(timeout_s * 1e8)
+        try:
+            stream = _lib.stream_ptr()
+            K = _lib.STAT_COPIES
+            src = torch.zeros(K * 2, dtype=torch.float64, device=self.device)
+            out = torch.zeros(3, dtype=torch.float64, device=self.device)
+            n = 1
+            for _ in range(rounds):
+                self.tick(stream)
+                g = int(self.gen.item())
+                src.fill_(float((self.rank + 1) * g))
+                self.lib.hrf_p2p_exchange(self.ctx, (ctypes.c_void_p * n)(src.data_ptr()), (ctypes.c_int * n)(1), n,
+                                          (ctypes.c_double * n)(float(self.rank + 7)), (ctypes.c_long * n)(self.test_slot[0]),
+                                          (ctypes.c_int * n)(self.test_slot[1]), out, 0, stream)
+                got = out.cpu().tolist()
+                self.check()
+                tri = self.world * (self.world + 1) // 2
+                want = [float(K * g * tri)] * 2 + [float(7 * self.world + tri - self.world)]
+                if got != want:
+                    raise _lib.HRFuserHipError(f'peer-to-peer SyncBN exchange: handshake generation {g} read {got}, expected {want}')
+        finally:
+            self.ctx.timeout_ticks = keep
+
+    def tick(self, stream):
+        """Once per training step, before the first exchange (a launch: part of a captured step)."""
+        self.lib.hrf_p2p_tick(self.gen, stream)
+
+    def exchange(self, sts, backward, rows, packed, stream):
+        """One launch: fold + push + wait + reduce for the BatchNorm states `sts` (forward moments or backward sums)."""
+        n = len(sts)
+        k = 1 if backward else 0
+        ptrs = (ctypes.c_void_p * n)(*[(st.gstats if backward else st.stats).data_ptr() for st in sts])
+        cs = (ctypes.c_int * n)(*[st.C for st in sts])
+        rw = (ctypes.c_double * n)(*[float(st.raw.numel() // st.C) for st in sts]) if rows else None
+        so = (ctypes.c_long * n)(*[self.slots[id(st.bn)][k][0] for st in sts])
+        si = (ctypes.c_int * n)(*[self.slots[id(st.bn)][k][1] for st in sts])
+        self.lib.hrf_p2p_exchange(self.ctx, ptrs, cs, n, rw, so, si, packed, 0, stream)
+        self.exchanges += 1
+
+    def check(self):
+        """Raise if an exchange timed out (reads one word from the device: call at a point that synchronises anyway)."""
+        e = int(self.err.item())
+        if e:
+            src, slot = (e >> 32) - 1, (e & 0xffffffff) - 1
+            raise _lib.HRFuserHipError(
+                f'peer-to-peer SyncBN exchange timed out on rank {self.rank}: rank {src} never delivered slot {slot} '
+                f'(BatchNorm {slot // 2}, {"backward" if slot & 1 else "forward"}) of generation {int(self.gen.item())} - a peer '
+                'died, runs a different model / schedule, or HRF_SYNC_P2P differs between the ranks')
+
+    def close(self):
+        for q in self.opened:
+            try:
+                self.lib.hrf_p2p_close(q)
+            except Exception:
+                pass
+        self.opened = []
+        if self.base:
+            try:
+                self.lib.hrf_p2p_free(self.base)
+            except Exception:
+                pass
+            self.base = None

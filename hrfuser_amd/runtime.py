@@ -43,8 +43,9 @@ _LANE_COMMS = os.environ.get('HRF_SYNC_LANE_COMMS', '0') == '1'
 
 
 def _p2p_mode_id():
-    """0: collectives through the communicator; 1: the peer-to-peer SyncBN exchange (HRF_SYNC_P2P=1)."""
-    return 1 if os.environ.get('HRF_SYNC_P2P', '0') == '1' else 0
+    """The rank's HRF_SYNC_P2P setting (hrfuser_amd/p2p.py): 0 off (collectives through the communicator), 1 on, 2 auto."""
+    from . import p2p
+    return {'off': 0, 'on': 1, 'auto': 2}[p2p.mode()]
 
 
 def set_lane_comms(on):
@@ -73,7 +74,7 @@ def check_sync_schedule(group, world):
     """Called when SyncBN is switched on (EngineOwner.set_sync_group): the batched exchange schedule needs `greenlet`
     (a missing module used to degrade silently to one collective per BatchNorm), and every rank must run the same
     schedule - the fingerprint is all-reduced (MIN and MAX) and a disagreement raises before the first exchange."""
-    if _greenlet is None and os.environ.get('HRF_SYNC_BATCH', '1') != '0' and not _LANE_COMMS:
+    if _greenlet is None and os.environ.get('HRF_SYNC_BATCH', '1') != '0' and not _LANE_COMMS and _p2p_mode_id() != 1:
         raise _lib.HRFuserHipError(
             'SyncBN: the batched exchange schedule needs the `greenlet` module, which is not importable here.  Install it, '
             'or set HRF_SYNC_BATCH=0 on EVERY rank to run one collective per BatchNorm (about 3x the collectives).')
@@ -353,12 +354,17 @@ class Ctx:
         self.n_collectives = 0
         self.xhist = {}                 # (lanes in an exchange, hub is the main lane) -> count
         self.coll = self.group is not None and (self.world > 1 or force_collectives())
+        # peer-to-peer SyncBN exchange (HRF_SYNC_P2P=1, hrfuser_amd/p2p.py): no communicator, hence no order to keep between the
+        # lanes - every BatchNorm exchanges on its own lane, at once, with ONE launch
+        self.p2p = owner._engine().p2p_context(self.group, self.world) if self.coll else None
+        self.n_p2p = 0
         self.pending = []               # forward BatchNorm exchanges parked by the strands (SyncBN)
         self.bpending = []              # backward ones: (BNState, lane)
         # lock-step strands need coroutines; HRF_LOCKSTEP=0 (or no greenlet) runs the bodies one after the other: no merged
         # launches, and one SyncBN collective per BatchNorm
         glet = _greenlet if os.environ.get('HRF_LOCKSTEP', '1') != '0' else None
-        self.sync_batch = self.coll and glet is not None and os.environ.get('HRF_SYNC_BATCH', '1') != '0' and not _LANE_COMMS
+        self.sync_batch = self.coll and glet is not None and os.environ.get('HRF_SYNC_BATCH', '1') != '0' and not _LANE_COMMS \
+            and self.p2p is None
         # multi-problem launches need a library compiled for them (hrf_group_count(3) = problems per launch; the shipped
         # build has 1: merged launches measured slower than a stream per sensor on MI355X)
         self.merge = glet is not None and os.environ.get('HRF_GROUP', '1') != '0' and hasattr(self.lib, 'hrf_group_begin') \
@@ -392,6 +398,8 @@ class Ctx:
         """What this pass actually did (bench.py `config.sync_schedule`): not the environment's wish."""
         if not self.coll:
             return None
+        if self.p2p is not None:
+            return 'peer-to-peer exchange (IPC inbox per rank, one launch per BatchNorm on its own lane; HRF_SYNC_P2P=1)'
         if _LANE_COMMS:
             return 'one communicator per lane, unbatched exchanges (HRF_SYNC_LANE_COMMS=1)'
         if self.sync_batch:
@@ -557,7 +565,7 @@ class Ctx:
 
     def sync_wait_bwd(self, st, lane):
         """Backward counterpart: the exchange of (sum du, sum du*y) of `st`, needed by the tape entry about to run."""
-        if _LANE_COMMS:                                  # exchanged at once on the entry's own lane / communicator
+        if _LANE_COMMS or self.p2p is not None:          # exchanged at once on the entry's own lane (communicator / inbox)
             self.flush_bwd([st], [lane])
             return
         self.bpending.append((st, lane))
@@ -582,7 +590,7 @@ class Ctx:
         forks do."""
         lanes = [l for l in dict.fromkeys(lanes) if l.stream is not None or l is self.main]
         hub = self.main
-        if (_XHUB or _LANE_COMMS) and self.multi and len(lanes) == 1:
+        if (_XHUB or _LANE_COMMS or self.p2p is not None) and self.multi and len(lanes) == 1:
             hub = lanes[0]
         others = [l for l in lanes if l is not hub and l.stream is not None]
         if self.multi:
@@ -594,13 +602,19 @@ class Ctx:
             # behind the sums: this rank's sample count of every layer - the same all-reduce yields the GLOBAL counts, so
             # ranks with unequal batches normalise like torch.nn.SyncBatchNorm (which all-gathers the counts)
             packed = _keep(torch.empty(total + (n if rows else 0), device=sts[0].raw.device, dtype=torch.float64))
-            ptrs = (ctypes.c_void_p * n)(*pack_ptrs)
-            cs = (ctypes.c_int * n)(*[st.C for st in sts])
-            rw = (ctypes.c_double * n)(*[float(st.raw.numel() // st.C) for st in sts]) if rows else None
-            self.lib.hrf_bn_pack(ptrs, cs, n, rw, packed, self.stream)
-            self._xlane = hub
-            finalize(packed)
-            self._xlane = None
+            if self.p2p is not None:
+                # fold + push to every peer's inbox + wait + reduce in rank order: one launch, no collective
+                self.p2p.exchange(sts, not rows, rows, packed, self.stream)
+                self.n_p2p += 1
+                finalize(packed, True)
+            else:
+                ptrs = (ctypes.c_void_p * n)(*pack_ptrs)
+                cs = (ctypes.c_int * n)(*[st.C for st in sts])
+                rw = (ctypes.c_double * n)(*[float(st.raw.numel() // st.C) for st in sts]) if rows else None
+                self.lib.hrf_bn_pack(ptrs, cs, n, rw, packed, self.stream)
+                self._xlane = hub
+                finalize(packed, False)
+                self._xlane = None
         if self.multi:
             for l in others:
                 l.stream.wait_stream(hub.stream)
@@ -616,8 +630,9 @@ class Ctx:
         box = []
         home, hstrand = self.cur, self.strand
 
-        def fin(packed):
-            self.all_reduce(packed)
+        def fin(packed, exchanged):
+            if not exchanged:
+                self.all_reduce(packed)
             box.append(packed)
         self._exchange(sts, [st.lane for st in sts], [P(st.stats) for st in sts], fin, rows=True)
         off = 0
@@ -640,10 +655,11 @@ class Ctx:
         box = []
         home, hstrand = self.cur, self.strand
 
-        def fin(packed):
+        def fin(packed, exchanged):
             # no rank-local copy: dgamma / dbeta come from the all-reduced sums, scaled by 1/world (hrf_bn_bfin_t.pgrad_scale);
             # the gradient all-reduce that follows restores the sum over ranks
-            self.all_reduce(packed)
+            if not exchanged:
+                self.all_reduce(packed)
             box.append((packed, None))
         self._exchange(sts, lanes, [P(st.gstats) for st in sts], fin)
         off = 0

@@ -90,6 +90,7 @@ class Trainer:
             o.grad = R.gpu_clone(c)         # synthetic loss  L = sum_i <out_i, cot_i>   
         ctx.run_backward()
         ncoll = ctx.n_collectives
+        self.p2p_exchanges_per_step = ctx.n_p2p
         if self.world > 1 or self.force:
             import torch.distributed as dist
             for a, b in self.buckets(eng.flat_g.numel()):
@@ -142,6 +143,14 @@ class Trainer:
 
     def replay(self):
         self.graph.replay()
+
+    def check(self):
+        """Raise if a peer-to-peer SyncBN exchange timed out (synchronises: call where the caller synchronises anyway - the
+        end of a timed loop, an evaluation interval)."""
+        px = self.net._engine().__dict__.get('_p2p')
+        if px is not None:
+            torch.cuda.synchronize()
+            px[2].check()
 
 
 def make_cotangents(net, x, mods, seed=5):

@@ -238,6 +238,37 @@ int hrf_bn_pack(const double* const* stats, const int* C, int n, const double* r
 int hrf_bn_finalize_packed(const hrf_bn_fin_t* fins, int n, const double* packed, void* stream);
 int hrf_bn_bwd_finalize_packed(const hrf_bn_bfin_t* bfins, int n, const double* packed, const double* packed_local /* nullable: see pgrad_scale */, void* stream);
 
+/* ---- peer-to-peer SyncBN exchange over xGMI (csrc/p2p_exchange.hip): what torch.nn.SyncBatchNorm's all-gather / all-reduce
+ * of the per-layer moments does in the reference (norm_cfg type SyncBN, configs/_base_/models/cascade_rcnn_hrfuser_fpn_nus_clr_
+ * fusion.py:2), without a communicator: every rank exposes an INBOX (fine-grained device memory, mapped by its peers through
+ * IPC handles) of `world` source regions x 2 generation parities x slot_doubles doubles plus world x 2 x nslots flags; every
+ * BatchNorm layer and direction owns a static slot (slot_off doubles into a region, flag index slot_id; 2*C + 1 doubles).
+ * hrf_p2p_exchange = ONE launch on the lane that needs the result: fold this rank's replicated moments of n layers (the job of
+ * hrf_bn_pack; rows as there), store them into the slot of every PEER's inbox, release flag = *gen at system scope, spin until
+ * all peers show *gen (time-out: *err = ((source+1) << 32) | (slot_id+1), the launch completes with garbage and the
+ * host raises), add the contributions in rank order into `packed` (layout of hrf_bn_pack: sums back to back, then n counts).
+ * phase: 0 / 3 = all of it (the product); 1 = fold + push only, 2 = wait + reduce only (single-thread emulator tests).
+ * hrf_p2p_tick: *gen += 1, once per training step before the first exchange (inside the captured graph).
+ * hrf_p2p_alloc / open / close / free: inbox memory and its 64-byte IPC handle (hipExtMallocWithFlags fine-grained,
+ * hipIpcGetMemHandle / hipIpcOpenMemHandle).  inbox[p] / flags[p]: rank p's data / flag area AS MAPPED INTO THIS PROCESS.     */
+#define HRF_P2P_MAX_RANKS 8
+typedef struct hrf_p2p {
+  int world, rank;
+  double* inbox[HRF_P2P_MAX_RANKS];
+  long* flags[HRF_P2P_MAX_RANKS];
+  long slot_doubles, nslots;
+  const long* gen;
+  long* err;
+  long timeout_ticks;            /* 100 MHz ticks; <= 0: wait for ever */
+} hrf_p2p_t;
+int hrf_p2p_exchange(const hrf_p2p_t* ctx, const double* const* stats, const int* C, int n, const double* rows,
+                     const long* slot_off, const int* slot_id, double* packed, int phase, void* stream);
+int hrf_p2p_tick(long* gen, void* stream);
+int hrf_p2p_alloc(long bytes, void** ptr, void* handle64);
+int hrf_p2p_open(const void* handle64, void** ptr);
+int hrf_p2p_close(void* ptr);
+int hrf_p2p_free(void* ptr);
+
 /* ---- GroupNorm (norm_cfg = dict(type='GN', num_groups=G): build_norm_layer at hrnet.py:338-339,438,459,476,
  * resnet.py:34-35,161-164, hrformer.py:269,278,281,518,542,552 -> nn.GroupNorm / F.group_norm).  Per-(sample, group)
  * statistics, no exchange between samples or ranks.  Three launches per direction:

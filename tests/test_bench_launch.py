@@ -58,8 +58,14 @@ def test_two_ranks_share_one_gpu_gloo():
     assert len(lines) == 1, p.stdout[-1000:]
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['config']['global_batch'] == 4 and line['finite'] is True
-    assert line['config']['collectives_per_step'] > 4 and 'packed exchanges' in line['config']['sync_schedule']
+    # HRF_SYNC_P2P unset = auto: two ranks -> the peer-to-peer exchange after its handshake (the ranks share a GPU: IPC works)
+    assert line['config']['collectives_per_step'] >= 1 and 'peer-to-peer' in line['config']['sync_schedule']
+    assert line['config']['p2p_exchanges_per_step'] > 100
     ab = line['sync_ab']
     assert 'error' not in ab, ab
     assert ab['grad_rel_l2_vs_main_lane'] < 1e-6 and ab['ms_per_step'] > 0
+    px = ab['p2p']                                       # third arm: the peer-to-peer exchange (IPC inboxes, no communicator)
+    assert 'error' not in px, px
+    assert px['grad_rel_l2_vs_main_lane'] < 1e-6 and px['p2p_exchanges_per_step'] > 100 and px['ms_per_step'] > 0
+    assert px['main_lane_ms_per_step'] > 0 and px['main_lane_collectives_per_step'] > 4
     print(json.dumps({k: line[k] for k in ('value', 'ms_per_step', 'sync_ab')}))
