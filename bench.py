@@ -90,11 +90,16 @@ def cpu_baseline(tag, B, H, W, mc, iters=3):
         ys = orc(x, [m.clone() for m in mods])
         sum(y.mean() for y in ys).backward()
 
+    def eval_fwd():
+        with torch.no_grad():
+            orc(x, [m.clone() for m in mods])
+
     phys = max(1, (os.cpu_count() or 2) // 2)
-    runs = []
+    runs, eruns = [], []
     prev = torch.get_num_threads()
     for n in sorted({min(8, phys), phys}):
         torch.set_num_threads(n)
+        orc.train()
         step()                                                        # warm-up (primitive creation)
         ts = []
         for _ in range(iters):
@@ -104,13 +109,27 @@ def cpu_baseline(tag, B, H, W, mc, iters=3):
         ts.sort()
         med = ts[len(ts) // 2]
         runs.append({'value': round(B / med, 4), 'cores': n, 'ms_per_step': round(med * 1e3, 1)})
+        # eval forward (BN running statistics) beside the GPU path's fwd_ms_per_img: BASELINE.md section 3 (2 warm-ups, 5 timed, median)
+        orc.eval()
+        eval_fwd()
+        eval_fwd()
+        es = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            eval_fwd()
+            es.append(time.perf_counter() - t0)
+        es.sort()
+        eruns.append({'cores': n, 'fwd_ms_per_img': round(es[len(es) // 2] / B * 1e3, 1)})
     torch.set_num_threads(prev)
     best = max(runs, key=lambda r: r['value'])
+    ebest = min(eruns, key=lambda r: r['fwd_ms_per_img'])
     return {'value': best['value'], 'unit': 'images/sec', 'cores': best['cores'], 'kind': 'port',
             'sample': f'median of {iters} timed train fwd+bwd iterations (after 1 warm-up) of the same {B}x3x{H}x{W} + '
                       f'{len(mc)} modality batch, torch CPU fp32, no optimizer step; run at 8 threads and at all '
                       f'{phys} physical cores, the faster one is `value`',
-            'ms_per_step': best['ms_per_step'], 'runs': runs}
+            'ms_per_step': best['ms_per_step'], 'runs': runs,
+            'eval_fwd_ms_per_img': ebest['fwd_ms_per_img'], 'eval_fwd_cores': ebest['cores'], 'eval_fwd_runs': eruns,
+            'eval_fwd_sample': f'median of 5 eval-mode forwards (after 2 warm-ups) of the same {B}-image batch per thread setting'}
 
 
 # --------------------------------------------------------------------------------------------------------------------

@@ -744,6 +744,7 @@ class HRFuserFusionBlock(nn.Module):
 _CAM_LANES = int(os.environ.get('HRF_CAM_LANES', '0') or 0)      # 0: one stream per camera branch (A/B knob)
 _FORK_EXCHANGE = os.environ.get('HRF_FORK_EXCHANGE', '1') != '0'   # exchange chains on sibling lanes (0: serial)
 _BRANCH_ORDER = os.environ.get('HRF_BRANCH_ORDER', '')
+_ONE_FORK = os.environ.get('HRF_MODULE_ONE_FORK', '1') != '0'      # one fork / join per HRFomerModule (0: the round-3 structure)
 
 
 class HRFomerModule(nn.Module):
@@ -815,6 +816,7 @@ class HRFomerModule(nn.Module):
             lanes = ctx.fork(nb, keep_first=ctx.keep_first)
 
         def branch(i):
+            xs[i] = R.force(ctx, xs[i])                   # the previous module's exchange sum for this branch, on this lane
             blocks = list(self.branches[i])
             for b, blk in enumerate(blocks):
                 last = b == len(blocks) - 1
@@ -822,20 +824,12 @@ class HRFomerModule(nn.Module):
                     xs[i] = blk.run(ctx, xs[i], defer=(not last) or (nb == 1 and defer_out))
                 else:
                     xs[i] = blk.run(ctx, R.force(ctx, xs[i]))
-        order = list(range(nb))
-        if _BRANCH_ORDER == 'rev':
-            order.reverse()                              # (experiment: which lane of a fork starts late - the last one, or the coarse one?)
-        ctx.parallel([lanes[i] for i in order], [lambda i=i: branch(i) for i in order])
-        ctx.join(lanes)
-        if nb == 1:
-            return [xs[0]]
-        # exchange: one lane per SOURCE branch j computes every conv chain that reads xs[j], so the
-        # backward of a lane accumulates into xs[j].grad only (no cross-lane gradient races)
-        nrows = len(self.fuse_layers)
+        nrows = len(self.fuse_layers) if nb > 1 else 0
         terms = [[None] * nb for _ in range(nrows)]
-        lanes = ctx.fork(nb, keep_first=ctx.keep_first) if _FORK_EXCHANGE else [ctx.cur] * nb
 
         def source(j):
+            # every conv chain that reads xs[j] (the backward of this lane accumulates into xs[j].grad only: no cross-lane
+            # gradient races)
             for i, row in enumerate(self.fuse_layers):
                 if j == i:
                     terms[i][j] = ('id', xs[j])
@@ -847,6 +841,25 @@ class HRFomerModule(nn.Module):
                         cur = R.dwconv_bn(ctx, cur, step[0], step[1], R.TF_AFFINE)
                         cur = R.conv_bn(ctx, cur, step[2], step[3], R.TF_RELU if len(step) == 5 else R.TF_AFFINE)
                     terms[i][j] = ('same', cur)
+        order = list(range(nb))
+        if _BRANCH_ORDER == 'rev':
+            order.reverse()                              # (experiment: which lane of a fork starts late - the last one, or the coarse one?)
+        if _ONE_FORK and nb > 1:
+            # ONE fork / join per module: lane j = [pending exchange sum of branch j] -> its blocks -> the exchange chains that
+            # read branch j.  (Rounds 1-3: branches | join | fork | exchange chains | join | all fuse_sums on the main lane:
+            # ~25 us of cross-queue latency and 70-90 us of serial fuse_sum launches per module and direction.)
+            def lane_body(i):
+                branch(i)
+                source(i)
+            ctx.parallel([lanes[i] for i in order], [lambda i=i: lane_body(i) for i in order])
+            ctx.join(lanes)
+            return [R.LazyFuse(tuple(xs[i].t.shape), terms[i]) for i in range(nrows)]
+        ctx.parallel([lanes[i] for i in order], [lambda i=i: branch(i) for i in order])
+        ctx.join(lanes)
+        if nb == 1:
+            return [xs[0]]
+        # exchange on sibling lanes of its own (HRF_MODULE_ONE_FORK=0), the sums on the main lane
+        lanes = ctx.fork(nb, keep_first=ctx.keep_first) if _FORK_EXCHANGE else [ctx.cur] * nb
         ctx.parallel(lanes, [lambda j=j: source(j) for j in range(nb)])
         ctx.join(lanes)
         return [R.fuse_sum(ctx, tuple(xs[i].t.shape), terms[i]) for i in range(nrows)]
@@ -1100,13 +1113,14 @@ class HipModule(nn.Module, EngineOwner):
         if ls is not None:
             ls.reset()
             ls.nfork = 0
+            ls.lane_fork = {}
         with torch.no_grad():
             srcs = self._wrap_inputs(inputs)
             if needs is not None:                       # static graph inputs: the flags of the caller's tensors
                 for src, n in zip(srcs, needs):
                     src.needs_grad = bool(n)
             ctx.mark('start')
-            outs = self._run(ctx, srcs)
+            outs = R.force_all(ctx, self._run(ctx, srcs))       # (a sub-module harness may hand back pending exchange sums)
             if ctx.probe is not None:
                 self.__dict__['_relu_masks'] = R.collect_relu_masks(ctx)
         return ctx, outs, srcs
@@ -1546,7 +1560,7 @@ class HRFuserHRFormerBased(HipModule):
                 xs = mod.run(ctx, xs, defer_out=True)       # single-branch stage (LidarStageB / C): the chain continues
             else:
                 xs = mod.run(ctx, xs)
-        return xs
+        return R.force_all(ctx, xs)                     # the last module's exchange sums (pending: LazyFuse), on sibling lanes
 
     def _run(self, ctx, srcs):
         M = self.num_fused_modalities
@@ -1620,7 +1634,8 @@ class HRFuserHRFormerBased(HipModule):
         stages are enqueued on their own lanes first; the camera stage then runs from the main lane,
         each of its modules forking branch lanes from main (flat, never nested)."""
         M = self.num_fused_modalities
-        lanes = ctx.bundle_lanes(M, 'stages', cap=ctx.mod_lanes)
+        cap = (max(1, 4 - len(xs)) if M <= 2 else 0) if ctx.mod_lanes == 'auto' else int(ctx.mod_lanes or 0)
+        lanes = ctx.bundle_lanes(M, 'stages', cap=cap)
         mods = [None] * M
         ys = [None]
 

@@ -230,198 +230,6 @@ __global__ __launch_bounds__(64 * NWV) void conv3_kernel(HrfGroup<Conv3Args> grp
 
 inline int conv3_nt(int C) { return C <= 32 ? 2 : 4; }
 
-// ---------------------------------------------------------------------------------------------------- stride-2 forward
-// 3x3 / stride-2 / pad-1 FORWARD on the halo scheme (round 4; the transitions 256->36, 36->72, 72->144, the modality
-// transitions from 18 channels and the stems' 64->64: hrnet.py:436-460, hrfuser_hrformer_based.py:375-412 - they ran on the
-// generic implicit-GEMM kernel, 115 us for 256->36 at 96x160 = 0.07 of the MFMA peak).  One block = RW output rows x 16 output
-// columns x up to 64 output channels; wave w owns output row w (one 16-pixel MFMA row tile).  The (2 RW + 1) x 33 input halo
-// of a 32-channel slab is staged once (BatchNorm / activation once per element); pixel pitch 33 floats makes the stride-2
-// fragment reads conflict-free (bank = 2 i + q).  K order inside a slab: tap row dy (one barrier interval = the three taps of
-// a row x 32 channels = 24 k-steps), weights through a 2-slot LDS ring, the next slab's halo and the next step's weights are
-// in flight in registers while the MFMAs of the current step issue.
-constexpr int S2_CS = 32, S2_CP = 33, S2_BP = 34, S2_IW = 2 * TW + 1;
-
-template <int NT, int RW>
-__global__ __launch_bounds__(64 * RW) void conv3s2_fwd_kernel(HrfGroup<Conv3Args> grp) {
-  const Conv3Args& a = grp.sel();
-  constexpr int NTH = 64 * RW, IHs = 2 * RW + 1, NPX = IHs * S2_IW, PG = NTH / 32, NHLs = (NPX + PG - 1) / PG;
-  constexpr int WROWS = (NT * 16 + PG - 1) / PG;                   // weight rows per thread and tap
-  HRF_DYN_SMEM(float, smem);
-  float* sIn = smem;                                               // [NPX][S2_CP]
-  float* sB = smem + NPX * S2_CP;                                  // [2 slots][3 taps][NT * 16][S2_BP]
-  __shared__ float sStat[RW * 2 * NT * 16];
-  __shared__ __attribute__((aligned(16))) float sFin[2 * HRF_FIN_MAXC];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  int t = blockIdx.x;
-  const int tx = t % a.tilesX; t /= a.tilesX;
-  const int ty = t % a.tilesY; const int b = t / a.tilesY;
-  const int y0 = ty * RW, x0 = tx * TW;                            // output tile origin
-  const int iy0 = 2 * y0 - 1, ix0 = 2 * x0 - 1;                    // input halo origin
-  const int n0 = blockIdx.y * (NT * 16);
-  const float* t0p = a.t0;
-  const float* t1p = a.t1;
-  if (a.fin.stats != nullptr) {
-    hrf_bn_fin_onload(a.fin, sFin, sFin + HRF_FIN_MAXC, tid, NTH, blockIdx.x == 0 && blockIdx.y == 0);
-    __syncthreads();
-    t0p = sFin; t1p = sFin + HRF_FIN_MAXC;
-  }
-  hrf_f4 acc[NT];
-#pragma unroll
-  for (int tt = 0; tt < NT; ++tt) acc[tt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-  const int hc = tid & 31, hg = tid >> 5;                          // halo / weight staging: channel (k) within the slab, group
-  const int nslab = (a.Cin + S2_CS - 1) / S2_CS;
-  float hv[NHLs];
-  auto load_halo = [&](int c0) {
-    const bool cv = c0 + hc < a.Cin;
-#pragma unroll
-    for (int e = 0; e < NHLs; ++e) {
-      const int pix = e * PG + hg;
-      const int py = pix / S2_IW, px = pix - py * S2_IW;
-      const int gy = iy0 + py, gx = ix0 + px;
-      const bool ok = cv && pix < NPX && (unsigned)gy < (unsigned)a.Hs && (unsigned)gx < (unsigned)a.Ws;
-      hv[e] = *(ok ? a.in + ((long)(b * a.Hs + gy) * a.Ws + gx) * a.ldIn + c0 + hc : g_zero1);
-    }
-  };
-  float bw[3][WROWS];
-  auto load_w = [&](int c0, int dy) {
-    const bool kv = c0 + hc < a.Cin;
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-      for (int e = 0; e < WROWS; ++e) {
-        const int j = hg + PG * e;
-        const bool ok = kv && j < NT * 16 && n0 + j < a.Cout;
-        bw[dx][e] = *(ok ? a.w + ((long)(n0 + j) * a.wCin + c0 + hc) * 9 + dy * 3 + dx : g_zero1);
-      }
-  };
-  auto store_w = [&](int slot) {
-    float* dst = sB + slot * (3 * NT * 16 * S2_BP);
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-      for (int e = 0; e < WROWS; ++e) {
-        const int j = hg + PG * e;
-        if (j < NT * 16) dst[(dx * NT * 16 + j) * S2_BP + hc] = bw[dx][e];
-      }
-  };
-  load_halo(0);
-  load_w(0, 0);
-  store_w(0);
-  int g = 0;
-  for (int sl = 0; sl < nslab; ++sl) {
-    const int c0 = sl * S2_CS;
-    const int csz = min(S2_CS, a.Cin - c0);
-    __syncthreads();                                               // the previous slab's readers are done
-    {
-      // raw values first (fully unrolled: the prefetched registers), then the transform as a ROLLED in-place pass over the
-      // thread's own elements (one copy of the BatchNorm / GELU code instead of 36; out-of-image pixels stay zero)
-      const bool cv = hc < csz;
-#pragma unroll
-      for (int e = 0; e < NHLs; ++e) {
-        const int pix = e * PG + hg;
-        if (pix < NPX) sIn[pix * S2_CP + hc] = hv[e];
-      }
-      if (a.tf_mode != HRF_TF_NONE) {
-        const float p0 = t0p[cv ? c0 + hc : 0], p1 = t1p[cv ? c0 + hc : 0];
-#pragma unroll 1
-        for (int e = 0; e < NHLs; ++e) {
-          const int pix = e * PG + hg;
-          const int py = pix / S2_IW, px = pix - py * S2_IW;
-          const int gy = iy0 + py, gx = ix0 + px;
-          const bool ok = cv && pix < NPX && (unsigned)gy < (unsigned)a.Hs && (unsigned)gx < (unsigned)a.Ws;
-          const int li = min(pix, NPX - 1) * S2_CP + hc;
-          const float v = hrf_tf_affine(a.tf_mode, sIn[li], p0, p1);
-          if (pix < NPX) sIn[li] = ok ? v : 0.f;
-        }
-      }
-    }
-    __syncthreads();
-    if (sl + 1 < nslab) load_halo(c0 + S2_CS);
-    const int nkk = (csz + 3) >> 2;
-#pragma unroll 1
-    for (int dy = 0; dy < 3; ++dy) {
-      const bool more = !(sl == nslab - 1 && dy == 2);
-      if (more) load_w(dy < 2 ? c0 : c0 + S2_CS, dy < 2 ? dy + 1 : 0);
-      const float* bs = sB + (g & 1) * (3 * NT * 16 * S2_BP) + i * S2_BP + q;
-      const float* as = sIn + ((2 * wave + dy) * S2_IW + 2 * i) * S2_CP + q;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const float* ap = as + dx * S2_CP;
-        const float* bp = bs + dx * (NT * 16 * S2_BP);
-#pragma unroll 4
-        for (int kk = 0; kk < nkk; ++kk) {
-          const float a0 = ap[kk * 4];
-#pragma unroll
-          for (int tt = 0; tt < NT; ++tt) acc[tt] = hrf_mfma16(a0, bp[tt * 16 * S2_BP + kk * 4], acc[tt]);
-        }
-      }
-      if (more) store_w((g + 1) & 1);
-      ++g;
-      if (dy < 2) __syncthreads();
-    }
-  }
-
-  // ---- epilogue: D[row = pixel 4q + r][col = channel i]: bias, store, (sum, sumsq) moments
-  const int xq = x0 + 4 * q, y = y0 + wave;
-  float s1[NT], s2[NT];
-#pragma unroll
-  for (int tt = 0; tt < NT; ++tt) {
-    s1[tt] = 0.f; s2[tt] = 0.f;
-    const int ch = n0 + tt * 16 + i;
-    const bool chv = ch < a.Cout;
-    const float bv = (a.bias != nullptr && chv) ? a.bias[ch] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int x = xq + r;
-      const bool ok = chv && y < a.H && x < a.W;
-      const long prow = (long)(b * a.H + y) * a.W + x;
-      float v = acc[tt][r] + bv;
-      if (a.res != nullptr) v += *(ok ? a.res + prow * a.ldR + ch : g_zero1);
-      if (a.res2 != nullptr) v += *(ok ? a.res2 + prow * a.ldR + ch : g_zero1);
-      if (ok) { a.out[prow * a.ldOut + a.ooff + ch] = v; s1[tt] += v; s2[tt] = fmaf(v, v, s2[tt]); }
-    }
-  }
-  if (a.stats != nullptr) {                                        // (uniform)
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-      float u1 = s1[tt], u2 = s2[tt];
-      u1 += __shfl_xor(u1, 16); u1 += __shfl_xor(u1, 32);
-      u2 += __shfl_xor(u2, 16); u2 += __shfl_xor(u2, 32);
-      if (lane < 16) { sStat[(wave * 2 + 0) * (NT * 16) + tt * 16 + lane] = u1; sStat[(wave * 2 + 1) * (NT * 16) + tt * 16 + lane] = u2; }
-    }
-    __syncthreads();
-    double* st = a.stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.Cout;
-    for (int e = tid; e < 2 * NT * 16; e += NTH) {
-      const int which = e / (NT * 16), cidx = e - which * (NT * 16);
-      const int ch = n0 + cidx;
-      if (ch < a.Cout) {
-        float sm = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < RW; ++wv) sm += sStat[(wv * 2 + which) * (NT * 16) + cidx];
-        hrf_atomic_add(&st[which * a.Cout + ch], (double)sm);
-      }
-    }
-  }
-}
-
-template <int NT, int RW>
-static int conv3s2_fwd_launch_t(Conv3Args a, void* stream) {
-  a.tilesX = hrf_cdiv(a.W, TW); a.tilesY = hrf_cdiv(a.H, RW);
-  constexpr size_t smem = ((size_t)(2 * RW + 1) * S2_IW * S2_CP + 2 * 3 * NT * 16 * S2_BP) * sizeof(float);
-#ifndef HRF_EMUL
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s2_fwd_kernel<NT, RW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess) return HRF_ERR_LAUNCH;
-    once = true;
-  }
-#endif
-  const dim3 grid(a.tilesX * a.tilesY * a.B, hrf_cdiv(a.Cout, NT * 16));
-  HRF_LAUNCH_G((conv3s2_fwd_kernel<NT, RW>), grid, dim3(64 * RW), (unsigned)smem, stream, a);
-  return hrf_check_launch();
-}
-
 }  // namespace
 
 template <int MODE, int KH>
@@ -439,12 +247,3 @@ int hrf_conv3_fwd_launch(const Conv3Args& a, void* stream) { return conv3_launch
 int hrf_conv3_bwd_data_launch(const Conv3Args& a, void* stream) { return conv3_launch<1, 3>(a, stream); }
 int hrf_conv3s2_bwd_data_launch(const Conv3Args& a, void* stream) { return conv3_launch<2, 3>(a, stream); }
 
-// a.H / a.W: OUTPUT grid, a.Hs / a.Ws: input grid.  Rows per block: 8, or 4 when the 8-row tiling would leave most CUs idle.
-int hrf_conv3s2_fwd_launch(const Conv3Args& a, int rows, void* stream) {
-  if (a.B <= 0 || a.H <= 0 || a.W <= 0) return HRF_OK;
-  const int nt = conv3_nt(a.Cout);
-  const long blocks8 = (long)hrf_cdiv(a.W, TW) * hrf_cdiv(a.H, 8) * a.B * hrf_cdiv(a.Cout, nt * 16);
-  const bool small = rows == 4 || (rows != 8 && blocks8 < 160);       // rows: 0 = choose, 4 / 8 = forced (tests)
-  if (nt == 2) return small ? conv3s2_fwd_launch_t<2, 4>(a, stream) : conv3s2_fwd_launch_t<2, 8>(a, stream);
-  return small ? conv3s2_fwd_launch_t<4, 4>(a, stream) : conv3s2_fwd_launch_t<4, 8>(a, stream);
-}

@@ -38,7 +38,7 @@ constexpr int BK = 64;      // K elements staged per step (16 MFMA k-substeps)
 constexpr int LDK = 65;     // LDS pitch of the [row][k] tiles: bank = (row + k) % 32
 constexpr float SENT = -1.0e30f;   // staged pre-activation of a zero-padded tap: relu/gelu(SENT) == 0
 
-static int g_knob[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 __device__ __forceinline__ float act_at_read(int tf, float u) {
   return tf == HRF_TF_AFFINE_RELU ? fmaxf(u, 0.f) : (tf == HRF_TF_AFFINE_GELU ? hrf_gelu(u) : u);
@@ -870,17 +870,6 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     if (rc3 == HRF_OK && ln_rowstat != nullptr) return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream);
     return rc3;
   }
-  if (KH == 3 && stride == 2 && Cin >= 16 && sC == 1 && sY == W * sX && sB == H * sY && g_knob[6] == 0) {
-    // stride-2 forward on the halo scheme (transitions, the stems' second convolution)
-    Conv3Args c{};
-    c.in = x; c.ldIn = sX; c.t0 = tf_scale; c.t1 = tf_shift; c.tf_mode = tf_mode; c.w = w; c.wCin = Cin; c.bias = bias;
-    c.out = y; c.ldOut = ldY; c.ooff = yoff; c.res = res; c.res2 = res2; c.ldR = ldR; c.stats = stats;
-    c.B = B; c.H = a.Ho; c.W = a.Wo; c.Hs = H; c.Ws = W; c.Cin = Cin; c.Cout = Cout;
-    c.fin = a.fin;
-    const int rc3 = hrf_conv3s2_fwd_launch(c, g_knob[8] == 4 || g_knob[8] == 8 ? g_knob[8] : 0, stream);   // (debug knob 8 = 4 / 8: rows per block)
-    if (rc3 == HRF_OK && ln_rowstat != nullptr) return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream);
-    return rc3;
-  }
   const int nt = pick_nt(Cout);
   if (KH == 1) {
     if (tf_mode == HRF_TF_LN) { HRF_CF_NT(1, HRF_TF_LN) } else { HRF_CF_TF(1) }
@@ -965,7 +954,7 @@ extern "C" int hrf_debug_knob(int key, int value) {
   if (key >= 28 && key < 32) return hrf_lin2_knob(key - 28, value);    // lin2_engine.hip: 28 = 1 force / 2 disable the LDS-tiled row GEMM
   if (key >= 16 && key < 20) return hrf_pw_knob(key - 16, value);      // pointwise.hip tuning aids
   if (key >= 24 && key < 28) return hrf_conv3w_knob(key - 24, value);  // conv3w_engine.hip tuning aids
-  if (key < 0 || key >= 12) return HRF_ERR_ARG;
+  if (key < 0 || key >= 8) return HRF_ERR_ARG;
   g_knob[key] = value;
   return HRF_OK;
 }

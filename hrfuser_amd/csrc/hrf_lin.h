@@ -58,4 +58,3 @@ struct Conv3Args {
 int hrf_conv3_fwd_launch(const Conv3Args& a, void* stream);
 int hrf_conv3_bwd_data_launch(const Conv3Args& a, void* stream);
 int hrf_conv3s2_bwd_data_launch(const Conv3Args& a, void* stream);   // stride-2 conv, parity-class blocks
-int hrf_conv3s2_fwd_launch(const Conv3Args& a, int rows, void* stream);        // stride-2 conv forward on the halo scheme (H / W = output grid)

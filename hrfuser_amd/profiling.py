@@ -408,23 +408,20 @@ def _row(key, t, peak_f, peak_b):
             'flops_per_launch': fl / n, 'bytes_per_launch': by / n}
 
 
-def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None):
-    """Roofline entry of the kernel FAMILY with the largest time per step (isolated per-launch durations).  `achieved` =
-    the family's algorithmic bytes (or flops) per launch / its average launch duration; `dominant_shape` = its heaviest
-    single (entry point, shape).  `traffic` = PMC-measured fabric bytes per launch of that shape when
-    <profiles_dir>/r03_hbm_traffic.json (else r02_) holds it (a SEPARATE `rocprofv3 --pmc` run; the source is stated), else null."""
-    key = max(table, key=lambda k: table[k][1])
+def _newest(profiles_dir, suffix):
+    """Newest committed profiles/rNN_<suffix> (by round number) or (None, None)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(profiles_dir or '', 'r[0-9][0-9]_' + suffix)):
+        m = re.match(r'r(\d+)_', os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return (best[1], os.path.basename(best[1])) if best else (None, None)
+
+
+def _family_row(table, key, peak_f, peak_b, traffic, tname):
     row = _row(key, table[key], peak_f, peak_b)
-    row['selection'] = 'kernel family with the largest summed isolated launch time per training step'
-    traffic, tname = {}, None
-    for cand in ('r03_hbm_traffic.json', 'r02_hbm_traffic.json'):          # the newest committed PMC pass
-        tpath = os.path.join(profiles_dir, cand) if profiles_dir else None
-        if tpath and os.path.exists(tpath):
-            import json
-            with open(tpath) as fh:
-                traffic = json.load(fh).get('shapes', {})
-            tname = cand
-            break
     sigs = [r for r in getattr(profile_step, 'last_signatures', []) if r['kernel'] == key]
     if sigs:
         top = sigs[0]
@@ -436,15 +433,59 @@ def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None):
                                  'bytes_per_launch': top['bytes_per_launch'], 'flops_per_launch': top['flops_per_launch'],
                                  'achieved': round(ach, 3), 'unit': 'GB/s' if bound_b else 'TFLOP/s',
                                  'frac': round(ach / ((peak_b / 1e9) if bound_b else (peak_f / 1e12)), 4)}
-        t = traffic.get(top['shape'])
+        t, tkey = traffic.get(top['shape']), top['shape']
+        if t is None:                                   # (the PMC pass keys the fused attention launches by kernel name)
+            t, tkey = traffic.get('kernel:' + key), key
         if t is not None:
             row['traffic'] = t['bytes_per_launch']
-            row['traffic_source'] = (f'profiles/{tname}[{top["shape"]}]: 2 x FETCH_SIZE + WRITE_SIZE of that launch from a '
+            row['traffic_source'] = (f'profiles/{tname}[{tkey}]: 2 x FETCH_SIZE + WRITE_SIZE of that launch (2 x 96 x 160 map) from a '
                                      f'separate rocprofv3 --pmc run (tools/prof_{tname[:3]}.sh); NOT measured in this bench run')
+    return row
+
+
+def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None):
+    """Roofline entry of the DOMINANT kernel family of the training step.  Which family dominates is read from the round's
+    committed step timeline (profiles/rNN_step_timeline.json: the family with the largest summed in-step kernel time of one
+    replayed step under `rocprofv3 --kernel-trace`, grouped launches as the step issues them) so that the bench line and the
+    timeline name the same kernel; its numbers are measured LIVE in this run: `achieved` = the family's
+    algorithmic bytes (or flops) per launch / its average isolated launch duration (HIP events), `dominant_shape` = its
+    heaviest single (entry point, shape).  `isolated_dominant` = the family with the largest summed ISOLATED launch time (the
+    selection of rounds 1-3) with the same fields.  Without a committed timeline the isolated selection is the entry.
+    `traffic` = PMC-measured fabric bytes per launch of the dominant shape when profiles/rNN_hbm_traffic.json holds it (a
+    SEPARATE `rocprofv3 --pmc` run; the source is stated), else null."""
+    import json
+    traffic, tname = {}, None
+    tpath, tname = _newest(profiles_dir, 'hbm_traffic.json')
+    if tpath:
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        traffic = dict(tj.get('shapes', {}))
+        traffic.update({'kernel:' + k: v for k, v in tj.get('kernels', {}).items()})
+    iso_key = max(table, key=lambda k: table[k][1])
+    key, sel = iso_key, 'kernel family with the largest summed isolated launch time per training step (no committed step timeline found)'
+    lpath, lname = _newest(profiles_dir, 'step_timeline.json')
+    if lpath:
+        with open(lpath) as fh:
+            fam = json.load(fh).get('families', {})
+        for name, _ in sorted(fam.items(), key=lambda kv: -kv[1].get('in_step_us', 0.0)):
+            cands = [k for k in table if k == name or k.startswith(name + '<')]
+            if cands:
+                key = max(cands, key=lambda k: table[k][1])
+                sel = (f'family with the largest summed IN-STEP kernel time in profiles/{lname} ({name}: '
+                       f'{fam[name]["in_step_us"] / 1e3:.2f} ms over {fam[name]["launches"]} launches of one replayed step under rocprofv3 '
+                       f'--kernel-trace; instantiation with the largest live isolated time: {key}); durations below are measured '
+                       'live in this run (isolated launches, HIP events)')
+                break
+    row = _family_row(table, key, peak_f, peak_b, traffic, tname)
+    row['selection'] = sel
+    if iso_key != key:
+        iso = _family_row(table, iso_key, peak_f, peak_b, traffic, tname)
+        iso['selection'] = 'kernel family with the largest summed isolated launch time per training step (the selection of rounds 1-3)'
+        row['isolated_dominant'] = iso
     # the next families, for context
-    others = sorted(table.items(), key=lambda kv: -kv[1][1])[1:6]
+    others = sorted(table.items(), key=lambda kv: -kv[1][1])[:7]
     row['next_families'] = [{k2: _row(k, t, peak_f, peak_b)[k2] for k2 in ('kernel', 'bound', 'frac', 'launches_per_step', 'time_per_step_ms')}
-                            for k, t in others]
+                            for k, t in others if k != key][:6]
     return row
 
 

@@ -207,9 +207,43 @@ class LazyTail:
         return materialize(ctx, self.lazy, ACT_GELU, res=self.res, act_first=True, rowscale=self.rowscale)
 
 
+class LazyFuse:
+    """One output branch of an HRModule exchange, ReLU(sum of terms) (hrnet.py:192-206), not launched yet: the module hands
+    it to its consumer, which forces it ON ITS OWN LANE - the next module's branch i starts with the fuse_sum of output i
+    instead of the main lane running all of a module's fuse_sums one after the other between a join and the next fork."""
+    __slots__ = ('dims', 'terms', 'out')
+
+    def __init__(self, dims, terms):
+        self.dims, self.terms, self.out = dims, terms, None
+
+    @property
+    def shape(self):
+        return self.dims
+
+    def force(self, ctx):
+        if self.out is None:
+            self.out = fuse_sum(ctx, self.dims, self.terms)
+            self.terms = None
+        return self.out
+
+
 def force(ctx, x):
-    """-> an Act: materialises a LazyTail, passes everything else through."""
-    return x.force(ctx) if isinstance(x, LazyTail) else x
+    """-> an Act: materialises a LazyTail / launches a pending LazyFuse on the current lane, passes everything else through."""
+    return x.force(ctx) if isinstance(x, (LazyTail, LazyFuse)) else x
+
+
+def force_all(ctx, xs):
+    """Acts for a list of stage outputs; pending exchange sums run on sibling lanes (they are independent of each other)."""
+    pend = [i for i, x in enumerate(xs) if isinstance(x, LazyFuse) and x.out is None]
+    xs = list(xs)
+    if len(pend) > 1:
+        lanes = ctx.fork(len(pend))
+
+        def one(i):
+            xs[i] = force(ctx, xs[i])
+        ctx.parallel(lanes, [lambda i=i: one(i) for i in pend])
+        ctx.join(lanes)
+    return [force(ctx, x) for x in xs]
 
 
 # the CrossFFN tail of a block formed on load by the next block's fused attention launch (HRF_TAIL_ONLOAD=0: materialised)
@@ -380,11 +414,12 @@ class Ctx:
         kf = os.environ.get('HRF_KEEP_FIRST')
         self.keep_first = (self.bundle and 'stages' in self.bundle_what) if kf is None else kf != '0'
         self.cam_first = os.environ.get('HRF_CAM_FIRST', '0') != '0'     # issue the camera stage before the modality stages
-        # the MI355X runtime drives 4 hardware queues; a step with more concurrently active HIP streams aliases two of them
-        # onto one queue, and a queue executes its streams' kernels in order: in stage 3 the camera's 72-channel branch sat
-        # behind a modality stream's six-block chain (rocprofv3 trace, profiles/r03_stage_trace.txt).  mod_lanes = HIP streams
-        # for the M modality stages that run beside a camera stage (0: one each)
-        self.mod_lanes = int(os.environ.get('HRF_MOD_LANES', '0') or 0)
+        # The hipGraph executor of ROCm 7.2 runs a captured graph on 4 streams (DEBUG_HIP_FORCE_GRAPH_QUEUES; its node -> stream
+        # assignment is printed by DEBUG_HIP_GRAPH_DOT_PRINT: first child inherits, siblings round-robin): more than 4 concurrent
+        # chains alias two of them onto one in-order stream.  Beside a camera stage of nb branches there is room for 4 - nb
+        # modality chains: mod_lanes = lanes for the M modality stages ('auto': max(1, 4 - nb) for M <= 2 - HRFuser-T 14.35 ->
+        # 13.84 ms - and one per modality for M = 3, where the serialised STF chains outlast the camera stage; N: forced).
+        self.mod_lanes = os.environ.get('HRF_MOD_LANES', 'auto').strip().lower()
         self._sweeper = None            # greenlet running the sweep (None: not inside parallel())
         self._strands = []              # live strands of the running sweep, all levels
         self._xlane = None
@@ -721,14 +756,21 @@ class Ctx:
         st = self.owner.__dict__.get('_lane_stamps')
         if st is None or not self.multi:
             return
-        k = st.__dict__.setdefault('nfork', 0)
+        ids = st.__dict__.setdefault('lane_fork', {})      # lane -> (fork number, index): a join closes the fork that opened the lane
         if what == 'fork':
-            st.nfork = k = k + 1
+            st.nfork = k = st.__dict__.get('nfork', 0) + 1
+            for i, l in enumerate(lanes):
+                ids[id(l)] = (k, i)
         tag = self.owner.__dict__.get('_stage_tag', '')
-        st.take(self, what, (k, 'parent', tag), parent.ptr)
+        seen = set()
         for i, l in enumerate(lanes):
-            if l.stream is not None:
-                st.take(self, what, (k, i, tag), l.ptr)
+            if l.stream is None:
+                continue
+            k, idx = ids.get(id(l), (0, i))
+            if k not in seen:
+                seen.add(k)
+                st.take(self, what, (k, 'parent', tag), parent.ptr)
+            st.take(self, what, (k, idx, tag), l.ptr)
 
     def _fork_anchor(self, parent):
         """EXPERIMENT (HRF_FORK_ANCHOR=1): one trivial kernel on the PARENT lane right after a fork.  The ROCm graph executor

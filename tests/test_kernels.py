@@ -114,8 +114,8 @@ CONV_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
     (1, 5, 3, 78, 78, 1, 1, 4, False, True),       # HRFuser-B width, fewer pixels than one batch
     (1, 50, 130, 64, 64, 3, 1, 2, True, True),
     (1, 18, 35, 64, 64, 3, 2, 2, True, True),      # stride-2 backward: parity-class kernel, ragged tiles
-    (1, 33, 47, 256, 36, 3, 2, 0, True, False),    # stride-2 FORWARD on the halo scheme: 8 channel slabs, odd grid (transition1)
-    (2, 21, 40, 18, 72, 3, 2, 1, True, True),      # ... a partly filled slab (modality transitions), two column blocks of 64
+    (1, 33, 47, 256, 36, 3, 2, 0, True, False),    # stride-2 forward at transition1's depth (2 304-deep contraction), odd grid
+    (2, 21, 40, 18, 72, 3, 2, 1, True, True),      # ... the modality transitions' 18 input channels, two column blocks
     (1, 70, 66, 64, 256, 1, 1, 2, True, True),     # wide 1x1 on the LDS-tiled engine (M >= 4096)
     (1, 66, 70, 256, 64, 1, 1, 1, True, False),      # M >= 128*.. exercises the BM=128 tile on GPU sizes
     (2, 5, 6, 288, 72, 1, 1, 3, True, True),         # few rows, deep contraction (HRFuser-B's coarse branches in miniature)
@@ -707,18 +707,6 @@ def test_conv_emul(case):
     run_conv(case, 'emul')
 
 
-@pytest.mark.parametrize('rows', [4, 8])
-def test_conv_stride2_halo_rows_emul(rows):
-    """both tilings of the stride-2 forward halo kernel (4 / 8 output rows per block), forced through debug knob 8"""
-    use_backend('emul')
-    L = _lib.lib()
-    L.hrf_debug_knob(8, rows)
-    try:
-        run_conv((1, 21, 37, 40, 36, 3, 2, 2, True, True), 'emul')
-    finally:
-        L.hrf_debug_knob(8, 0)
-
-
 @pytest.mark.parametrize('case', DW_CASES, ids=str)
 def test_dwconv_emul(case):
     run_dw(case, 'emul')
@@ -738,21 +726,6 @@ def test_pointwise_emul():
 @pytest.mark.parametrize('case', CONV_CASES, ids=str)
 def test_conv_gpu(case):
     run_conv(case, 'hip')
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('rows', [4, 8])
-@pytest.mark.parametrize('case', [(1, 33, 47, 256, 36, 3, 2, 0, True, False), (2, 96, 160, 64, 64, 3, 2, 2, True, True),
-                                  (1, 48, 80, 72, 144, 3, 2, 3, True, True)], ids=str)
-def test_conv_stride2_halo_gpu(case, rows):
-    """the stride-2 forward halo kernel at transition / stem sizes, both tilings"""
-    use_backend('hip')
-    L = _lib.lib()
-    L.hrf_debug_knob(8, rows)
-    try:
-        run_conv(case, 'hip')
-    finally:
-        L.hrf_debug_knob(8, 0)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,28 @@
+# Round artifact collection on ONE box: bash tools/final_round.sh r04 -> gpurun_out/final_r04/ (copy what is to be judged into
+# profiles/): the bench lines (headline, HRFuser-B, STF, forced SyncBN schedules), rocprofv3 kernel trace + PMC passes, the step
+# timeline, the profiler-free lane stamps and the stage trace.
+set -u
+R=${1:?round tag, e.g. r04}
+cd "${GRAFT_REPO_ROOT:?run through gpurun}"
+O=gpurun_out/final_$R; rm -rf $O; mkdir -p $O
+export TMPDIR=/tmp
+python bench.py --dump-kernels $O/${R}_kernels_graph_timed.json > $O/${R}_bench_line.json 2> $O/bench.err
+python bench.py --model b_nus_bn --no-cpu-baseline --no-neck --no-eager --steps 20 --warmup 5 --dump-kernels $O/${R}_kernels_b_nus.json > $O/${R}_bench_b_nus.json 2>> $O/bench.err
+python bench.py --model t_stf_bn --no-cpu-baseline --no-neck --no-eager --steps 30 --warmup 5 --dump-kernels $O/${R}_kernels_t_stf.json > $O/${R}_bench_t_stf.json 2>> $O/bench.err
+# the SyncBN configuration on ONE GPU (forced one-rank group): collective main-lane schedule, one communicator per lane, peer-to-peer exchange
+HRF_FORCE_COLLECTIVES=1 HRF_SYNC_P2P=0 python bench.py --no-cpu-baseline --no-neck --no-eager --no-roofline > $O/${R}_bench_forced_rccl.json 2>> $O/bench.err
+HRF_FORCE_COLLECTIVES=1 HRF_SYNC_P2P=0 HRF_SYNC_LANE_COMMS=1 python bench.py --no-cpu-baseline --no-neck --no-eager --no-roofline > $O/${R}_bench_forced_rccl_lane_comms.json 2>> $O/bench.err
+HRF_FORCE_COLLECTIVES=1 HRF_SYNC_P2P=1 python bench.py --no-cpu-baseline --no-neck --no-eager --no-roofline > $O/${R}_bench_forced_p2p.json 2>> $O/bench.err
+HRF_FORCE_COLLECTIVES=1 HRF_SYNC_P2P=1 python bench.py --model b_nus_bn --no-cpu-baseline --no-neck --no-eager --no-roofline --steps 20 --warmup 5 > $O/${R}_bench_forced_p2p_b_nus.json 2>> $O/bench.err
+# two ranks sharing this GPU (gloo control plane, IPC inboxes): the launcher, the auto-selected peer-to-peer exchange, the sync_ab arms
+python bench.py --gpus 2 --backend gloo --steps 3 --warmup 1 --height 128 --width 192 --no-roofline --sync-ab-timeout 600 > $O/${R}_bench_two_ranks_one_gpu.json 2>> $O/bench.err
+python bench.py --gpus 2 --steps 2 --warmup 1 > $O/${R}_bench_gpus2_on_one_gpu.txt 2>&1; echo "rc $?" >> $O/${R}_bench_gpus2_on_one_gpu.txt
+python tools/lane_stamps.py > $O/${R}_lane_stamps.txt 2>> $O/bench.err
+bash tools/prof_round.sh $R > $O/prof.log 2>&1
+cp gpurun_out/prof_$R/${R}_* gpurun_out/prof_$R/bench_under_rocprof.log $O/ 2>/dev/null
+bash tools/prof_pmc_sq.sh $R > $O/prof_sq.log 2>&1
+cp gpurun_out/pmc_sq_$R/${R}_pmc_sq.json $O/ 2>/dev/null
+bash tools/prof_timeline.sh > /dev/null 2>&1
+cp gpurun_out/timeline/step_timeline.txt $O/${R}_step_timeline.txt; cp gpurun_out/timeline/step_timeline.json $O/${R}_step_timeline.json
+bash tools/stage_trace.sh final_$R/st t_nus_bn -- "fwd stage3" "bwd stage3" "fwd stage4" > /dev/null 2>&1; cp $O/st/stage_trace.txt $O/${R}_stage_trace.txt 2>/dev/null; rm -rf $O/st
+for f in $O/${R}_bench_*.json; do echo $f; tail -1 $f | cut -c1-260; done

@@ -1,6 +1,7 @@
-# round 3: SQ counters (MFMA busy, LDS conflicts, waves) of the hot kernels at their branch-0 shapes (tools/pmc_kernels.py),
+R=${1:?round tag, e.g. r04}; export HRF_ROUND=$R
+# SQ counters (MFMA busy, LDS conflicts, waves) of the hot kernels at their branch-0 shapes (tools/pmc_kernels.py),
 # one rocprofv3 --pmc pass per counter group, --kernel-trace only
-cd "${GRAFT_REPO_ROOT:?run through gpurun}"; export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq_r03; rm -rf $OUT; mkdir -p $OUT; cd /tmp
+cd "${GRAFT_REPO_ROOT:?run through gpurun}"; export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq_$R; rm -rf $OUT; mkdir -p $OUT; cd /tmp
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU"; do
   tag=$(echo $grp | tr ' ' '_')
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -o p -- python3 $GRAFT_REPO_ROOT/tools/pmc_kernels.py > $OUT/$tag.log 2>&1; echo "$grp rc=$?"
@@ -8,7 +9,7 @@ done
 cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 python3 - <<'PY'
 import csv,glob,collections,json,shutil,os,re
-OUT='gpurun_out/pmc_sq_r03'
+OUT='gpurun_out/pmc_sq_$R'
 def short(n):
     n=n.replace('(anonymous namespace)::',''); n=re.sub(r'\(.*','',n); return n.replace('void ','')
 res=collections.defaultdict(lambda: collections.defaultdict(lambda:[0,0.0]))
@@ -26,7 +27,7 @@ for k,d in res.items():
     if 'SQ_LDS_BANK_CONFLICT' in v and v.get('SQ_LDS_IDX_ACTIVE',0)>0:
         v['lds_conflict_frac']=round(v['SQ_LDS_BANK_CONFLICT']/v['SQ_LDS_IDX_ACTIVE'],4)
     out[k]=v
-json.dump(out, open(OUT+'/r03_pmc_sq.json','w'), indent=1)
+json.dump(out, open(OUT+'/'+R+'_pmc_sq.json','w'), indent=1)
 for k,v in out.items(): print(k, {c:(round(x,4) if x<10 else round(x)) for c,x in v.items()})
 for d in os.listdir(OUT):
     if os.path.isdir(OUT+'/'+d): shutil.rmtree(OUT+'/'+d, ignore_errors=True)

@@ -1,27 +1,29 @@
-# round-2 profiles: kernel trace + stats of the bench command, PMC fabric traffic of the hot kernels (separate passes)
+# per-round profiles: bash tools/prof_round.sh r04 -> gpurun_out/prof_r04/: kernel trace + stats of the bench command, PMC fabric
+# traffic of the hot kernels (separate --pmc passes, --kernel-trace only; gfx950 corrections: profiles/README.md)
+R=${1:?round tag, e.g. r04}; export HRF_ROUND=$R
 cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r02 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-neck --no-eager > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $R -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-neck --no-eager > $OUT/bench_under_rocprof.log 2>&1
 echo trace rc=$?
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 $GRAFT_REPO_ROOT/tools/pmc_kernels.py > $OUT/pmc_fetch.log 2>&1; echo fetch rc=$?
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 $GRAFT_REPO_ROOT/tools/pmc_kernels.py > $OUT/pmc_write.log 2>&1; echo write rc=$?
 cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 python3 - <<'PY'
 import csv,glob,collections,os,json,re,shutil
-OUT='gpurun_out/prof_r02'
+OUT='gpurun_out/prof_$R'
 def short(n):
     n=n.replace('(anonymous namespace)::',''); n=re.sub(r'\(.*','',n); return n.replace('void ','')
-for f in glob.glob(OUT+'/trace/**/*kernel_stats.csv', recursive=True): os.replace(f, OUT+'/r02_kernel_stats.csv')
+for f in glob.glob(OUT+'/trace/**/*kernel_stats.csv', recursive=True): os.replace(f, OUT+'/'+R+'_kernel_stats.csv')
 tr=glob.glob(OUT+'/trace/**/*kernel_trace.csv', recursive=True)
 if tr:
     rows=list(csv.DictReader(open(tr[0])))
     agg=collections.defaultdict(lambda:[0,0])
     for r in rows:
         d=int(r['End_Timestamp'])-int(r['Start_Timestamp']); k=short(r['Kernel_Name']); agg[k][0]+=1; agg[k][1]+=d
-    with open(OUT+'/r02_kernel_trace_summary.csv','w') as fh:
+    with open(OUT+'/'+R+'_kernel_trace_summary.csv','w') as fh:
         fh.write('kernel,calls,total_ns,avg_ns\n')
         for k,v in sorted(agg.items(), key=lambda kv:-kv[1][1]): fh.write(f'"{k}",{v[0]},{v[1]},{v[1]/v[0]:.1f}\n')
     print('trace dispatches',len(rows))
@@ -36,13 +38,17 @@ for tag,cn in (('pmc_fetch','FETCH_SIZE'),('pmc_write','WRITE_SIZE')):
         if 'at::' in k or 'rocclr' in k: continue
         agg[k][0]+=1; agg[k][1]+=float(r['Counter_Value'])
     res[cn]={k:{'calls':v[0],'avg_per_launch':v[1]/v[0]} for k,v in agg.items()}
-json.dump(res, open(OUT+'/r02_pmc_raw.json','w'), indent=1)
+json.dump(res, open(OUT+'/'+R+'_pmc_raw.json','w'), indent=1)
 for cn,d in res.items():
     for k,v in d.items(): print(cn,k,v)
 # fabric traffic per launch: FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE reports half of the bytes of wide
 # coalesced reads (MI355X_MICROARCH.md, HBM section: 128-B requests tallied at 64 B), hence 2 x FETCH + WRITE
 F, Wr = res.get('FETCH_SIZE', {}), res.get('WRITE_SIZE', {})
-SHAPES = {'wgrad_dense_kernel<2, 5, true, 2, 0>': ('conv_bwd_weight[B=2,H=96,W=160,Cin=72,Cout=18,KH=1,stride=1,tf_mode=3,bnb=1]', 13276224)}
+SHAPES = {'wgrad_dense_kernel<2, 5, true, 2, 0>': ('conv_bwd_weight[B=2,H=96,W=160,Cin=72,Cout=18,KH=1,stride=1,tf_mode=3,bnb=1]', 13276224),
+          # HRFuser-B fc1 forward 78 -> 312 (x + rowstat + y), fc3 data gradient (dy, yraw, xraw, dx), fc1 weight gradient (dy, yraw, x)
+          'lin2_fwd_kernel<Tile<2, 10, 2>, 4>': ('conv_fwd[B=2,H=96,W=160,Cin=78,Cout=312,KH=1,stride=1,tf_mode=4]', 30720 * (78 + 2 + 312) * 4),
+          'lin2_bwd_data_kernel<Tile<2, 10, 2>, true>': ('conv_bwd_data[B=2,H=96,W=160,Cin=312,Cout=78,KH=1,stride=1,epi=1,accumulate=0,bnb=1]', 30720 * (78 + 78 + 312 + 312) * 4),
+          'wgrad_dense_kernel<5, 5, true, 0, 0>': ('conv_bwd_weight[B=2,H=96,W=160,Cin=78,Cout=312,KH=1,stride=1,tf_mode=4,bnb=1]', 30720 * (312 + 312 + 78 + 2) * 4)}
 traffic = {'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over tools/pmc_kernels.py (each hot kernel '
                      'launched eagerly on its branch-0 shape, 2x96x160); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch',
            'kernels': {}, 'shapes': {}}
@@ -52,7 +58,7 @@ for k in sorted(set(F) & set(Wr)):
     if k in SHAPES:
         tag, alg = SHAPES[k]
         traffic['shapes'][tag] = {'bytes_per_launch': round(b), 'algorithmic_bytes': alg, 'ratio': round(b / alg, 3), 'kernel': k}
-json.dump(traffic, open(OUT+'/r02_hbm_traffic.json','w'), indent=1)
+json.dump(traffic, open(OUT+'/'+R+'_hbm_traffic.json','w'), indent=1)
 for d in ('trace','pmc_fetch','pmc_write'): shutil.rmtree(OUT+'/'+d, ignore_errors=True)
 PY
 tail -1 $OUT/bench_under_rocprof.log | cut -c1-300
