@@ -744,6 +744,7 @@ class HRFuserFusionBlock(nn.Module):
 _CAM_LANES = int(os.environ.get('HRF_CAM_LANES', '0') or 0)      # 0: one stream per camera branch (A/B knob)
 _FORK_EXCHANGE = os.environ.get('HRF_FORK_EXCHANGE', '1') != '0'   # exchange chains on sibling lanes (0: serial)
 _BRANCH_ORDER = os.environ.get('HRF_BRANCH_ORDER', '')
+_PENDING_FUSION = os.environ.get('HRF_PENDING_FUSION', '1') != '0'
 _ONE_FORK = os.environ.get('HRF_MODULE_ONE_FORK', '1') != '0'      # one fork / join per HRFomerModule (0: the round-3 structure)
 
 
@@ -915,6 +916,7 @@ class HRModule(nn.Module):
         lanes = ctx.fork(nb, keep_first=ctx.keep_first)
 
         def branch(i):
+            xs[i] = R.force(ctx, xs[i])                   # (a pending fusion block in front of the stage runs on this lane)
             for blk in self.branches[i]:
                 xs[i] = blk.run(ctx, xs[i])
         ctx.parallel(lanes, [lambda i=i: branch(i) for i in range(nb)])
@@ -1523,16 +1525,16 @@ class HRFuserHRFormerBased(HipModule):
         ctx.parallel(lanes, [cam_trans] + [lambda k=k: mod_trans(k) for k in range(M)])
         ctx.join(lanes)
         ctx.mark('transitions_' + tag)
-        # phase 2 - one fusion block per branch, in parallel
-        xs = [None] * nb
-        lanes = ctx.fork(nb, keep_first=ctx.keep_first)
-
-        def fuse(i):
-            xs[i] = fusion[i].run(ctx, cams[i], ms[i])
-        ctx.parallel(lanes, [lambda i=i: fuse(i) for i in range(nb)])
-        ctx.join(lanes)
-        ctx.mark('fusion_' + tag)
-        return xs, ms[0]
+        # phase 2 - one fusion block per branch: PENDING - the stage's first module runs fusion block i at the head of branch
+        # lane i (no fork / join of its own), and the modality stages, which need the transitions only, start beside them
+        # instead of behind them.  The modality stage k and fusion block 0 both read ms[0][k] and back-propagate on different
+        # lanes: the stage gets a handle with a gradient slot of its own (split_grad).
+        xs = [R.Pending(tuple(cams[i].t.shape), lambda c, i=i: fusion[i].run(c, cams[i], ms[i])) for i in range(nb)]
+        m0 = [R.split_grad(ctx, ms[0][k]) for k in range(M)]
+        if not _PENDING_FUSION:                              # (HRF_PENDING_FUSION=0: the round-3 structure, A/B)
+            xs = R.force_all(ctx, xs)
+            ctx.mark('fusion_' + tag)
+        return xs, m0
 
     def _bare_conv(self, ctx, x, conv):
         """3x3 conv WITHOUT BatchNorm (transition1[0][0] quirk)."""
@@ -1599,7 +1601,7 @@ class HRFuserHRFormerBased(HipModule):
         outs = [None] * nb
         for i in range(nb):
             with ctx.on(lanes[i]):
-                outs[i] = self._relu(ctx, xs[i])                                  # :622-623 y_list[i] = self.relu(x_list[i])
+                outs[i] = self._relu(ctx, R.force(ctx, xs[i]))                                  # :622-623 y_list[i] = self.relu(x_list[i])
         ctx.join(lanes)
         return outs
 
@@ -1634,7 +1636,7 @@ class HRFuserHRFormerBased(HipModule):
         stages are enqueued on their own lanes first; the camera stage then runs from the main lane,
         each of its modules forking branch lanes from main (flat, never nested)."""
         M = self.num_fused_modalities
-        cap = (max(1, 4 - len(xs)) if M <= 2 else 0) if ctx.mod_lanes == 'auto' else int(ctx.mod_lanes or 0)
+        cap = max(1, 4 - len(xs)) if ctx.mod_lanes == 'auto' else int(ctx.mod_lanes or 0)
         lanes = ctx.bundle_lanes(M, 'stages', cap=cap)
         mods = [None] * M
         ys = [None]

@@ -338,7 +338,25 @@ def stage_table(trainer, x, mods, cots, tag, peak_f, peak_b, replays=10):
             return None, None
         return round(B * gflop * 1e9 / (us * 1e-6) / peak_f, 4), round(B * mb * 1e6 / (us * 1e-6) / peak_b, 4)
     tot_g = tot_mb = 0.0
-    for reg, parts in _REGIONS:
+    regions = list(_REGIONS)
+    if 'fusion_a' not in order:
+        # the fusion blocks run at the head of the following stage's branch lanes (no boundary of their own, backbone.
+        # _fuse_stage): the stamp interval named after the stage contains them
+        merged, pend = [], None
+        for reg, parts in regions:
+            if reg.startswith('fusion_'):
+                pend = (reg, parts)
+            elif pend is not None and reg.startswith('stage'):
+                merged.append((reg, pend[1] + parts, pend[0] + '+' + reg, (pend[0], reg)))
+                pend = None
+            else:
+                merged.append((reg, parts))
+        regions = merged
+    pmc_keys = {}
+    for ent in regions:
+        reg, parts = ent[0], ent[1]
+        label = ent[2] if len(ent) > 2 else reg
+        pmc_keys[label] = ent[3] if len(ent) > 3 else None
         keys = [k for k in order if k == reg or (reg == 'transitions' and k.startswith('transitions_'))]
         if not keys:
             continue
@@ -348,14 +366,19 @@ def stage_table(trainer, x, mods, cots, tag, peak_f, peak_b, replays=10):
         tot_g, tot_mb = tot_g + g, tot_mb + mb
         ff, fb = frac(g, mb, f_us)
         bf, bb = frac(g, mb, b_us)
-        rows.append({'name': reg, 'fwd_ms': round(f_us / 1e3, 4), 'bwd_ms': round(b_us / 1e3, 4), 'fwd_gflop': round(B * g, 2),
+        rows.append({'name': label, 'fwd_ms': round(f_us / 1e3, 4), 'bwd_ms': round(b_us / 1e3, 4), 'fwd_gflop': round(B * g, 2),
                      'fwd_eager_MB': round(B * mb, 1), 'fwd_flops_frac': ff, 'fwd_bytes_frac': fb, 'bwd_flops_frac': bf, 'bwd_bytes_frac': bb})
     # MEASURED fabric traffic per stage (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one eager single-stream step, cut at the same
     # stamps: tools/pmc_stages.py -> profiles/r03_stage_hbm_traffic.json; a separate run - the source is stated)
     pmc = _stage_pmc(tag)
     if pmc is not None:
         for row in rows:
-            keys = [k for k in order if k == row['name'] or (row['name'] == 'transitions' and k.startswith('transitions_'))]
+            if pmc_keys.get(row['name']):
+                keys = list(pmc_keys[row['name']])                # a merged row: the PMC pass's rows of its parts
+            else:
+                keys = [k for k in (list(order) + ['transitions_a', 'transitions_b', 'transitions_c'])
+                        if k == row['name'] or (row['name'] == 'transitions' and k.startswith('transitions_'))]
+                keys = list(dict.fromkeys(keys))
             fmb = sum(pmc.get('fwd ' + k, {}).get('MB', 0.0) for k in keys)
             bmb = sum(pmc.get('bwd ' + k, {}).get('MB', 0.0) for k in keys)
             row['fwd_pmc_MB'], row['bwd_pmc_MB_incl_weight_gradients'] = round(fmb, 1), round(bmb, 1)

@@ -207,14 +207,14 @@ class LazyTail:
         return materialize(ctx, self.lazy, ACT_GELU, res=self.res, act_first=True, rowscale=self.rowscale)
 
 
-class LazyFuse:
-    """One output branch of an HRModule exchange, ReLU(sum of terms) (hrnet.py:192-206), not launched yet: the module hands
-    it to its consumer, which forces it ON ITS OWN LANE - the next module's branch i starts with the fuse_sum of output i
-    instead of the main lane running all of a module's fuse_sums one after the other between a join and the next fork."""
-    __slots__ = ('dims', 'terms', 'out')
+class Pending:
+    """An Act that is not launched yet: `fn(ctx) -> Act` runs when the CONSUMER forces it, on the consumer's lane.  The output
+    branches of an HRModule exchange (LazyFuse) and the fusion blocks in front of a stage are handed over this way: the next
+    module's branch i starts with them instead of the main lane running them between a join and the next fork."""
+    __slots__ = ('dims', 'fn', 'out')
 
-    def __init__(self, dims, terms):
-        self.dims, self.terms, self.out = dims, terms, None
+    def __init__(self, dims, fn):
+        self.dims, self.fn, self.out = tuple(dims), fn, None
 
     @property
     def shape(self):
@@ -222,19 +222,38 @@ class LazyFuse:
 
     def force(self, ctx):
         if self.out is None:
-            self.out = fuse_sum(ctx, self.dims, self.terms)
-            self.terms = None
+            self.out = self.fn(ctx)
+            self.fn = None
         return self.out
+
+
+def LazyFuse(dims, terms):
+    """One output branch of an HRModule exchange, ReLU(sum of terms) (hrnet.py:192-206), pending."""
+    return Pending(dims, lambda ctx: fuse_sum(ctx, tuple(dims), terms))
+
+
+def split_grad(ctx, act):
+    """A second handle on `act` with a gradient slot of its own, for a consumer that back-propagates on ANOTHER lane while
+    `act` itself collects gradients elsewhere (the modality stage and the fusion block of branch 0 read the same map and run
+    concurrently): the two slots are added where this call sits in the tape - on the current lane, after both consumers."""
+    alias = Act(act.t, act.needs_grad)
+    alias.rowstat = act.rowstat
+
+    def bwd():
+        if alias.grad is not None and act.needs_grad:
+            act.add_grad(alias.grad)
+    ctx.push(bwd)
+    return alias
 
 
 def force(ctx, x):
     """-> an Act: materialises a LazyTail / launches a pending LazyFuse on the current lane, passes everything else through."""
-    return x.force(ctx) if isinstance(x, (LazyTail, LazyFuse)) else x
+    return x.force(ctx) if isinstance(x, (LazyTail, Pending)) else x
 
 
 def force_all(ctx, xs):
     """Acts for a list of stage outputs; pending exchange sums run on sibling lanes (they are independent of each other)."""
-    pend = [i for i, x in enumerate(xs) if isinstance(x, LazyFuse) and x.out is None]
+    pend = [i for i, x in enumerate(xs) if isinstance(x, Pending) and x.out is None]
     xs = list(xs)
     if len(pend) > 1:
         lanes = ctx.fork(len(pend))
@@ -417,8 +436,8 @@ class Ctx:
         # The hipGraph executor of ROCm 7.2 runs a captured graph on 4 streams (DEBUG_HIP_FORCE_GRAPH_QUEUES; its node -> stream
         # assignment is printed by DEBUG_HIP_GRAPH_DOT_PRINT: first child inherits, siblings round-robin): more than 4 concurrent
         # chains alias two of them onto one in-order stream.  Beside a camera stage of nb branches there is room for 4 - nb
-        # modality chains: mod_lanes = lanes for the M modality stages ('auto': max(1, 4 - nb) for M <= 2 - HRFuser-T 14.35 ->
-        # 13.84 ms - and one per modality for M = 3, where the serialised STF chains outlast the camera stage; N: forced).
+        # modality chains: mod_lanes = lanes for the M modality stages ('auto': max(1, 4 - nb); HRFuser-T 14.35 -> 13.84 ms, STF
+        # 28.1 -> 27.8 ms same-box A/B; N: forced, 0: one per modality).
         self.mod_lanes = os.environ.get('HRF_MOD_LANES', 'auto').strip().lower()
         self._sweeper = None            # greenlet running the sweep (None: not inside parallel())
         self._strands = []              # live strands of the running sweep, all levels

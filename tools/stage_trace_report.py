@@ -6,7 +6,7 @@ import csv
 import re
 import sys
 
-ORDER = ['start', 'stems', 'transitions_a', 'fusion_a', 'stage2+stage_b', 'transitions_b', 'fusion_b', 'stage3+stage_c', 'transitions_c',
+ORDER = None  # stage names come from the stamps printed by tools/stage_trace.py
          'fusion_c', 'stage4']
 
 
