@@ -247,6 +247,14 @@ class Engine:
             L.hrf_fold_copies(self.ps_scratch, self.ps_n, self.ps_map, self.flat_g, self.ps_n, stream)
             R.gpu_zero_(self.ps_scratch)
         self.ps_dirty = False
+        self.fold_slots_now(L, stream)
+
+    def fs_bytes(self):
+        """Bytes of slot data the pending hrf_fold_slots launch reads (cost model of the leaf balancer)."""
+        return 4.0 * sum(self.fs_layers[k]['nslots'] * self.fs_layers[k]['n'] for k in self.fs_used)
+
+    def fold_slots_now(self, L, stream):
+        """hrf_fold_slots over the slots of this backward pass (once: as a leaf of the weight-gradient phase, or by fold_grads)."""
         if self.fs_used:
             L.hrf_fold_slots(self.fs_arena, self.fs_seg, len(self.fs_used), self.fs_map, self.flat_g, self.fs_maxn, stream)
             self.fs_used = []

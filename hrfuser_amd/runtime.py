@@ -929,6 +929,12 @@ class Ctx:
         self._run_tape(self.root)
         if self._deferred and os.environ.get('HRF_DEBUG_SKIP_WGRAD') == '1':
             self._deferred = []                 # timing experiments only: drops the weight-gradient phase
+        eng0 = self.owner._engine()
+        if self._deferred and self.multi and eng0.fs_used and os.environ.get('HRF_FOLD_LEAF', '1') != '0':
+            # the per-window slots of the fused attention blocks are complete (every attn_block_bwd has run) and their targets
+            # in the gradient arena are touched by no other leaf: the fold (370 MB for HRFuser-T) joins the weight-gradient
+            # phase as one more leaf instead of running alone on the main lane behind it
+            self._deferred.append((4.0 * eng0.fs_bytes(), lambda: eng0.fold_slots_now(self.L, self.stream)))
         if self._deferred:
             items, self._deferred = self._deferred, []
             k = int(os.environ.get('HRF_WGRAD_LANES', '4'))
