@@ -287,12 +287,16 @@ def _stage_pmc(tag):
     """stage name -> {'MB': ...} of the committed per-stage PMC pass (HRFuser-T nus only), or None"""
     if tag.replace('_bn', '') != 't_nus':
         return None
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r03_stage_hbm_traffic.json')
-    if not os.path.exists(path):
+    path, name = _newest(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles'), 'stage_hbm_traffic.json')
+    if path is None:
         return None
     import json
     with open(path) as fh:
-        return json.load(fh).get('stages')
+        st = json.load(fh).get('stages')
+    if st is not None:
+        st = dict(st)
+        st['_file'] = name
+    return st
 
 
 def stage_table(trainer, x, mods, cots, tag, peak_f, peak_b, replays=10):
@@ -373,11 +377,12 @@ def stage_table(trainer, x, mods, cots, tag, peak_f, peak_b, replays=10):
     pmc = _stage_pmc(tag)
     if pmc is not None:
         for row in rows:
-            if pmc_keys.get(row['name']):
-                keys = list(pmc_keys[row['name']])                # a merged row: the PMC pass's rows of its parts
+            if pmc_keys.get(row['name']) and all(('fwd ' + k) in pmc for k in pmc_keys[row['name']]):
+                keys = list(pmc_keys[row['name']])                # a merged row over a PMC pass that still had the fusion stamps
             else:
+                reg = pmc_keys[row['name']][1] if pmc_keys.get(row['name']) else row['name']
                 keys = [k for k in (list(order) + ['transitions_a', 'transitions_b', 'transitions_c'])
-                        if k == row['name'] or (row['name'] == 'transitions' and k.startswith('transitions_'))]
+                        if k == reg or (reg == 'transitions' and k.startswith('transitions_'))]
                 keys = list(dict.fromkeys(keys))
             fmb = sum(pmc.get('fwd ' + k, {}).get('MB', 0.0) for k in keys)
             bmb = sum(pmc.get('bwd ' + k, {}).get('MB', 0.0) for k in keys)
@@ -388,10 +393,10 @@ def stage_table(trainer, x, mods, cots, tag, peak_f, peak_b, replays=10):
                  'fwd_gflop': round(B * tot_g, 2), 'fwd_eager_MB': round(B * tot_mb, 1), 'bwd_flops_frac': wf, 'bwd_bytes_frac': wb})
     step_pmc = None
     if pmc is not None:
-        tot = sum(v.get('MB', 0.0) for v in pmc.values())
+        tot = sum(v.get('MB', 0.0) for k, v in pmc.items() if k != '_file')
         step_ms = (end if end is not None else t[('bwd', 'weight_gradients')]) / 1e3
         step_pmc = {'MB': round(tot, 1), 'hbm_frac': round(tot * 1e6 / (step_ms * 1e-3) / peak_b, 4),
-                    'source': 'profiles/r03_stage_hbm_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of every dispatch of ONE eager single-stream '
+                    'source': f'profiles/{pmc.get("_file")}: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of every dispatch of ONE eager single-stream '
                               'step from separate rocprofv3 --pmc passes (tools/pmc_stages.py), cut at the stage stamps; NOT measured in this '
                               'bench run; backward rows include the weight gradients of the stage (issued inline in that step)'}
     out = {'stages': rows, 'step_pmc_traffic': step_pmc, 'turnaround_ms': round(turn / 1e3, 4),

@@ -1,13 +1,12 @@
 """Per-stage fabric traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/pmc_stages.py:
-    python tools/pmc_stages_report.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+    python tools/pmc_stages_report.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <stdout of pmc_stages.py>
 bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md)."""
 import csv
 import json
 import re
 import sys
 
-ORDER = ['start', 'stems', 'transitions_a', 'fusion_a', 'stage2+stage_b', 'transitions_b', 'fusion_b', 'stage3+stage_c', 'transitions_c',
-         'fusion_c', 'stage4']
+NAMES = None            # [(direction, stage)] of every stamp of the step, from the JSON line tools/pmc_stages.py printed
 
 
 def short(n):
@@ -24,11 +23,11 @@ def per_stage(path, counter):
         rows[d] = (short(r['Kernel_Name']), rows.get(d, ('', 0.0))[1] + float(r['Counter_Value']))
     seq = [rows[d] for d in sorted(rows)]
     stamps = [i for i, (k, _) in enumerate(seq) if k.startswith('stamp_kernel')]
-    per = len(ORDER) * 2 + 2
+    names = NAMES
+    per = len(names)
     if len(stamps) < per:
         raise SystemExit(f'{path}: {len(stamps)} stamp kernels, expected {per}')
     last = stamps[-per:]
-    names = [('fwd', n) for n in ORDER] + [('bwd', n) for n in reversed(ORDER)] + [('bwd', 'weight_gradients'), ('step', 'step_end')]
     out = {}
     for k in range(1, len(last)):
         d, n = names[k]
@@ -38,7 +37,14 @@ def per_stage(path, counter):
     return out
 
 
-def main(fetch, write, out):
+def main(fetch, write, out, stdout_file):
+    global NAMES
+    for line in reversed(open(stdout_file).read().splitlines()):
+        if line.startswith('[['):
+            NAMES = [(d, n) for d, n, _ in json.loads(line)]
+            break
+    if NAMES is None:
+        raise SystemExit(f'no stamp list in {stdout_file}')
     F, Wr = per_stage(fetch, 'FETCH_SIZE'), per_stage(write, 'WRITE_SIZE')
     res = {'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in SEPARATE passes over ONE eager, single-stream training step '
                      '(tools/pmc_stages.py), dispatches cut at the stage-stamp kernels; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024',
@@ -56,4 +62,4 @@ def main(fetch, write, out):
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])

@@ -1,13 +1,11 @@
 """Cut a rocprofv3 kernel trace (csv) of tools/stage_trace.py at the stamp kernels and report per stage:
-    python tools/stage_trace_report.py <kernel_trace.csv> [stage-name-substring ...]
+    python tools/stage_trace_report.py <kernel_trace.csv> <stdout of stage_trace.py> [stage-name-substring ...]
 For each stage of the LAST replayed step: wall time, number of kernels, sum of kernel durations, and (for the stages named on
 the command line) every kernel with queue id, start offset (us) and duration - the dependency chain is readable from it."""
 import csv
 import re
 import sys
 
-ORDER = None  # stage names come from the stamps printed by tools/stage_trace.py
-         'fusion_c', 'stage4']
 
 
 def short(n):
@@ -16,18 +14,27 @@ def short(n):
     return n.replace('void ', '')
 
 
-def main(path, show):
+def stamp_names(outfile):
+    """(direction, stage) of every stamp of one step, in issue order: the JSON line tools/stage_trace.py printed."""
+    import json
+    for line in reversed(open(outfile).read().splitlines()):
+        if line.startswith('[['):
+            return [(d, n) for d, n, _ in json.loads(line)]
+    raise SystemExit(f'no stamp list in {outfile}')
+
+
+def main(path, outfile, show):
+    names = stamp_names(outfile)
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']), r.get('Queue_Id', '?'), r.get('Stream_Id', '?')))
     rows.sort()
     stamps = [i for i, r in enumerate(rows) if r[2].startswith('stamp_kernel')]
-    per = len(ORDER) * 2 + 2                       # fwd marks + bwd marks + weight_gradients + step_end
+    per = len(names)                               # fwd marks + bwd marks + weight_gradients + step_end
     if len(stamps) < per:
         print('not enough stamps', len(stamps))
         return
     last = stamps[-per:]
-    names = [('fwd', n) for n in ORDER] + [('bwd', n) for n in reversed(ORDER)] + [('bwd', 'weight_gradients'), ('step', 'step_end')]
     t0 = rows[last[0]][0]
     print(f'step (first to last stamp): {(rows[last[-1]][0] - t0) / 1e3:.1f} us')
     for k in range(1, len(last)):
@@ -44,4 +51,4 @@ def main(path, show):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2:])
+    main(sys.argv[1], sys.argv[2], sys.argv[3:])
