@@ -9,7 +9,9 @@ done
 cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 python3 - <<'PY'
 import csv,glob,collections,json,shutil,os,re
-OUT='gpurun_out/pmc_sq_$R'
+import os as _os
+R=_os.environ['HRF_ROUND']
+OUT='gpurun_out/pmc_sq_'+R
 def short(n):
     n=n.replace('(anonymous namespace)::',''); n=re.sub(r'\(.*','',n); return n.replace('void ','')
 res=collections.defaultdict(lambda: collections.defaultdict(lambda:[0,0.0]))

@@ -13,7 +13,9 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OU
 cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 python3 - <<'PY'
 import csv,glob,collections,os,json,re,shutil
-OUT='gpurun_out/prof_$R'
+import os as _os
+R=_os.environ['HRF_ROUND']
+OUT='gpurun_out/prof_'+R
 def short(n):
     n=n.replace('(anonymous namespace)::',''); n=re.sub(r'\(.*','',n); return n.replace('void ','')
 for f in glob.glob(OUT+'/trace/**/*kernel_stats.csv', recursive=True): os.replace(f, OUT+'/'+R+'_kernel_stats.csv')
