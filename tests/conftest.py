@@ -30,7 +30,7 @@ _FIRST = [
     'test_p2p_exchange.py::',                                                   # e: peer-to-peer SyncBN exchange
     'test_pipeline.py::',                                                       # f3
     'test_parity_wholenet.py::test_pre_neck_fusion_gpu[True]',                  # f4
-    'test_parity_wholenet.py::test_fullres_gradient_digest_gpu[t_nus]',         # configs[1] at full size
+    'test_parity_wholenet.py::test_wholenet_gpu_train_fullsize[t_nus',          # configs[1] at full size, every gradient tensor
     'test_abi.py::',                                                            # b
     'test_module_graph.py::',                                                   # b: captured graphs at the module boundary
     'test_neck.py::test_backbone_into_neck_gpu',                                # f1

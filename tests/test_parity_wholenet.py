@@ -113,6 +113,17 @@ def test_wholenet_gpu_train_medium(tag, B, H, W):
     _fwd_bwd(tag, B, H, W, True, 'hip')
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag,B,H,W', [('t_nus', 2, 384, 640), ('b_nus', 2, 384, 640), ('t_stf', 2, 384, 1248)])
+def test_wholenet_gpu_train_fullsize(tag, B, H, W):
+    """The BASELINE configurations at their FULL size (configs[1], [3], [4]: 2 images, 384x640 / 384x1248) under the same gate as
+    the small shapes: outputs at 1e-3 against the fp64 oracle, EVERY gradient tensor (inputs and parameters) within
+    max(1e-3, 3 x the oracle's own fp32-vs-fp64 error) with the product's ReLU decisions pinned (the tight
+    gate used to top out at 2x192x320 and the full-size gradients were digest-checked only).  CPU oracle legs at 8 threads:
+    about 20 s (T), 50 s (STF), 2 min (B) on the box."""
+    _fwd_bwd(tag, B, H, W, True, 'hip')
+
+
 def _digest_close(f, samples, meta, tol=1e-3):
     idx = torch.linspace(0, f.numel() - 1, min(4096, f.numel())).long()
     assert relmax(f[idx], torch.as_tensor(samples)) < tol * max(1.0, meta[2] / float(f[idx].abs().max()))
