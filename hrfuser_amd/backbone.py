@@ -205,30 +205,7 @@ class Engine:
             cur[2].close()
         import torch.distributed as dist
         rank = dist.get_rank(group) if world > 1 else 0
-        strict = p2p.mode() == 'on'
-        ctx, why = None, ''
-        try:
-            ctx = p2p.P2PExchange(self.root._lib_handle(), self._bns, group, world, rank, self.device)
-            if world > 1:
-                ctx.handshake()
-        except Exception as e:                                    # (no IPC on this driver, a peer on another node, a time-out ...)
-            if strict or world == 1:
-                raise
-            why = f'{type(e).__name__}: {str(e)[:200]}'
-            if ctx is not None:
-                ctx.close()
-            ctx = None
-        if world > 1 and not strict:
-            # every rank takes the SAME schedule: one failure sends all of them back to the communicator
-            dev = self.device if dist.get_backend(group) == 'nccl' else torch.device('cpu')
-            ok = torch.tensor([1 if ctx is not None else 0], dtype=torch.int64, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-            if int(ok) == 0:
-                if ctx is not None:
-                    ctx.close()
-                ctx = None
-                warnings.warn('SyncBN: the peer-to-peer exchange is not available on every rank'
-                              + (f' (this rank: {why})' if why else '') + '; using the collective schedule (HRF_SYNC_P2P=0 silences this)')
+        ctx = p2p.P2PExchange.create(self.root._lib_handle(), self._bns, group, world, rank, self.device, strict=p2p.mode() == 'on')
         self.__dict__['_p2p'] = (group, world, ctx, p2p.mode())
         return ctx
 

@@ -37,7 +37,9 @@ class P2PExchange:
     """Inbox of this rank + the mapped inboxes of its peers + the static slot of every BatchNorm (layer, direction)."""
 
     def __init__(self, lib, bns, group, world, rank, device, timeout_s=None):
-        self.lib, self.world, self.rank, self.device = lib, int(world), int(rank), device
+        """LOCAL part only (slot table, inbox allocation): nothing here talks to the other ranks - `create` drives the collective
+        steps so that a rank whose local step fails still takes part in every collective the others are in."""
+        self.lib, self.world, self.rank, self.device, self.group = lib, int(world), int(rank), device, group
         if not (1 <= self.world <= 8):
             raise _lib.HRFuserHipError(f'peer-to-peer SyncBN exchange: 1..8 ranks of one node, got {world}')
         off = 0
@@ -51,35 +53,39 @@ class P2PExchange:
         self.slot_doubles, self.nslots = off, 2 * len(bns) + 1
         self.data_bytes = self.world * 2 * self.slot_doubles * 8
         self.bytes = self.data_bytes + self.world * 2 * self.nslots * 8
+        self.base, self.handle, self.opened, self.ctx = None, None, [], None
+        self.peers = [None] * self.world
+        self.exchanges = 0
+        self.timeout_s = float(os.environ.get('HRF_P2P_TIMEOUT_S', '20')) if timeout_s is None else float(timeout_s)
         base = ctypes.c_void_p()
         handle = (ctypes.c_char * 64)()
-        need_ipc = self.world > 1
-        lib.hrf_p2p_alloc(self.bytes, ctypes.addressof(base), ctypes.addressof(handle) if need_ipc else None)
-        self.base = base.value
-        self.peers = [None] * self.world
+        lib.hrf_p2p_alloc(self.bytes, ctypes.addressof(base), ctypes.addressof(handle) if self.world > 1 else None)
+        self.base, self.handle = base.value, bytes(handle.raw)
         self.peers[self.rank] = self.base
-        self.opened = []
-        if need_ipc:
-            import torch.distributed as dist
-            mine = (bytes(handle.raw), os.getpid(), self.bytes)
-            everyone = [None] * self.world
-            dist.all_gather_object(everyone, mine, group=group)
-            for p, (h, pid, nbytes) in enumerate(everyone):
-                if p == self.rank:
-                    continue
-                if nbytes != self.bytes:
-                    raise _lib.HRFuserHipError(f'peer-to-peer SyncBN exchange: rank {p} built a different slot table '
-                                               f'({nbytes} vs {self.bytes} bytes) - the ranks do not run the same model')
-                if pid == os.getpid():
-                    raise _lib.HRFuserHipError('peer-to-peer SyncBN exchange: two ranks in one process')
-                q = ctypes.c_void_p()
-                hb = (ctypes.c_char * 64).from_buffer_copy(h)
-                lib.hrf_p2p_open(ctypes.addressof(hb), ctypes.addressof(q))
-                self.peers[p] = q.value
-                self.opened.append(q.value)
-        self.gen = torch.zeros(1, dtype=torch.int64, device=device)
-        self.err = torch.zeros(1, dtype=torch.int64, device=device)
-        t = float(os.environ.get('HRF_P2P_TIMEOUT_S', '20')) if timeout_s is None else float(timeout_s)
+
+    def open_peers(self, everyone):
+        """Map the peers' inboxes (`everyone`: the all-gathered (handle, pid, bytes) of every rank; None where a rank failed)."""
+        for p, ent in enumerate(everyone):
+            if p == self.rank:
+                continue
+            if ent is None:
+                raise _lib.HRFuserHipError(f'peer-to-peer SyncBN exchange: rank {p} could not allocate its inbox')
+            h, pid, nbytes = ent
+            if nbytes != self.bytes:
+                raise _lib.HRFuserHipError(f'peer-to-peer SyncBN exchange: rank {p} built a different slot table '
+                                           f'({nbytes} vs {self.bytes} bytes) - the ranks do not run the same model')
+            if pid == os.getpid():
+                raise _lib.HRFuserHipError('peer-to-peer SyncBN exchange: two ranks in one process')
+            q = ctypes.c_void_p()
+            hb = (ctypes.c_char * 64).from_buffer_copy(h)
+            self.lib.hrf_p2p_open(ctypes.addressof(hb), ctypes.addressof(q))
+            self.peers[p] = q.value
+            self.opened.append(q.value)
+
+    def finish(self):
+        """The kernel-side context, once every inbox is mapped."""
+        self.gen = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.err = torch.zeros(1, dtype=torch.int64, device=self.device)
         c = _lib.P2p()
         c.world, c.rank = self.world, self.rank
         for p in range(self.world):
@@ -87,12 +93,55 @@ class P2PExchange:
             c.flags[p] = self.peers[p] + self.data_bytes
         c.slot_doubles, c.nslots = self.slot_doubles, self.nslots
         c.gen, c.err = self.gen.data_ptr(), self.err.data_ptr()
-        c.timeout_ticks = int(t * 1e8)
+        c.timeout_ticks = int(self.timeout_s * 1e8)
         self.ctx = c
-        self.exchanges = 0
-        if need_ipc:
-            import torch.distributed as dist
-            dist.barrier(group=group)                 # nobody pushes into an inbox that is not mapped everywhere yet
+
+    @classmethod
+    def create(cls, lib, bns, group, world, rank, device, strict):
+        """-> a ready exchange context, or None when the ranks agreed to use the communicator schedule instead.  COLLECTIVE: every
+        rank walks through the same sequence of collectives (object all-gather of the handles, agreement all-reduces) whatever
+        fails locally in between; only the AGREED outcome raises (strict) or falls back (auto) - on every rank alike."""
+        import torch.distributed as dist
+        why, px = '', None
+
+        def agree(ok):
+            if world <= 1:
+                return ok
+            dev = device if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+            t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(t))
+        try:
+            px = cls(lib, bns, group, world, rank, device)
+        except Exception as e:
+            why = f'{type(e).__name__}: {str(e)[:200]}'
+        if world > 1:
+            everyone = [None] * world
+            dist.all_gather_object(everyone, (px.handle, os.getpid(), px.bytes) if px is not None else None, group=group)
+            if px is not None:
+                try:
+                    px.open_peers(everyone)
+                except Exception as e:
+                    why = f'{type(e).__name__}: {str(e)[:200]}'
+        ok = agree(px is not None and not why)            # (also the barrier: nobody pushes into an inbox that is not mapped everywhere)
+        if ok:
+            px.finish()
+            if world > 1:
+                try:
+                    px.handshake()
+                except Exception as e:
+                    why = f'{type(e).__name__}: {str(e)[:200]}'
+                ok = agree(not why)
+        if ok:
+            return px
+        if px is not None:
+            px.close()
+        msg = 'SyncBN: the peer-to-peer exchange is not available on every rank' + (f' (this rank: {why})' if why else '')
+        if strict:
+            raise _lib.HRFuserHipError(msg + ' and HRF_SYNC_P2P=1 demands it')
+        import warnings
+        warnings.warn(msg + '; using the collective schedule (HRF_SYNC_P2P=0 silences this)')
+        return None
 
     def handshake(self, rounds=6, timeout_s=5.0):
         """A few verified test exchanges on the reserved slot (both parities, a short time-out): every rank contributes

@@ -858,7 +858,7 @@ class Ctx:
         fns = [fn for _, fn in self._deferred]
         self._deferred = []
         pool = self.owner._side_pool()
-        k = min(len(pool), int(os.environ.get('HRF_WGRAD_LANES', '4')))
+        k = min(len(pool), int(os.environ.get('HRF_WGRAD_FLUSH_LANES', os.environ.get('HRF_WGRAD_LANES', '4'))))
         group = os.environ.get('HRF_WGRAD_GROUP', '1') != '0'
         for j in range(k):
             lane = pool[(self._side_i + j) % len(pool)]
