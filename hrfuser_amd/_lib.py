@@ -12,7 +12,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'hrfuser_hip.h')
-LIB_PATH = os.path.join(_HERE, 'libhrfuser_hip.so')
+# HRF_LIB_PATH: another build of the same library (same-box A/B of two kernel versions: tools/gpu_ab_lib.sh)
+LIB_PATH = os.environ.get('HRF_LIB_PATH') or os.path.join(_HERE, 'libhrfuser_hip.so')
 
 def _header_int(name, default):
     m = re.search(r'#define\s+' + name + r'\s+(\d+)', open(HEADER).read())

@@ -48,6 +48,15 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
     __syncthreads();
     scp = sFin - c0; shp = sFin + CB - c0;
   }
+  // the filter taps and the bias join the first batch of global loads (they used to be a round trip of their own behind the
+  // staging barrier)
+  float wr[9];
+  {
+    const int cgw = c0 + (tid & 31);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[k] = a.w[(cgw < a.C ? cgw : c0) * 9 + k];
+  }
+  const float bv0 = a.bias ? a.bias[c0 + (tid & 31) < a.C ? c0 + (tid & 31) : c0] : 0.f;
   {
     const int c = tid & 31, cg = c0 + c;
     const bool cv = cg < a.C;
@@ -78,10 +87,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
   __syncthreads();
   const int c = tid & 31, cg = c0 + c, rg = tid >> 5;
   const bool cv = cg < a.C;
-  float wr[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) wr[k] = cv ? a.w[cg * 9 + k] : 0.f;
-  const float bv = (a.bias && cv) ? a.bias[cg] : 0.f;
+  const float bv = cv ? bv0 : 0.f;
   // S=1: thread = one output row of 16; S=2: 8 row-groups over 4 rows -> half rows of 8
   const int row = S == 1 ? rg : (rg >> 1);
   const int xbeg = S == 1 ? 0 : (rg & 1) * 8, xcnt = S == 1 ? 16 : 8;
@@ -155,6 +161,22 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs
     __syncthreads();
     cAp = sFin - c0; cBp = sFin + CB - c0; cCp = sFin + 2 * CB - c0;
   }
+  // everything the epilogue needs from memory is requested with the first batch of loads: the filter taps, the producer's
+  // affine, and this thread's row of raw producer outputs / previous dx values (they were a round trip behind the barrier)
+  const int r = tid >> 5;                                 // input row within tile (0..7)
+  float wr[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wr[k] = a.w[(cv ? cg : c0) * 9 + k];
+  float sc = 1.f, sh = 0.f;
+  if (a.epi == 1) { sc = a.tf_scale[cv ? cg : c0]; sh = a.tf_shift[cv ? cg : c0]; }
+  const int yi = y0 + r;
+  float pre[TW];                                          // epi 1: raw producer output; else previous dx
+#pragma unroll
+  for (int q = 0; q < TW; ++q) {
+    const bool ok = cv && yi < a.H && x0 + q < a.W;
+    const long o = ok ? (((long)b * a.H + yi) * a.W + x0 + q) * a.C + cg : 0;
+    pre[q] = a.epi == 1 ? a.xraw[o] : (a.accumulate ? a.dx[o] : 0.f);
+  }
   {
     const bool bnb = a.cA != nullptr;
     float ca = 1.f, cb = 0.f, cc = 0.f;
@@ -183,24 +205,10 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs
     }
   }
   __syncthreads();
-  const int r = tid >> 5;                                 // input row within tile (0..7)
-  float wr[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) wr[k] = cv ? a.w[cg * 9 + k] : 0.f;
-  float sc = 1.f, sh = 0.f;
-  if (a.epi == 1 && cv) { sc = a.tf_scale[cg]; sh = a.tf_shift[cg]; }
-  const int yi = y0 + r;
   float s1 = 0.f, s2 = 0.f;
   float wacc[WG ? 10 : 1];
 #pragma unroll
   for (int k = 0; k < (WG ? 10 : 1); ++k) wacc[k] = 0.f;
-  float pre[TW];                                          // epi 1: raw producer output; else previous dx
-#pragma unroll
-  for (int q = 0; q < TW; ++q) {
-    const bool ok = cv && yi < a.H && x0 + q < a.W;
-    const long o = ok ? (((long)b * a.H + yi) * a.W + x0 + q) * a.C + cg : 0;
-    pre[q] = a.epi == 1 ? a.xraw[o] : (a.accumulate ? a.dx[o] : 0.f);
-  }
 #pragma unroll
   for (int q = 0; q < TW; ++q) {
     const int xi = x0 + q;
