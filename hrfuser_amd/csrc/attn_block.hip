@@ -86,6 +86,19 @@ __device__ __forceinline__ void acc_bias(const float* bias, int n0, int N, int l
   }
 }
 
+// acc_bias from a staged LDS vector: acc[t] = sB[n0 + 16t + 4q .. +3] (zero beyond lim, a multiple of 4)
+template <int NT>
+__device__ __forceinline__ void acc_bias_l(const float* sB, int n0, int lim, int lane, hrf_f4* acc) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int nb = n0 + 16 * t + 4 * q;
+    const hrf_f4 v = hrf_ld4(sB + (nb < lim ? nb : 0));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = nb < lim ? v[r] : 0.f;
+  }
+}
+
 // Stage the 49 rows of a window (zeros for tokens outside the image and for rows 49..63) and LayerNorm them in place.
 // Four lanes cooperate on one token; all global loads of a thread are issued before its first LDS store.
 // `tail` (uniform): the rows are FORMED here - x = x[.] + rs * GELU(sTs[c] * traw[.] + sTs[C + c]), the CrossFFN tail of the
@@ -679,6 +692,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
   __shared__ float sCo[3 * (4 * C)];                       // BatchNorm-backward coefficients of h1 (cA | cB | cC)
   __shared__ float sTs[2 * C];                             // scale | shift of the preceding block's tail BatchNorm
   __shared__ float sTst[4][2 * C];                         // per wave: (sum tail_du | sum tail_du * tail_raw)
+  __shared__ __attribute__((aligned(16))) float sB3[3][(C + 3) & ~3];   // bq | bk | bv (pads zero)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 15, q = lane >> 4;
   const int win = blockIdx.x;
@@ -690,39 +704,22 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
     sPix[tid] = px; sReal[tid] = px >= 0 ? 1.f : 0.f;
   }
   AB_T(0);
-  // zero: the tiles whose pad rows / columns are read (rows 49..63, pitch column), the dS plane
-  for (int e = tid; e < 8 * TILE + 32 + (cross ? TILE : 0); e += 256) sX[e] = 0.f;
-  __syncthreads();
   const int tok0 = 16 * wave, tok = tok0 + i;
-  const int pix = sPix[tok];
+  const int pix = tok < NTOK ? ab_tok_pixel(a, b, wy, wx, tok) : -1;   // (== sPix[tok]; computed so that no load waits for LDS)
   const long pc = pix >= 0 ? pix : 0;
   const bool tokv = pix >= 0;
 
-  AB_T(1);
-  // ---- the one batch of global loads: weights, parameters, incoming gradients, source rows
+  // ---- the first batch of global loads goes out BEFORE the tiles are zeroed (it used to queue behind the zeroing and its
+  // barrier): incoming gradients, source rows, dy1 operands, the scalars of later phases; the q / k / v / out weights too
+  // where the register budget allows (WE)
   hrf_f4 gx[CT];                                                    // d/d(out row), this lane's 4-channel groups
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
     const int nb = 16 * t + 4 * q;
     gx[t] = ld_sel(16 * (t + 1) <= C, a.gout, pc * C + nb, tokv ? C - nb : 0);
   }
-  if (ffn) stage_weight<C, PW>(a.w1, N1, sW1);
-  stage_weight<C, PW>(a.wo, C, sWo);
-  stage_weight<C, PW>(a.wq, C, sWq);
-  stage_weight<C, PW>(a.wk, C, sWk);
-  stage_weight<C, PW>(a.wv, C, sWv);
-  for (int e = tid; e < HEADS * 176; e += 256) { const int h = e / 176, k = e - h * 176; sT[e] = k < 169 ? a.rpb[k * HEADS + h] : 0.f; }
-  for (int e = tid; e < C; e += 256) {
-    sGam[0][e] = ffn ? a.ln2_g[e] : 0.f; sBet[0][e] = ffn ? a.ln2_b[e] : 0.f;
-    sGam[1][e] = a.lnq_g[e]; sBet[1][e] = a.lnq_b[e];
-    sGam[2][e] = a.lnkv_g[e]; sBet[2][e] = a.lnkv_b[e];
-  }
-  for (int e = tid; e < 4 * 3 * 2 * C; e += 256) (&sPar[0][0][0])[e] = 0.f;
-  if (tail) for (int e = tid; e < C; e += 256) { sTs[e] = a.tail_scale[e]; sTs[C + e] = a.tail_shift[e]; }
-  if (ffn) {
-    if (bf.gstats != nullptr) hrf_bn_bfin_onload(bf, sCo, sCo + N1, sCo + 2 * N1, tid, 256, blockIdx.x == 0);
-    else for (int e = tid; e < N1; e += 256) { sCo[e] = a.cA1[e]; sCo[N1 + e] = a.cB1[e]; sCo[2 * N1 + e] = a.cC1[e]; }
-  }
+  const float rs_out = (a.rowscale != nullptr ? a.rowscale[pc / a.rows_per_sample] : 1.f) * a.mscale;
+  const float rs_tail = (tail && a.tail_rowscale != nullptr) ? a.tail_rowscale[b] : 1.f;
   constexpr bool EARLY = C <= 18;                                   // register budget: dy1 operands join the first batch
   constexpr int NHG = EARLY ? (NTOK * (N1 / 4) + 255) / 256 : 1;
   hrf_f4 hdu[NHG], hh1[NHG];
@@ -731,31 +728,76 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
     for (int u = 0; u < NHG; ++u) {
       const int e = tid + 256 * u, ec = e < NTOK * (N1 / 4) ? e : 0;
       const int j = ec / (N1 / 4), n = 4 * (ec - j * (N1 / 4));
-      const long pp = sPix[j] >= 0 ? sPix[j] : 0;
+      const int px = ab_tok_pixel(a, b, wy, wx, j);
+      const long pp = px >= 0 ? px : 0;
       hdu[u] = hrf_ld4(a.du1 + pp * N1 + n); hh1[u] = hrf_ld4(a.h1 + pp * N1 + n);
     }
   }
-  {
-    // raw rows of x' (-> sO), the query source (-> sX) and the key/value source (-> sXkv): loads first, stores after
-    constexpr int NE = (NTOK * C + 255) / 256;
-    float v2[NE], vq[NE], vk[NE];
+  // raw rows of x' (-> sO), the query source (-> sX) and the key/value source (-> sXkv)
+  constexpr int NE = (NTOK * C + 255) / 256;
+  float v2[NE], vq[NE], vk[NE];
 #pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      const int e = tid + 256 * u, ec = e < NTOK * C ? e : 0;
-      const int j = ec / C, c = ec - j * C;
-      const int px = sPix[j];
-      const long o = (long)(px >= 0 ? px : 0) * C + c;
-      v2[u] = ffn ? a.out[o] : 0.f; vq[u] = a.xq[o]; vk[u] = cross ? a.xkv[o] : 0.f;
-      if (px < 0) { v2[u] = 0.f; vq[u] = 0.f; vk[u] = 0.f; }
+  for (int u = 0; u < NE; ++u) {
+    const int e = tid + 256 * u, ec = e < NTOK * C ? e : 0;
+    const int j = ec / C, c = ec - j * C;
+    const int px = ab_tok_pixel(a, b, wy, wx, j);
+    const long o = (long)(px >= 0 ? px : 0) * C + c;
+    v2[u] = ffn ? a.out[o] : 0.f; vq[u] = a.xq[o]; vk[u] = cross ? a.xkv[o] : 0.f;
+    if (px < 0) { v2[u] = 0.f; vq[u] = 0.f; vk[u] = 0.f; }
+  }
+  constexpr bool WE = C <= 18;                                      // C * PW / 4 <= 256: one 16-byte group per thread and weight
+  hrf_f4 wreg[WE ? 4 : 1];
+  if (WE) {
+    const int n = tid / (PW / 4), kb = 4 * (tid - n * (PW / 4));
+    const bool in = tid < C * (PW / 4);
+    const long off = in ? (long)n * C + kb : 0;
+    const int kval = in ? C - kb : 0;
+    wreg[0] = ld_sel(kb + 4 <= C, a.wo, off, kval); wreg[1] = ld_sel(kb + 4 <= C, a.wq, off, kval);
+    wreg[2] = ld_sel(kb + 4 <= C, a.wk, off, kval); wreg[3] = ld_sel(kb + 4 <= C, a.wv, off, kval);
+  }
+  // zero: the tiles whose pad rows / columns are read (rows 49..63, pitch column), the dS plane
+  for (int e = tid; e < 8 * TILE + 32 + (cross ? TILE : 0); e += 256) sX[e] = 0.f;
+  __syncthreads();
+
+  AB_T(1);
+  // ---- weights, parameters
+  if (ffn) stage_weight<C, PW>(a.w1, N1, sW1);
+  if (WE) {
+    if (tid < C * (PW / 4)) {
+      const int n = tid / (PW / 4), kb = 4 * (tid - n * (PW / 4));
+      hrf_st4(sWo + n * PW + kb, wreg[0]); hrf_st4(sWq + n * PW + kb, wreg[1]);
+      hrf_st4(sWk + n * PW + kb, wreg[2]); hrf_st4(sWv + n * PW + kb, wreg[3]);
     }
+  } else {
+    stage_weight<C, PW>(a.wo, C, sWo);
+    stage_weight<C, PW>(a.wq, C, sWq);
+    stage_weight<C, PW>(a.wk, C, sWk);
+    stage_weight<C, PW>(a.wv, C, sWv);
+  }
+  for (int e = tid; e < HEADS * 176; e += 256) { const int h = e / 176, k = e - h * 176; sT[e] = k < 169 ? a.rpb[k * HEADS + h] : 0.f; }
+  for (int e = tid; e < C; e += 256) {
+    sGam[0][e] = ffn ? a.ln2_g[e] : 0.f; sBet[0][e] = ffn ? a.ln2_b[e] : 0.f;
+    sGam[1][e] = a.lnq_g[e]; sBet[1][e] = a.lnq_b[e];
+    sGam[2][e] = a.lnkv_g[e]; sBet[2][e] = a.lnkv_b[e];
+  }
+  for (int e = tid; e < 3 * PW; e += 256) {                         // q / k / v biases of the recomputed projections
+    const int which = e / PW, c = e - which * PW;
+    const float* bp = which == 0 ? a.bq : (which == 1 ? a.bk : a.bv);
+    sB3[which][c] = *((bp != nullptr && c < C) ? bp + c : g_zero4);
+  }
+  for (int e = tid; e < 4 * 3 * 2 * C; e += 256) (&sPar[0][0][0])[e] = 0.f;
+  if (tail) for (int e = tid; e < C; e += 256) { sTs[e] = a.tail_scale[e]; sTs[C + e] = a.tail_shift[e]; }
+  if (ffn) {
+    if (bf.gstats != nullptr) hrf_bn_bfin_onload(bf, sCo, sCo + N1, sCo + 2 * N1, tid, 256, blockIdx.x == 0);
+    else for (int e = tid; e < N1; e += 256) { sCo[e] = a.cA1[e]; sCo[N1 + e] = a.cB1[e]; sCo[2 * N1 + e] = a.cC1[e]; }
+  }
 #pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      const int e = tid + 256 * u;
-      if (e < NTOK * C) {
-        const int j = e / C, o = j * PC + (e - j * C);
-        sO[o] = v2[u]; sX[o] = vq[u];
-        if (cross) sXkv[o] = vk[u];
-      }
+  for (int u = 0; u < NE; ++u) {
+    const int e = tid + 256 * u;
+    if (e < NTOK * C) {
+      const int j = e / C, o = j * PC + (e - j * C);
+      sO[o] = v2[u]; sX[o] = vq[u];
+      if (cross) sXkv[o] = vk[u];
     }
   }
   AB_T(2);
@@ -840,7 +882,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
   AB_T(4);
   // dy rows = gx * dropout mask * scales  (the out_proj output enters the residual through Dropout / DropPath)
   {
-    const float rs = (a.rowscale != nullptr ? a.rowscale[pc / a.rows_per_sample] : 1.f) * a.mscale;
+    const float rs = rs_out;
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       const int nb = 16 * t + 4 * q;
@@ -875,7 +917,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
   {
     hrf_f4 acc[CT];
     auto proj = [&](const float* sW, const float* bias, const float* xh, int ln, float* dstT, float mul) {
-      acc_bias<CT>(bias, 0, C, lane, acc);
+      acc_bias_l<CT>(bias, 0, PW, lane, acc);
       const bool real = sReal[tok] != 0.f;
       constexpr int NS = (C + 15) / 16;
 #pragma unroll
@@ -902,9 +944,9 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) dstT[tok * PC + n] = acc[t][r] * mul; }
     };
-    proj(sWq, a.bq, sX, 1, sQ, a.scale);
-    proj(sWk, a.bk, sXk, lkv, sK, 1.f);
-    proj(sWv, a.bv, sXk, lkv, sV, 1.f);
+    proj(sWq, sB3[0], sX, 1, sQ, a.scale);
+    proj(sWk, sB3[1], sXk, lkv, sK, 1.f);
+    proj(sWv, sB3[2], sXk, lkv, sV, 1.f);
   }
   __syncthreads();
 
@@ -1100,7 +1142,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
     }
     if (tail) {
       // x = tail_res + rs * GELU(u): tail_du = dx * rs * GELU'(u) and its BatchNorm moments (what hrf_act_bwd computed)
-      const float rs = a.tail_rowscale != nullptr ? a.tail_rowscale[b] : 1.f;
+      const float rs = rs_tail;
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         const int nb = 16 * t + 4 * q;

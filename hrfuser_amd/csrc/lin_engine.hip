@@ -26,7 +26,12 @@ namespace {
 constexpr int LIN_BWD_EPI_MAX_NT = 5;
 // forward: 5 tiles per wave at most (HRFuser-B: 56.3 -> 55.5 ms; 9 tiles starve the launch of waves)
 constexpr int LIN_FWD_MAX_NT = 5;
-constexpr int SB = 2;     // 16-deep K slabs whose loads are issued before the first use
+// 16-deep K slabs whose loads are issued before the first use (one dependent round trip per batch).  Same-box A/B of the
+// captured HRFuser-T step: 2 slabs 13.27 ms, 3 slabs 13.06 ms, 4 slabs (tiles <= 2) 13.35 ms (registers).
+#ifndef HRF_LIN_SB
+#define HRF_LIN_SB 3
+#endif
+constexpr int SB = HRF_LIN_SB;
 
 // Out-of-range fragment groups are read from this zero block instead of being masked after the
 // load: `cond ? loaded : 0` makes the compiler sink the load into an exec-masked branch with its own
