@@ -373,6 +373,7 @@ struct AffineActResArgs {
   int C;
   hrf_bn_fin_t fin1;
   hrf_bn_fin_t fin2;
+  int vec4;
 };
 __global__ __launch_bounds__(256) void affine_act_res_kernel(HrfGroup<AffineActResArgs> grp) {
   const AffineActResArgs& pa_ = grp.sel();
@@ -397,6 +398,40 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(HrfGroup<AffineActR
   if (fin1.stats != nullptr) { hrf_bn_fin_onload(fin1, sFin, sFin + HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0); sc1 = sFin; sh1 = sFin + HRF_FIN_MAXC; }
   if (fin2.stats != nullptr) { hrf_bn_fin_onload(fin2, sFin + 2 * HRF_FIN_MAXC, sFin + 3 * HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0); sc2 = sFin + 2 * HRF_FIN_MAXC; sh2 = sFin + 3 * HRF_FIN_MAXC; }
   if (fin1.stats != nullptr || fin2.stats != nullptr) __syncthreads();
+  if (pa_.vec4) {
+    // 16-byte path (C % 4 == 0, every tensor 16-byte aligned): a thread owns 4 consecutive channels of a row; the channel
+    // group advances by a constant per iteration (no 64-bit modulo per element - the dword loop below spends more
+    // instructions on `i % C` than on the arithmetic - and a quarter of the memory instructions)
+    const long n4 = total >> 2, stride = (long)gridDim.x * 256;
+    const int C4 = C >> 2, dc = (int)(stride % C4);
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int c4 = (int)(i % C4);
+    for (; i < n4; i += stride) {
+      const int c = 4 * c4;
+      const hrf_f4 yv = hrf_ld4(y1 + 4 * i);
+      hrf_f4 rv = hrf_f4{0.f, 0.f, 0.f, 0.f}, y2v = hrf_f4{0.f, 0.f, 0.f, 0.f};
+      if (res) rv = hrf_ld4(res + 4 * i);
+      if (y2) y2v = hrf_ld4(y2 + 4 * i);
+      const float rsc = (act_first && rowscale) ? rowscale[((4 * i) / C) / rows_per_sample] : 1.f;
+      hrf_f4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = fmaf(yv[e], sc1[c + e], sh1[c + e]);
+        if (act_first) {
+          v = hrf_act(act, v) * rsc;
+          if (res) v += rv[e];
+        } else {
+          if (res) v += rv[e];
+          if (y2) v += fmaf(y2v[e], sc2[c + e], sh2[c + e]);
+          v = hrf_act(act, v);
+        }
+        o[e] = v;
+      }
+      hrf_st4(out + 4 * i, o);
+      c4 += dc; if (c4 >= C4) c4 -= C4;
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     float v = fmaf(y1[i], sc1[c], sh1[c]);
@@ -581,6 +616,83 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(HrfGroup<ActBwdArgs> grp) 
       if (st1) hrf_atomic_add(&sacc[C + cj], a1[j]);
       if (st2) hrf_atomic_add(&sacc[2 * C + cj], a2[j]);
       if (st3) hrf_atomic_add(&sacc[3 * C + cj], a3[j]);
+    }
+  }
+  __syncthreads();
+  const size_t cp = (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
+  for (int cc = threadIdx.x; cc < C; cc += 256) {
+    const double s = (double)sacc[cc];
+    if (st1) { hrf_atomic_add(&st1[cp + cc], s); hrf_atomic_add(&st1[cp + C + cc], (double)sacc[C + cc]); }
+    if (st2) { hrf_atomic_add(&st2[cp + cc], s); hrf_atomic_add(&st2[cp + C + cc], (double)sacc[2 * C + cc]); }
+    if (st3) { hrf_atomic_add(&st3[cp + cc], s); hrf_atomic_add(&st3[cp + C + cc], (double)sacc[3 * C + cc]); }
+  }
+}
+
+// 16-byte variant (C % 4 == 0, C <= 1024, every tensor 16-byte aligned): a thread keeps FOUR consecutive channels for its
+// whole life, 1024/C rows per pass - a quarter of the memory instructions of the dword kernel, which left the 256-channel
+// stem launches at 3 TB/s.
+__global__ __launch_bounds__(256) void act_bwd_v4_kernel(HrfGroup<ActBwdArgs> grp) {
+  const ActBwdArgs& pa_ = grp.sel();
+  const float* dout = pa_.dout;
+  const float* out = pa_.out;
+  const float* y1 = pa_.y1;
+  const float* rowscale = pa_.rowscale;
+  const int rows_per_sample = pa_.rows_per_sample, mode = pa_.mode, C = pa_.C;
+  float* g = pa_.g;
+  const float* y2 = pa_.y2;
+  const float* y3 = pa_.y3;
+  double* st1 = pa_.st1;
+  double* st2 = pa_.st2;
+  double* st3 = pa_.st3;
+  const long rows = pa_.rows;
+  HRF_DYN_SMEM(float, sacc);                              // [4*C]: sum g, sum g*y1, sum g*y2, sum g*y3
+  for (int i = threadIdx.x; i < 4 * C; i += 256) sacc[i] = 0.f;
+  const int cw = C >> 2, R = 256 / cw;
+  const int r = threadIdx.x / cw, c = 4 * (threadIdx.x - r * cw);
+  const bool active = r < R;
+  hrf_f4 a0 = hrf_f4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  float scv[4], shv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    scv[e] = 1.f; shv[e] = 0.f;
+    if (mode == 1) { scv[e] = pa_.sc[active ? c + e : 0]; shv[e] = pa_.sh[active ? c + e : 0]; }
+  }
+  const bool need1 = mode == 1 || st1 != nullptr;
+#pragma unroll 2
+  for (long row0 = (long)blockIdx.x * R; row0 < rows; row0 += (long)gridDim.x * R) {
+    const long row = row0 + r;
+    const bool ok = active && row < rows;
+    float rs = 1.f;
+    if (rowscale) rs = rowscale[(ok ? row : 0) / rows_per_sample];
+    const long idx = ok ? row * C + c : 0;
+    hrf_f4 v = hrf_ld4(dout + idx);
+    hrf_f4 ov = hrf_f4{1.f, 1.f, 1.f, 1.f}, y1v = hrf_f4{0.f, 0.f, 0.f, 0.f}, y2v = y1v, y3v = y1v;
+    if (mode == 0) ov = hrf_ld4(out + idx);
+    if (need1) y1v = hrf_ld4(y1 + idx);
+    if (st2) y2v = hrf_ld4(y2 + idx);
+    if (st3) y3v = hrf_ld4(y3 + idx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = v[e];
+      if (mode == 0) t = ov[e] > 0.f ? t : 0.f;
+      else if (mode == 1) t *= hrf_gelu_grad(fmaf(y1v[e], scv[e], shv[e])) * rs;
+      t = ok ? t : 0.f;
+      v[e] = t;
+      a0[e] += t;
+      a1[e] = fmaf(t, y1v[e], a1[e]);
+      a2[e] = fmaf(t, y2v[e], a2[e]);
+      a3[e] = fmaf(t, y3v[e], a3[e]);
+    }
+    if (ok) hrf_st4(g + idx, v);
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hrf_atomic_add(&sacc[c + e], a0[e]);
+      if (st1) hrf_atomic_add(&sacc[C + c + e], a1[e]);
+      if (st2) hrf_atomic_add(&sacc[2 * C + c + e], a2[e]);
+      if (st3) hrf_atomic_add(&sacc[3 * C + c + e], a3[e]);
     }
   }
   __syncthreads();
@@ -1006,6 +1118,13 @@ __global__ void adamw_tick_kernel(float* state, float b1, float b2) {
 
 static int g_pw_knob[4] = {0, 0, 0, 0};      // tuning aids (hrf_debug_knob keys 16..19)
 
+// every non-null pointer 16-byte aligned (the 16-byte paths of the elementwise kernels)
+inline bool hrf_aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr,
+                          const void* e = nullptr, const void* f = nullptr) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+           reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f)) & 15) == 0;
+}
+
 inline int ew_grid(long total) {
   long g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -1110,8 +1229,9 @@ extern "C" int hrf_affine_act_res(const float* y1, const float* sc1, const float
     else if (nch <= 10) { HRF_FT(10); } else if (nch <= 20) { HRF_FT(20); } else { HRF_FT(40); }
     return hrf_check_launch();
   }
-  HRF_LAUNCH_G(affine_act_res_kernel, dim3(ew_grid(total)), dim3(256), 0, stream,
-               (AffineActResArgs{y1, sc1, sh1, y2, sc2, sh2, res, rowscale, rows_per_sample, act, act_first, out, total, C, f1, f2}));
+  const int vec4 = (C % 4 == 0 && hrf_aligned16(y1, y2, res, out)) ? 1 : 0;
+  HRF_LAUNCH_G(affine_act_res_kernel, dim3(ew_grid(vec4 ? total / 4 : total)), dim3(256), 0, stream,
+               (AffineActResArgs{y1, sc1, sh1, y2, sc2, sh2, res, rowscale, rows_per_sample, act, act_first, out, total, C, f1, f2, vec4}));
   if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(out, (int)rows, C, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();
 }
@@ -1133,8 +1253,16 @@ extern "C" int hrf_act_bwd(const float* dout, const float* out, const float* y1,
   HRF_GROUP_CALL();
   if (rows * C <= 0) return HRF_OK;
   if (C > 768) return HRF_ERR_ARG;
+  const int passes = g_pw_knob[1] > 0 ? g_pw_knob[1] : 4;                          // passes per block
+  if (C % 4 == 0 && C >= 16 && C <= 1024 && g_pw_knob[2] != 1 && hrf_aligned16(dout, out, y1, y2, y3, g)) {
+    int grid = hrf_cdiv(hrf_cdiv(rows, 256 / (C / 4)), passes);
+    if (grid > 2048) grid = 2048;
+    HRF_LAUNCH_G(act_bwd_v4_kernel, dim3(grid), dim3(256), (unsigned)(4 * C * sizeof(float)), stream,
+                 (ActBwdArgs{dout, out, y1, sc, sh, rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, rows, C}));
+    return hrf_check_launch();
+  }
   const int R = C <= 256 ? 256 / C : 1;
-  int grid = hrf_cdiv(hrf_cdiv(rows, R), g_pw_knob[1] > 0 ? g_pw_knob[1] : 4);   // passes per block
+  int grid = hrf_cdiv(hrf_cdiv(rows, R), passes);
   if (grid > 2048) grid = 2048;
   HRF_LAUNCH_G(act_bwd_kernel, dim3(grid), dim3(256), (unsigned)(4 * C * sizeof(float)), stream,
                (ActBwdArgs{dout, out, y1, sc, sh, rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, rows, C}));

@@ -480,6 +480,22 @@ def run_pointwise(backend):
         assert r(gk, gref) < TOL
         for st_, y_ in ((sa, ya), (sb, yb), (sc3, yc)):
             assert r(fold(st_)[:Ca], gref.sum(0)) < TOL and r(fold(st_)[Ca:], (gref * y_.double()).sum(0)) < TOL
+    # ---- the same two kernels on tensors that are NOT 16-byte aligned (C % 4 == 0 but the dword path must be taken)
+    def unal(t):
+        buf = torch.zeros(t.numel() + 1, device=dev)
+        buf[1:] = t.reshape(-1).to(dev)
+        return buf[1:].view(t.shape)
+    rows, Ca = 45, 20
+    dd, oo, ya = rn(rows, Ca), rn(rows, Ca), rn(rows, Ca)
+    gk = unal(torch.zeros(rows, Ca))
+    sa = zstat(Ca, dev)
+    L.hrf_act_bwd(unal(dd), unal(oo), unal(ya), None, None, None, 1, 0, gk, None, None, sa, None, None, rows, Ca, s)
+    gref = (dd * (oo > 0)).double()
+    assert gk.data_ptr() % 16 != 0 and r(gk, gref) < TOL and r(fold(sa)[Ca:], (gref * ya.double()).sum(0)) < TOL
+    scu, shu = torch.rand(Ca, generator=g) + 0.5, rn(Ca)
+    ou = unal(torch.zeros(rows, Ca))
+    L.hrf_affine_act_res(unal(dd), D(scu), D(shu), None, None, None, unal(oo), None, 1, 1, 0, ou, rows, Ca, None, 0.0, None, None, s)
+    assert r(ou, F.relu(dd * scu + shu + oo)) < TOL
     # ---- cross-resolution exchange + bilinear adjoint (x2, x4, non-integer ratio)
     B, H, W, C = 2, 12, 20, 10
     x0 = rn(B, H, W, C).requires_grad_(True)
