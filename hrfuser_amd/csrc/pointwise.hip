@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(HrfGroup<AffineActR
     }
     return;
   }
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  auto body = [&](auto i) {
     const int c = (int)(i % C);
     float v = fmaf(y1[i], sc1[c], sh1[c]);
     if (act_first) {
@@ -445,6 +445,11 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(HrfGroup<AffineActR
       v = hrf_act(act, v);
     }
     out[i] = v;
+  };
+  if (total <= 0x7fffffffL) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) body(i);
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) body(i);
   }
 }
 
@@ -731,13 +736,19 @@ __global__ __launch_bounds__(256) void scale_add_kernel(HrfGroup<ScaleAddArgs> g
   float* out = pa_.out;
   long total = pa_.total;
   int C = pa_.C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  // (index arithmetic in 32 bits whenever the tensor allows it: a 64-bit division is ~100 instructions on this ISA)
+  auto body = [&](auto i) {
     float v = y[i] * mscale;
     if (mask) v *= mask[i];
     if (rowscale) v *= rowscale[(i / C) / rows_per_sample];
     if (res) v += res[i];
     if (res2) v += res2[i];
     out[i] = v;
+  };
+  if (total <= 0x7fffffffL) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) body(i);
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) body(i);
   }
 }
 
@@ -774,10 +785,12 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(HrfGroup<FuseArgs> grp) {
     }
   }
   if (any) __syncthreads();
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  // (index arithmetic in 32 bits whenever the tensor allows it: four 64-bit divisions per element cost more than the sum)
+  auto body = [&](auto i) {
     const int c = (int)(i % a.C);
-    const long pix = i / a.C;
-    const int x = (int)(pix % a.W), y = (int)((pix / a.W) % a.H), b = (int)(pix / ((long)a.W * a.H));
+    const auto pix = i / a.C;
+    const auto prow = pix / a.W;
+    const int x = (int)(pix - prow * a.W), b = (int)(prow / a.H), y = (int)(prow - (decltype(prow))b * a.H);
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -803,6 +816,11 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(HrfGroup<FuseArgs> grp) {
       }
     }
     a.out[i] = fmaxf(acc, 0.f);
+  };
+  if (total <= 0x7fffffffL) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) body(i);
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) body(i);
   }
 }
 
