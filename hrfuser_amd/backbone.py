@@ -238,11 +238,13 @@ class Engine:
 
     # ---- parameter-gradient slots of the fused attention blocks (runtime.attn_block): every window's workgroup writes
     # the complete partial sums of its window with plain stores (no atomics, deterministic), hrf_fold_slots adds them up
-    def fs_register(self, key, nslots, entries):
+    def fs_register(self, key, nslots, entries, rpb=None, heads=0):
         """Called by the forward of a fused layer: slot layout {name: offset, '_n': slot size} of layer `key`;
-        entries = [(name, parameter, first element, count)]."""
+        entries = [(name, parameter, first element, count)].  `rpb` (a trainable relative-position-bias table): the layer's dS
+        planes [nslots][heads][49][49] live in the same arena, behind its slots, and hrf_rpb_grad_all gathers every layer's
+        table gradient in one launch (rpb_grad_now)."""
         lay = self.fs_layers.get(key)
-        rg = tuple(bool(p.requires_grad) for _, p, _, _ in entries)      # freezing / unfreezing a parameter re-maps its slot
+        rg = tuple(bool(p.requires_grad) for _, p, _, _ in entries) + (rpb is not None, heads)   # freezing / unfreezing re-maps
         if lay is None or lay['nslots'] != nslots or lay['rg'] != rg:
             offs, idx, o = {}, [], 0
             for name, p, first, cnt in entries:
@@ -252,7 +254,7 @@ class Engine:
                            else torch.full((cnt,), -1, dtype=torch.int32))
                 o += cnt
             offs['_n'] = o
-            lay = self.fs_layers[key] = dict(nslots=nslots, offs=offs, map=torch.cat(idx), n=o, rg=rg)
+            lay = self.fs_layers[key] = dict(nslots=nslots, offs=offs, map=torch.cat(idx), n=o, rg=rg, rpb=rpb, heads=heads)
             self.fs_sig = None
         self.fs_step.append(key)
         return lay['offs']
@@ -263,6 +265,7 @@ class Engine:
         keys = tuple(self.fs_step)
         self.fs_step = []
         self.fs_used = list(keys)
+        self._rpb_todo = bool(keys)
         self.fs_tables(keys)
 
     def fs_tables(self, keys):
@@ -271,7 +274,8 @@ class Engine:
         if not keys or keys == self.fs_sig:
             return
         seg, maps, off, moff = [], [], 0, 0
-        self.fs_off = {}
+        rseg, self.fs_rpb_geo, self.fs_rpb_bytes = [], (0, 0), 0.0
+        self.fs_off, self.fs_plane_off = {}, {}
         for k in keys:
             lay = self.fs_layers[k]
             self.fs_off[k] = off
@@ -279,15 +283,40 @@ class Engine:
             maps.append(lay['map'])
             off += lay['nslots'] * lay['n']
             moff += lay['n']
+            if lay['rpb'] is not None:                         # dS planes of the layer + its row of hrf_rpb_grad_all's table
+                off = (off + 3) & ~3
+                self.fs_plane_off[k] = off
+                acc, cs = self.grad_acc(lay['rpb'])
+                rseg.append([off, lay['nslots'], lay['heads'], acc.data_ptr(), cs])
+                off += lay['nslots'] * lay['heads'] * 49 * 49
+                self.fs_rpb_geo = (max(self.fs_rpb_geo[0], lay['nslots']), max(self.fs_rpb_geo[1], lay['heads']))
+                self.fs_rpb_bytes += 4.0 * lay['nslots'] * lay['heads'] * 49 * 49
         if self.fs_arena is None or self.fs_arena.numel() < off:
             self.fs_arena = torch.empty(off, device=self.device, dtype=torch.float32)
         self.fs_seg = torch.tensor(seg, dtype=torch.long).to(self.device)
         self.fs_map = torch.cat(maps).to(self.device)
+        self.fs_rpb = torch.tensor(rseg, dtype=torch.long).to(self.device) if rseg else None
         self.fs_maxn = max(self.fs_layers[k]['n'] for k in keys)
         self.fs_sig = keys
 
     def fs_buffer(self, key):
         return self.fs_arena.data_ptr() + 4 * self.fs_off[key]
+
+    def fs_plane(self, key):
+        """dS planes of fused layer `key` (written by hrf_attn_block_bwd, read by rpb_grad_now)."""
+        return self.fs_arena.data_ptr() + 4 * self.fs_plane_off[key]
+
+    def rpb_pending(self):
+        """True between the start of a backward pass with fused layers (fs_prepare) and its rpb_grad_now."""
+        return self.__dict__.get('_rpb_todo', False) and getattr(self, 'fs_rpb', None) is not None
+
+    def rpb_grad_now(self, L, stream):
+        """relative_position_bias_table.grad of every fused layer of this backward pass, gathered from the dS planes in ONE
+        launch (a leaf of the weight-gradient phase; it adds into the replicated accumulators, so it precedes fold_grads)."""
+        if self.rpb_pending():
+            L.hrf_rpb_grad_all(self.fs_arena, self.fs_rpb, int(self.fs_rpb.shape[0]), self.fs_rpb_geo[0], self.fs_rpb_geo[1], stream)
+            self.ps_dirty = True
+            self._rpb_todo = False
 
     # ---- per-step random pools: ONE Bernoulli launch (per drop probability) and one DropPath draw per step
     # instead of one torch RNG kernel chain per fusion block (every graph node costs ~5 us of host time)
@@ -1178,7 +1207,8 @@ class HipModule(nn.Module, EngineOwner):
         such tensor alive for as long as it exists, so a later eager step or a second captured signature can rebind the
         engine's attributes (new tensors) without the replays of THIS entry reading freed or reused memory."""
         ent.refs = getattr(ent, 'refs', None) or []
-        for t in (eng.fs_arena, getattr(eng, 'fs_seg', None), getattr(eng, 'fs_map', None), eng.ps_scratch, eng.ps_map):
+        for t in (eng.fs_arena, getattr(eng, 'fs_seg', None), getattr(eng, 'fs_map', None), getattr(eng, 'fs_rpb', None),
+                  eng.ps_scratch, eng.ps_map):
             if t is not None:
                 ent.refs.append(t)
         ent.refs.extend(eng.__dict__.get('_rng_pool', {}).values())

@@ -1265,7 +1265,7 @@ int launch_bwd(const hrf_attn_block_t& a, const hrf_bn_bfin_t& bf, int nwin, voi
 // Relative-position-bias gradient from the dS planes the backward kernel left in memory (a LEAF of the backward graph:
 // issued with the deferred weight gradients, off the dependency chain): drpb[(yi-yj+6)*13 + (xi-xj+6)][h] += dS[j][i].
 // grid = (window chunks, heads); the planes of a chunk pass through LDS, thread e < 169 owns bin e.
-__global__ __launch_bounds__(256) void rpb_grad_kernel(const float* ds, int nwin, int heads, float* drpb, long copy_stride) {
+__device__ __forceinline__ void rpb_grad_body(const float* ds, int nwin, int heads, float* drpb, long copy_stride) {
   __shared__ float sP[NTOK * NTOK];
   const int h = blockIdx.y, e = threadIdx.x;
   const int dy = e / 13 - 6, dx = e - (e / 13) * 13 - 6;
@@ -1284,7 +1284,19 @@ __global__ __launch_bounds__(256) void rpb_grad_kernel(const float* ds, int nwin
   if (e < 169) hrf_atomic_add(&drpb[(long)(blockIdx.x % HRF_STAT_COPIES) * copy_stride + e * heads + h], acc);
 }
 
-// dst[map[i]] += sum over the slots of one fused layer (blockIdx.y = segment)
+__global__ __launch_bounds__(256) void rpb_grad_kernel(const float* ds, int nwin, int heads, float* drpb, long copy_stride) {
+  rpb_grad_body(ds, nwin, heads, drpb, copy_stride);
+}
+
+// every fused layer of a step in ONE launch (blockIdx.z = layer): seg rows of 5 longs {plane offset (floats) into `planes`,
+// windows, heads, accumulator address, copy_stride}; blocks beyond a layer's heads / windows leave at once
+__global__ __launch_bounds__(256) void rpb_grad_all_kernel(const float* planes, const long* seg) {
+  const long* sg = seg + 5 * blockIdx.z;
+  const int nwin = (int)sg[1], heads = (int)sg[2];
+  if ((int)blockIdx.y >= heads || (int)blockIdx.x >= nwin) return;   // (uniform)
+  rpb_grad_body(planes + sg[0], nwin, heads, reinterpret_cast<float*>(sg[3]), sg[4]);
+}
+
 __global__ __launch_bounds__(256) void fold_slots_kernel(const float* slots, const long* seg, const int* map, float* dst) {
   const long* sg = seg + 5 * blockIdx.y;
   const long base = sg[0], nslots = sg[1], stride = sg[2], n = sg[3], moff = sg[4];
@@ -1343,6 +1355,14 @@ extern "C" int hrf_rpb_grad(const float* ds_plane, int nwin, int heads, float* d
   if (nwin <= 0 || heads <= 0) return HRF_OK;
   const int chunks = nwin < 1024 ? nwin : 1024;                    // one or two windows per workgroup: the kernel is latency-bound
   HRF_LAUNCH(rpb_grad_kernel, dim3(chunks, heads), dim3(256), 0, stream, ds_plane, nwin, heads, drpb, copy_stride);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_rpb_grad_all(const float* planes, const long* seg, int nseg, int max_nwin, int max_heads, void* stream) {
+  if (nseg <= 0 || max_nwin <= 0 || max_heads <= 0) return HRF_OK;
+  if (planes == nullptr || seg == nullptr || nseg > 65535 || max_heads > 65535) return HRF_ERR_ARG;
+  const int chunks = max_nwin < 1024 ? max_nwin : 1024;
+  HRF_LAUNCH(rpb_grad_all_kernel, dim3(chunks, max_heads, nseg), dim3(256), 0, stream, planes, seg);
   return hrf_check_launch();
 }
 

@@ -930,6 +930,13 @@ class Ctx:
         if self._deferred and os.environ.get('HRF_DEBUG_SKIP_WGRAD') == '1':
             self._deferred = []                 # timing experiments only: drops the weight-gradient phase
         eng0 = self.owner._engine()
+        if eng0.rpb_pending():
+            # every attn_block_bwd has left its dS planes: ONE gather launch for all relative-position-bias tables, a leaf of the
+            # weight-gradient phase (52 launches of its own for HRFuser-T before)
+            if self._deferred and self.multi:
+                self._deferred.append((eng0.fs_rpb_bytes, lambda: eng0.rpb_grad_now(self.L, self.stream)))
+            else:
+                eng0.rpb_grad_now(self.L, self.stream)
         if self._deferred and self.multi and eng0.fs_used and os.environ.get('HRF_FOLD_LEAF', '1') != '0':
             # the per-window slots of the fused attention blocks are complete (every attn_block_bwd has run) and their targets
             # in the gradient arena are touched by no other leaf: the fold (370 MB for HRFuser-T) joins the weight-gradient
@@ -1561,7 +1568,8 @@ def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, r
     entries += [('gq', lnq.weight, 0, C), ('btq', lnq.bias, 0, C)]
     if cross:
         entries += [('gkv', lnkv.weight, 0, C), ('btkv', lnkv.bias, 0, C)]
-    offs = eng.fs_register(key, nwin, entries)
+    rpb_one = rpb.requires_grad and os.environ.get('HRF_RPB_ONE', '1') != '0'      # one gather launch per step (0: one per layer)
+    offs = eng.fs_register(key, nwin, entries, rpb if rpb_one else None, heads if rpb_one else 0)
 
     def bwd():
         a = fill()
@@ -1598,12 +1606,12 @@ def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, r
             g, acc = xq.grad_target()
             a.dq, a.dq_acc, a.dq_add_res = P(g), acc, 1
         a.pslot, a.slot_stride = eng.fs_buffer(key), offs['_n']
-        dsp = _new((nwin * heads * 49 * 49,), dev)
-        a.ds_plane = P(dsp)
+        dsp = None if rpb_one else _new((nwin * heads * 49 * 49,), dev)
+        a.ds_plane = eng.fs_plane(key) if rpb_one else P(dsp)
         for nm in ('w1', 'b1', 'g2', 'bt2', 'wo', 'bo', 'wq', 'bq', 'wk', 'bk', 'wv', 'bv', 'gq', 'btq', 'gkv', 'btkv', 'rpb'):
             setattr(a, 'off_' + nm, offs.get(nm, -1))
         L.hrf_attn_block_bwd(a, s)
-        if rpb.requires_grad:                       # leaf: gathered from the dS planes with the deferred weight gradients
+        if rpb.requires_grad and not rpb_one:       # leaf: gathered from the dS planes with the deferred weight gradients
             racc, cs = eng.grad_acc(rpb)
             ctx.side_launch(lambda: L.hrf_rpb_grad(dsp, nwin, heads, racc, cs, ctx.stream), cost=4.0 * dsp.numel())
         if st is not None:

@@ -207,6 +207,10 @@ int hrf_attn_block_bwd_supported(int C, int heads);
 int hrf_attn_block_fwd(const hrf_attn_block_t* p, void* stream);
 int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream);
 int hrf_rpb_grad(const float* ds_plane, int nwin, int heads, float* drpb, long copy_stride, void* stream);
+/* the same gather for EVERY fused layer of a step in one launch: seg = nseg rows of 5 longs on the device {offset (floats) of the
+ * layer's ds_plane in `planes`, windows, heads, address of its drpb accumulator, copy_stride}; max_nwin / max_heads = the
+ * largest of the rows (launch geometry).                                                                               */
+int hrf_rpb_grad_all(const float* planes, const long* seg, int nseg, int max_nwin, int max_heads, void* stream);
 /* dst[map[i]] += sum_{s < nslots} slots[s*slot_stride + i]  (i < n; map[i] < 0: skipped).  One launch folds the slots of
  * every fused layer of a step: seg = nseg rows of 5 longs {slot offset (floats) into `slots`, nslots, slot_stride, n,
  * offset into `map`} on the device.                                                                                  */

@@ -196,6 +196,19 @@ def _run(C, heads, B, H, W, cross, with_ffn, backward, backend, tail=False):
     drpb = torch.zeros(KC * 169 * heads, device=dev)
     L.hrf_rpb_grad(dsp, nwin, heads, drpb, 169 * heads, _lib.stream_ptr())
     assert r(drpb.view(KC, 169, heads).sum(0), msa.relative_position_bias_table.grad) < 1e-4
+    # ---- hrf_rpb_grad_all: the same gather for several layers in one launch (here: this layer at an offset of a common arena,
+    # a second row that is the first half of its windows with its own accumulator, geometry larger than either row needs)
+    arena = torch.zeros(8 + dsp.numel(), device=dev)
+    arena[8:] = dsp
+    acc2 = torch.zeros(2, KC * 169 * heads, device=dev)
+    h1 = max(1, nwin // 2)
+    seg = torch.tensor([[8, nwin, heads, acc2[0].data_ptr(), 169 * heads],
+                        [8, h1, heads, acc2[1].data_ptr(), 169 * heads]], dtype=torch.long).to(dev)
+    L.hrf_rpb_grad_all(arena, seg, 2, nwin + 3, heads + 1, _lib.stream_ptr())
+    want1 = torch.zeros(KC * 169 * heads, device=dev)
+    L.hrf_rpb_grad(dsp, h1, heads, want1, 169 * heads, _lib.stream_ptr())
+    assert r(acc2[0].view(KC, 169, heads).sum(0), msa.relative_position_bias_table.grad) < 1e-4
+    assert r(acc2[1].view(KC, 169, heads).sum(0), want1.view(KC, 169, heads).sum(0)) < 1e-5
 
 
 EDGE = [  # C, heads, B, H, W
