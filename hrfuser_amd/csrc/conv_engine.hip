@@ -1107,6 +1107,9 @@ static int wgrad_dense_launch(int key, const WgradGroup& d, int total_blocks, vo
 
 // ---- grouped weight-gradient launches (see WgradGroup): between begin and end every hrf_conv_bwd_weight call that
 // maps to the pixel-major kernel is queued; end issues them, WGMAX problems of one kernel variant per launch.
+bool hrf_wgrad_collecting() { return g_wg_collect; }
+int hrf_dw_wgt_flush(void* stream);     // dwconv.hip: the depthwise weight gradients queued while collecting
+
 extern "C" int hrf_wgrad_group_begin(void) {
   g_wg_pending.clear();
   g_wg_collect = true;
@@ -1194,5 +1197,6 @@ extern "C" int hrf_wgrad_group_end(void* stream) {
     if (r != HRF_OK) rc = r;
   }
   g_wg_pending.clear();
-  return rc;
+  const int rd = hrf_dw_wgt_flush(stream);
+  return rc != HRF_OK ? rc : rd;
 }

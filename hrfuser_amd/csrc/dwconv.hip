@@ -6,6 +6,8 @@
 // (128 B) and each LDS bank holds exactly one channel: the 3x3 window walks the LDS tile with zero
 // bank conflicts.  The producer BatchNorm+GELU/ReLU is applied ONCE per element while staging the
 // halo tile ("transform on load"), never per tap.
+#include <algorithm>
+#include <vector>
 #include "hrf_common.h"
 #include "hrf_group.h"
 #include "../../include/hrfuser_hip.h"
@@ -287,7 +289,7 @@ struct DwBwdWgtArgs {
 };
 
 template <int S>
-__global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) {
+__device__ __forceinline__ void dw_bwd_wgt_body(const DwBwdWgtArgs& a) {
   constexpr int TH = DwTile<S>::TH, IH = DwTile<S>::IH, IW = DwTile<S>::IW;
   __shared__ float sIn[IH * IW * CB];
   __shared__ float sAcc[8 * 10 * CB];                    // per row-group partials (plain stores, no LDS atomics)
@@ -376,7 +378,53 @@ __global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) {
   }
 }
 
+template <int S>
+__global__ __launch_bounds__(256) void dw_bwd_wgt_kernel(DwBwdWgtArgs a) { dw_bwd_wgt_body<S>(a); }
+
+// Weight gradients are leaves of the backward graph: between hrf_wgrad_group_begin and _end the depthwise ones are queued like
+// the dense ones and issued DWG problems per launch (blockIdx.z = problem; blocks beyond a problem's own grid leave at once):
+// HRFuser-T has 33 of these 10 us launches per step, 8 per lane of the weight-gradient phase.
+constexpr int DWG = 12;
+struct DwWgtGroup { DwBwdWgtArgs p[DWG]; };
+template <int S>
+__global__ __launch_bounds__(256) void dw_bwd_wgt_grp_kernel(DwWgtGroup g) {
+  const DwBwdWgtArgs& a = g.p[blockIdx.z];
+  if ((int)blockIdx.x >= a.tilesX * a.tilesY * a.B || (int)blockIdx.y * CB >= a.C) return;   // (uniform)
+  dw_bwd_wgt_body<S>(a);
+}
+
+struct DwWgtPending { int stride; DwBwdWgtArgs a; };
+std::vector<DwWgtPending> g_dw_pending;
+
 }  // namespace
+
+bool hrf_wgrad_collecting();            // conv_engine.hip: inside hrf_wgrad_group_begin / _end
+
+// called by hrf_wgrad_group_end: issue the queued depthwise weight gradients
+int hrf_dw_wgt_flush(void* stream) {
+  int rc = HRF_OK;
+  for (int stride = 1; stride <= 2; ++stride) {
+    size_t i = 0;
+    while (true) {
+      DwWgtGroup g;
+      int n = 0, gx = 0, gy = 0;
+      for (; i < g_dw_pending.size() && n < DWG; ++i) {
+        if (g_dw_pending[i].stride != stride) continue;
+        const DwBwdWgtArgs& a = g_dw_pending[i].a;
+        g.p[n++] = a;
+        gx = std::max(gx, a.tilesX * a.tilesY * a.B); gy = std::max(gy, hrf_cdiv(a.C, CB));
+      }
+      if (n == 0) break;
+      for (int k = n; k < DWG; ++k) g.p[k] = g.p[0];
+      const dim3 grid(gx, gy, n);
+      if (stride == 1) { HRF_LAUNCH(dw_bwd_wgt_grp_kernel<1>, grid, dim3(256), 0, stream, g); }
+      else { HRF_LAUNCH(dw_bwd_wgt_grp_kernel<2>, grid, dim3(256), 0, stream, g); }
+      if (hrf_check_launch() != HRF_OK) rc = HRF_ERR_LAUNCH;
+    }
+  }
+  g_dw_pending.clear();
+  return rc;
+}
 
 extern "C" int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias,
                               int stride, int tf_mode, const float* tf_scale, const float* tf_shift, float* y,
@@ -454,6 +502,7 @@ extern "C" int hrf_dwconv_bwd_weight(const float* dy, const float* yraw, const f
   const int th = stride == 1 ? 8 : 4;
   a.tilesX = hrf_cdiv(a.Wo, TW); a.tilesY = hrf_cdiv(a.Ho, th);
   if ((long)B * a.Ho * a.Wo <= 0) return HRF_OK;
+  if (hrf_wgrad_collecting()) { g_dw_pending.push_back(DwWgtPending{stride, a}); return HRF_OK; }
   dim3 grid(a.tilesX * a.tilesY * B, hrf_cdiv(C, CB));
   if (stride == 1) { HRF_LAUNCH(dw_bwd_wgt_kernel<1>, grid, dim3(256), 0, stream, a); }
   else { HRF_LAUNCH(dw_bwd_wgt_kernel<2>, grid, dim3(256), 0, stream, a); }

@@ -311,6 +311,26 @@ def run_dw(case, backend):
     L.hrf_dwconv_bwd_weight(D(du), D(yraw), *co, D(xr), B, H, W, C, S, tf, D(sc) if tf else None,
                             D(sh) if tf else None, dw, db, 0, _lib.stream_ptr())
     assert r(dw, wq.grad) < TOL and r(db, bq.grad) < TOL
+    # the same call QUEUED between hrf_wgrad_group_begin / _end (how the weight-gradient phase issues it: DWG problems per
+    # launch), twice and next to a half-height problem of the same stride: geometry larger than a member's own grid
+    dwg, dbg = torch.zeros(2, *w.shape, device=dev), torch.zeros(2, C, device=dev)
+    Hh = max(1, H // 2)
+    duh, yrh, xrh = D(du)[:, :((Hh - 1) // S + 1)].contiguous(), D(yraw)[:, :((Hh - 1) // S + 1)].contiguous(), D(xr)[:, :Hh].contiguous()
+    dwh, dbh = torch.zeros_like(w, device=dev), torch.zeros(C, device=dev)
+    dwr, dbr = torch.zeros_like(w, device=dev), torch.zeros(C, device=dev)
+    L.hrf_dwconv_bwd_weight(duh, yrh, *co, xrh, B, Hh, W, C, S, tf, D(sc) if tf else None, D(sh) if tf else None, dwr, dbr, 0,
+                            _lib.stream_ptr())
+    held = (D(du), D(yraw), D(xr), D(sc) if tf else None, D(sh) if tf else None, dwg[0], dwg[1], dbg[0], dbg[1])
+    L.hrf_wgrad_group_begin()                  # (queued launches read their operands at _end: no temporaries here)
+    for k in range(2):
+        L.hrf_dwconv_bwd_weight(held[0], held[1], *co, held[2], B, H, W, C, S, tf, held[3], held[4], held[5 + k], held[7 + k], 0,
+                                _lib.stream_ptr())
+    L.hrf_dwconv_bwd_weight(duh, yrh, *co, xrh, B, Hh, W, C, S, tf, held[3], held[4], dwh, dbh, 0, _lib.stream_ptr())
+    assert float(dwg.abs().max()) == 0.0                                  # nothing launched yet
+    L.hrf_wgrad_group_end(_lib.stream_ptr())
+    for k in range(2):
+        assert r(dwg[k], wq.grad) < TOL and r(dbg[k], bq.grad) < TOL
+    assert r(dwh, dwr) < 1e-6 and r(dbh, dbr) < 1e-6
     # replicated accumulators (copy_stride > 0) + hrf_fold_copies into a "gradient arena"
     n = 10 * C
     scr = torch.zeros(KC * n, device=dev)
