@@ -467,7 +467,7 @@ def _family_row(table, key, peak_f, peak_b, traffic, tname):
         if t is not None:
             row['traffic'] = t['bytes_per_launch']
             row['traffic_source'] = (f'profiles/{tname}[{tkey}]: 2 x FETCH_SIZE + WRITE_SIZE of that launch (2 x 96 x 160 map) from a '
-                                     f'separate rocprofv3 --pmc run (tools/prof_{tname[:3]}.sh); NOT measured in this bench run')
+                                     f'separate rocprofv3 --pmc run (tools/prof_round.sh {tname[:3]}); NOT measured in this bench run')
     return row
 
 

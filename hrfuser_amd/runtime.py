@@ -832,7 +832,7 @@ class Ctx:
     def on(self, lane):
         return _LaneScope(self, lane)
 
-    def side_launch(self, fn, cost=1.0):
+    def side_launch(self, fn, cost=1.0, key=None):
         """Run `fn` (one off-critical-path launch) on a side lane that starts after the current lane's
         work so far and is joined into the main lane at the end of the backward pass."""
         mode = os.environ.get('HRF_WGRAD', 'defer')
@@ -842,7 +842,7 @@ class Ctx:
         if mode in ('defer', 'flush'):
             # weight-gradient launches are leaves of the backward graph: collect them and issue them
             # as one wide, fully parallel phase after the (serial, latency-bound) data-gradient chain
-            self._deferred.append((float(cost), fn))
+            self._deferred.append((float(cost), fn, key))
             return
         pool = self.owner._side_pool()
         lane = pool[self._side_i % len(pool)]
@@ -855,7 +855,7 @@ class Ctx:
     def _flush_deferred(self):
         """Issue the queued leaf launches on side lanes that start after the main lane's work so far (flat fork from
         main; joined at the end of run_backward)."""
-        fns = [fn for _, fn in self._deferred]
+        fns = [it[1] for it in self._deferred]
         self._deferred = []
         pool = self.owner._side_pool()
         k = min(len(pool), int(os.environ.get('HRF_WGRAD_FLUSH_LANES', os.environ.get('HRF_WGRAD_LANES', '4'))))
@@ -949,7 +949,7 @@ class Ctx:
             self.strand = self.root
             lanes = self.fork(k)
             parts = _balance(items, k) if os.environ.get('HRF_WGRAD_BALANCE', '1') != '0' else \
-                [[fn for _, fn in items[j::k]] for j in range(k)]
+                [[it[1] for it in items[j::k]] for j in range(k)]
             for j in range(k):
                 with _LaneScope(self, lanes[j]):
                     # the dense weight gradients of a lane are queued and issued as a few grouped launches
@@ -978,15 +978,32 @@ class Ctx:
             entry.wait_stream(self.main.stream)
 
 
-def _balance(items, k):
-    """Longest-processing-time-first split of (cost, fn) leaf launches over k lanes (the lanes of the deferred
-    weight-gradient phase run concurrently; the phase ends with the slowest one)."""
+def _balance(items, k, chunk=None):
+    """Longest-processing-time-first split of (cost, fn[, key]) leaf launches over k lanes (the lanes of the deferred
+    weight-gradient phase run concurrently; the phase ends with the slowest one).  Items with the same `key` map to the same
+    kernel variant of the grouped weight-gradient launches (hrf_wgrad_group_end issues up to 16 of them as ONE launch, per
+    lane): they travel in chunks of `chunk` (8: 12.73 ms; 16: 12.76; 1 = every item on its own: 12.81, same box) so that a variant is not
+    scattered over all lanes as 4 small launches."""
+    if chunk is None:
+        chunk = int(os.environ.get('HRF_WGRAD_CHUNK', '8'))
+    units, byk = [], {}
+    for it in items:
+        key = it[2] if len(it) > 2 else None
+        if key is None or chunk <= 1:
+            units.append((it[0], [it[1]]))
+        else:
+            byk.setdefault(key, []).append(it)
+    for grp in byk.values():
+        grp.sort(key=lambda t: -t[0])
+        for i in range(0, len(grp), chunk):
+            part = grp[i:i + chunk]
+            units.append((sum(t[0] for t in part), [t[1] for t in part]))
     loads = [0.0] * k
     parts = [[] for _ in range(k)]
-    for cost, fn in sorted(items, key=lambda t: -t[0]):
+    for cost, fns in sorted(units, key=lambda t: -t[0]):
         j = loads.index(min(loads))
         loads[j] += cost
-        parts[j].append(fn)
+        parts[j].extend(fns)
     return parts
 
 
@@ -1262,7 +1279,8 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
         cost = 4.0 * B * (H * W * Cin + Ho * Wo * Cout * (2 if cA is not None else 1)) + 0.2 * B * Ho * Wo * Cout * Cin * KH * KH
         ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
             dy, ldD, doff, yraw, cA, cB, cC, xw, *sw, B, H, W, Cin, KH, stride, Cout,
-            tf, sc, sh, rowstat, weight.grad, bgrad, ctx.stream), cost=cost)
+            tf, sc, sh, rowstat, weight.grad, bgrad, ctx.stream), cost=cost,
+            key=('conv_w', Cin, Cout, KH, stride, tf, cA is not None))
 
 
 # ----------------------------------------------------------------------------- GroupNorm (norm_cfg type 'GN')
@@ -1652,7 +1670,7 @@ def dwconv_bn(ctx, src, conv, bn, mode):
                 bacc = eng.grad_acc(b)[0] if b is not None else None
                 ctx.side_launch(lambda: L.hrf_dwconv_bwd_weight(
                     draw, None, None, None, None, x, B, H, W, C, stride, tf, sc, sh, wacc, bacc, cs, ctx.stream),
-                    cost=4.0 * B * H * W * C * (1.0 + 2.0 / (stride * stride)))
+                    cost=4.0 * B * H * W * C * (1.0 + 2.0 / (stride * stride)), key=('dw_w', stride))
             gst.du = None
         ctx.push(gbwd)
         return gout
@@ -1694,7 +1712,7 @@ def dwconv_bn(ctx, src, conv, bn, mode):
             bacc = eng.grad_acc(b)[0] if b is not None else None
             ctx.side_launch(lambda: L.hrf_dwconv_bwd_weight(
                 du_, st.raw, cA, cB, cC, x, B, H, W, C, stride, tf, sc, sh, wacc, bacc, cs, ctx.stream),
-                cost=4.0 * B * H * W * C * (1.0 + 2.0 / (stride * stride)))
+                cost=4.0 * B * H * W * C * (1.0 + 2.0 / (stride * stride)), key=('dw_w', stride))
         st.du = None
     ctx.push(bwd, sync=st)
     return out
