@@ -8,6 +8,8 @@
 //
 // Reference ops replaced: F.batch_norm, F.layer_norm, F.relu/gelu, torch.add, F.interpolate
 // (bilinear, align_corners=False) call sites listed in SURVEY.md 2.1a.
+#include <cstring>
+#include <type_traits>
 #include "hrf_common.h"
 #include "hrf_group.h"
 #include "../../include/hrfuser_hip.h"
@@ -353,6 +355,25 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* du, const floa
   }
 }
 
+// VW consecutive floats as one global access (VW = 4 | 2; like hrf_ld4, natural alignment is not needed on gfx950)
+#ifdef HRF_EMUL
+template <int VW> inline void hrf_ldv(const float* p, float* v) { std::memcpy(v, p, VW * sizeof(float)); }
+template <int VW> inline void hrf_stv(float* p, const float* v) { std::memcpy(p, v, VW * sizeof(float)); }
+#else
+template <int VW> struct HrfVec { typedef float T __attribute__((ext_vector_type(VW), aligned(4))); };
+template <int VW> __device__ __forceinline__ void hrf_ldv(const float* p, float* v) {
+  const typename HrfVec<VW>::T t = *reinterpret_cast<const typename HrfVec<VW>::T*>(p);
+#pragma unroll
+  for (int e = 0; e < VW; ++e) v[e] = t[e];
+}
+template <int VW> __device__ __forceinline__ void hrf_stv(float* p, const float* v) {
+  typename HrfVec<VW>::T t;
+#pragma unroll
+  for (int e = 0; e < VW; ++e) t[e] = v[e];
+  *reinterpret_cast<typename HrfVec<VW>::T*>(p) = t;
+}
+#endif
+
 // ------------------------------------------------------------------------------- BN apply + act + residual
 // act_first=1: out = res + rowscale*act(sc1*y1+sh1)            (CrossFFN tail: x + GELU(BN(h3)))
 // act_first=0: out = act(sc1*y1+sh1 [+ res] [+ sc2*y2+sh2])    (Bottleneck tail / transition ReLU)
@@ -398,24 +419,26 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(HrfGroup<AffineActR
   if (fin1.stats != nullptr) { hrf_bn_fin_onload(fin1, sFin, sFin + HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0); sc1 = sFin; sh1 = sFin + HRF_FIN_MAXC; }
   if (fin2.stats != nullptr) { hrf_bn_fin_onload(fin2, sFin + 2 * HRF_FIN_MAXC, sFin + 3 * HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0); sc2 = sFin + 2 * HRF_FIN_MAXC; sh2 = sFin + 3 * HRF_FIN_MAXC; }
   if (fin1.stats != nullptr || fin2.stats != nullptr) __syncthreads();
-  if (pa_.vec4) {
-    // 16-byte path (C % 4 == 0, every tensor 16-byte aligned): a thread owns 4 consecutive channels of a row; the channel
-    // group advances by a constant per iteration (no 64-bit modulo per element - the dword loop below spends more
-    // instructions on `i % C` than on the arithmetic - and a quarter of the memory instructions)
-    const long n4 = total >> 2, stride = (long)gridDim.x * 256;
-    const int C4 = C >> 2, dc = (int)(stride % C4);
+  // vector paths (C % 4 == 0: 16 bytes, C % 2 == 0: 8 bytes - the 18 / 78-channel rows): a thread owns VW consecutive channels of
+  // a row; the channel group advances by a constant per iteration (no 64-bit modulo per element - the dword loop below spends
+  // more instructions on `i % C` than on the arithmetic - and 1/VW of the memory instructions)
+  auto vbody = [&](auto vw) {
+    constexpr int VW = decltype(vw)::value;
+    const long nv = total / VW, stride = (long)gridDim.x * 256;
+    const int CV = C / VW, dc = (int)(stride % CV);
     long i = (long)blockIdx.x * 256 + threadIdx.x;
-    int c4 = (int)(i % C4);
-    for (; i < n4; i += stride) {
-      const int c = 4 * c4;
-      const hrf_f4 yv = hrf_ld4(y1 + 4 * i);
-      hrf_f4 rv = hrf_f4{0.f, 0.f, 0.f, 0.f}, y2v = hrf_f4{0.f, 0.f, 0.f, 0.f};
-      if (res) rv = hrf_ld4(res + 4 * i);
-      if (y2) y2v = hrf_ld4(y2 + 4 * i);
-      const float rsc = (act_first && rowscale) ? rowscale[((4 * i) / C) / rows_per_sample] : 1.f;
-      hrf_f4 o;
+    int cv = (int)(i % CV);
+    for (; i < nv; i += stride) {
+      const int c = VW * cv;
+      float yv[VW], rv[VW], y2v[VW], o[VW];
+      hrf_ldv<VW>(y1 + VW * i, yv);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < VW; ++e) { rv[e] = 0.f; y2v[e] = 0.f; }
+      if (res) hrf_ldv<VW>(res + VW * i, rv);
+      if (y2) hrf_ldv<VW>(y2 + VW * i, y2v);
+      const float rsc = (act_first && rowscale) ? rowscale[((VW * i) / C) / rows_per_sample] : 1.f;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
         float v = fmaf(yv[e], sc1[c + e], sh1[c + e]);
         if (act_first) {
           v = hrf_act(act, v) * rsc;
@@ -427,11 +450,12 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(HrfGroup<AffineActR
         }
         o[e] = v;
       }
-      hrf_st4(out + 4 * i, o);
-      c4 += dc; if (c4 >= C4) c4 -= C4;
+      hrf_stv<VW>(out + VW * i, o);
+      cv += dc; if (cv >= CV) cv -= CV;
     }
-    return;
-  }
+  };
+  if (pa_.vec4 == 4) { vbody(std::integral_constant<int, 4>{}); return; }
+  if (pa_.vec4 == 2) { vbody(std::integral_constant<int, 2>{}); return; }
   auto body = [&](auto i) {
     const int c = (int)(i % C);
     float v = fmaf(y1[i], sc1[c], sh1[c]);
@@ -633,10 +657,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(HrfGroup<ActBwdArgs> grp) 
   }
 }
 
-// 16-byte variant (C % 4 == 0, C <= 1024, every tensor 16-byte aligned): a thread keeps FOUR consecutive channels for its
-// whole life, 1024/C rows per pass - a quarter of the memory instructions of the dword kernel, which left the 256-channel
-// stem launches at 3 TB/s.
-__global__ __launch_bounds__(256) void act_bwd_v4_kernel(HrfGroup<ActBwdArgs> grp) {
+// Vector variants (VW = 4 for C % 4 == 0, VW = 2 for C % 2 == 0 - the 18 / 78-channel rows; C / VW <= 256): a thread keeps VW
+// consecutive channels for its whole life, 256 * VW / C rows per pass - 1/VW of the memory instructions of the dword kernel, which
+// left the 256-channel stem launches at 3 TB/s.
+template <int VW>
+__global__ __launch_bounds__(256) void act_bwd_vec_kernel(HrfGroup<ActBwdArgs> grp) {
   const ActBwdArgs& pa_ = grp.sel();
   const float* dout = pa_.dout;
   const float* out = pa_.out;
@@ -652,13 +677,13 @@ __global__ __launch_bounds__(256) void act_bwd_v4_kernel(HrfGroup<ActBwdArgs> gr
   const long rows = pa_.rows;
   HRF_DYN_SMEM(float, sacc);                              // [4*C]: sum g, sum g*y1, sum g*y2, sum g*y3
   for (int i = threadIdx.x; i < 4 * C; i += 256) sacc[i] = 0.f;
-  const int cw = C >> 2, R = 256 / cw;
-  const int r = threadIdx.x / cw, c = 4 * (threadIdx.x - r * cw);
+  const int cw = C / VW, R = 256 / cw;
+  const int r = threadIdx.x / cw, c = VW * (threadIdx.x - r * cw);
   const bool active = r < R;
-  hrf_f4 a0 = hrf_f4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-  float scv[4], shv[4];
+  float a0[VW], a1[VW], a2[VW], a3[VW], scv[VW], shv[VW];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < VW; ++e) {
+    a0[e] = a1[e] = a2[e] = a3[e] = 0.f;
     scv[e] = 1.f; shv[e] = 0.f;
     if (mode == 1) { scv[e] = pa_.sc[active ? c + e : 0]; shv[e] = pa_.sh[active ? c + e : 0]; }
   }
@@ -670,14 +695,16 @@ __global__ __launch_bounds__(256) void act_bwd_v4_kernel(HrfGroup<ActBwdArgs> gr
     float rs = 1.f;
     if (rowscale) rs = rowscale[(ok ? row : 0) / rows_per_sample];
     const long idx = ok ? row * C + c : 0;
-    hrf_f4 v = hrf_ld4(dout + idx);
-    hrf_f4 ov = hrf_f4{1.f, 1.f, 1.f, 1.f}, y1v = hrf_f4{0.f, 0.f, 0.f, 0.f}, y2v = y1v, y3v = y1v;
-    if (mode == 0) ov = hrf_ld4(out + idx);
-    if (need1) y1v = hrf_ld4(y1 + idx);
-    if (st2) y2v = hrf_ld4(y2 + idx);
-    if (st3) y3v = hrf_ld4(y3 + idx);
+    float v[VW], ov[VW], y1v[VW], y2v[VW], y3v[VW];
+    hrf_ldv<VW>(dout + idx, v);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < VW; ++e) { ov[e] = 1.f; y1v[e] = 0.f; y2v[e] = 0.f; y3v[e] = 0.f; }
+    if (mode == 0) hrf_ldv<VW>(out + idx, ov);
+    if (need1) hrf_ldv<VW>(y1 + idx, y1v);
+    if (st2) hrf_ldv<VW>(y2 + idx, y2v);
+    if (st3) hrf_ldv<VW>(y3 + idx, y3v);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
       float t = v[e];
       if (mode == 0) t = ov[e] > 0.f ? t : 0.f;
       else if (mode == 1) t *= hrf_gelu_grad(fmaf(y1v[e], scv[e], shv[e])) * rs;
@@ -688,12 +715,12 @@ __global__ __launch_bounds__(256) void act_bwd_v4_kernel(HrfGroup<ActBwdArgs> gr
       a2[e] = fmaf(t, y2v[e], a2[e]);
       a3[e] = fmaf(t, y3v[e], a3[e]);
     }
-    if (ok) hrf_st4(g + idx, v);
+    if (ok) hrf_stv<VW>(g + idx, v);
   }
   __syncthreads();
   if (active) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < VW; ++e) {
       hrf_atomic_add(&sacc[c + e], a0[e]);
       if (st1) hrf_atomic_add(&sacc[C + c + e], a1[e]);
       if (st2) hrf_atomic_add(&sacc[2 * C + c + e], a2[e]);
@@ -1136,13 +1163,6 @@ __global__ void adamw_tick_kernel(float* state, float b1, float b2) {
 
 static int g_pw_knob[4] = {0, 0, 0, 0};      // tuning aids (hrf_debug_knob keys 16..19)
 
-// every non-null pointer 16-byte aligned (the 16-byte paths of the elementwise kernels)
-inline bool hrf_aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr,
-                          const void* e = nullptr, const void* f = nullptr) {
-  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
-           reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f)) & 15) == 0;
-}
-
 inline int ew_grid(long total) {
   long g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -1247,8 +1267,8 @@ extern "C" int hrf_affine_act_res(const float* y1, const float* sc1, const float
     else if (nch <= 10) { HRF_FT(10); } else if (nch <= 20) { HRF_FT(20); } else { HRF_FT(40); }
     return hrf_check_launch();
   }
-  const int vec4 = (C % 4 == 0 && hrf_aligned16(y1, y2, res, out)) ? 1 : 0;
-  HRF_LAUNCH_G(affine_act_res_kernel, dim3(ew_grid(vec4 ? total / 4 : total)), dim3(256), 0, stream,
+  const int vec4 = g_pw_knob[2] == 1 ? 0 : (C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 0));   // channels per thread (hrf_debug_knob 18 = 1: dword paths)
+  HRF_LAUNCH_G(affine_act_res_kernel, dim3(ew_grid(vec4 ? total / vec4 : total)), dim3(256), 0, stream,
                (AffineActResArgs{y1, sc1, sh1, y2, sc2, sh2, res, rowscale, rows_per_sample, act, act_first, out, total, C, f1, f2, vec4}));
   if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(out, (int)rows, C, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();
@@ -1272,11 +1292,13 @@ extern "C" int hrf_act_bwd(const float* dout, const float* out, const float* y1,
   if (rows * C <= 0) return HRF_OK;
   if (C > 768) return HRF_ERR_ARG;
   const int passes = g_pw_knob[1] > 0 ? g_pw_knob[1] : 4;                          // passes per block
-  if (C % 4 == 0 && C >= 16 && C <= 1024 && g_pw_knob[2] != 1 && hrf_aligned16(dout, out, y1, y2, y3, g)) {
-    int grid = hrf_cdiv(hrf_cdiv(rows, 256 / (C / 4)), passes);
+  const int vw = g_pw_knob[2] == 1 ? 0 : (C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 0));   // (hrf_debug_knob 18 = 1: dword kernel)
+  if (vw != 0 && C >= 4 * vw && C / vw <= 256) {
+    int grid = hrf_cdiv(hrf_cdiv(rows, 256 / (C / vw)), passes);
     if (grid > 2048) grid = 2048;
-    HRF_LAUNCH_G(act_bwd_v4_kernel, dim3(grid), dim3(256), (unsigned)(4 * C * sizeof(float)), stream,
-                 (ActBwdArgs{dout, out, y1, sc, sh, rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, rows, C}));
+    const ActBwdArgs a{dout, out, y1, sc, sh, rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, rows, C};
+    if (vw == 4) { HRF_LAUNCH_G(act_bwd_vec_kernel<4>, dim3(grid), dim3(256), (unsigned)(4 * C * sizeof(float)), stream, a); }
+    else { HRF_LAUNCH_G(act_bwd_vec_kernel<2>, dim3(grid), dim3(256), (unsigned)(4 * C * sizeof(float)), stream, a); }
     return hrf_check_launch();
   }
   const int R = C <= 256 ? 256 / C : 1;

@@ -500,7 +500,17 @@ def run_pointwise(backend):
         assert r(gk, gref) < TOL
         for st_, y_ in ((sa, ya), (sb, yb), (sc3, yc)):
             assert r(fold(st_)[:Ca], gref.sum(0)) < TOL and r(fold(st_)[Ca:], (gref * y_.double()).sum(0)) < TOL
-    # ---- the same two kernels on tensors that are NOT 16-byte aligned (C % 4 == 0 but the dword path must be taken)
+    # ---- odd channel counts: the dword kernels (vector paths need C % 2 == 0)
+    rows, Ca = 33, 15
+    dd, oo, ya = rn(rows, Ca), rn(rows, Ca), rn(rows, Ca)
+    gk, sa = torch.zeros(rows, Ca, device=dev), zstat(Ca, dev)
+    L.hrf_act_bwd(D(dd), D(oo), D(ya), None, None, None, 1, 0, gk, None, None, sa, None, None, rows, Ca, s)
+    gref = (dd * (oo > 0)).double()
+    assert r(gk, gref) < TOL and r(fold(sa)[Ca:], (gref * ya.double()).sum(0)) < TOL
+    sco, sho, oo2 = torch.rand(Ca, generator=g) + 0.5, rn(Ca), torch.zeros(rows, Ca, device=dev)
+    L.hrf_affine_act_res(D(dd), D(sco), D(sho), None, None, None, D(oo), None, 1, 1, 0, oo2, rows, Ca, None, 0.0, None, None, s)
+    assert r(oo2, F.relu(dd * sco + sho + oo)) < TOL
+    # ---- the same two kernels on tensors that are only 4-byte aligned (16-byte accesses on 4-byte aligned addresses)
     def unal(t):
         buf = torch.zeros(t.numel() + 1, device=dev)
         buf[1:] = t.reshape(-1).to(dev)
