@@ -445,6 +445,7 @@ def main(argv=None):
             torch.cuda.synchronize()
     run = trainer.replay if use_graph else (lambda: trainer.step(x, mods, cots))
     dt, per = time_steps(args, run, world, dev)
+    trainer.check()                                               # a timed-out peer-to-peer SyncBN exchange is not a result
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     pick = lambda f: round(per[min(len(per) - 1, int(f * len(per)))], 4)
