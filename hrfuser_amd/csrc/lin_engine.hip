@@ -23,15 +23,20 @@
 
 namespace {
 
-constexpr int LIN_BWD_EPI_MAX_NT = 5;
-// forward: 5 tiles per wave at most (HRFuser-B: 56.3 -> 55.5 ms; 9 tiles starve the launch of waves)
-constexpr int LIN_FWD_MAX_NT = 5;
-// 16-deep K slabs whose loads are issued before the first use (one dependent round trip per batch).  Same-box A/B of the
-// captured HRFuser-T step: 2 slabs 13.27 ms, 3 slabs 13.06 ms, 4 slabs (tiles <= 2) 13.35 ms (registers).
-#ifndef HRF_LIN_SB
-#define HRF_LIN_SB 3
+#ifndef HRF_LIN_BWD_EPI_MAX_NT
+#define HRF_LIN_BWD_EPI_MAX_NT 5
 #endif
-constexpr int SB = HRF_LIN_SB;
+constexpr int LIN_BWD_EPI_MAX_NT = HRF_LIN_BWD_EPI_MAX_NT;
+// forward: 5 tiles per wave at most (HRFuser-B: 56.3 -> 55.5 ms; 9 tiles starve the launch of waves)
+#ifndef HRF_LIN_FWD_MAX_NT
+#define HRF_LIN_FWD_MAX_NT 5
+#endif
+constexpr int LIN_FWD_MAX_NT = HRF_LIN_FWD_MAX_NT;
+// SB = 16-deep K slabs whose loads are issued before the first use (one dependent round trip per batch).  Same-box A/B of the
+// captured steps: HRFuser-T (narrow tiles, K <= 64 where the tiles are wide) 2 slabs 13.27 ms, 3 slabs 13.06, 4 slabs 13.35
+// (registers); HRFuser-B (5 channel tiles per wave, K = 78 ... 1 248) 2 slabs 46.4 ms, 3 slabs 46.8, 4 slabs 46.9.  Hence 3,
+// except for >= 5 tiles per wave with a long contraction (chosen at launch: LIN_SB_WIDE_K).
+constexpr int LIN_SB = 3, LIN_SB_WIDE = 2, LIN_SB_WIDE_K = 64;
 
 // Out-of-range fragment groups are read from this zero block instead of being masked after the
 // load: `cond ? loaded : 0` makes the compiler sink the load into an exec-masked branch with its own
@@ -110,7 +115,7 @@ __device__ __forceinline__ void flush_moments(const float* sStat, double* stats,
 
 // --------------------------------------------------------------------------------- forward
 // NT = 16-channel output tiles per wave (compile time: the unrolled code carries no guards)
-template <int NT, int TF>
+template <int NT, int TF, int SB>
 __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) {
   const LinFwdArgs& a = grp.sel();
   __shared__ float sStat[4 * 2 * NT * 16];
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) 
 }
 
 // --------------------------------------------------------------------------------- backward data
-template <int NT, bool BNB>
+template <int NT, bool BNB, int SB>
 __global__ __launch_bounds__(256) void lin_bwd_data_kernel(HrfGroup<LinBwdDataArgs> grp) {
   const LinBwdDataArgs& a = grp.sel();
   __shared__ float sStat[4 * 2 * NT * 16];
@@ -312,14 +317,15 @@ inline int pick_ntw(int M, int T) {
 
 }  // namespace
 
-#define HRF_LF_LAUNCH(NT_, TF_, V4_) HRF_LAUNCH_G((lin_fwd_kernel<NT_, TF_>), grid, dim3(256), 0, stream, a)
+#define HRF_LF_LAUNCH(NT_, TF_, SB_) HRF_LAUNCH_G((lin_fwd_kernel<NT_, TF_, SB_>), grid, dim3(256), 0, stream, a)
+#define HRF_LF_WIDE(NT_, TF_) { if (a.K <= LIN_SB_WIDE_K) { HRF_LF_LAUNCH(NT_, TF_, LIN_SB); } else { HRF_LF_LAUNCH(NT_, TF_, LIN_SB_WIDE); } }
 #define HRF_LF_NT(TF_, V4_)                          \
   switch (ntw) {                                     \
-    case 1: HRF_LF_LAUNCH(1, TF_, V4_); break;       \
-    case 2: HRF_LF_LAUNCH(2, TF_, V4_); break;       \
-    case 3: HRF_LF_LAUNCH(3, TF_, V4_); break;       \
-    case 5: HRF_LF_LAUNCH(5, TF_, V4_); break;       \
-    default: HRF_LF_LAUNCH(9, TF_, V4_); break;      \
+    case 1: HRF_LF_LAUNCH(1, TF_, LIN_SB); break;    \
+    case 2: HRF_LF_LAUNCH(2, TF_, LIN_SB); break;    \
+    case 3: HRF_LF_LAUNCH(3, TF_, LIN_SB); break;    \
+    case 5: HRF_LF_WIDE(5, TF_) break;               \
+    default: HRF_LF_WIDE(9, TF_) break;              \
   }
 #define HRF_LF_V4(TF_) { HRF_LF_NT(TF_, true) }
 
@@ -348,14 +354,15 @@ int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
   return hrf_check_launch();
 }
 
-#define HRF_LB_LAUNCH(NT_, BNB_, V4_) HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_>), grid, dim3(256), 0, stream, a)
+#define HRF_LB_LAUNCH(NT_, BNB_, SB_) HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_, SB_>), grid, dim3(256), 0, stream, a)
+#define HRF_LB_WIDE(NT_, BNB_) { if (a.K <= LIN_SB_WIDE_K) { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB); } else { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB_WIDE); } }
 #define HRF_LB_NT(BNB_, V4_)                         \
   switch (ntw) {                                     \
-    case 1: HRF_LB_LAUNCH(1, BNB_, V4_); break;      \
-    case 2: HRF_LB_LAUNCH(2, BNB_, V4_); break;      \
-    case 3: HRF_LB_LAUNCH(3, BNB_, V4_); break;      \
-    case 5: HRF_LB_LAUNCH(5, BNB_, V4_); break;      \
-    default: HRF_LB_LAUNCH(9, BNB_, V4_); break;     \
+    case 1: HRF_LB_LAUNCH(1, BNB_, LIN_SB); break;   \
+    case 2: HRF_LB_LAUNCH(2, BNB_, LIN_SB); break;   \
+    case 3: HRF_LB_LAUNCH(3, BNB_, LIN_SB); break;   \
+    case 5: HRF_LB_WIDE(5, BNB_) break;              \
+    default: HRF_LB_WIDE(9, BNB_) break;             \
   }
 #define HRF_LB_V4(BNB_) { HRF_LB_NT(BNB_, true) }
 
