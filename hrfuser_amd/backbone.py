@@ -595,6 +595,9 @@ class LocalWindowSelfAttention(nn.Module):
         return R.linear_residual(ctx, o, a.out_proj, x, drop=drop)
 
 
+_DEBUG_PAD = {int(k): float(v) for k, v in (kv.split(':') for kv in os.environ.get('HRF_DEBUG_PAD', '').split(',') if ':' in kv)}
+
+
 class HRFormerBlock(nn.Module):
     """hrformer.py:365-373: x += DropPath(LSA(LN1(x))); x += DropPath(CrossFFN(LN2(x))).  DropPath is Identity on
     the HRFuser path (App. D-2: the rate never reaches the stages); the plain HRFormer applies its linspace schedule."""
@@ -623,6 +626,12 @@ class HRFormerBlock(nn.Module):
             s1, s2 = eng.droppath_scale(x.shape[0], p), eng.droppath_scale(x.shape[0], p)
         msa = self.attn.attn
         C = x.shape[-1]
+        if _DEBUG_PAD.get(C):
+            # critical-lane probe (HRF_DEBUG_PAD="18:10,72:10": 10 us of idle time per block of that width, forward and
+            # backward): a lane whose padding shows up in the step time is on the critical path
+            ticks = int(_DEBUG_PAD[C] * 100)
+            ctx.L.hrf_debug_spin(ticks, ctx.stream)
+            ctx.push(lambda: ctx.L.hrf_debug_spin(ticks, ctx.stream))
         if R.attn_block_ok(ctx, C, msa.num_heads) and self.ffn.layers[0].weight.shape[0] == 4 * C and not R.is_gn(self.ffn.layers[1]):
             # one launch: norm1 -> qkv -> window attention -> out_proj -> residual -> norm2 -> CrossFFN 1x1 expansion
             # (x may be the previous block's lazy tail: the launch forms it on load)

@@ -1487,6 +1487,22 @@ extern "C" int hrf_stamp(long long* dst, void* stream) {
   return hrf_check_launch();
 }
 
+// critical-lane probe: one workgroup that does nothing for `ticks` of the 100 MHz wall clock (see hrf_debug_spin in the header)
+__global__ void spin_kernel(long long ticks) {
+#ifndef HRF_EMUL
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+#else
+  (void)ticks;
+#endif
+}
+
+extern "C" int hrf_debug_spin(long ticks, void* stream) {
+  if (ticks < 0 || ticks > 100000000L) return HRF_ERR_ARG;          // at most 1 s
+  HRF_LAUNCH(spin_kernel, dim3(1), dim3(1), 0, stream, (long long)ticks);
+  return hrf_check_launch();
+}
+
 extern "C" int hrf_memset(void* ptr, int value, long bytes, void* stream) {
   if (bytes <= 0) return HRF_OK;
 #ifdef HRF_EMUL

@@ -436,6 +436,10 @@ int hrf_adamw(float* p, const float* g, float* m, float* v, const float* wd_mask
  * the captured training step with it (stems, transitions, fusion_a/b/c, stage2-4 with the modality stages beside them;
  * hrfuser_hrformer_based.py:535-607) for the per-stage roofline report. */
 int hrf_stamp(long long* dst, void* stream);
+/* Critical-lane probe (measurement aid, never on the product path): one idle workgroup that lasts `ticks` of the same clock.
+ * Padding ONE lane of a multi-lane schedule with it and watching the step time tells whether that lane is on the critical
+ * path (HRF_DEBUG_PAD in hrfuser_amd/backbone.py).                                                                       */
+int hrf_debug_spin(long ticks, void* stream);
 
 /* hipMemsetAsync on `stream` (the per-step zeroing of the replicated accumulators). */
 int hrf_memset(void* ptr, int value, long bytes, void* stream);
