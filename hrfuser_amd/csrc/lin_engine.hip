@@ -115,17 +115,22 @@ __device__ __forceinline__ void flush_moments(const float* sStat, double* stats,
 
 // --------------------------------------------------------------------------------- forward
 // NT = 16-channel output tiles per wave (compile time: the unrolled code carries no guards)
-template <int NT, int TF, int SB>
+// SK ("split K"): few rows, long contraction (the 24x40 / 12x20 branches: K = 288 ... 2 496 at 480 ... 1 920 rows) - the four
+// waves of a block share ONE 16-pixel tile and take a quarter of the K slabs each (K / 64 dependent load round trips per wave
+// instead of K / 16 / SB ... and four times the waves in flight); partial tiles meet in LDS, wave 0 runs the epilogue.
+template <int NT, int TF, int SB, bool SK>
 __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) {
   const LinFwdArgs& a = grp.sel();
   __shared__ float sStat[4 * 2 * NT * 16];
+  __shared__ __attribute__((aligned(16))) float sRed[SK ? 3 * NT * 256 : 4];
   __shared__ __attribute__((aligned(16))) float sFin[(TF >= HRF_TF_AFFINE && TF <= HRF_TF_AFFINE_GELU) ? 2 * HRF_FIN_MAXC : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int n0w = blockIdx.y * (NT * 16);
-  const int pix = blockIdx.x * 64 + wave * 16 + j;
-  const bool pixv = pix < a.M;
-  const long pc = pixv ? pix : a.M - 1;
+  const int pix = SK ? blockIdx.x * 16 + j : blockIdx.x * 64 + wave * 16 + j;
+  const bool pixin = pix < a.M;
+  const bool pixv = pixin && (!SK || wave == 0);           // the wave that owns the tile's epilogue
+  const long pc = pixin ? pix : a.M - 1;
   // BatchNorm of the input finalised on load (hrf_bn_fin_t): scale / shift come from LDS instead of memory
   const float* scp = a.tf_scale;
   const float* shp = a.tf_shift;
@@ -143,9 +148,10 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) 
   for (int t = 0; t < NT; ++t) {
     const int chb = n0w + 16 * t + 4 * q, nval = a.N - chb;
     const bool nfull = n0w + 16 * (t + 1) <= a.N;
-    acc[t] = ld_sel(nfull, a.bias, chb, a.bias != nullptr ? nval : 0);
-    const hrf_f4 r1 = ld_sel(nfull, a.res, pc * a.ldR + chb, a.res != nullptr ? nval : 0);
-    const hrf_f4 r2 = ld_sel(nfull, a.res2, pc * a.ldR + chb, a.res2 != nullptr ? nval : 0);
+    const bool own = !SK || wave == 0;                      // (uniform per wave)
+    acc[t] = ld_sel(nfull, a.bias, chb, (own && a.bias != nullptr) ? nval : 0);
+    const hrf_f4 r1 = ld_sel(nfull, a.res, pc * a.ldR + chb, (own && a.res != nullptr) ? nval : 0);
+    const hrf_f4 r2 = ld_sel(nfull, a.res2, pc * a.ldR + chb, (own && a.res2 != nullptr) ? nval : 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[t][r] += r1[r] + r2[r];
   }
@@ -153,13 +159,15 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) 
   if (TF == HRF_TF_LN) { mean = a.tf_rowstat[2 * pc]; rstd = a.tf_rowstat[2 * pc + 1]; }
 
   const int nslab = (a.K + 15) >> 4;
+  const int kper = SK ? (nslab + 3) >> 2 : nslab;
+  const int k0 = SK ? wave * kper : 0, k1 = SK ? min(nslab, k0 + kper) : nslab;
   const long xrow = pc * a.ldX;
 #pragma unroll 1
-  for (int kb = 0; kb < nslab; kb += SB) {
+  for (int kb = k0; kb < k1; kb += SB) {
     hrf_f4 xa[SB], sc[SB], sh[SB], wv[SB][NT];
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
-      const int kbase = 16 * (kb + s) + 4 * q, kval = a.K - kbase;
+      const int kbase = 16 * (kb + s) + 4 * q, kval = (!SK || kb + s < k1) ? a.K - kbase : 0;   // (slabs of the next wave: masked)
       const bool kfull = 16 * (kb + s + 1) <= a.K;
       xa[s] = ld_sel(kfull, a.x, xrow + kbase, kval);
       if (TF != HRF_TF_NONE) { sc[s] = ld_sel(kfull, scp, kbase, kval); sh[s] = ld_sel(kfull, shp, kbase, kval); }
@@ -180,6 +188,23 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) 
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = hrf_mfma16(wv[s][t][r], v, acc[t]);   // k beyond K: W == 0
       }
+    }
+  }
+  if (SK) {                                                // partial tiles of waves 1..3 -> wave 0
+    if (wave != 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) hrf_st4(sRed + (((wave - 1) * NT + t) * 64 + lane) * 4, acc[t]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const hrf_f4 v = hrf_ld4(sRed + ((w * NT + t) * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][r] += v[r];
+        }
     }
   }
 
@@ -215,17 +240,19 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) 
 }
 
 // --------------------------------------------------------------------------------- backward data
-template <int NT, bool BNB, int SB>
+template <int NT, bool BNB, int SB, bool SK>
 __global__ __launch_bounds__(256) void lin_bwd_data_kernel(HrfGroup<LinBwdDataArgs> grp) {
   const LinBwdDataArgs& a = grp.sel();
   __shared__ float sStat[4 * 2 * NT * 16];
+  __shared__ __attribute__((aligned(16))) float sRed[SK ? 3 * NT * 256 : 4];
   __shared__ __attribute__((aligned(16))) float sFin[BNB ? 3 * HRF_FIN_MAXC : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int n0w = blockIdx.y * (NT * 16);
-  const int pix = blockIdx.x * 64 + wave * 16 + j;
-  const bool pixv = pix < a.M;
-  const long pc = pixv ? pix : a.M - 1;
+  const int pix = SK ? blockIdx.x * 16 + j : blockIdx.x * 64 + wave * 16 + j;
+  const bool pixin = pix < a.M;
+  const bool pixv = pixin && (!SK || wave == 0);           // (SK: see lin_fwd_kernel)
+  const long pc = pixin ? pix : a.M - 1;
   // BatchNorm-backward coefficients of dY derived on load (hrf_bn_bfin_t)
   const float* cAp = a.cA;
   const float* cBp = a.cB;
@@ -244,17 +271,19 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(HrfGroup<LinBwdDataAr
     const int chb = n0w + 16 * t + 4 * q, nval = a.N - chb;
     const bool nfull = n0w + 16 * (t + 1) <= a.N;
     xr[t] = ld_sel(nfull, a.xraw, pc * a.ldXr + chb, a.epi == 1 ? nval : 0);
-    acc[t] = ld_sel(nfull, a.dx, pc * a.ldDx + chb, (a.epi != 1 && a.accumulate) ? nval : 0);
+    acc[t] = ld_sel(nfull, a.dx, pc * a.ldDx + chb, (a.epi != 1 && a.accumulate && (!SK || wave == 0)) ? nval : 0);
   }
 
   const int nslab = (a.K + 15) >> 4;
+  const int kper = SK ? (nslab + 3) >> 2 : nslab;
+  const int k0 = SK ? wave * kper : 0, k1 = SK ? min(nslab, k0 + kper) : nslab;
   const long drow = pc * a.ldD + a.doff;
 #pragma unroll 1
-  for (int kb = 0; kb < nslab; kb += SB) {
+  for (int kb = k0; kb < k1; kb += SB) {
     hrf_f4 dv[SB], yv[SB], ca[SB], cb[SB], cc[SB], wv[SB][NT];
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
-      const int kbase = 16 * (kb + s) + 4 * q, kval = a.K - kbase;
+      const int kbase = 16 * (kb + s) + 4 * q, kval = (!SK || kb + s < k1) ? a.K - kbase : 0;
       const bool kfull = 16 * (kb + s + 1) <= a.K;
       dv[s] = ld_sel(kfull, a.dy, drow + kbase, kval);
       if (BNB) {
@@ -277,6 +306,23 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(HrfGroup<LinBwdDataAr
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = hrf_mfma16(wv[s][t][r], d, acc[t]);
       }
+    }
+  }
+  if (SK) {                                                // partial tiles of waves 1..3 -> wave 0
+    if (wave != 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) hrf_st4(sRed + (((wave - 1) * NT + t) * 64 + lane) * 4, acc[t]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const hrf_f4 v = hrf_ld4(sRed + ((w * NT + t) * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][r] += v[r];
+        }
     }
   }
 
@@ -317,32 +363,42 @@ inline int pick_ntw(int M, int T) {
 
 }  // namespace
 
-#define HRF_LF_LAUNCH(NT_, TF_, SB_) HRF_LAUNCH_G((lin_fwd_kernel<NT_, TF_, SB_>), grid, dim3(256), 0, stream, a)
-#define HRF_LF_WIDE(NT_, TF_) { if (a.K <= LIN_SB_WIDE_K) { HRF_LF_LAUNCH(NT_, TF_, LIN_SB); } else { HRF_LF_LAUNCH(NT_, TF_, LIN_SB_WIDE); } }
-#define HRF_LF_NT(TF_, V4_)                          \
-  switch (ntw) {                                     \
-    case 1: HRF_LF_LAUNCH(1, TF_, LIN_SB); break;    \
-    case 2: HRF_LF_LAUNCH(2, TF_, LIN_SB); break;    \
-    case 3: HRF_LF_LAUNCH(3, TF_, LIN_SB); break;    \
-    case 5: HRF_LF_WIDE(5, TF_) break;               \
-    default: HRF_LF_WIDE(9, TF_) break;              \
+// split K over the four waves of a block (lin_*_kernel<..., SK = true>): few rows and a long contraction
+constexpr int LIN_SK_MAX_M = 4096, LIN_SK_MIN_SLABS = 8;
+inline bool lin_use_sk(int M, int K) { return M <= LIN_SK_MAX_M && ((K + 15) >> 4) >= LIN_SK_MIN_SLABS; }
+// tiles per wave and the split decision of a forward launch (hrf_lin_fwd_emits_ln must agree with the launch)
+inline void lin_fwd_plan(const LinFwdArgs& a, int& ntw, bool& sk) {
+  const int T = (a.N + 15) / 16;
+  sk = lin_use_sk(a.M, a.K);
+  ntw = pick_ntw(sk ? 4 * a.M : a.M, T);                  // (a 16-pixel tile per BLOCK: four times the blocks for the same rows)
+  if (ntw > LIN_FWD_MAX_NT) ntw = LIN_FWD_MAX_NT;
+}
+
+#define HRF_LF_LAUNCH(NT_, TF_, SB_, SK_) HRF_LAUNCH_G((lin_fwd_kernel<NT_, TF_, SB_, SK_>), grid, dim3(256), 0, stream, a)
+#define HRF_LF_WIDE(NT_, TF_, SK_) { if (a.K <= LIN_SB_WIDE_K) { HRF_LF_LAUNCH(NT_, TF_, LIN_SB, SK_); } else { HRF_LF_LAUNCH(NT_, TF_, LIN_SB_WIDE, SK_); } }
+#define HRF_LF_NT(TF_, SK_)                              \
+  switch (ntw) {                                         \
+    case 1: HRF_LF_LAUNCH(1, TF_, LIN_SB, SK_); break;   \
+    case 2: HRF_LF_LAUNCH(2, TF_, LIN_SB, SK_); break;   \
+    case 3: HRF_LF_LAUNCH(3, TF_, LIN_SB, SK_); break;   \
+    case 5: HRF_LF_WIDE(5, TF_, SK_) break;              \
+    default: HRF_LF_WIDE(9, TF_, SK_) break;             \
   }
-#define HRF_LF_V4(TF_) { HRF_LF_NT(TF_, true) }
+#define HRF_LF_V4(TF_) { if (sk) { HRF_LF_NT(TF_, true) } else { HRF_LF_NT(TF_, false) } }
 
 bool hrf_lin_fwd_emits_ln(const LinFwdArgs& a) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return false;
-  const int T = (a.N + 15) / 16;
-  int ntw = pick_ntw(a.M, T);
-  if (ntw > LIN_FWD_MAX_NT) ntw = LIN_FWD_MAX_NT;
-  return hrf_cdiv(T, ntw) == 1;
+  int ntw; bool sk;
+  lin_fwd_plan(a, ntw, sk);
+  return hrf_cdiv((a.N + 15) / 16, ntw) == 1;
 }
 
 int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return -1;
   const int T = (a.N + 15) / 16;
-  int ntw = pick_ntw(a.M, T);
-  if (ntw > LIN_FWD_MAX_NT) ntw = LIN_FWD_MAX_NT;
-  const dim3 grid(hrf_cdiv(a.M, 64), hrf_cdiv(T, ntw));
+  int ntw; bool sk;
+  lin_fwd_plan(a, ntw, sk);
+  const dim3 grid(hrf_cdiv(a.M, sk ? 16 : 64), hrf_cdiv(T, ntw));
   switch (a.tf_mode) {
     case HRF_TF_NONE: HRF_LF_V4(HRF_TF_NONE) break;
     case HRF_TF_AFFINE: HRF_LF_V4(HRF_TF_AFFINE) break;
@@ -354,26 +410,29 @@ int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
   return hrf_check_launch();
 }
 
-#define HRF_LB_LAUNCH(NT_, BNB_, SB_) HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_, SB_>), grid, dim3(256), 0, stream, a)
-#define HRF_LB_WIDE(NT_, BNB_) { if (a.K <= LIN_SB_WIDE_K) { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB); } else { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB_WIDE); } }
-#define HRF_LB_NT(BNB_, V4_)                         \
-  switch (ntw) {                                     \
-    case 1: HRF_LB_LAUNCH(1, BNB_, LIN_SB); break;   \
-    case 2: HRF_LB_LAUNCH(2, BNB_, LIN_SB); break;   \
-    case 3: HRF_LB_LAUNCH(3, BNB_, LIN_SB); break;   \
-    case 5: HRF_LB_WIDE(5, BNB_) break;              \
-    default: HRF_LB_WIDE(9, BNB_) break;             \
+#define HRF_LB_LAUNCH(NT_, BNB_, SB_, SK_) HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_, SB_, SK_>), grid, dim3(256), 0, stream, a)
+#define HRF_LB_WIDE(NT_, BNB_, SK_) { if (a.K <= LIN_SB_WIDE_K) { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB, SK_); } else { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB_WIDE, SK_); } }
+#define HRF_LB_NT(BNB_, SK_)                             \
+  switch (ntw) {                                         \
+    case 1: HRF_LB_LAUNCH(1, BNB_, LIN_SB, SK_); break;  \
+    case 2: HRF_LB_LAUNCH(2, BNB_, LIN_SB, SK_); break;  \
+    case 3: HRF_LB_LAUNCH(3, BNB_, LIN_SB, SK_); break;  \
+    case 5: HRF_LB_WIDE(5, BNB_, SK_) break;             \
+    default: HRF_LB_WIDE(9, BNB_, SK_) break;            \
   }
-#define HRF_LB_V4(BNB_) { HRF_LB_NT(BNB_, true) }
+#define HRF_LB_V4(BNB_) { if (sk) { HRF_LB_NT(BNB_, true) } else { HRF_LB_NT(BNB_, false) } }
 
 int hrf_lin_bwd_data_launch(const LinBwdDataArgs& a, void* stream) {
   if (a.K < 4 || a.N < 4 || a.M <= 0) return -1;
   const int T = (a.N + 15) / 16;
-  int ntw = pick_ntw(a.M, T);
+  // (split K: only where the output is narrow - with >= 10 channel tiles a launch has blocks enough, and HRFuser-B's 1 248 -> 312 /
+  // 2 496 -> 624 data gradients lost 0.4 ms per step to it)
+  const bool sk = T <= 9 && lin_use_sk(a.M, a.K);
+  int ntw = pick_ntw(sk ? 4 * a.M : a.M, T);
   // the epilogue variants keep their raw-input tile and the activation temporaries next to the accumulators: 9 tiles per
   // wave do not fit the register file (HRFuser-B, 312 output channels: 150 us at 10 TFLOP/s); more channel groups instead
   if (a.epi == 1 && ntw > LIN_BWD_EPI_MAX_NT) ntw = LIN_BWD_EPI_MAX_NT;
-  const dim3 grid(hrf_cdiv(a.M, 64), hrf_cdiv(T, ntw));
+  const dim3 grid(hrf_cdiv(a.M, sk ? 16 : 64), hrf_cdiv(T, ntw));
   if (a.cA != nullptr) { HRF_LB_V4(true) } else { HRF_LB_V4(false) }
   return hrf_check_launch();
 }
