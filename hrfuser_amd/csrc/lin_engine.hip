@@ -364,7 +364,13 @@ inline int pick_ntw(int M, int T) {
 }  // namespace
 
 // split K over the four waves of a block (lin_*_kernel<..., SK = true>): few rows and a long contraction
-constexpr int LIN_SK_MAX_M = 4096, LIN_SK_MIN_SLABS = 8;
+#ifndef HRF_LIN_SK_MAX_M
+#define HRF_LIN_SK_MAX_M 4096
+#endif
+#ifndef HRF_LIN_SK_MIN_SLABS
+#define HRF_LIN_SK_MIN_SLABS 8
+#endif
+constexpr int LIN_SK_MAX_M = HRF_LIN_SK_MAX_M, LIN_SK_MIN_SLABS = HRF_LIN_SK_MIN_SLABS;
 inline bool lin_use_sk(int M, int K) { return M <= LIN_SK_MAX_M && ((K + 15) >> 4) >= LIN_SK_MIN_SLABS; }
 // tiles per wave and the split decision of a forward launch (hrf_lin_fwd_emits_ln must agree with the launch)
 inline void lin_fwd_plan(const LinFwdArgs& a, int& ntw, bool& sk) {
