@@ -1031,7 +1031,12 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     // atomic fan-in per output element (128 x 25 ns = 3 us tail); the 3x3 path already has 9x the blocks
     const int gxy0 = hrf_cdiv(Cout, 16 * mt) * d.gyc;
     const int cap_tapb = gxy0 >= 64 ? 8 : (512 / gxy0 > 128 ? 128 : 512 / gxy0);       // ~512 blocks
-    const int cap2 = g_knob[3] > 0 ? g_knob[3] : (tapb ? cap_tapb : (tap3 ? 32 : 128));
+    // The problems of a step are issued GROUPED (8 ... 16 per launch), so a problem does not have to fill the chip on its own: with
+    // 16 pixel splits instead of 128 every block streams 8x the pixels per 8-wave merge + atomic pass (same-box A/B of the captured
+    // steps, cap 128 / 64 / 32 / 16 / 8 / 4: HRFuser-T 12.66 / 12.63 / 12.56 / 12.49 / 12.46 / 13.6 ms, HRFuser-B 46.3 / 45.9 / 45.6 /
+    // 45.5 / 46.1 ms)
+    const int cap_split = 16;
+    const int cap2 = g_knob[3] > 0 ? g_knob[3] : (tapb ? (cap_tapb < cap_split ? cap_tapb : cap_split) : cap_split);
     if (sp > cap2) sp = cap2;
     if (sp < 1) sp = 1;
     const int gxy = hrf_cdiv(Cout, 16 * mt) * d.gyc;
