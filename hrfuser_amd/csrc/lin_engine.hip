@@ -353,7 +353,10 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(HrfGroup<LinBwdDataAr
 // rounded up to an instantiated size (masked tiles cost MFMA issue slots only)
 inline int pick_ntw(int M, int T) {
   const long ptiles = (M + 15) / 16;
-  long groups = (768 + ptiles - 1) / ptiles;               // channel groups wanted for parallelism
+#ifndef HRF_LIN_WAVES
+#define HRF_LIN_WAVES 768
+#endif
+  long groups = (HRF_LIN_WAVES + ptiles - 1) / ptiles;     // channel groups wanted for parallelism
   if (groups > T) groups = T;
   const long gmin = (T + 8) / 9;
   if (groups < gmin) groups = gmin;
