@@ -374,6 +374,10 @@ inline int pick_ntw(int M, int T) {
 #define HRF_LIN_SK_MIN_SLABS 8
 #endif
 constexpr int LIN_SK_MAX_M = HRF_LIN_SK_MAX_M, LIN_SK_MIN_SLABS = HRF_LIN_SK_MIN_SLABS;
+#ifndef HRF_LIN_LN_ROW_MAX_M
+#define HRF_LIN_LN_ROW_MAX_M 8192
+#endif
+constexpr int LIN_LN_ROW_MAX_M = HRF_LIN_LN_ROW_MAX_M;
 inline bool lin_use_sk(int M, int K) { return M <= LIN_SK_MAX_M && ((K + 15) >> 4) >= LIN_SK_MIN_SLABS; }
 // tiles per wave and the split decision of a forward launch (hrf_lin_fwd_emits_ln must agree with the launch)
 inline void lin_fwd_plan(const LinFwdArgs& a, int& ntw, bool& sk) {
@@ -381,6 +385,10 @@ inline void lin_fwd_plan(const LinFwdArgs& a, int& ntw, bool& sk) {
   sk = lin_use_sk(a.M, a.K);
   ntw = pick_ntw(sk ? 4 * a.M : a.M, T);                  // (a 16-pixel tile per BLOCK: four times the blocks for the same rows)
   if (ntw > LIN_FWD_MAX_NT) ntw = LIN_FWD_MAX_NT;
+  // the caller wants the LayerNorm statistics of the output rows (the per-op transformer blocks: out_proj -> norm2): a wave that holds
+  // the WHOLE row (<= 144 channels) emits them from its accumulators and the hrf_ln_stats launch behind this one disappears - worth
+  // more than the parallelism of several channel groups when the rows are few (72 / 144 channels at 24x40 / 12x20)
+  if (a.ln_out != nullptr && T <= 9 && a.M <= LIN_LN_ROW_MAX_M) ntw = T <= 1 ? 1 : (T <= 2 ? 2 : (T <= 3 ? 3 : (T <= 5 ? 5 : 9)));
 }
 
 #define HRF_LF_LAUNCH(NT_, TF_, SB_, SK_) HRF_LAUNCH_G((lin_fwd_kernel<NT_, TF_, SB_, SK_>), grid, dim3(256), 0, stream, a)

@@ -120,6 +120,7 @@ CONV_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
     (1, 66, 70, 256, 64, 1, 1, 1, True, False),      # M >= 128*.. exercises the BM=128 tile on GPU sizes
     (2, 5, 6, 288, 72, 1, 1, 3, True, True),         # few rows, deep contraction (HRFuser-B's coarse branches in miniature)
     (1, 6, 7, 330, 300, 1, 1, 4, True, False),       # deep in both directions, ragged K and N
+    (2, 6, 5, 144, 144, 1, 1, 4, True, False),       # 9 channel tiles in ONE wave (whole-row LayerNorm statistics) + split K
 ]
 
 
