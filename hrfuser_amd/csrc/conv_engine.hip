@@ -1035,7 +1035,8 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     // 16 pixel splits instead of 128 every block streams 8x the pixels per 8-wave merge + atomic pass (same-box A/B of the captured
     // steps, cap 128 / 64 / 32 / 16 / 8 / 4: HRFuser-T 12.66 / 12.63 / 12.56 / 12.49 / 12.46 / 13.6 ms, HRFuser-B 46.3 / 45.9 / 45.6 /
     // 45.5 / 46.1 ms)
-    const int cap_split = 16;
+    // (a problem launched on its own - outside hrf_wgrad_group_begin / _end - keeps the wide split: it has the chip to itself)
+    const int cap_split = g_wg_collect ? 16 : (tap3 ? 32 : 128);
     const int cap2 = g_knob[3] > 0 ? g_knob[3] : (tapb ? (cap_tapb < cap_split ? cap_tapb : cap_split) : cap_split);
     if (sp > cap2) sp = cap2;
     if (sp < 1) sp = 1;
