@@ -595,7 +595,15 @@ class LocalWindowSelfAttention(nn.Module):
         return R.linear_residual(ctx, o, a.out_proj, x, drop=drop)
 
 
-_DEBUG_PAD = {int(k): float(v) for k, v in (kv.split(':') for kv in os.environ.get('HRF_DEBUG_PAD', '').split(',') if ':' in kv)}
+_DEBUG_PAD_CACHE = {}
+
+
+def _debug_pad():
+    """HRF_DEBUG_PAD="18:10,72:10" -> {width: microseconds} (read per call: tools/race_check.py changes it between steps)."""
+    env = os.environ.get('HRF_DEBUG_PAD', '')
+    if env not in _DEBUG_PAD_CACHE:
+        _DEBUG_PAD_CACHE[env] = {int(k): float(v) for k, v in (kv.split(':') for kv in env.split(',') if ':' in kv)}
+    return _DEBUG_PAD_CACHE[env]
 
 
 class HRFormerBlock(nn.Module):
@@ -626,10 +634,10 @@ class HRFormerBlock(nn.Module):
             s1, s2 = eng.droppath_scale(x.shape[0], p), eng.droppath_scale(x.shape[0], p)
         msa = self.attn.attn
         C = x.shape[-1]
-        if _DEBUG_PAD.get(C):
+        if _debug_pad().get(C):
             # critical-lane probe (HRF_DEBUG_PAD="18:10,72:10": 10 us of idle time per block of that width, forward and
             # backward): a lane whose padding shows up in the step time is on the critical path
-            ticks = int(_DEBUG_PAD[C] * 100)
+            ticks = int(_debug_pad()[C] * 100)
             ctx.L.hrf_debug_spin(ticks, ctx.stream)
             ctx.push(lambda: ctx.L.hrf_debug_spin(ticks, ctx.stream))
         if R.attn_block_ok(ctx, C, msa.num_heads) and self.ffn.layers[0].weight.shape[0] == 4 * C and not R.is_gn(self.ffn.layers[1]):
@@ -1784,6 +1792,17 @@ class HRFormer(HipModule):
         previous stage; None keeps branch i."""
         nb = len(trans)
         xs = [None] * nb
+        # Several transition convolutions may read the SAME map (transition1: every new branch reads the stage-1 output) and
+        # back-propagate on different lanes: each consumer after the first gets a handle with a gradient slot of its own
+        # (R.split_grad; the slots are added on this lane, behind the join) - two lanes writing one gradient buffer, one with
+        # "overwrite" and one with "accumulate", is a race (seen as a 12 % error of every stage-1 gradient when the second
+        # lane's launch happened to run first).
+        srcs, seen = [None] * nb, set()
+        for i in range(nb):
+            if trans[i] is not None:
+                src = prev if first else prev[-1]
+                srcs[i] = src if id(src) not in seen else R.split_grad(ctx, src)
+                seen.add(id(src))
         lanes = ctx.fork(nb)
         for i in range(nb):
             tr = trans[i]
@@ -1791,8 +1810,7 @@ class HRFormer(HipModule):
                 xs[i] = prev[i]
                 continue
             with ctx.on(lanes[i]):
-                src = prev if first else prev[-1]
-                xs[i] = _run_conv_chain(ctx, src, [tr] if isinstance(tr[0], nn.Conv2d) else list(tr))
+                xs[i] = _run_conv_chain(ctx, srcs[i], [tr] if isinstance(tr[0], nn.Conv2d) else list(tr))
         ctx.join(lanes)
         return xs
 

@@ -186,3 +186,16 @@ def test_stale_backward_raises_emul():
         assert x1.grad is not None and torch.isfinite(x1.grad).all()
     finally:
         T.use_backend('hip')
+
+
+@pytest.mark.gpu
+def test_lane_timing_does_not_change_gradients_gpu():
+    """tools/race_check.py on the plain HRFormer and on HRFuser-T: one eager training step under lane-timing perturbations (one leaf
+    lane, idle launches in front of the blocks of one width, no grouping) gives the same gradients.  Regression test of the
+    transition1 race (two lanes writing one gradient buffer, one overwriting, one accumulating)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'race_check.py'), 'hrformer_t_bn', 't_nus_bn'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'RACE CHECK OK' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
