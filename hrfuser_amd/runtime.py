@@ -926,10 +926,7 @@ class Ctx:
         # the strand tree of the forward pass, in reverse: 'P' entries re-run the sibling strands' tapes in lock-step
         # (merged data-gradient launches; SyncBN backward exchanges parked and flushed as ONE packed collective)
         self.strand = self.root
-        _dbg = os.environ.get('HRF_DEBUG_SYNC', '')
-        if 'a' in _dbg: torch.cuda.synchronize()
         self._run_tape(self.root)
-        if 'b' in _dbg: torch.cuda.synchronize()
         if self._deferred and os.environ.get('HRF_DEBUG_SKIP_WGRAD') == '1':
             self._deferred = []                 # timing experiments only: drops the weight-gradient phase
         eng0 = self.owner._engine()
@@ -966,7 +963,6 @@ class Ctx:
                         if group:
                             self.L.hrf_wgrad_group_end(self.stream)
             self.join(lanes)
-            if 'c' in _dbg: torch.cuda.synchronize()
             self.root.tape.clear()              # (fork / join recorded markers: the pass is over)
         if self.multi:
             for lane in self._side_used.values():
