@@ -4,7 +4,8 @@ instead of four, idle launches in front of the blocks of one width (HRF_DEBUG_PA
 compared with the first run: rel-L2 <= 1e-3 passes (two UNPERTURBED runs differ by up to 5e-4 in a few BatchNorm-gamma gradients
 that are small differences of large sums - the order of the fp32 atomics upstream; everything else repeats to 1e-5).  A writer that overwrites a buffer
 another lane accumulates into shows up as a per-tensor difference of several percent (found this way: the two transition1
-convolutions of the plain HRFormer).   python tools/race_check.py [t_nus_bn|b_nus_bn|t_stf_bn|hrformer_t_bn|hrnet|stage_d ...]"""
+convolutions of the plain HRFormer).  For the HRFuser models the captured step (hipGraph replay: another stream assignment) is replayed 8 times
+against the eager step as well.   python tools/race_check.py [t_nus_bn|b_nus_bn|t_stf_bn|hrformer_t_bn|hrnet|stage_d ...]"""
 import copy, json, os, sys
 os.environ['HRF_MODULE_GRAPH'] = '0'              # eager launches on the lanes: the timing perturbations must act on every call
 import torch
@@ -77,8 +78,39 @@ def check(tag):
     return worst_all
 
 
+def check_captured(tag, size=(2, 192, 320), replays=8):
+    """The product path: ONE captured training step (hrfuser_amd.trainer.Trainer, learning rate 0 so that the parameters stay put)
+    replayed `replays` times must reproduce the gradient arena of the eager step (rel-L2 of the whole arena)."""
+    from hrfuser_amd.trainer import Trainer, make_cotangents
+    dev = torch.device('cuda:0')
+    cfg = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'backbone_cfgs.json')))[tag]
+    mc = cfg.get('mod_in_channels', [3, 3])
+    torch.manual_seed(0)
+    net = build_backbone(copy.deepcopy(cfg)).to(dev)
+    T.disable_stochastic(net)
+    net.train(True)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(size[0], 3, size[1], size[2], generator=g).to(dev)
+    mods = [torch.randn(size[0], c, size[1], size[2], generator=g).to(dev) for c in mc]
+    cots = make_cotangents(net, x, mods)
+    tr = Trainer(net, lr=0.0)
+    eng = net._engine()
+    tr.step(x, mods, cots)
+    torch.cuda.synchronize()
+    ref = eng.flat_g.detach().clone()
+    tr.capture(x, mods, cots)
+    worst = 0.0
+    for _ in range(replays):
+        tr.replay()
+        torch.cuda.synchronize()
+        worst = max(worst, float((eng.flat_g.detach() - ref).norm() / ref.norm()))
+    print(f'{tag:14s} {replays} captured replays vs the eager step: worst rel-L2 of the gradient arena {worst:.2e}')
+    return worst
+
+
 if __name__ == '__main__':
     tags = sys.argv[1:] or ['t_nus_bn', 'b_nus_bn', 't_stf_bn', 'hrformer_t_bn', 'hrnet', 'stage_d']
     w = max(check(t) for t in tags)
+    w = max([w] + [check_captured(t) for t in tags if t in ('t_nus_bn', 'b_nus_bn', 't_stf_bn')])
     print('RACE CHECK', 'OK' if w <= 1e-3 else 'FAILED', f'(worst {w:.2e})')
     sys.exit(0 if w <= 1e-3 else 1)
