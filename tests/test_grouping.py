@@ -128,3 +128,37 @@ def test_lockstep_equals_serial_emul():
 @pytest.mark.parametrize('tag,B,H,W', [('t_nus_bn', 2, 64, 96), ('t_stf_bn', 1, 64, 128)])
 def test_lockstep_equals_serial_gpu(tag, B, H, W):
     _lockstep_equals_serial('hip', tag, B, H, W)
+
+
+def test_leaf_balancer_keeps_variants_together():
+    """runtime._balance: every leaf exactly once; leaves with the same key (one kernel variant of the grouped weight-gradient
+    launches) travel in chunks of `chunk`, i.e. a variant with n problems is spread over at most ceil(n / chunk) lanes; keyless
+    leaves are placed one by one; the lane loads stay balanced (longest-processing-time-first over the chunks)."""
+    from hrfuser_amd.runtime import _balance
+    log = []
+    mk = lambda name: (lambda: log.append(name))
+    items = [(10.0 + i, mk(f'a{i}'), ('conv_w', 72, 18)) for i in range(19)] + \
+            [(3.0, mk(f'b{i}'), ('conv_w', 288, 72)) for i in range(5)] + \
+            [(50.0, mk('fold')), (7.0, mk('rpb'), None)] + [(1.0, mk(f'd{i}'), ('dw_w', 2)) for i in range(9)]
+    parts = _balance(items, 4, chunk=8)
+    assert len(parts) == 4
+    lanes = []
+    for p in parts:
+        log.clear()
+        for fn in p:
+            fn()
+        lanes.append(list(log))
+    flat = [n for lane in lanes for n in lane]
+    assert sorted(flat) == sorted([f'a{i}' for i in range(19)] + [f'b{i}' for i in range(5)] + ['fold', 'rpb'] + [f'd{i}' for i in range(9)])
+    for prefix, n in (('a', 19), ('b', 5), ('d', 9)):
+        used = [sum(1 for x in lane if x.startswith(prefix)) for lane in lanes]
+        assert sum(used) == n and sum(1 for u in used if u) <= -(-n // 8), (prefix, used)
+    loads = []
+    cost = {f'a{i}': 10.0 + i for i in range(19)}
+    cost.update({f'b{i}': 3.0 for i in range(5)}); cost.update({'fold': 50.0, 'rpb': 7.0}); cost.update({f'd{i}': 1.0 for i in range(9)})
+    for lane in lanes:
+        loads.append(sum(cost[x] for x in lane))
+    assert max(loads) <= 0.5 * sum(loads)                      # no lane carries more than half of the phase
+    # chunk = 1: the round-3 behaviour (every leaf on its own)
+    parts1 = _balance(items, 4, chunk=1)
+    assert sum(len(p) for p in parts1) == len(items)
