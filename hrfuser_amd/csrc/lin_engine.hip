@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) 
 }
 
 // --------------------------------------------------------------------------------- backward data
-template <int NT, bool BNB, int SB, bool SK>
+template <int NT, bool BNB, int SB, bool SK, bool ONE = false>
 __global__ __launch_bounds__(256) void lin_bwd_data_kernel(HrfGroup<LinBwdDataArgs> grp) {
   const LinBwdDataArgs& a = grp.sel();
   __shared__ float sStat[4 * 2 * NT * 16];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(HrfGroup<LinBwdDataAr
   const int k0 = SK ? wave * kper : 0, k1 = SK ? min(nslab, k0 + kper) : nslab;
   const long drow = pc * a.ldD + a.doff;
 #pragma unroll 1
-  for (int kb = k0; kb < k1; kb += SB) {
+  for (int kb = k0; kb < (ONE ? k0 + 1 : k1); kb += SB) {        // ONE: the whole contraction is one batch (K <= 16 * SB): straight-line code
     hrf_f4 dv[SB], yv[SB], ca[SB], cb[SB], cc[SB], wv[SB][NT];
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
@@ -428,7 +428,8 @@ int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
 }
 
 #define HRF_LB_LAUNCH(NT_, BNB_, SB_, SK_) HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_, SB_, SK_>), grid, dim3(256), 0, stream, a)
-#define HRF_LB_WIDE(NT_, BNB_, SK_) { if (a.K <= LIN_SB_WIDE_K) { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB, SK_); } else { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB_WIDE, SK_); } }
+#define HRF_LB_WIDE(NT_, BNB_, SK_) { if (a.K <= 32 && !SK_) { HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_, 2, false, true>), grid, dim3(256), 0, stream, a); } \
+  else if (a.K <= LIN_SB_WIDE_K) { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB, SK_); } else { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB_WIDE, SK_); } }
 #define HRF_LB_NT(BNB_, SK_)                             \
   switch (ntw) {                                         \
     case 1: HRF_LB_LAUNCH(1, BNB_, LIN_SB, SK_); break;  \
