@@ -118,7 +118,7 @@ __device__ __forceinline__ void flush_moments(const float* sStat, double* stats,
 // SK ("split K"): few rows, long contraction (the 24x40 / 12x20 branches: K = 288 ... 2 496 at 480 ... 1 920 rows) - the four
 // waves of a block share ONE 16-pixel tile and take a quarter of the K slabs each (K / 64 dependent load round trips per wave
 // instead of K / 16 / SB ... and four times the waves in flight); partial tiles meet in LDS, wave 0 runs the epilogue.
-template <int NT, int TF, int SB, bool SK>
+template <int NT, int TF, int SB, bool SK, bool ONE = false>
 __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) {
   const LinFwdArgs& a = grp.sel();
   __shared__ float sStat[4 * 2 * NT * 16];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(HrfGroup<LinFwdArgs> grp) 
   const int k0 = SK ? wave * kper : 0, k1 = SK ? min(nslab, k0 + kper) : nslab;
   const long xrow = pc * a.ldX;
 #pragma unroll 1
-  for (int kb = k0; kb < k1; kb += SB) {
+  for (int kb = k0; kb < (ONE ? k0 + 1 : k1); kb += SB) {        // ONE: the whole contraction is one batch (K <= 16 * SB): straight-line code
     hrf_f4 xa[SB], sc[SB], sh[SB], wv[SB][NT];
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
@@ -392,8 +392,22 @@ inline void lin_fwd_plan(const LinFwdArgs& a, int& ntw, bool& sk) {
 }
 
 #define HRF_LF_LAUNCH(NT_, TF_, SB_, SK_) HRF_LAUNCH_G((lin_fwd_kernel<NT_, TF_, SB_, SK_>), grid, dim3(256), 0, stream, a)
+// the whole contraction in ONE batch of 1 / 2 / 3 slabs (K <= 48): straight-line variants with fewer live registers
+#define HRF_LF_ONE(NT_, TF_)                                                                                                   \
+  { if (a.K <= 16) { HRF_LAUNCH_G((lin_fwd_kernel<NT_, TF_, 1, false, true>), grid, dim3(256), 0, stream, a); }                  \
+    else if (a.K <= 32) { HRF_LAUNCH_G((lin_fwd_kernel<NT_, TF_, 2, false, true>), grid, dim3(256), 0, stream, a); }             \
+    else { HRF_LAUNCH_G((lin_fwd_kernel<NT_, TF_, 3, false, true>), grid, dim3(256), 0, stream, a); } }
 #define HRF_LF_WIDE(NT_, TF_, SK_) { if (a.K <= LIN_SB_WIDE_K) { HRF_LF_LAUNCH(NT_, TF_, LIN_SB, SK_); } else { HRF_LF_LAUNCH(NT_, TF_, LIN_SB_WIDE, SK_); } }
 #define HRF_LF_NT(TF_, SK_)                              \
+  if (!SK_ && a.K <= 48) {                               \
+    switch (ntw) {                                       \
+      case 1: HRF_LF_ONE(1, TF_) break;                  \
+      case 2: HRF_LF_ONE(2, TF_) break;                  \
+      case 3: HRF_LF_ONE(3, TF_) break;                  \
+      case 5: HRF_LF_ONE(5, TF_) break;                  \
+      default: HRF_LF_ONE(9, TF_) break;                 \
+    }                                                    \
+  } else                                                 \
   switch (ntw) {                                         \
     case 1: HRF_LF_LAUNCH(1, TF_, LIN_SB, SK_); break;   \
     case 2: HRF_LF_LAUNCH(2, TF_, LIN_SB, SK_); break;   \
@@ -428,9 +442,21 @@ int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
 }
 
 #define HRF_LB_LAUNCH(NT_, BNB_, SB_, SK_) HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_, SB_, SK_>), grid, dim3(256), 0, stream, a)
-#define HRF_LB_WIDE(NT_, BNB_, SK_) { if (a.K <= 32 && !SK_) { HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_, 2, false, true>), grid, dim3(256), 0, stream, a); } \
-  else if (a.K <= LIN_SB_WIDE_K) { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB, SK_); } else { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB_WIDE, SK_); } }
+#define HRF_LB_ONE(NT_, BNB_)                                                                                                   \
+  { if (a.K <= 16) { HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_, 1, false, true>), grid, dim3(256), 0, stream, a); }             \
+    else if (a.K <= 32) { HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_, 2, false, true>), grid, dim3(256), 0, stream, a); }        \
+    else { HRF_LAUNCH_G((lin_bwd_data_kernel<NT_, BNB_, 3, false, true>), grid, dim3(256), 0, stream, a); } }
+#define HRF_LB_WIDE(NT_, BNB_, SK_) { if (a.K <= LIN_SB_WIDE_K) { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB, SK_); } else { HRF_LB_LAUNCH(NT_, BNB_, LIN_SB_WIDE, SK_); } }
 #define HRF_LB_NT(BNB_, SK_)                             \
+  if (!SK_ && a.K <= 48) {                               \
+    switch (ntw) {                                       \
+      case 1: HRF_LB_ONE(1, BNB_) break;                 \
+      case 2: HRF_LB_ONE(2, BNB_) break;                 \
+      case 3: HRF_LB_ONE(3, BNB_) break;                 \
+      case 5: HRF_LB_ONE(5, BNB_) break;                 \
+      default: HRF_LB_ONE(9, BNB_) break;                \
+    }                                                    \
+  } else                                                 \
   switch (ntw) {                                         \
     case 1: HRF_LB_LAUNCH(1, BNB_, LIN_SB, SK_); break;  \
     case 2: HRF_LB_LAUNCH(2, BNB_, LIN_SB, SK_); break;  \
