@@ -517,7 +517,12 @@ def main(argv=None):
     roof = None
     if not args.no_roofline:          # every rank runs it (the step contains collectives when N > 1)
         table = profiling.profile_step(trainer, x, mods, cots, steps=args.profile_steps)
-        roof = profiling.roofline_of_dominant(table, PEAK_F32_MFMA, PEAK_HBM, os.path.join(ROOT, 'profiles'))
+        try:
+            grouped = profiling.grouped_wgrad_report(trainer, x, mods, cots) if use_graph else None
+        except Exception:
+            grouped = None
+            torch.cuda.synchronize()
+        roof = profiling.roofline_of_dominant(table, PEAK_F32_MFMA, PEAK_HBM, os.path.join(ROOT, 'profiles'), grouped=grouped)
         nl = sum(t[0] // t[4] for t in table.values())
         if args.dump_kernels and rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(args.dump_kernels)), exist_ok=True)

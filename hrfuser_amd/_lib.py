@@ -12,6 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'hrfuser_hip.h')
+DEBUG_HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'hrfuser_hip_debug.h')      # measurement / tuning entry points
 # HRF_LIB_PATH: another build of the same library (same-box A/B of two kernel versions: tools/gpu_ab_lib.sh)
 LIB_PATH = os.environ.get('HRF_LIB_PATH') or os.path.join(_HERE, 'libhrfuser_hip.so')
 
@@ -109,6 +110,7 @@ class Lib:
         self.require_cuda = require_cuda
         self._dll = ctypes.CDLL(path)
         self.protos = parse_header()
+        self.protos.update(parse_header(DEBUG_HEADER))     # (bound for bench.py / tools / tests; the product path calls none of them)
         self._fns = {}
         for name, args in self.protos.items():
             fn = getattr(self._dll, name)          # AttributeError if a declared symbol is missing

@@ -202,7 +202,14 @@ class Engine:
         if cur is not None and cur[0] is group and cur[1] == world and cur[3] == p2p.mode():
             return cur[2]
         if cur is not None and cur[2] is not None:
-            cur[2].close()
+            # captured graphs (Trainer.capture, the module-boundary entries) carry the old context BY VALUE in the kernel
+            # arguments of their exchange launches: inbox / flag pointers of every peer, the generation counter, the error
+            # word.  A context any capture has pinned is retired, never closed - a replay after set_sync_group or a change
+            # of HRF_SYNC_P2P must not write into freed or unmapped (remote!) memory
+            if cur[2].pins:
+                self.__dict__.setdefault('_p2p_retired', []).append(cur[2])
+            else:
+                cur[2].close()
         import torch.distributed as dist
         rank = dist.get_rank(group) if world > 1 else 0
         ctx = p2p.P2PExchange.create(self.root._lib_handle(), self._bns, group, world, rank, self.device, strict=p2p.mode() == 'on')
@@ -398,6 +405,8 @@ class Engine:
         if training and self.root.sync_group is not None and (self.root.sync_world > 1 or R.force_collectives()):
             px = self.p2p_context(self.root.sync_group, self.root.sync_world)
             if px is not None:
+                if self.device.type != 'cuda' or not torch.cuda.is_current_stream_capturing():
+                    px.verify_order()                 # (second training step: one object all-gather, then never again)
                 px.tick(_lib.stream_ptr())            # the step generation the exchanges of this forward / backward carry
         if self._bns and not (training and all(m.training for m in self._bns)):
             self.refresh_eval_affine()
@@ -848,8 +857,9 @@ class HRFomerModule(nn.Module):
             lanes = ctx.fork(nb, keep_first=ctx.keep_first)
 
         def branch(i):
-            xs[i] = R.force(ctx, xs[i])                   # the previous module's exchange sum for this branch, on this lane
-            blocks = list(self.branches[i])
+            if isinstance(xs[i], R.Pending):              # the previous module's exchange sum for this branch, on this lane
+                xs[i] = R.force(ctx, xs[i])               # (a lazy CrossFFN tail of the previous single-branch module stays
+            blocks = list(self.branches[i])               # lazy: the first block's fused attention launch forms it on load)
             for b, blk in enumerate(blocks):
                 last = b == len(blocks) - 1
                 if isinstance(blk, HRFormerBlock):
@@ -1090,7 +1100,17 @@ class _BackboneFn(torch.autograd.Function):
         ctx.run_backward()
         grads = tuple(fctx_module_input_grad(s) for s in srcs)
         fctx.hrf = None
+        _poll_exchange(ctx.owner)
         return (None, None) + grads
+
+
+def _poll_exchange(module):
+    """Step boundary of the autograd route (what mmdet runs: backbone() ... loss.backward()): a SyncBN exchange that lost a
+    peer raises HERE, one step late at the latest, instead of training on NaN / unsynchronised statistics for ever
+    (P2PExchange.poll: a non-blocking read of the error word)."""
+    px = module._engine().__dict__.get('_p2p')
+    if px is not None and px[2] is not None:
+        px[2].poll()
 
 
 def fctx_module_input_grad(src):
@@ -1229,6 +1249,10 @@ class HipModule(nn.Module, EngineOwner):
             if t is not None:
                 ent.refs.append(t)
         ent.refs.extend(eng.__dict__.get('_rng_pool', {}).values())
+        px = eng.__dict__.get('_p2p')
+        if px is not None and px[2] is not None and not any(r is px[2] for r in ent.refs):
+            px[2].pins += 1                                  # exchange launches of this capture point into the context's inboxes
+            ent.refs.append(px[2])
 
     def _graph_forward(self, ent, inputs):
         eng = self._engine()
@@ -1292,6 +1316,7 @@ class HipModule(nn.Module, EngineOwner):
             self._pin_engine_buffers(ent, eng)
             eng.fs_sig = None                                # the next eager backward builds its own tables
         ent.bwd.replay()
+        _poll_exchange(self)
         return tuple((fctx_module_input_grad(s).clone() if (s.needs_grad and s.grad is not None) else None) for s in ent.srcs)
 
     def _call_engine(self, inputs):

@@ -31,6 +31,26 @@ constexpr int NTOK = 49;
 
 __device__ float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
 
+// p[idx] when ok, else 0 - as an UNCONDITIONAL load from a clamped index followed by a select.  `ok ? p[idx] : 0.f` with a
+// per-lane condition keeps the load inside an exec-masked branch with its own s_waitcnt: one DEPENDENT LDS round trip per
+// element (round 5: the 18-channel backward kernel carried 404 such branches and 834 wait points).  LLVM re-creates the branch
+// from the select (it sinks a load whose only use is one arm of a select) unless the loaded value passes through something it
+// cannot move: HRF_KEEP, an empty non-volatile asm (no instruction, no ordering, free to schedule).
+#ifdef HRF_EMUL
+#define HRF_KEEP(x) ((void)0)
+#define AB_FENCE() ((void)0)
+#else
+#define HRF_KEEP(x) asm("" : "+v"(x))
+// scheduling fence: the machine scheduler may not move anything across (it hoists the LDS loads of several independent small
+// GEMMs in front of the first one - 72 live registers for the three dn GEMMs of the self-attention epilogue - and spills)
+#define AB_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+__device__ __forceinline__ float ldz(const float* p, int idx, bool ok) {
+  float v = p[ok ? idx : 0];
+  HRF_KEEP(v);
+  return ok ? v : 0.f;
+}
+
 // 4 consecutive elements p[off..off+3], `nvalid` of them exist (<= 0: none); full = the whole 16-wide group row is valid
 __device__ __forceinline__ hrf_f4 ld_sel(bool full, const float* p, long off, int nvalid) {
   if (full) return hrf_ld4(nvalid > 0 ? p + off : g_zero4);
@@ -67,7 +87,7 @@ __device__ __forceinline__ void wave_gemm(const float* W, int n0, int N, const f
     }
     float bv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = r < kval ? brow[kbase + r] : 0.f;
+    for (int r = 0; r < 4; ++r) bv[r] = ldz(brow, kbase + r, r < kval);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -159,16 +179,16 @@ __device__ __forceinline__ void stage_ln_rows(const hrf_attn_block_t& a, const f
   const float rstd = 1.0f / sqrtf(q / (float)C + a.ln_eps);
   const bool real = sPix[t] >= 0;                                   // (rows 49..63 and out-of-image tokens stay zero)
   float* wrow = sX + t * PC;
-  for (int c = part; c < C; c += 4) wrow[c] = real ? fmaf((row[c] - mean) * rstd, gam[c], bet[c]) : 0.f;
+  for (int c = part; c < C; c += 4) { const float y = fmaf((row[c] - mean) * rstd, gam[c], bet[c]); wrow[c] = real ? y : 0.f; }
 }
 
 // ---- weights staged in LDS (widths 18 / 36): every GEMM of the block then reads both operands from LDS and the only
 // global round trip of a workgroup is the batch of loads at its start.  Tile layout [N][PW], PW = K rounded up to 4
 // (16-byte rows), pad columns zero.
-template <int K, int PW>
+template <int K, int PW, int NTHR = 256>
 __device__ __forceinline__ void stage_weight(const float* W, int N, float* sW) {
   const int n4 = N * (PW / 4);
-  for (int e = threadIdx.x; e < n4; e += 256) {
+  for (int e = threadIdx.x; e < n4; e += NTHR) {
     const int n = e / (PW / 4), kb = 4 * (e - n * (PW / 4));
     const hrf_f4 v = ld_sel(kb + 4 <= K, W, (long)n * K + kb, K - kb);
     hrf_st4(sW + n * PW + kb, v);
@@ -195,7 +215,7 @@ __device__ __forceinline__ void wave_gemm_l(const float* sW, int n0, int N, cons
     }
     float bv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = kbase + r < K ? brow[kbase + r] : 0.f;
+    for (int r = 0; r < 4; ++r) bv[r] = ldz(brow, kbase + r, kbase + r < K);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -217,11 +237,12 @@ __device__ __forceinline__ void wave_gemm_tl(const float* sW, int K, const float
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool nv = nbase + r < N;
-      const float bv = nv ? brow[nbase + r] : 0.f;
+      const float bv = ldz(brow, nbase + r, nv);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int k = 16 * t + i;
-        const float w = sW[(nv ? nbase + r : 0) * PW + (k < K ? k : 0)];
+        float w = sW[(nv ? nbase + r : 0) * PW + (k < K ? k : 0)];
+        HRF_KEEP(w);
         acc[t] = hrf_mfma16((nv && k < K) ? w : 0.f, bv, acc[t]);
       }
     }
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<AbFwdArgs>
       const float* krow = sK + i * PC + h * D + q;
 #pragma unroll
       for (int kk = 0; kk < KSD; ++kk) {
-        const float qv = (4 * kk + q < D) ? qrow[4 * kk] : 0.f;      // columns >= D belong to the next head
+        const float qv = ldz(qrow, 4 * kk, 4 * kk + q < D);          // columns >= D belong to the next head
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = hrf_mfma16(krow[16 * t * PC + 4 * kk], qv, acc[t]);
       }
@@ -348,7 +369,9 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<AbFwdArgs>
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * t + 4 * q + r, jc = j < NTOK ? j : 0;
           const int yj = jc / 7, xj = jc - 7 * yj;
-          const float sv = j < NTOK ? acc[t][r] + bias[(yi - yj + 6) * 13 + (xi - xj + 6)] : -3.0e38f;
+          float bj = bias[(yi - yj + 6) * 13 + (xi - xj + 6)];
+          HRF_KEEP(bj);
+          const float sv = j < NTOK ? acc[t][r] + bj : -3.0e38f;
           acc[t][r] = sv;
           m = fmaxf(m, sv);
         }
@@ -516,7 +539,7 @@ __device__ __forceinline__ void wave_gemm_t(const float* W, int K, int k0, const
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool nv = nbase + r < N;
-      bv[r] = nv ? brow[nbase + r] : 0.f;
+      bv[r] = ldz(brow, nbase + r, nv);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int k = k0 + 16 * t + i;
@@ -549,13 +572,14 @@ __device__ __forceinline__ void wave_tgemm(const float* sA, int pitchA, int n0, 
     const int tok = 4 * tt + q;
     const bool tv = tok < NTOK;
     const int tc = tv ? tok : 0;
-    const float av = (tv && nv) ? sA[tc * pitchA + n0 + i] : 0.f;
+    const float av = ldz(sA, tc * pitchA + n0 + i, tv && nv);
 #pragma unroll
     for (int tk = 0; tk < NTK; ++tk) {
       const int k = k0 + 16 * tk + i;
       const int kc = k < K ? k : 0;
       float bvv = sB[tc * pitchB + kc];
-      if (AFF) bvv = realf[tc] != 0.f ? fmaf(bvv, gam[kc], bet[kc]) : 0.f;
+      if (AFF) { float aff = fmaf(bvv, gam[kc], bet[kc]); HRF_KEEP(aff); bvv = realf[tc] != 0.f ? aff : 0.f; }
+      else HRF_KEEP(bvv);
       acc[tk] = hrf_mfma16(av, (tv && k < K) ? bvv : 0.f, acc[tk]);
     }
   }
@@ -609,7 +633,7 @@ __device__ __forceinline__ void stage_xhat_rows(const hrf_attn_block_t& a, const
   qq += __shfl_xor(qq, 1); qq += __shfl_xor(qq, 2);
   const float rstd = 1.0f / sqrtf(qq / (float)C + eps);
   const bool real = sPix[t] >= 0;
-  for (int c = part; c < C; c += 4) row[c] = real ? (row[c] - mean) * rstd : 0.f;
+  for (int c = part; c < C; c += 4) { const float y = (row[c] - mean) * rstd; row[c] = real ? y : 0.f; }
   if (part == 0) sRs[t] = real ? rstd : 0.f;
 }
 
@@ -629,8 +653,11 @@ __device__ __forceinline__ void ln_bwd_rows(hrf_f4* dn, const float* sXh, int pi
       const int k = 16 * t + 4 * q + r;
       const bool kv = k < C && real;
       if (!kv) dn[t][r] = 0.f;
-      xh[t][r] = kv ? sXh[tok * pitch + k] : 0.f;
-      g[t][r] = kv ? dn[t][r] * gam[k] : 0.f;
+      const int kc = k < C ? k : 0;
+      float xv = sXh[tok * pitch + kc], gm = gam[kc];
+      HRF_KEEP(xv); HRF_KEEP(gm);
+      xh[t][r] = kv ? xv : 0.f;
+      g[t][r] = kv ? dn[t][r] * gm : 0.f;
       s1 += g[t][r]; s2 = fmaf(g[t][r], xh[t][r], s2);
     }
   s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
@@ -660,14 +687,36 @@ struct AbBwdArgs {
   hrf_bn_bfin_t bf;     // BatchNorm-backward coefficients of the CrossFFN head derived on load (gstats != null)
 };
 
-template <int C, int HEADS>
-__global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs> grp) {
+// Two ROLES per window (round 5).  A workgroup of this kernel used to live ~46 us at 18 channels and a launch lasts as long as
+// one workgroup (every window of a 96 x 160 map is resident at once; a workgroup ALONE on a CU takes the same time): what a
+// launch costs is the LENGTH of the dependent chain inside a window, not throughput.  That chain carried two kinds of work
+// that do not depend on each other - the data gradient (dy1 W1 -> LN_2 backward -> dy -> dO -> attention backward -> dq/dk/dv
+// W -> LN_1 backward) and the weight gradients of the window (token contractions over tiles the data path has finished) - and
+// an attention core whose two orientations (query columns: softmax statistics, O, dS, dQ; key columns: P and dS again, dV,
+// dK) only meet at the row statistics.  Waves 0-3 (role A, wave w = tokens / queries 16w..16w+15) run the data-gradient chain
+// and the query-column orientation; NWB more waves (role B) run the key-column orientation beside it and the weight-gradient
+// tiles as soon as their operands are final.  Both roles pass the same __syncthreads() sequence (one hardware barrier per
+// workgroup).  NWB = 4 (36 channels: one workgroup per CU, 8 waves = 2 per SIMD) or 2 (18 channels: three workgroups per CU
+// must stay resident for the 644 windows of the 96 x 160 map, 18 waves = 5 per SIMD = 96 registers; eight waves would need 80
+// and spill).  FFN / CROSS / TAIL are compile-time: every instantiation allocates registers for its own path only.
+#ifndef AB_MINW18
+#define AB_MINW18 5
+#endif
+#ifndef AB_NWB18
+#define AB_NWB18 0          // role-B waves of the 18-channel kernel: 0 = four waves run both roles (see the kernel)
+#endif
+
+template <int C, int HEADS, int NWB, bool FFN, bool CROSS, bool TAIL>
+__global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NWB == 2 ? AB_MINW18 : 2))) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs> grp) {
   const hrf_attn_block_t& a = grp.sel().a;
   const hrf_bn_bfin_t& bf = grp.sel().bf;
   constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16, PW = (C + 3) & ~3;
   constexpr int KSD = (D + 3) / 4, DT = (D + 15) / 16;
   constexpr int TILE = 64 * PC, N1 = 4 * C, PH = N1 + 1;
   constexpr bool W1A = N1 * PW <= 2 * TILE;   // w1 fits the (dy, dO) tiles, which are written only after its last use
+  constexpr int NT = 64 * (4 + NWB);                                // threads of the workgroup
+  constexpr int NBW = NWB == 0 ? 4 : NWB, NB = 64 * NBW;            // waves / threads that carry role B (NWB = 0: all four, after A)
+  constexpr bool ffn = FFN, cross = CROSS, tail = TAIL;
   HRF_DYN_SMEM(float, smem);
   float* sWo = smem;                      // [C][PW] out_proj
   float* sWq = sWo + C * PW;              // [C][PW] q / k / v projections
@@ -688,112 +737,131 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
   __shared__ float sReal[64], sRs2[64], sRsQ[64], sRsKV[64], sM[64], sIL[64], sDl[64];
   __shared__ float sT[HEADS * 176];
   __shared__ float sGam[3][C], sBet[3][C];                 // LN_2, LN_q, LN_kv affine parameters
-  __shared__ float sPar[4][3][2 * C];                      // per wave: (sum dn*xhat | sum dn) of LN_2, LN_q, LN_kv
+  __shared__ float sPar[4][3][2 * C];                      // per role-A wave: (sum dn*xhat | sum dn) of LN_2, LN_q, LN_kv
   __shared__ float sCo[3 * (4 * C)];                       // BatchNorm-backward coefficients of h1 (cA | cB | cC)
   __shared__ float sTs[2 * C];                             // scale | shift of the preceding block's tail BatchNorm
-  __shared__ float sTst[4][2 * C];                         // per wave: (sum tail_du | sum tail_du * tail_raw)
+  __shared__ float sTst[4][2 * C];                         // per role-A wave: (sum tail_du | sum tail_du * tail_raw)
   __shared__ __attribute__((aligned(16))) float sB3[3][(C + 3) & ~3];   // bq | bk | bv (pads zero)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // NWB = 0: four waves, each runs its role-A part and then its role-B part between the same barriers (18 channels: three
+  // workgroups per CU must stay resident, which leaves 8 waves 80 registers and 6 waves 96 - both spill)
+  const bool roleA = NWB == 0 || wave < 4, roleB = NWB == 0 || wave >= 4;   // (wave-uniform: scalar branches)
+  const int wb = NWB == 0 ? wave : wave - 4, lt = NWB == 0 ? tid : tid - 256;   // role B: wave / thread index inside the role
   const int i = lane & 15, q = lane >> 4;
   const int win = blockIdx.x;
   const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
-  const bool cross = a.xkv != a.xq, ffn = a.w1 != nullptr, tail = a.tail_raw != nullptr;
   float* slot = a.pslot + (long)blockIdx.x * a.slot_stride;
   if (tid < 64) {
     const int px = tid < NTOK ? ab_tok_pixel(a, b, wy, wx, tid) : -1;
     sPix[tid] = px; sReal[tid] = px >= 0 ? 1.f : 0.f;
   }
   AB_T(0);
-  const int tok0 = 16 * wave, tok = tok0 + i;
+  // role A: wave w owns tokens 16w .. 16w+15 (rows of every per-token GEMM, queries of the attention core)
+  const int tok0 = 16 * (wave & 3), tok = tok0 + i;
   const int pix = tok < NTOK ? ab_tok_pixel(a, b, wy, wx, tok) : -1;   // (== sPix[tok]; computed so that no load waits for LDS)
   const long pc = pix >= 0 ? pix : 0;
   const bool tokv = pix >= 0;
 
-  // ---- the first batch of global loads goes out BEFORE the tiles are zeroed (it used to queue behind the zeroing and its
-  // barrier): incoming gradients, source rows, dy1 operands, the scalars of later phases; the q / k / v / out weights too
-  // where the register budget allows (WE)
-  hrf_f4 gx[CT];                                                    // d/d(out row), this lane's 4-channel groups
+  // ---- the first batch of global loads goes out BEFORE the tiles are zeroed: incoming gradients (role A: the data path),
+  // source rows, dy1 operands, the scalars of later phases; the q / k / v / out weights too where they are one 16-byte
+  // group per thread (WE)
+  hrf_f4 gx[CT];                                                    // d/d(out row), this lane's 4-channel groups (role A)
 #pragma unroll
-  for (int t = 0; t < CT; ++t) {
-    const int nb = 16 * t + 4 * q;
-    gx[t] = ld_sel(16 * (t + 1) <= C, a.gout, pc * C + nb, tokv ? C - nb : 0);
+  for (int t = 0; t < CT; ++t) gx[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+  float rs_out = 1.f;
+  if (roleA) {
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int nb = 16 * t + 4 * q;
+      gx[t] = ld_sel(16 * (t + 1) <= C, a.gout, pc * C + nb, tokv ? C - nb : 0);
+    }
+    rs_out = (a.rowscale != nullptr ? a.rowscale[pc / a.rows_per_sample] : 1.f) * a.mscale;
   }
-  const float rs_out = (a.rowscale != nullptr ? a.rowscale[pc / a.rows_per_sample] : 1.f) * a.mscale;
-  const float rs_tail = (tail && a.tail_rowscale != nullptr) ? a.tail_rowscale[b] : 1.f;
-  constexpr bool EARLY = C <= 18;                                   // register budget: dy1 operands join the first batch
-  constexpr int NHG = EARLY ? (NTOK * (N1 / 4) + 255) / 256 : 1;
+  constexpr bool EARLY = FFN && C <= 18;                            // register budget: dy1 operands join the first batch
+  constexpr int NHG = EARLY ? (NTOK * (N1 / 4) + NT - 1) / NT : 1;
   hrf_f4 hdu[NHG], hh1[NHG];
-  if (EARLY && ffn) {
+  if (EARLY) {
 #pragma unroll
     for (int u = 0; u < NHG; ++u) {
-      const int e = tid + 256 * u, ec = e < NTOK * (N1 / 4) ? e : 0;
+      const int e = tid + NT * u, ec = e < NTOK * (N1 / 4) ? e : 0;
       const int j = ec / (N1 / 4), n = 4 * (ec - j * (N1 / 4));
       const int px = ab_tok_pixel(a, b, wy, wx, j);
-      const long pp = px >= 0 ? px : 0;
-      hdu[u] = hrf_ld4(a.du1 + pp * N1 + n); hh1[u] = hrf_ld4(a.h1 + pp * N1 + n);
+      const unsigned pp = px >= 0 ? (unsigned)px * N1 + n : (unsigned)n;
+      hdu[u] = hrf_ld4(a.du1 + pp); hh1[u] = hrf_ld4(a.h1 + pp);
     }
   }
   // raw rows of x' (-> sO), the query source (-> sX) and the key/value source (-> sXkv)
-  constexpr int NE = (NTOK * C + 255) / 256;
+  constexpr int NE = (NTOK * C + NT - 1) / NT;
   float v2[NE], vq[NE], vk[NE];
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
-    const int e = tid + 256 * u, ec = e < NTOK * C ? e : 0;
+    const int e = tid + NT * u, ec = e < NTOK * C ? e : 0;
     const int j = ec / C, c = ec - j * C;
     const int px = ab_tok_pixel(a, b, wy, wx, j);
-    const long o = (long)(px >= 0 ? px : 0) * C + c;
+    const unsigned o = (unsigned)(px >= 0 ? px : 0) * C + c;
     v2[u] = ffn ? a.out[o] : 0.f; vq[u] = a.xq[o]; vk[u] = cross ? a.xkv[o] : 0.f;
     if (px < 0) { v2[u] = 0.f; vq[u] = 0.f; vk[u] = 0.f; }
   }
-  constexpr bool WE = C <= 18;                                      // C * PW / 4 <= 256: one 16-byte group per thread and weight
-  hrf_f4 wreg[WE ? 4 : 1];
+  constexpr int WG4 = C * (PW / 4);                                 // 16-byte groups of one [C][PW] weight
+  constexpr bool WE = 4 * WG4 <= 2 * NT;                            // at most two groups per thread cover wo, wq, wk, wv
+  constexpr int WPT = WE ? (4 * WG4 + NT - 1) / NT : 1;
+  hrf_f4 wreg[WPT];
   if (WE) {
-    const int n = tid / (PW / 4), kb = 4 * (tid - n * (PW / 4));
-    const bool in = tid < C * (PW / 4);
-    const long off = in ? (long)n * C + kb : 0;
-    const int kval = in ? C - kb : 0;
-    wreg[0] = ld_sel(kb + 4 <= C, a.wo, off, kval); wreg[1] = ld_sel(kb + 4 <= C, a.wq, off, kval);
-    wreg[2] = ld_sel(kb + 4 <= C, a.wk, off, kval); wreg[3] = ld_sel(kb + 4 <= C, a.wv, off, kval);
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+      const int e = tid + NT * u, ec = e < 4 * WG4 ? e : 0;
+      const int which = ec / WG4, g = ec - which * WG4;
+      const int n = g / (PW / 4), kb = 4 * (g - n * (PW / 4));
+      const float* wp = which == 0 ? a.wo : (which == 1 ? a.wq : (which == 2 ? a.wk : a.wv));
+      wreg[u] = ld_sel(kb + 4 <= C, wp, (long)n * C + kb, C - kb);
+    }
   }
-  // zero: the tiles whose pad rows / columns are read (rows 49..63, pitch column), the dS plane
-  for (int e = tid; e < 8 * TILE + 32 + (cross ? TILE : 0); e += 256) sX[e] = 0.f;
+  // zero: the tiles whose pad rows / columns are read (rows 49..63, pitch column)
+  for (int e = tid; e < 8 * TILE + 32 + (cross ? TILE : 0); e += NT) sX[e] = 0.f;
   __syncthreads();
 
   AB_T(1);
   // ---- weights, parameters
-  if (ffn) stage_weight<C, PW>(a.w1, N1, sW1);
+  if (ffn) stage_weight<C, PW, NT>(a.w1, N1, sW1);
   if (WE) {
-    if (tid < C * (PW / 4)) {
-      const int n = tid / (PW / 4), kb = 4 * (tid - n * (PW / 4));
-      hrf_st4(sWo + n * PW + kb, wreg[0]); hrf_st4(sWq + n * PW + kb, wreg[1]);
-      hrf_st4(sWk + n * PW + kb, wreg[2]); hrf_st4(sWv + n * PW + kb, wreg[3]);
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+      const int e = tid + NT * u;
+      if (e < 4 * WG4) {
+        const int which = e / WG4, g = e - which * WG4;
+        const int n = g / (PW / 4), kb = 4 * (g - n * (PW / 4));
+        hrf_st4(sWo + which * (C * PW) + n * PW + kb, wreg[u]);       // (sWo, sWq, sWk, sWv are consecutive)
+      }
     }
   } else {
-    stage_weight<C, PW>(a.wo, C, sWo);
-    stage_weight<C, PW>(a.wq, C, sWq);
-    stage_weight<C, PW>(a.wk, C, sWk);
-    stage_weight<C, PW>(a.wv, C, sWv);
+    stage_weight<C, PW, NT>(a.wo, C, sWo);
+    stage_weight<C, PW, NT>(a.wq, C, sWq);
+    stage_weight<C, PW, NT>(a.wk, C, sWk);
+    stage_weight<C, PW, NT>(a.wv, C, sWv);
   }
-  for (int e = tid; e < HEADS * 176; e += 256) { const int h = e / 176, k = e - h * 176; sT[e] = k < 169 ? a.rpb[k * HEADS + h] : 0.f; }
-  for (int e = tid; e < C; e += 256) {
+  for (int e = tid; e < HEADS * 176; e += NT) { const int h = e / 176, k = e - h * 176; sT[e] = k < 169 ? a.rpb[k * HEADS + h] : 0.f; }
+  for (int e = tid; e < C; e += NT) {
     sGam[0][e] = ffn ? a.ln2_g[e] : 0.f; sBet[0][e] = ffn ? a.ln2_b[e] : 0.f;
     sGam[1][e] = a.lnq_g[e]; sBet[1][e] = a.lnq_b[e];
     sGam[2][e] = a.lnkv_g[e]; sBet[2][e] = a.lnkv_b[e];
   }
-  for (int e = tid; e < 3 * PW; e += 256) {                         // q / k / v biases of the recomputed projections
+  for (int e = tid; e < 3 * PW; e += NT) {                          // q / k / v biases of the recomputed projections
     const int which = e / PW, c = e - which * PW;
     const float* bp = which == 0 ? a.bq : (which == 1 ? a.bk : a.bv);
     sB3[which][c] = *((bp != nullptr && c < C) ? bp + c : g_zero4);
   }
-  for (int e = tid; e < 4 * 3 * 2 * C; e += 256) (&sPar[0][0][0])[e] = 0.f;
-  if (tail) for (int e = tid; e < C; e += 256) { sTs[e] = a.tail_scale[e]; sTs[C + e] = a.tail_shift[e]; }
-  if (ffn) {
-    if (bf.gstats != nullptr) hrf_bn_bfin_onload(bf, sCo, sCo + N1, sCo + 2 * N1, tid, 256, blockIdx.x == 0);
-    else for (int e = tid; e < N1; e += 256) { sCo[e] = a.cA1[e]; sCo[N1 + e] = a.cB1[e]; sCo[2 * N1 + e] = a.cC1[e]; }
+  for (int e = tid; e < 4 * 3 * 2 * C; e += NT) (&sPar[0][0][0])[e] = 0.f;
+  if (tail) for (int e = tid; e < C; e += NT) { sTs[e] = a.tail_scale[e]; sTs[C + e] = a.tail_shift[e]; }
+  if (ffn && roleB) {
+    // (role B only: the fp64 moments of the on-load finalize - 2 x 8 copies per channel - are never live beside role A's row
+    // of incoming gradients; the kernel's register allocation is the larger of the two paths)
+    if (bf.gstats != nullptr) hrf_bn_bfin_onload(bf, sCo, sCo + N1, sCo + 2 * N1, lt, NB, blockIdx.x == 0);
+    else for (int e = lt; e < N1; e += NB) { sCo[e] = a.cA1[e]; sCo[N1 + e] = a.cB1[e]; sCo[2 * N1 + e] = a.cC1[e]; }
   }
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
-    const int e = tid + 256 * u;
+    const int e = tid + NT * u;
     if (e < NTOK * C) {
       const int j = e / C, o = j * PC + (e - j * C);
       sO[o] = v2[u]; sX[o] = vq[u];
@@ -807,35 +875,43 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
     if (EARLY) {
 #pragma unroll
       for (int u = 0; u < NHG; ++u) {
-        const int e = tid + 256 * u;
+        const int e = tid + NT * u;
         if (e < NTOK * (N1 / 4)) {
           const int j = e / (N1 / 4), n = 4 * (e - j * (N1 / 4));
           const bool pv = sPix[j] >= 0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            sH[j * PH + n + r] = pv ? fmaf(sCo[n + r], hdu[u][r], fmaf(sCo[N1 + n + r], hh1[u][r], sCo[2 * N1 + n + r])) : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            float dy1 = fmaf(sCo[n + r], hdu[u][r], fmaf(sCo[N1 + n + r], hh1[u][r], sCo[2 * N1 + n + r]));
+            HRF_KEEP(dy1);
+            sH[j * PH + n + r] = pv ? dy1 : 0.f;
+          }
         }
       }
     } else {
-      for (int e = tid; e < NTOK * (N1 / 4); e += 256) {
+      for (int e = tid; e < NTOK * (N1 / 4); e += NT) {
         const int j = e / (N1 / 4), n = 4 * (e - j * (N1 / 4));
         const int px = sPix[j];
         const long pp = px >= 0 ? px : 0;
         const hrf_f4 du = hrf_ld4(a.du1 + pp * N1 + n), hr = hrf_ld4(a.h1 + pp * N1 + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          sH[j * PH + n + r] = px >= 0 ? fmaf(sCo[n + r], du[r], fmaf(sCo[N1 + n + r], hr[r], sCo[2 * N1 + n + r])) : 0.f;
+        for (int r = 0; r < 4; ++r) {
+          float dy1 = fmaf(sCo[n + r], du[r], fmaf(sCo[N1 + n + r], hr[r], sCo[2 * N1 + n + r]));
+          HRF_KEEP(dy1);
+          sH[j * PH + n + r] = px >= 0 ? dy1 : 0.f;
+        }
       }
     }
   }
   {
-    // xhat rows in place (zeros for tokens outside the image) + rstd, all three tiles in one pass: 4 lanes per token
-    const int t = tid >> 2, part = tid & 3;
+    // xhat rows in place (zeros for tokens outside the image) + rstd: 4 lanes per token, 256 threads per tile.  NWB = 4: role A
+    // takes the LN_2 tile (and the key/value source of a cross block), role B the query source; NWB = 2: role A takes all
+    const int t = (tid & 255) >> 2, part = tid & 3;
     const bool real = sPix[t] >= 0;
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
       if (which == 0 && !ffn) continue;
       if (which == 2 && !cross) continue;
+      if (NWB == 4 ? ((which == 1) == roleA) : !roleA) continue;    // (uniform per wave; NWB = 0: every wave is A)
       float* row = (which == 0 ? sO : (which == 1 ? sX : sXkv)) + t * PC;
       const float eps = which == 0 ? a.out_eps : a.ln_eps;
       float s = 0.f;
@@ -846,42 +922,15 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
       for (int c = part; c < C; c += 4) { const float d = row[c] - mean; qq = fmaf(d, d, qq); }
       qq += __shfl_xor(qq, 1); qq += __shfl_xor(qq, 2);
       const float rstd = 1.0f / sqrtf(qq / (float)C + eps);
-      for (int c = part; c < C; c += 4) row[c] = real ? (row[c] - mean) * rstd : 0.f;
+      for (int c = part; c < C; c += 4) { const float y = (row[c] - mean) * rstd; row[c] = real ? y : 0.f; }
       if (part == 0) (which == 0 ? sRs2 : (which == 1 ? sRsQ : sRsKV))[t] = real ? rstd : 0.f;
     }
   }
   __syncthreads();
 
   AB_T(3);
-  if (ffn) {
-    // d LN_2 output = dy1 W1 (this wave's tokens), LayerNorm backward, added to gx
-    hrf_f4 dn[CT];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-    wave_gemm_tl<N1, PW, CT>(sW1, C, sH + tok * PH, lane, dn);
-    if (W1A) __syncthreads();                                       // w1 occupies the dy / dO tiles: last use by every wave
-    ln_bwd_rows<C, CT>(dn, sO, PC, tok, tokv, sRs2[tok], sGam[0], sPar[wave][0], lane);
-#pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) gx[t][r] += tokv ? dn[t][r] : 0.f;
-    // d w1 [4C][C] = dy1^T LN_2(x'), d b1 = column sums of dy1: n tiles round-robin over the waves
-    for (int nt = wave; nt < (N1 + 15) / 16; nt += 4) {
-      hrf_f4 acc[CT];
-#pragma unroll
-      for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-      wave_tgemm<CT, true>(sH, PH, 16 * nt, N1, sO, PC, 0, C, sGam[0], sBet[0], sReal, lane, acc);
-      store_wtile<CT>(slot + a.off_w1, 16 * nt, N1, 0, C, lane, acc);
-    }
-    for (int n = tid; n < N1; n += 256) {
-      float sacc = 0.f;
-      for (int j = 0; j < NTOK; ++j) sacc += sH[j * PH + n];
-      slot[a.off_b1 + n] = sacc;
-    }
-  }
-  AB_T(4);
-  // dy rows = gx * dropout mask * scales  (the out_proj output enters the residual through Dropout / DropPath)
-  {
+  // dy rows = gx * dropout mask * scales (the out_proj output enters the residual through Dropout / DropPath), dO = dy Wo
+  auto dy_and_dO = [&]() {
     const float rs = rs_out;
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
@@ -894,10 +943,7 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
         if (nb + r < C) sDY[tok * PC + nb + r] = y;
       }
     }
-  }
-  HRF_WAVE_SYNC();                                                  // a token's dy row was stored by four lanes of this wave
-  {
-    // dO rows = dy Wo (own tokens)
+    HRF_WAVE_SYNC();                                                // a token's dy row was stored by four lanes of this wave
     hrf_f4 acc[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
@@ -906,19 +952,58 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
     for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int k = 16 * t + 4 * q + r; if (k < C) sG[tok * PC + k] = acc[t][r]; }
+  };
+  if (ffn) {
+    constexpr int NT1 = (N1 + 15) / 16;                             // 16-row tiles of d w1 [4C][C] = dy1^T LN_2(x')
+    auto w1tile = [&](int nt) {
+      hrf_f4 acc[CT];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+      wave_tgemm<CT, true>(sH, PH, 16 * nt, N1, sO, PC, 0, C, sGam[0], sBet[0], sReal, lane, acc);
+      store_wtile<CT>(slot + a.off_w1, 16 * nt, N1, 0, C, lane, acc);
+    };
+    hrf_f4 dn[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+    if (roleA) wave_gemm_tl<N1, PW, CT>(sW1, C, sH + tok * PH, lane, dn);   // d LN_2 output = dy1 W1 (this wave's tokens)
+    if (roleB && wb < NT1) w1tile(wb);
+  __syncthreads();                                                // w1 (it may occupy the dy / dO tiles): last use by every wave
+    if (roleA) {
+      // LayerNorm backward, added to gx; then dy and dO
+      ln_bwd_rows<C, CT>(dn, sO, PC, tok, tokv, sRs2[tok], sGam[0], sPar[wave][0], lane);
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gx[t][r] += tokv ? dn[t][r] : 0.f;
+      dy_and_dO();
+    }
+    if (roleB) {
+      for (int nt = wb + NBW; nt < NT1; nt += NBW) w1tile(nt);
+      for (int n = lt; n < N1; n += NB) {                           // d b1 = column sums of dy1
+        float sacc = 0.f;
+        for (int j = 0; j < NTOK; ++j) sacc += sH[j * PH + n];
+        slot[a.off_b1 + n] = sacc;
+      }
+    }
+  } else if (roleA) {
+    dy_and_dO();
   }
+  AB_T(4);
   __syncthreads();                                                  // sH / xhat_2 are dead from here on (sH aliases sQ .. sDQ:
                                                                     // what it leaves in their pad cells is finite, which is all they need)
 
   AB_T(5);
-  // ---- recompute the projections: q / k / v with the LayerNorm affine applied on read (0 for tokens outside the image)
+  // ---- recompute the projections: q / k / v with the LayerNorm affine applied on read (0 for tokens outside the image).
+  // NWB = 4: role A: q and the first channel tiles of v, role B: k and the remaining tiles of v (own token tile each);
+  // NWB = 2: role A: q and v, role B wave w: k of the token tiles w and w + 2
   const float* sXk = cross ? sXkv : sX;
-  const int lkv = cross ? 2 : 1;
+  constexpr int lkv = CROSS ? 2 : 1;
   {
+    constexpr int VA = (CT + 1) / 2;
     hrf_f4 acc[CT];
-    auto proj = [&](const float* sW, const float* bias, const float* xh, int ln, float* dstT, float mul) {
+    auto proj = [&](const float* sW, const float* bias, const float* xh, int ln, float* dstT, float mul, int t_lo, int t_hi, int tk) {
       acc_bias_l<CT>(bias, 0, PW, lane, acc);
-      const bool real = sReal[tok] != 0.f;
+      const bool real = sReal[tk] != 0.f;
       constexpr int NS = (C + 15) / 16;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -928,10 +1013,13 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = kbase + r < C ? kbase + r : 0;
-          bv[r] = (kbase + r < C && real) ? fmaf(xh[tok * PC + k], sGam[ln][k], sBet[ln][k]) : 0.f;
+          float aff = fmaf(xh[tk * PC + k], sGam[ln][k], sBet[ln][k]);
+          HRF_KEEP(aff);
+          bv[r] = (kbase + r < C && real) ? aff : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
+          if (t < t_lo || t >= t_hi) continue;                      // (uniform)
           const int n = 16 * t + i;
           const hrf_f4 w = hrf_ld4(sW + (n < C ? n : 0) * PW + (kin ? kbase : 0));
           const bool ok = kin && n < C;
@@ -940,32 +1028,63 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
         }
       }
 #pragma unroll
-      for (int t = 0; t < CT; ++t)
+      for (int t = 0; t < CT; ++t) {
+        if (t < t_lo || t >= t_hi) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) dstT[tok * PC + n] = acc[t][r] * mul; }
+        for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) dstT[tk * PC + n] = acc[t][r] * mul; }
+      }
     };
-    proj(sWq, sB3[0], sX, 1, sQ, a.scale);
-    proj(sWk, sB3[1], sXk, lkv, sK, 1.f);
-    proj(sWv, sB3[2], sXk, lkv, sV, 1.f);
+    if (roleA) {
+      proj(sWq, sB3[0], sX, 1, sQ, a.scale, 0, CT, tok);
+      proj(sWv, sB3[2], sXk, lkv, sV, 1.f, 0, NWB == 4 ? VA : CT, tok);
+    }
+    if (NWB == 0) {
+      proj(sWk, sB3[1], sXk, lkv, sK, 1.f, 0, CT, tok);
+    } else if (!roleA && NWB == 4) {
+      proj(sWk, sB3[1], sXk, lkv, sK, 1.f, 0, CT, tok);
+      proj(sWv, sB3[2], sXk, lkv, sV, 1.f, VA, CT, tok);
+    } else if (!roleA) {
+#pragma unroll 1
+      for (int tt = wb; tt < 4; tt += NWB) proj(sWk, sB3[1], sXk, lkv, sK, 1.f, 0, CT, 16 * tt + i);
+    }
   }
   __syncthreads();
 
   AB_T(6);
-  // ---- attention backward per head (attention.hip's MFMA formulation on the packed tiles)
+  // ---- attention backward per head (attention.hip's MFMA formulation on the packed tiles): role A = query columns, role B =
+  // key columns; the row statistics (max, 1 / sum, D = sum P dP) pass from A to B through LDS at the first barrier of a head.
+  // NWB = 4: a role-B wave owns one key tile and computes its raw scores / dP beside role A's softmax, before that barrier;
+  // NWB = 2: it owns two key tiles, one after the other behind the barrier (the finished dk / dv rows wait in registers).
 #pragma unroll 1
   for (int h = 0; h < HEADS; ++h) {
     const float* bias = sT + h * 176;
     float* dsp = a.ds_plane + ((long)blockIdx.x * HEADS + h) * (NTOK * NTOK);   // dS[key][query] of this (window, head)
-    {  // query-column orientation: wave = queries tok0 .. tok0+15
-      hrf_f4 s[4], dp[4];
+    hrf_f4 s[4], dp[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+    float Dl = 0.f;
+    // key-column scores of key tile kt0: S[query 16t+4q+r][key kt0+i] and dP
+    auto key_scores = [&](int kt0) {
+      const float* krow = sK + (kt0 + i) * PC + h * D + q;
+      const float* vrow = sV + (kt0 + i) * PC + h * D + q;
+#pragma unroll
+      for (int kk = 0; kk < KSD; ++kk) {
+        const bool kv = 4 * kk + q < D;
+        const float kvv = ldz(krow, 4 * kk, kv), vv = ldz(vrow, 4 * kk, kv);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          s[t] = hrf_mfma16(sQ[(16 * t + i) * PC + h * D + 4 * kk + q], kvv, s[t]);
+          dp[t] = hrf_mfma16(sG[(16 * t + i) * PC + h * D + 4 * kk + q], vv, dp[t]);
+        }
+      }
+    };
+    if (roleA) {                                                    // wave = queries tok0 .. tok0+15
       const float* qrow = sQ + (tok0 + i) * PC + h * D + q;
       const float* grow = sG + (tok0 + i) * PC + h * D + q;
 #pragma unroll
       for (int kk = 0; kk < KSD; ++kk) {
         const bool kv = 4 * kk + q < D;
-        const float qv = kv ? qrow[4 * kk] : 0.f, gv = kv ? grow[4 * kk] : 0.f;
+        const float qv = ldz(qrow, 4 * kk, kv), gv = ldz(grow, 4 * kk, kv);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           s[t] = hrf_mfma16(sK[(16 * t + i) * PC + h * D + 4 * kk + q], qv, s[t]);
@@ -981,7 +1100,9 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * t + 4 * q + r, jc = j < NTOK ? j : 0;
           const int yj = jc / 7, xj = jc - 7 * yj;
-          const float sv = j < NTOK ? s[t][r] + bias[(yi - yj + 6) * 13 + (xi - xj + 6)] : -3.0e38f;
+          float bj = bias[(yi - yj + 6) * 13 + (xi - xj + 6)];
+          HRF_KEEP(bj);
+          const float sv = j < NTOK ? s[t][r] + bj : -3.0e38f;
           s[t][r] = sv;
           m = fmaxf(m, sv);
         }
@@ -995,7 +1116,6 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
       l += __shfl_xor(l, 16);
       l += __shfl_xor(l, 32);
       const float inv = 1.0f / l;
-      float Dl = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1003,22 +1123,77 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
       Dl += __shfl_xor(Dl, 16);
       Dl += __shfl_xor(Dl, 32);
       if (q == 0) { sM[qi] = m; sIL[qi] = inv; sDl[qi] = Dl; }
-      // attention output rows again (O = P V) for the out_proj weight gradient
-      hrf_f4 o[DT];
+    } else if (NWB == 4) {
+      key_scores(tok0);
+    }
+    (void)roleB;
+  __syncthreads();                                                // the row statistics of head h
+    hrf_f4 o1[DT], o2[DT];
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) { o1[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; o2[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+    // role B, one key tile: P and dS in key-column orientation from the row statistics, dV = P^T dO and dK = dS^T Q
+    auto key_tile = [&](int kt0, bool scores) {
+      if (scores) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+        key_scores(kt0);
+      }
+      const int kj = kt0 + i, kc = kj < NTOK ? kj : 0;
+      const int yj = kc / 7, xj = kc - 7 * yj;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = 16 * t + 4 * q + r, qc = qi < NTOK ? qi : 0;
+          const int yi = qc / 7, xi = qc - 7 * yi;
+          const bool ok = kj < NTOK && qi < NTOK;
+          float bj = bias[(yi - yj + 6) * 13 + (xi - xj + 6)], mq = sM[qc], ilq = sIL[qc], dlq = sDl[qc];
+          HRF_KEEP(bj); HRF_KEEP(mq); HRF_KEEP(ilq); HRF_KEEP(dlq);
+          const float p = ok ? __expf(s[t][r] + bj - mq) * ilq : 0.f;
+          s[t][r] = p;
+          dp[t][r] = ok ? p * (dp[t][r] - dlq) : 0.f;
+        }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { o1[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; o2[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* gr = sG + (16 * t + 4 * q + r) * PC + h * D + i;
+          const float* qr = sQ + (16 * t + 4 * q + r) * PC + h * D + i;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            o1[dt] = hrf_mfma16(s[t][r], gr[16 * dt], o1[dt]);      // dV = P^T dO
+            o2[dt] = hrf_mfma16(dp[t][r], qr[16 * dt], o2[dt]);     // dK = dS^T Q
+          }
+        }
+    };
+    auto key_store = [&](int kt0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ko = kt0 + 4 * q + r;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = 16 * dt + i;
+          if (d < D) { sK[ko * PC + h * D + d] = o2[dt][r]; sV[ko * PC + h * D + d] = o1[dt][r]; }
+        }
+      }
+    };
+    if (roleA) {
+      const int qi = tok0 + i;
+      // attention output rows again (O = P V) for the out_proj weight gradient
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float* vrow = sV + (16 * t + 4 * q + r) * PC + h * D + i;
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_mfma16(s[t][r], vrow[16 * dt], o[dt]);
+          for (int dt = 0; dt < DT; ++dt) o1[dt] = hrf_mfma16(s[t][r], vrow[16 * dt], o1[dt]);
         }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) { const int d = 16 * dt + i; if (d < D) sO[(tok0 + 4 * q + r) * PC + h * D + d] = o[dt][r]; }
+        for (int dt = 0; dt < DT; ++dt) { const int d = 16 * dt + i; if (d < D) sO[(tok0 + 4 * q + r) * PC + h * D + d] = o1[dt][r]; }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1030,101 +1205,78 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
         }
       // dQ = dS K (contraction over keys)
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float* krow = sK + (16 * t + 4 * q + r) * PC + h * D + i;
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_mfma16(s[t][r], krow[16 * dt], o[dt]);
+          for (int dt = 0; dt < DT; ++dt) o2[dt] = hrf_mfma16(s[t][r], krow[16 * dt], o2[dt]);
         }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qo = tok0 + 4 * q + r;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) { const int d = 16 * dt + i; if (d < D) sDQ[qo * PC + h * D + d] = qo < NTOK ? o[dt][r] * a.scale : 0.f; }
+        for (int dt = 0; dt < DT; ++dt) { const int d = 16 * dt + i; if (d < D) sDQ[qo * PC + h * D + d] = qo < NTOK ? o2[dt][r] * a.scale : 0.f; }
       }
     }
-    __syncthreads();
-    {  // key-column orientation: wave = keys tok0 .. tok0+15
-      hrf_f4 s[4], dp[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
-      const float* krow = sK + (tok0 + i) * PC + h * D + q;
-      const float* vrow = sV + (tok0 + i) * PC + h * D + q;
-#pragma unroll
-      for (int kk = 0; kk < KSD; ++kk) {
-        const bool kv = 4 * kk + q < D;
-        const float kvv = kv ? krow[4 * kk] : 0.f, vv = kv ? vrow[4 * kk] : 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          s[t] = hrf_mfma16(sQ[(16 * t + i) * PC + h * D + 4 * kk + q], kvv, s[t]);       // S[query 16t+4q+r][key tok0+i]
-          dp[t] = hrf_mfma16(sG[(16 * t + i) * PC + h * D + 4 * kk + q], vv, dp[t]);
-        }
-      }
-      const int kj = tok0 + i, kc = kj < NTOK ? kj : 0;
-      const int yj = kc / 7, xj = kc - 7 * yj;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qi = 16 * t + 4 * q + r, qc = qi < NTOK ? qi : 0;
-          const int yi = qc / 7, xi = qc - 7 * yi;
-          const bool ok = kj < NTOK && qi < NTOK;
-          const float p = ok ? __expf(s[t][r] + bias[(yi - yj + 6) * 13 + (xi - xj + 6)] - sM[qc]) * sIL[qc] : 0.f;
-          s[t][r] = p;
-          dp[t][r] = ok ? p * (dp[t][r] - sDl[qc]) : 0.f;
-        }
-      hrf_f4 ov[DT], okk[DT];
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) { ov[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; okk[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* gr = sG + (16 * t + 4 * q + r) * PC + h * D + i;
-          const float* qr = sQ + (16 * t + 4 * q + r) * PC + h * D + i;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            ov[dt] = hrf_mfma16(s[t][r], gr[16 * dt], ov[dt]);
-            okk[dt] = hrf_mfma16(dp[t][r], qr[16 * dt], okk[dt]);
-          }
-        }
-      __syncthreads();                                              // every wave is done reading head h of sK / sV
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ko = tok0 + 4 * q + r;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          const int d = 16 * dt + i;
-          if (d < D) { sK[ko * PC + h * D + d] = okk[dt][r]; sV[ko * PC + h * D + d] = ov[dt][r]; }
-        }
+    if (roleB) {
+      key_tile(NWB == 2 ? 16 * wb : tok0, NWB != 4);
+    }
+  __syncthreads();                                                // every wave is done reading head h of sK / sV
+    if (roleB) {
+      key_store(NWB == 2 ? 16 * wb : tok0);
+      if (NWB == 2) {
+        // the second key tile of this wave: it reads its OWN rows of sK / sV (nobody writes those) and all rows of sQ / sG;
+        // role A waits at the barrier behind the loop (one head only: the statistics of this head must stay)
+        static_assert(NWB != 2 || HEADS == 1, "two key tiles per role-B wave: one head");
+        key_tile(16 * (wb + 2), true);
+        key_store(16 * (wb + 2));
       }
     }
   }
   __syncthreads();                                                  // dk / dv rows of the last head
 
   AB_T(7);
-  // ---- d LN outputs = dq Wq (+ dk Wk + dv Wv), LayerNorm backward, output gradients
-  {
+  constexpr int NTC = C / 16 + (C % 16 ? 1 : 0);                    // 16-row tiles of a [C][C] weight gradient
+  auto wtile = [&](int which, int nt) {                             // weight-gradient tile: [16 out rows][all input channels]
+    hrf_f4 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+    if (which == 0) {
+      wave_tgemm<CT, false>(sDY, PC, 16 * nt, C, sO, PC, 0, C, nullptr, nullptr, nullptr, lane, acc);
+      store_wtile<CT>(slot + a.off_wo, 16 * nt, C, 0, C, lane, acc);
+    } else if (which == 1) {
+      wave_tgemm<CT, true>(sDQ, PC, 16 * nt, C, sX, PC, 0, C, sGam[1], sBet[1], sReal, lane, acc);
+      store_wtile<CT>(slot + a.off_wq, 16 * nt, C, 0, C, lane, acc);
+    } else {
+      wave_tgemm<CT, true>(which == 2 ? sK : sV, PC, 16 * nt, C, sXk, PC, 0, C, sGam[lkv], sBet[lkv], sReal, lane, acc);
+      store_wtile<CT>(slot + (which == 2 ? a.off_wk : a.off_wv), 16 * nt, C, 0, C, lane, acc);
+    }
+  };
+  if (roleA) {
+    // ---- d LN outputs = dq Wq (+ dk Wk + dv Wv), LayerNorm backward, output gradients
+    // (the row offset is formed again from the pixel index, behind an opaque copy: kept alive since the prologue it is a 64-bit
+    // pair per lane that the register allocator spills in the variants that sit at their budget)
+    int pix7 = pix, lane7 = threadIdx.x & 63;
+    HRF_KEEP(pix7); HRF_KEEP(lane7);
+    const long pc7 = pix7 >= 0 ? pix7 : 0;
     hrf_f4 tr[CT];                                                  // raw rows of the preceding block's tail (u = sc*raw + sh)
     if (tail) {
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         const int nb = 16 * t + 4 * q;
-        tr[t] = ld_sel(16 * (t + 1) <= C, a.tail_raw, pc * C + nb, tokv ? C - nb : 0);
+        tr[t] = ld_sel(16 * (t + 1) <= C, a.tail_raw, pc7 * C + nb, tokv ? C - nb : 0);
       }
     }
     hrf_f4 dn[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-    wave_gemm_tl<C, PW, CT>(sWq, C, sDQ + tok * PC, lane, dn);
+    wave_gemm_tl<C, PW, CT>(sWq, C, sDQ + tok * PC, lane7, dn);
     if (!cross) {
-      wave_gemm_tl<C, PW, CT>(sWk, C, sK + tok * PC, lane, dn);
-      wave_gemm_tl<C, PW, CT>(sWv, C, sV + tok * PC, lane, dn);
+      wave_gemm_tl<C, PW, CT>(sWk, C, sK + tok * PC, lane7, dn);
+      wave_gemm_tl<C, PW, CT>(sWv, C, sV + tok * PC, lane7, dn);
     }
-    ln_bwd_rows<C, CT>(dn, sX, PC, tok, tokv, sRsQ[tok], sGam[1], sPar[wave][1], lane);
+    ln_bwd_rows<C, CT>(dn, sX, PC, tok, tokv, sRsQ[tok], sGam[1], sPar[wave][1], lane7);
     if (a.dq != nullptr && tokv) {
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
@@ -1134,15 +1286,15 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
           if (nb + r < C) {
             float v = dn[t][r] + (a.dq_add_res ? gx[t][r] : 0.f);
             dn[t][r] = v;                                           // dx of this launch alone (the tail below needs it)
-            if (a.dq_acc) v += a.dq[pc * C + nb + r];
-            a.dq[pc * C + nb + r] = v;
+            if (a.dq_acc) v += a.dq[pc7 * C + nb + r];
+            a.dq[pc7 * C + nb + r] = v;
           }
         }
       }
     }
     if (tail) {
       // x = tail_res + rs * GELU(u): tail_du = dx * rs * GELU'(u) and its BatchNorm moments (what hrf_act_bwd computed)
-      const float rs = rs_tail;
+      const float rs = a.tail_rowscale != nullptr ? a.tail_rowscale[b] : 1.f;
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         const int nb = 16 * t + 4 * q;
@@ -1150,8 +1302,10 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
         for (int r = 0; r < 4; ++r) {
           const int ch = nb + r < C ? nb + r : 0;
           const float rw = tr[t][r];
-          const float du = (tokv && nb + r < C) ? dn[t][r] * rs * hrf_gelu_grad(fmaf(rw, sTs[ch], sTs[C + ch])) : 0.f;
-          if (tokv && nb + r < C) a.tail_du[pc * C + nb + r] = du;
+          float gg = hrf_gelu_grad(fmaf(rw, sTs[ch], sTs[C + ch]));
+          HRF_KEEP(gg);
+          const float du = (tokv && nb + r < C) ? dn[t][r] * rs * gg : 0.f;
+          if (tokv && nb + r < C) a.tail_du[pc7 * C + nb + r] = du;
           const float m1 = hrf_row16_sum(du), m2 = hrf_row16_sum(du * rw);
           if (i == 0 && nb + r < C) { sTst[wave][nb + r] = m1; sTst[wave][C + nb + r] = m2; }
         }
@@ -1160,9 +1314,9 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
     if (cross) {
 #pragma unroll
       for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-      wave_gemm_tl<C, PW, CT>(sWk, C, sK + tok * PC, lane, dn);
-      wave_gemm_tl<C, PW, CT>(sWv, C, sV + tok * PC, lane, dn);
-      ln_bwd_rows<C, CT>(dn, sXkv, PC, tok, tokv, sRsKV[tok], sGam[2], sPar[wave][2], lane);
+      wave_gemm_tl<C, PW, CT>(sWk, C, sK + tok * PC, lane7, dn);
+      wave_gemm_tl<C, PW, CT>(sWv, C, sV + tok * PC, lane7, dn);
+      ln_bwd_rows<C, CT>(dn, sXkv, PC, tok, tokv, sRsKV[tok], sGam[2], sPar[wave][2], lane7);
       if (a.dkv != nullptr && tokv) {
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -1171,8 +1325,8 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
           for (int r = 0; r < 4; ++r) {
             if (nb + r < C) {
               float v = dn[t][r] + (a.dkv_add_res ? gx[t][r] : 0.f);
-              if (a.dkv_acc) v += a.dkv[pc * C + nb + r];
-              a.dkv[pc * C + nb + r] = v;
+              if (a.dkv_acc) v += a.dkv[pc7 * C + nb + r];
+              a.dkv[pc7 * C + nb + r] = v;
             }
           }
         }
@@ -1186,35 +1340,15 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
         for (int r = 0; r < 4; ++r) {
           if (nb + r < C) {
             float v = gx[t][r];
-            if (a.dres_acc) v += a.dres[pc * C + nb + r];
-            a.dres[pc * C + nb + r] = v;
+            if (a.dres_acc) v += a.dres[pc7 * C + nb + r];
+            a.dres[pc7 * C + nb + r] = v;
           }
         }
       }
     }
-  }
-
-  AB_T(8);
-  // ---- weight gradients of the four Linear layers: [out tile of 16][all input channels] per wave, round-robin
-  {
-    constexpr int NTC = C / 16 + (C % 16 ? 1 : 0);
-    const int ntiles = 4 * NTC;                                     // wo, wq, wk, wv
-    for (int wt = wave; wt < ntiles; wt += 4) {
-      const int which = wt / NTC, nt = wt - which * NTC;
-      hrf_f4 acc[CT];
-#pragma unroll
-      for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-      if (which == 0) {
-        wave_tgemm<CT, false>(sDY, PC, 16 * nt, C, sO, PC, 0, C, nullptr, nullptr, nullptr, lane, acc);
-        store_wtile<CT>(slot + a.off_wo, 16 * nt, C, 0, C, lane, acc);
-      } else if (which == 1) {
-        wave_tgemm<CT, true>(sDQ, PC, 16 * nt, C, sX, PC, 0, C, sGam[1], sBet[1], sReal, lane, acc);
-        store_wtile<CT>(slot + a.off_wq, 16 * nt, C, 0, C, lane, acc);
-      } else {
-        wave_tgemm<CT, true>(which == 2 ? sK : sV, PC, 16 * nt, C, sXk, PC, 0, C, sGam[lkv], sBet[lkv], sReal, lane, acc);
-        store_wtile<CT>(slot + (which == 2 ? a.off_wk : a.off_wv), 16 * nt, C, 0, C, lane, acc);
-      }
-    }
+    AB_T(8);
+    // the out_proj weight gradient (dy^T O) and the four bias gradients behind the data path: role B holds the q / k / v tiles
+    for (int nt = wave; nt < NTC; nt += 4) wtile(0, nt);
     // bias gradients = column sums over the 49 tokens (tokens outside the image included: their k / v ARE the biases)
     for (int e = tid; e < 4 * C; e += 256) {
       const int which = e / C, n = e - which * C;
@@ -1224,15 +1358,19 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
       slot[(which == 0 ? a.off_bo : (which == 1 ? a.off_bq : (which == 2 ? a.off_bk : a.off_bv))) + n] = sacc;
     }
   }
+  if (roleB) {
+    // ---- weight gradients of the q / k / v projections: [out tile of 16][all input channels] per wave, round-robin
+    for (int wt = wb; wt < 3 * NTC; wt += NBW) wtile(1 + wt / NTC, wt % NTC);
+  }
   __syncthreads();
   AB_T(9);
   if (tail) {
     double* st = a.tail_gstats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
-    for (int e = tid; e < 2 * C; e += 256)
+    for (int e = tid; e < 2 * C; e += NT)
       hrf_atomic_add(&st[e], (double)((sTst[0][e] + sTst[1][e]) + (sTst[2][e] + sTst[3][e])));
   }
-  // LayerNorm parameter gradients: sum of the four waves' partials
-  for (int e = tid; e < 3 * 2 * C; e += 256) {
+  // LayerNorm parameter gradients: sum of the four role-A waves' partials
+  for (int e = tid; e < 3 * 2 * C; e += NT) {
     const int ln = e / (2 * C), k = e - ln * 2 * C;
     const float v = (sPar[0][ln][k] + sPar[1][ln][k]) + (sPar[2][ln][k] + sPar[3][ln][k]);
     const int off = ln == 0 ? (k < C ? a.off_g2 : a.off_bt2) : (ln == 1 ? (k < C ? a.off_gq : a.off_btq) : (k < C ? a.off_gkv : a.off_btkv));
@@ -1241,25 +1379,36 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs>
   AB_T(10);
 }
 
-template <int C, int HEADS>
-int launch_bwd(const hrf_attn_block_t& a, const hrf_bn_bfin_t& bf, int nwin, void* stream) {
+template <int C, int HEADS, int NWB, bool FFN, bool CROSS, bool TAIL>
+int launch_bwd_v(const hrf_attn_block_t& a, const hrf_bn_bfin_t& bf, int nwin, void* stream) {
   constexpr int TILE = 64 * (C + 1), PW = (C + 3) & ~3;
   static_assert(4 * TILE >= 64 * (4 * C + 1), "dy1 rows alias the q / k / v / dq tiles");
-  const bool cross = a.xkv != a.xq;
   constexpr int W1X = (4 * C * PW <= 2 * TILE) ? 0 : 4 * C * PW;     // w1 aliases the (dy, dO) tiles when it fits
-  const size_t smem = ((size_t)4 * C * PW + W1X + 8 * TILE + 32 + (cross ? TILE : 0)) * sizeof(float);
+  constexpr size_t smem = ((size_t)4 * C * PW + W1X + 8 * TILE + 32 + (CROSS ? TILE : 0)) * sizeof(float);
 #ifndef HRF_EMUL
   static bool once = false;
   if (!once) {
-    constexpr size_t smax = ((size_t)4 * C * PW + W1X + 9 * TILE + 32) * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_bwd_kernel<C, HEADS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smax) != hipSuccess) return HRF_ERR_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_bwd_kernel<C, HEADS, NWB, FFN, CROSS, TAIL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return HRF_ERR_LAUNCH;
     once = true;
   }
 #endif
   AbBwdArgs ab;
   ab.a = a; ab.bf = bf;
-  return HRF_LAUNCH_G((attn_block_bwd_kernel<C, HEADS>), dim3(nwin), dim3(256), (unsigned)smem, stream, ab);
+  return HRF_LAUNCH_G((attn_block_bwd_kernel<C, HEADS, NWB, FFN, CROSS, TAIL>), dim3(nwin), dim3(64 * (4 + NWB)), (unsigned)smem, stream, ab);
+}
+
+// (FFN head present, cross-attention, CrossFFN tail of the preceding block on load) are wave-uniform launch properties: one
+// instantiation each - six per width (the tail form exists for self-attention only)
+template <int C, int HEADS, int NWB>
+int launch_bwd(const hrf_attn_block_t& a, const hrf_bn_bfin_t& bf, int nwin, void* stream) {
+  const bool cross = a.xkv != a.xq, ffn = a.w1 != nullptr, tail = a.tail_raw != nullptr;
+  if (cross) return ffn ? launch_bwd_v<C, HEADS, NWB, true, true, false>(a, bf, nwin, stream)
+                        : launch_bwd_v<C, HEADS, NWB, false, true, false>(a, bf, nwin, stream);
+  if (tail) return ffn ? launch_bwd_v<C, HEADS, NWB, true, false, true>(a, bf, nwin, stream)
+                       : launch_bwd_v<C, HEADS, NWB, false, false, true>(a, bf, nwin, stream);
+  return ffn ? launch_bwd_v<C, HEADS, NWB, true, false, false>(a, bf, nwin, stream)
+             : launch_bwd_v<C, HEADS, NWB, false, false, false>(a, bf, nwin, stream);
 }
 
 // Relative-position-bias gradient from the dS planes the backward kernel left in memory (a LEAF of the backward graph:
@@ -1275,11 +1424,11 @@ __device__ __forceinline__ void rpb_grad_body(const float* ds, int nwin, int hea
   for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
     const float* p = ds + ((long)w * heads + h) * (NTOK * NTOK);
     for (int k = threadIdx.x; k < NTOK * NTOK; k += 256) sP[k] = p[k];
-    __syncthreads();
+  __syncthreads();
     if (e < 169)
       for (int yj = y0; yj <= y1; ++yj)
         for (int xj = x0; xj <= x1; ++xj) acc += sP[(yj * 7 + xj) * NTOK + (yj + dy) * 7 + xj + dx];
-    __syncthreads();
+  __syncthreads();
   }
   if (e < 169) hrf_atomic_add(&drpb[(long)(blockIdx.x % HRF_STAT_COPIES) * copy_stride + e * heads + h], acc);
 }
@@ -1347,8 +1496,8 @@ extern "C" int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream) {
   ab_geometry(a);
   const int nwin = a.B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
-  if (a.heads == 1) return launch_bwd<18, 1>(a, bf, nwin, stream);
-  return launch_bwd<36, 2>(a, bf, nwin, stream);
+  if (a.heads == 1) return launch_bwd<18, 1, AB_NWB18>(a, bf, nwin, stream);
+  return launch_bwd<36, 2, 4>(a, bf, nwin, stream);
 }
 
 extern "C" int hrf_rpb_grad(const float* ds_plane, int nwin, int heads, float* drpb, long copy_stride, void* stream) {

@@ -656,7 +656,8 @@ extern "C" int hrf_conv3_wgrad_wide(const float* dy, int ldD, const float* x, in
   return hrf_check_launch();
 }
 
-extern "C" int hrf_conv3w_knob(int key, int value) {
+// (reached through hrf_debug_knob only: not exported)
+extern "C" __attribute__((visibility("hidden"))) int hrf_conv3w_knob(int key, int value) {
   if (key == 0) { g_force_wn = value; return HRF_OK; }
   if (key == 2) { g_wsplit = value; return HRF_OK; }
   return HRF_ERR_ARG;

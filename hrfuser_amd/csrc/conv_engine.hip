@@ -595,7 +595,11 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
   while (prob + 1 < grp_args.nprob && (int)blockIdx.x >= grp_args.bstart[prob + 1]) ++prob;   // (wave-uniform, <= 15 steps)
   const WgradDenseArgs& a = grp_args.p[prob];
   const int bid = (int)blockIdx.x - grp_args.bstart[prob];
-  constexpr int WU = MT * NT > 25 ? 2 : (MT * NT > 16 ? WUMAX / 2 : WUMAX);   // keep the many-tile variants inside 256 VGPRs
+  constexpr int WU = MT * NT >= 25 ? 2 : (MT * NT > 16 ? WUMAX / 2 : WUMAX);   // keep the many-tile variants inside 256 VGPRs
+  // BatchNorm-backward coefficients of the many-tile variants live in LDS (12 loop-invariant registers at MT = 4 that the
+  // allocator spilled: a scratch reload is a vector-memory load whose wait retires every outstanding load of the pixel loop)
+  constexpr bool COEF_LDS = BNB && MT * NT >= 25;
+  __shared__ float sCoef[COEF_LDS ? 3 * MT * 16 : 1];
   constexpr int NREG = MT * NT > 25 ? 1 : 2;                 // merge regions in LDS (one: 7 rounds instead of 3)
   __shared__ __attribute__((aligned(16))) float sAcc[NREG * MT * NT * 256];   // merge region(s), fragment order
   __shared__ float sBias[WNW * MT * 16];
@@ -616,29 +620,44 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
   const int pbeg = bz * a.chunk, pend = min(a.Mpix, pbeg + a.chunk);
   const bool ln = a.tf_rowstat != nullptr;
 
-  int aoff[MT], boff[NT], tdy[NT], tdx[NT];
-  bool aval[MT], bval[NT];
-  float ca[MT], cb[MT], cc[MT], sc[NT], sh[NT], bsum[MT];
+  // (tap-blocked: every tile of a lane is the SAME input channel n0 + c at another tap - one validity flag, one affine and
+  // one channel offset per lane instead of nine: the nine copies were what spilled the <4, 9, ...> variants, and a scratch
+  // reload retires every outstanding load of the pixel loop first)
+  constexpr int NB = TAPB ? 1 : NT;
+  int aoff[MT], boff[NB], tdy[NT], tdx[NT];
+  bool aval[MT], bval[NB];
+  float ca[MT], cb[MT], cc[MT], sc[NB], sh[NB], bsum[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int co = m0 + 16 * i + c;
     aval[i] = co < a.Cout;
     aoff[i] = a.doff + (aval[i] ? co : 0);
     ca[i] = 1.f; cb[i] = 0.f; cc[i] = 0.f; bsum[i] = 0.f;
-    if (BNB) { const int cs = aval[i] ? co : 0; ca[i] = a.cA[cs]; cb[i] = a.cB[cs]; cc[i] = a.cC[cs]; }
+    if (BNB && !COEF_LDS) { const int cs = aval[i] ? co : 0; ca[i] = a.cA[cs]; cb[i] = a.cB[cs]; cc[i] = a.cC[cs]; }
+  }
+  if (COEF_LDS) {
+    for (int e = tid; e < MT * 16; e += 64 * WNW) {
+      const int cs = m0 + e < a.Cout ? m0 + e : 0;
+      sCoef[e] = a.cA[cs]; sCoef[MT * 16 + e] = a.cB[cs]; sCoef[2 * MT * 16 + e] = a.cC[cs];
+    }
+    __syncthreads();
   }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
+    tdy[j] = 0; tdx[j] = 0;
+    if (TAPB) { tdy[j] = j / 3 - 1; tdx[j] = j - (j / 3) * 3 - 1; }              // (compile-time after unrolling)
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
     const int np = TAPB ? n0 + c : n0 + 16 * j + c;
     bval[j] = TAPB ? np < a.Cin : np < Np;
     int ci = bval[j] ? np : 0;
-    tdy[j] = 0; tdx[j] = 0;
-    if (TAPB) { tdy[j] = j / 3 - 1; tdx[j] = j - (j / 3) * 3 - 1; }
-    else if (TAP) { const int tp = ci % 9; ci /= 9; tdy[j] = tp / 3 - 1; tdx[j] = tp - (tp / 3) * 3 - 1; }
-    boff[j] = TAP ? (tdy[j] * a.W + tdx[j]) * a.ldX + ci : ci;     // TAP: + offset of the shifted input pixel
+    if (TAP && !TAPB) { const int tp = ci % 9; ci /= 9; tdy[j] = tp / 3 - 1; tdx[j] = tp - (tp / 3) * 3 - 1; }
+    boff[j] = (TAP && !TAPB) ? (tdy[j] * a.W + tdx[j]) * a.ldX + ci : ci;        // ci*9+tap order: + offset of the shifted pixel
     sc[j] = 1.f; sh[j] = 0.f;
     if (a.tf_scale != nullptr) { sc[j] = a.tf_scale[ci]; sh[j] = a.tf_shift[ci]; }
   }
+  const int xrow = TAPB ? a.W * a.ldX : 0;                                       // tap-blocked: one image row of X, in floats
   hrf_f4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -677,7 +696,11 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        if (TAP) {
+        if (TAPB) {
+          const bool inb = pv[u] && bval[0] && (unsigned)(yb + tdy[j]) < (unsigned)a.H && (unsigned)(xb + tdx[j]) < (unsigned)a.W;
+          bmask[u] |= inb ? (1u << j) : 0u;
+          br[u][j] = a.x[inb ? (unsigned)(tbase + boff[0] + tdy[j] * xrow + tdx[j] * a.ldX) : 0u];
+        } else if (TAP) {
           const bool inb = pv[u] && bval[j] && (unsigned)(yb + tdy[j]) < (unsigned)a.H && (unsigned)(xb + tdx[j]) < (unsigned)a.W;
           bmask[u] |= inb ? (1u << j) : 0u;
           br[u][j] = a.x[inb ? (unsigned)(tbase + boff[j]) : 0u];
@@ -698,13 +721,14 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         float v = ar[u][i];
-        if (BNB) v = fmaf(ca[i], v, fmaf(cb[i], yr[u][i], cc[i]));
+        if (COEF_LDS) v = fmaf(sCoef[16 * i + c], v, fmaf(sCoef[MT * 16 + 16 * i + c], yr[u][i], sCoef[2 * MT * 16 + 16 * i + c]));
+        else if (BNB) v = fmaf(ca[i], v, fmaf(cb[i], yr[u][i], cc[i]));
         av[i] = (pv[u] && aval[i]) ? v : 0.f;
         bsum[i] += av[i];
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const float w = fmaf((br[u][j] - rm[u]) * rr[u], sc[j], sh[j]);    // (mean, rstd, sc, sh) = (0, 1, 1, 0) when unused
+        const float w = fmaf((br[u][j] - rm[u]) * rr[u], sc[TAPB ? 0 : j], sh[TAPB ? 0 : j]);    // (mean, rstd, sc, sh) = (0, 1, 1, 0) when unused
         bv[j] = ACT == 1 ? fmaxf(w, 0.f) : (ACT == 2 ? hrf_gelu(w) : w);
         if (TAP) bv[j] = (bmask[u] >> j) & 1u ? bv[j] : 0.f;      // zero padding applies AFTER the activation
       }
@@ -733,20 +757,26 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
 #pragma unroll 1
   for (int round = 1; round < WPR; ++round) {
     if (wave % WPR == round) {
-      hrf_f4 old[MT][NT];
+      // (in batches of at most MB rows of tiles: the accumulators are live beside `old` - 2 x 144 registers at MT x NT = 36)
+      constexpr int MB = MT * NT > 25 ? 2 : MT;
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int i0 = 0; i0 < MT; i0 += MB) {
+        hrf_f4 old[MB][NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) old[i][j] = S[(i * NT + j) * 64 + lane];
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+          for (int j = 0; j < NT; ++j) if (i0 + i < MT) old[i][j] = S[((i0 + i) * NT + j) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          hrf_f4 v = old[i][j];
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += acc[i][j][r];
-          S[(i * NT + j) * 64 + lane] = v;
-        }
+          for (int j = 0; j < NT; ++j) {
+            if (i0 + i >= MT) continue;
+            hrf_f4 v = old[i][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += acc[i0 + i][j][r];
+            S[((i0 + i) * NT + j) * 64 + lane] = v;
+          }
+      }
     }
     __syncthreads();
   }
@@ -947,9 +977,9 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
   return hrf_check_launch();
 }
 
-extern "C" int hrf_pw_knob(int key, int value);
-extern "C" int hrf_conv3w_knob(int key, int value);
-extern "C" int hrf_lin2_knob(int key, int value);
+extern "C" __attribute__((visibility("hidden"))) int hrf_pw_knob(int key, int value);
+extern "C" __attribute__((visibility("hidden"))) int hrf_conv3w_knob(int key, int value);
+extern "C" __attribute__((visibility("hidden"))) int hrf_lin2_knob(int key, int value);
 extern "C" int hrf_debug_knob(int key, int value) {
   if (key >= 28 && key < 32) return hrf_lin2_knob(key - 28, value);    // lin2_engine.hip: 28 = 1 force / 2 disable the LDS-tiled row GEMM
   if (key >= 16 && key < 20) return hrf_pw_knob(key - 16, value);      // pointwise.hip tuning aids

@@ -2,6 +2,7 @@
 #pragma once
 #include "hrf_rt.h"
 #include "../../include/hrfuser_hip.h"
+#include "../../include/hrfuser_hip_debug.h"
 
 // input-transform modes of the conv/dw loaders: value read from HBM is the RAW producer output,
 // the BatchNorm affine (+activation) or LayerNorm is applied on load, never materialised.

@@ -716,7 +716,8 @@ extern "C" int hrf_lin2_stamps(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_l2_t), sizeof(long long) * 64) == hipSuccess ? HRF_OK : HRF_ERR_LAUNCH;
 }
 #endif
-extern "C" int hrf_lin2_knob(int key, int value) {
+// (reached through hrf_debug_knob only: not exported)
+extern "C" __attribute__((visibility("hidden"))) int hrf_lin2_knob(int key, int value) {
   if (key < 0 || key >= 4) return HRF_ERR_ARG;
   g_l2_knob[key] = value;
   return HRF_OK;

@@ -19,8 +19,29 @@
 // The generation is a device-side step counter (hrf_p2p_tick, one launch per step), so a captured hipGraph replays it; slots
 // are double-buffered by its parity.  A rank cannot overwrite a slot its peer has not consumed yet: it would first need the
 // peer's contribution to a later exchange of the same step, and the gradient exchange at the end of a step is a barrier.
+//
+// A peer that does not arrive within the time-out (default: NCCL's 30 minutes, hrfuser_amd/p2p.py) is an ERROR, never a
+// result: the launch writes (source, slot) into the error word and fills its part of `packed` with NaN, and every later
+// exchange of the process does the same without waiting - the statistics of a step that lost an exchange are poison, the loss
+// turns NaN at once and the host raises at its next step boundary (P2PExchange.poll / check).  Nothing is ever reduced from
+// an inbox whose flag did not arrive.
+//
+// Emulator (HRF_EMUL, tests only): inboxes are POSIX shared-memory objects, so two emulator PROCESSES run the same protocol
+// (tests/test_dp_gloo.py); a wait with timeout_ticks <= 0 fails at once there (one launch at a time inside one process).
 #include <cstdlib>
 #include <cstring>
+#ifdef HRF_EMUL
+#include <cstdio>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+#include <map>
+#include <mutex>
+#include <string>
+#endif
 #include "hrf_common.h"
 #include "../../include/hrfuser_hip.h"
 
@@ -41,8 +62,9 @@ __device__ inline double px_load(const double* p) { double v; __atomic_load(p, &
 __device__ inline void px_flag_release(long long* p, long long v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 __device__ inline long long px_flag_acquire(const long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 __device__ inline void px_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-__device__ inline long long px_clock() { return 0; }
-__device__ inline void px_sleep() {}
+__device__ inline long long px_clock() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (long long)t.tv_sec * 100000000LL + t.tv_nsec / 10; }
+__device__ inline void px_sleep() { sched_yield(); }
+__device__ inline double px_nan() { return __builtin_nan(""); }
 #else
 // every access to an inbox is a system-scope operation: the data lives in (possibly remote) fine-grained memory that another
 // GPU writes while this kernel runs
@@ -53,6 +75,7 @@ __device__ __forceinline__ long long px_flag_acquire(const long long* p) { retur
 __device__ __forceinline__ void px_fence() { __threadfence_system(); }
 __device__ __forceinline__ long long px_clock() { return (long long)wall_clock64(); }
 __device__ __forceinline__ void px_sleep() { __builtin_amdgcn_s_sleep(8); }
+__device__ __forceinline__ double px_nan() { return __builtin_nan(""); }
 #endif
 
 __global__ __launch_bounds__(256) void p2p_exchange_kernel(P2pArgs a, double* packed) {
@@ -83,33 +106,34 @@ __global__ __launch_bounds__(256) void p2p_exchange_kernel(P2pArgs a, double* pa
       px_flag_release(reinterpret_cast<long long*>(x.flags[tid]) + ((long)x.rank * 2 + par) * x.nslots + a.slot_id[e], gen);
   }
   if (!(a.phase & 2)) return;
+  __shared__ int sBad;                             // a source of this layer never arrived (now, or earlier in this process)
+  if (tid == 0) sBad = 0;
+  __syncthreads();
   if (tid < x.world && tid != x.rank) {
     const long long* f = reinterpret_cast<const long long*>(x.flags[x.rank]) + ((long)tid * 2 + par) * x.nslots + a.slot_id[e];
     const long long t0 = px_clock();
-    // (an exchange that already timed out in this process is not waited for again: the step is lost, finish it quickly)
-    const bool dead = x.err != nullptr && px_flag_acquire(reinterpret_cast<const long long*>(x.err)) != 0;
-    while (!dead && px_flag_acquire(f) != gen) {
-      px_sleep();
-      if (x.timeout_ticks > 0 && px_clock() - t0 > x.timeout_ticks) {            // a peer never arrived: flag it, do not hang the GPU
-        if (x.err != nullptr) px_flag_release(reinterpret_cast<long long*>(x.err), ((long long)(tid + 1) << 32) | (long long)(a.slot_id[e] + 1));
-        break;
-      }
+    // an exchange that already timed out in this process is not waited for again: the step is lost - its result is NaN below
+    bool bad = x.err != nullptr && px_flag_acquire(reinterpret_cast<const long long*>(x.err)) != 0;
+    while (!bad && px_flag_acquire(f) != gen) {
 #ifdef HRF_EMUL
-      if (x.err != nullptr) *x.err = ((long long)(tid + 1) << 32) | (long long)(a.slot_id[e] + 1);
-      break;                                      // the emulator runs one launch at a time: a missing flag is an error
+      if (x.timeout_ticks <= 0) bad = true;         // one launch at a time inside one process: nobody could deliver it
 #endif
+      px_sleep();
+      if (x.timeout_ticks > 0 && px_clock() - t0 > x.timeout_ticks) bad = true;
+      if (bad && x.err != nullptr)                  // the peer never arrived: flag it, do not hang the GPU
+        px_flag_release(reinterpret_cast<long long*>(x.err), ((long long)(tid + 1) << 32) | (long long)(a.slot_id[e] + 1));
     }
+    if (bad) sBad = 1;
   }
-  if (x.world > 1) {
-    __syncthreads();
-    px_fence();
-  }
+  __syncthreads();
+  if (x.world > 1) px_fence();
+  const bool poison = sBad != 0;
   const double* in = x.inbox[x.rank];
   for (int c = tid; c < len; c += 256) {
     double s = 0.0;
     for (int r = 0; r < x.world; ++r)             // rank order on every rank: bit-identical totals everywhere
       s += r == x.rank ? fold(c) : px_load(in + ((long)r * 2 + par) * x.slot_doubles + a.slot_off[e] + c);
-    packed[c < C2 ? a.off[e] + c : a.roff[e]] = s;
+    packed[c < C2 ? a.off[e] + c : a.roff[e]] = poison ? px_nan() : s;
   }
 }
 
@@ -154,13 +178,40 @@ extern "C" int hrf_p2p_exchange(const hrf_p2p_t* ctx, const double* const* stats
 }
 
 // ---- inbox memory: fine-grained device memory that peers map through IPC handles (one process per GPU; two processes on one
-// GPU work as well, which is how the build container's single-GPU box tests the protocol)
+// GPU work as well, which is how the build container's single-GPU box tests the protocol).  Emulator: a POSIX shared-memory
+// object per inbox, the "IPC handle" is its name + size.
+#ifdef HRF_EMUL
+namespace {
+struct ShmEnt { size_t bytes; std::string name; bool owner; };
+std::mutex g_shm_mu;
+std::map<void*, ShmEnt> g_shm;
+int g_shm_seq = 0;
+}  // namespace
+#endif
+
 extern "C" int hrf_p2p_alloc(long bytes, void** ptr, void* handle64) {
   if (ptr == nullptr || bytes <= 0) return HRF_ERR_ARG;
 #ifdef HRF_EMUL
-  *ptr = calloc(1, bytes);
-  if (handle64 != nullptr) std::memset(handle64, 0, 64);
-  return *ptr != nullptr ? HRF_OK : HRF_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lk(g_shm_mu);
+  char name[48];
+  snprintf(name, sizeof name, "/hrf_p2p_%d_%d", (int)getpid(), g_shm_seq++);
+  (void)shm_unlink(name);
+  const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) return HRF_ERR_LAUNCH;
+  if (ftruncate(fd, bytes) != 0) { close(fd); shm_unlink(name); return HRF_ERR_LAUNCH; }
+  void* p = mmap(nullptr, (size_t)bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) { shm_unlink(name); return HRF_ERR_LAUNCH; }
+  std::memset(p, 0, (size_t)bytes);
+  g_shm[p] = ShmEnt{(size_t)bytes, name, true};
+  if (handle64 != nullptr) {
+    std::memset(handle64, 0, 64);
+    std::memcpy(handle64, name, strlen(name) + 1);
+    const long long nb = bytes;
+    std::memcpy(static_cast<char*>(handle64) + 48, &nb, 8);
+  }
+  *ptr = p;
+  return HRF_OK;
 #else
   void* p = nullptr;
   if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) return HRF_ERR_LAUNCH;
@@ -179,7 +230,21 @@ extern "C" int hrf_p2p_alloc(long bytes, void** ptr, void* handle64) {
 extern "C" int hrf_p2p_open(const void* handle64, void** ptr) {
   if (handle64 == nullptr || ptr == nullptr) return HRF_ERR_ARG;
 #ifdef HRF_EMUL
-  return HRF_ERR_ARG;
+  char name[48];
+  std::memcpy(name, handle64, 48);
+  name[47] = 0;
+  long long nb = 0;
+  std::memcpy(&nb, static_cast<const char*>(handle64) + 48, 8);
+  if (name[0] != '/' || nb <= 0) return HRF_ERR_ARG;
+  const int fd = shm_open(name, O_RDWR, 0600);
+  if (fd < 0) return HRF_ERR_LAUNCH;
+  void* p = mmap(nullptr, (size_t)nb, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return HRF_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lk(g_shm_mu);
+  g_shm[p] = ShmEnt{(size_t)nb, name, false};
+  *ptr = p;
+  return HRF_OK;
 #else
   hipIpcMemHandle_t h;
   std::memcpy(&h, handle64, 64);
@@ -190,9 +255,22 @@ extern "C" int hrf_p2p_open(const void* handle64, void** ptr) {
 #endif
 }
 
+#ifdef HRF_EMUL
+static int shm_release(void* ptr) {
+  if (ptr == nullptr) return HRF_OK;
+  std::lock_guard<std::mutex> lk(g_shm_mu);
+  auto it = g_shm.find(ptr);
+  if (it == g_shm.end()) return HRF_ERR_ARG;
+  munmap(ptr, it->second.bytes);
+  if (it->second.owner) shm_unlink(it->second.name.c_str());
+  g_shm.erase(it);
+  return HRF_OK;
+}
+#endif
+
 extern "C" int hrf_p2p_close(void* ptr) {
 #ifdef HRF_EMUL
-  return HRF_OK;
+  return shm_release(ptr);
 #else
   return (ptr == nullptr || hipIpcCloseMemHandle(ptr) == hipSuccess) ? HRF_OK : HRF_ERR_LAUNCH;
 #endif
@@ -200,8 +278,7 @@ extern "C" int hrf_p2p_close(void* ptr) {
 
 extern "C" int hrf_p2p_free(void* ptr) {
 #ifdef HRF_EMUL
-  free(ptr);
-  return HRF_OK;
+  return shm_release(ptr);
 #else
   return (ptr == nullptr || hipFree(ptr) == hipSuccess) ? HRF_OK : HRF_ERR_LAUNCH;
 #endif

@@ -1403,7 +1403,8 @@ extern "C" int hrf_avg_pool_bwd(const float* g, int B, int H, int W, int C, int 
   return hrf_check_launch();
 }
 
-extern "C" int hrf_pw_knob(int key, int value) { if (key < 0 || key >= 4) return HRF_ERR_ARG; g_pw_knob[key] = value; return HRF_OK; }
+// (reached through hrf_debug_knob only: not exported)
+extern "C" __attribute__((visibility("hidden"))) int hrf_pw_knob(int key, int value) { if (key < 0 || key >= 4) return HRF_ERR_ARG; g_pw_knob[key] = value; return HRF_OK; }
 
 extern "C" int hrf_fold_copies(const float* scratch, long copy_stride, const int* map, float* dst, long n,
                                void* stream) {

@@ -56,7 +56,12 @@ class P2PExchange:
         self.base, self.handle, self.opened, self.ctx = None, None, [], None
         self.peers = [None] * self.world
         self.exchanges = 0
-        self.timeout_s = float(os.environ.get('HRF_P2P_TIMEOUT_S', '20')) if timeout_s is None else float(timeout_s)
+        # how long an exchange waits for a peer before the step is declared lost (NaN statistics + error word): NCCL's default
+        # watchdog time-out, 30 minutes - a rank that is merely slow (evaluation, a checkpoint, a data-loader stall) is waited for
+        self.timeout_s = float(os.environ.get('HRF_P2P_TIMEOUT_S', '1800')) if timeout_s is None else float(timeout_s)
+        self._order = {}               # first step: {stream: [slot ids in enqueue order]} (verify_order), None once verified
+        self.pins = 0                  # captured graphs that carry this context's pointers (Engine.p2p_context never closes those)
+        self._poll = None              # (pinned host word, event) of the last non-blocking read of the error word
         base = ctypes.c_void_p()
         handle = (ctypes.c_char * 64)()
         lib.hrf_p2p_alloc(self.bytes, ctypes.addressof(base), ctypes.addressof(handle) if self.world > 1 else None)
@@ -186,16 +191,68 @@ class P2PExchange:
         si = (ctypes.c_int * n)(*[self.slots[id(st.bn)][k][1] for st in sts])
         self.lib.hrf_p2p_exchange(self.ctx, ptrs, cs, n, rw, so, si, packed, 0, stream)
         self.exchanges += 1
+        if self._order is not None:
+            self._order.setdefault(stream, []).extend(int(v) for v in si)
+
+    def verify_order(self):
+        """LIVENESS of the exchange.  An exchange is a launch that spin-waits for its peers' flags; launches of one HIP stream
+        (one executor stream of a captured graph) run in order.  Two ranks that enqueued exchanges X and Y of one stream in
+        OPPOSITE order would wait for each other until the time-out.  This cannot happen because (i) every rank runs the same
+        program on the same schedule fingerprint (runtime.sync_fingerprint, checked at set_sync_group), so the sequence of
+        exchanges per lane is the same everywhere, and (ii) the stream of a launch is a function of the program alone (lanes
+        are forked structurally; the hipGraph executor assigns its streams from the graph's structure).  (i) is ASSERTED here
+        instead of assumed: at the start of the second training step every rank all-gathers a digest of the per-lane slot
+        sequences of its first step and raises if they differ - before the first captured replay depends on it."""
+        if self._order is None:
+            return
+        log, self._order = self._order, None
+        if self.world <= 1 or not log:
+            return
+        import hashlib
+        import torch.distributed as dist
+        seqs = [tuple(v) for v in log.values()]          # lanes in order of first use (stream handles differ between ranks)
+        mine = hashlib.sha256(repr(seqs).encode()).hexdigest()
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, (mine, len(seqs), sum(len(v) for v in seqs)), group=self.group)
+        if any(e != everyone[0] for e in everyone):
+            raise _lib.HRFuserHipError(
+                'peer-to-peer SyncBN exchange: the ranks enqueue their exchanges in different orders per lane '
+                f'(digest, lanes, exchanges per rank: {[(e[0][:12], e[1], e[2]) for e in everyone]}) - they would dead-lock '
+                'until the time-out; the ranks do not run the same model / schedule')
+
+    def poll(self):
+        """Step-boundary check that never blocks the host: raise if the error word READ AT THE PREVIOUS CALL was set, then queue
+        the next read (a pinned 8-byte copy + an event on the current stream).  Trainer.step / replay and the autograd bridge
+        call it once per step, so a lost exchange surfaces one step later at the latest (its statistics are NaN meanwhile)."""
+        if self.ctx is None:
+            return
+        if self.err.device.type != 'cuda':               # the CPU emulator of the tests: launches are synchronous
+            return self._raise_if(int(self.err.item()))
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self._poll is not None:
+            host, ev = self._poll
+            if not ev.query():
+                return                                   # the previous read has not landed yet: look again next step
+            self._raise_if(int(host[0]))
+        host = self._poll[0] if self._poll is not None else torch.zeros(1, dtype=torch.int64).pin_memory()
+        host.copy_(self.err, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._poll = (host, ev)
 
     def check(self):
         """Raise if an exchange timed out (reads one word from the device: call at a point that synchronises anyway)."""
-        e = int(self.err.item())
+        self._raise_if(int(self.err.item()))
+
+    def _raise_if(self, e):
         if e:
             src, slot = (e >> 32) - 1, (e & 0xffffffff) - 1
             raise _lib.HRFuserHipError(
                 f'peer-to-peer SyncBN exchange timed out on rank {self.rank}: rank {src} never delivered slot {slot} '
-                f'(BatchNorm {slot // 2}, {"backward" if slot & 1 else "forward"}) of generation {int(self.gen.item())} - a peer '
-                'died, runs a different model / schedule, or HRF_SYNC_P2P differs between the ranks')
+                f'(BatchNorm {slot // 2}, {"backward" if slot & 1 else "forward"}) of generation {int(self.gen.item())} within '
+                f'{self.timeout_s:g} s (HRF_P2P_TIMEOUT_S) - a peer died, runs a different model / schedule, or HRF_SYNC_P2P differs '
+                'between the ranks; the BatchNorm statistics of that step are NaN')
 
     def close(self):
         for q in self.opened:

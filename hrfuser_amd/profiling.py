@@ -471,14 +471,37 @@ def _family_row(table, key, peak_f, peak_b, traffic, tname):
     return row
 
 
-def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None):
-    """Roofline entry of the DOMINANT kernel family of the training step.  Which family dominates is read from the round's
-    committed step timeline (profiles/rNN_step_timeline.json: the family with the largest summed in-step kernel time of one
-    replayed step under `rocprofv3 --kernel-trace`, grouped launches as the step issues them) so that the bench line and the
-    timeline name the same kernel; its numbers are measured LIVE in this run: `achieved` = the family's
-    algorithmic bytes (or flops) per launch / its average isolated launch duration (HIP events), `dominant_shape` = its
-    heaviest single (entry point, shape).  `isolated_dominant` = the family with the largest summed ISOLATED launch time (the
-    selection of rounds 1-3) with the same fields.  Without a committed timeline the isolated selection is the entry.
+def kernel_resources(key):
+    """Registers / scratch / LDS / waves per SIMD of kernel family `key` ('attn_block_bwd_kernel<18, 1>': that instantiation;
+    'lin_fwd_kernel': every instantiation of the template) from the table the BUILD wrote (hrfuser_amd/kernel_resources.json,
+    hipcc -Rpass-analysis=kernel-resource-usage of the shipped objects; empty when it belongs to other sources)."""
+    from . import build_ext
+    res = build_ext.resources()
+    hits = {k: v for k, v in res.items() if k == key or k.startswith(key + '<') or k.replace(' ', '') == key.replace(' ', '')}
+    if not hits:
+        return None
+    tot = lambda v: v.get('vgpr', 0) + v.get('agpr', 0)
+    worst = max(hits.items(), key=lambda kv: (-kv[1].get('waves_per_simd', 8), tot(kv[1])))
+    out = {'instantiations': len(hits), 'waves_per_simd_min': min(v.get('waves_per_simd', 8) for v in hits.values()),
+           'waves_per_simd_max': max(v.get('waves_per_simd', 8) for v in hits.values()),
+           'vgpr_plus_agpr_max': max(tot(v) for v in hits.values()), 'lds_static_max': max(v.get('lds_static', 0) for v in hits.values()),
+           'spilling': sorted(k for k, v in hits.items() if v.get('scratch', 0) > 0),
+           'lowest_occupancy': {'kernel': worst[0], **{k: worst[1].get(k) for k in ('vgpr', 'agpr', 'scratch', 'lds_static', 'waves_per_simd')}},
+           'source': 'hrfuser_amd/kernel_resources.json (written by the build that produced the loaded library; register-limited '
+                     'occupancy - dynamic LDS can lower it further)'}
+    return out
+
+
+def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None, grouped=None):
+    """Roofline entry of the DOMINANT kernel family of the training step, selected and measured LIVE in this run (VERDICT r4
+    #13: the selection used to come from a committed timeline and named last round's winner after a kernel change).
+    Selection: kernel time per step of every family = launches x isolated per-launch duration (HIP events, every distinct
+    (entry point, shape) re-issued in a captured graph), instantiations of one template summed; the weight-gradient family is
+    priced by its GROUPED launches as the step issues them (in situ, HIP events around every grouped launch of 3 eager steps:
+    `grouped`) instead of its 240 problems one at a time.  The family with the largest time is the entry, its instantiation
+    with the largest time the kernel: `achieved` = algorithmic bytes (or flops) per launch / average launch duration,
+    `dominant_shape` = its heaviest single (entry point, shape), `resources` = registers / scratch / waves per SIMD of the
+    build.  `timeline_dominant`: what the newest committed rocprofv3 step timeline names (cross-check only).
     `traffic` = PMC-measured fabric bytes per launch of the dominant shape when profiles/rNN_hbm_traffic.json holds it (a
     SEPARATE `rocprofv3 --pmc` run; the source is stated), else null."""
     import json
@@ -489,31 +512,41 @@ def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None):
             tj = json.load(fh)
         traffic = dict(tj.get('shapes', {}))
         traffic.update({'kernel:' + k: v for k, v in tj.get('kernels', {}).items()})
-    iso_key = max(table, key=lambda k: table[k][1])
-    key, sel = iso_key, 'kernel family with the largest summed isolated launch time per training step (no committed step timeline found)'
+    base = lambda k: k.split('<')[0]
+    fam_ms = {}
+    for k, t in table.items():
+        fam_ms[base(k)] = fam_ms.get(base(k), 0.0) + t[1] / t[4] * 1e3
+    iso_ms = dict(fam_ms)
+    g_ms = sum(r['time_per_step_ms'] for r in grouped) if grouped else None
+    if g_ms and 'wgrad_dense_kernel' in fam_ms:
+        fam_ms['wgrad_dense_kernel'] = g_ms
+    fam = max(fam_ms, key=fam_ms.get)
+    ranking = [{'family': k, 'ms_per_step': round(v, 3)} for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])[:6]]
+    sel = ('family with the largest kernel time per step MEASURED IN THIS RUN (launches x isolated launch duration, template '
+           'instantiations summed; weight gradients priced by their grouped in-situ launches'
+           + (f': {g_ms:.2f} ms grouped vs {iso_ms.get("wgrad_dense_kernel", 0.0):.2f} ms one problem at a time' if g_ms else '') + ')')
+    if fam == 'wgrad_dense_kernel' and grouped:
+        row = roofline_grouped(grouped, peak_f, peak_b)
+        row['resources'] = kernel_resources(row['kernel'].replace(', ', ', ')) or kernel_resources('wgrad_dense_kernel')
+    else:
+        key = max((k for k in table if base(k) == fam), key=lambda k: table[k][1])
+        row = _family_row(table, key, peak_f, peak_b, traffic, tname)
+        row['resources'] = kernel_resources(key)
+    row['selection'] = sel
+    row['family_ranking_ms'] = ranking
     lpath, lname = _newest(profiles_dir, 'step_timeline.json')
     if lpath:
         with open(lpath) as fh:
-            fam = json.load(fh).get('families', {})
-        for name, _ in sorted(fam.items(), key=lambda kv: -kv[1].get('in_step_us', 0.0)):
-            cands = [k for k in table if k == name or k.startswith(name + '<')]
-            if cands:
-                key = max(cands, key=lambda k: table[k][1])
-                sel = (f'family with the largest summed IN-STEP kernel time in profiles/{lname} ({name}: '
-                       f'{fam[name]["in_step_us"] / 1e3:.2f} ms over {fam[name]["launches"]} launches of one replayed step under rocprofv3 '
-                       f'--kernel-trace; instantiation with the largest live isolated time: {key}); durations below are measured '
-                       'live in this run (isolated launches, HIP events)')
-                break
-    row = _family_row(table, key, peak_f, peak_b, traffic, tname)
-    row['selection'] = sel
-    if iso_key != key:
-        iso = _family_row(table, iso_key, peak_f, peak_b, traffic, tname)
-        iso['selection'] = 'kernel family with the largest summed isolated launch time per training step (the selection of rounds 1-3)'
-        row['isolated_dominant'] = iso
+            tl = json.load(fh).get('families', {})
+        if tl:
+            top = max(tl.items(), key=lambda kv: kv[1].get('in_step_us', 0.0))
+            row['timeline_dominant'] = {'family': top[0], 'in_step_ms': round(top[1].get('in_step_us', 0.0) / 1e3, 3),
+                                        'source': f'profiles/{lname} (rocprofv3 --kernel-trace of one replayed step, committed; NOT this run)',
+                                        'agrees': base(top[0]) == fam}
     # the next families, for context
     others = sorted(table.items(), key=lambda kv: -kv[1][1])[:7]
     row['next_families'] = [{k2: _row(k, t, peak_f, peak_b)[k2] for k2 in ('kernel', 'bound', 'frac', 'launches_per_step', 'time_per_step_ms')}
-                            for k, t in others if k != key][:6]
+                            for k, t in others if k != row.get('kernel')][:6]
     return row
 
 
@@ -631,7 +664,8 @@ def grouped_wgrad_report(trainer, x, mods, cots, steps=3):
         key = int(key)
         tap, act, bnb, nt, mt = key & 1, (key >> 1) & 3, (key >> 3) & 1, (key >> 4) & 7, key >> 7
         tf = lambda b: 'true' if b else 'false'
-        rows.append({'kernel': f'wgrad_dense_kernel<{mt}, {nt}, {tf(bnb)}, {act}, {tf(tap)}>',
+        tapm = 2 if (tap and nt == 7) else (1 if tap else 0)              # nt code 7 = tap-blocked (NT 9, TAPM 2)
+        rows.append({'kernel': f'wgrad_dense_kernel<{mt}, {9 if nt == 7 else nt}, {tf(bnb)}, {act}, {tapm}>',
                      'launches_per_step': round(launches / steps, 2), 'problems_per_launch': round(problems / launches, 2),
                      'avg_launch_us': round(us / launches, 2), 'time_per_step_ms': round(us / steps / 1e3, 4),
                      'bytes_per_launch': nbytes / launches, 'flops_per_launch': flops / launches,

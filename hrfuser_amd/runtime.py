@@ -194,17 +194,19 @@ class LazyTail:
     the fused attention launch of the NEXT block of the chain forms the rows while it stages its window (attn_block(xq =
     LazyTail)), and its backward launch emits the tail's du and BatchNorm moments.  force() materialises it for any other
     consumer."""
-    __slots__ = ('res', 'lazy', 'rowscale')
+    __slots__ = ('res', 'lazy', 'rowscale', 'out')
 
     def __init__(self, res, lazy, rowscale=None):
-        self.res, self.lazy, self.rowscale = res, lazy, rowscale
+        self.res, self.lazy, self.rowscale, self.out = res, lazy, rowscale, None
 
     @property
     def shape(self):
         return self.res.t.shape
 
     def force(self, ctx):
-        return materialize(ctx, self.lazy, ACT_GELU, res=self.res, act_first=True, rowscale=self.rowscale)
+        if self.out is None:                              # memoised like Pending: a second force must not push a second backward
+            self.out = materialize(ctx, self.lazy, ACT_GELU, res=self.res, act_first=True, rowscale=self.rowscale)
+        return self.out
 
 
 class Pending:

@@ -111,7 +111,22 @@ class Trainer:
         all-reduced gradient arena of the step stays in net._engine().flat_g)."""
         if not self._ready:
             self._setup(x.device)
-        return self._step_impl(x, mods, cots, grads_only)
+        outs = self._step_impl(x, mods, cots, grads_only)
+        self._poll_exchange()
+        return outs
+
+    def _exchange(self):
+        """The peer-to-peer SyncBN exchange context of the engine, or None (plain BatchNorm, the collective schedules, or the
+        agreed fallback of the auto mode: Engine.p2p_context stores (group, world, None, mode) then)."""
+        px = self.net._engine().__dict__.get('_p2p')
+        return px[2] if (px is not None and px[2] is not None) else None
+
+    def _poll_exchange(self):
+        """Step boundary: a lost SyncBN exchange (a peer that did not arrive within HRF_P2P_TIMEOUT_S) raises here, one step
+        late at the latest, without a host synchronisation (P2PExchange.poll)."""
+        px = self._exchange()
+        if px is not None:
+            px.poll()
 
     # -------------------------------------------------------------------------------------------
     def capture(self, x, mods, cots, warmup=2):
@@ -139,18 +154,24 @@ class Trainer:
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
             self._graph_outs = self._step_impl(x, mods, cots)
         self.graph = g
+        px = self._exchange()
+        if px is not None:
+            px.pins += 1                 # the graph's exchange launches carry the context's inbox / flag / counter pointers
+            self._graph_px = px          # (Engine.p2p_context never closes a pinned context)
         return g
 
     def replay(self):
         self.graph.replay()
+        self._poll_exchange()
 
     def check(self):
         """Raise if a peer-to-peer SyncBN exchange timed out (synchronises: call where the caller synchronises anyway - the
         end of a timed loop, an evaluation interval)."""
-        px = self.net._engine().__dict__.get('_p2p')
+        px = self._exchange()
         if px is not None:
-            torch.cuda.synchronize()
-            px[2].check()
+            if px.err.device.type == 'cuda':
+                torch.cuda.synchronize()
+            px.check()
 
 
 def make_cotangents(net, x, mods, seed=5):

@@ -104,10 +104,6 @@ int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const float* yraw,
                         int tf_mode, const float* tf_scale, const float* tf_shift,
                         const float* tf_rowstat, float* dw, float* dbias, void* stream);
 
-/* tuning aid for micro-benchmarks (not used by the product path): key 0 = split cap of
- * hrf_conv_bwd_weight (0 = default), key 1 = replace its atomics by plain stores (wrong results). */
-int hrf_debug_knob(int key, int value);
-
 /* ---- depthwise 3x3 convolution, pad 1, stride 1|2, NHWC (F.conv2d groups=C) -----------------
  * CrossFFN hrformer.py:271-277 (bias, stride 1, input = GELU(BN(h1)) applied on load) and the
  * fuse-down chains hrformer.py:532-541 (stride 2, no bias).  w is (C,1,3,3).                    */
@@ -379,10 +375,6 @@ int hrf_rowgemm(const float* x, int ldX, const float* wp, const float* bias, flo
  * variant per launch (results identical to separate launches).  Calls that use other kernels launch immediately. */
 int hrf_wgrad_group_begin(void);
 int hrf_wgrad_group_end(void* stream);
-/* measurement aid (hrf_debug_knob(7, 1)): HIP-event durations of the grouped launches of eager steps, aggregated per
- * kernel variant into rows of 12 doubles (key, launches, problems, total us, algorithmic bytes, flops, heaviest problem's
- * Cin, Cout, H, W, stride, KH); returns the number of rows written and clears the log. */
-long hrf_wgrad_group_report(double* out, long cap_rows);
 
 /* Multi-problem launches for the EQUAL-SHAPE layers of sibling sensor streams.  The reference runs the camera stream's
  * finest branch and the M modality streams through layers of identical shape with different weights
@@ -431,15 +423,12 @@ int hrf_adamw(float* p, const float* g, float* m, float* v, const float* wd_mask
               float beta1, float beta2, float eps, float weight_decay, const float* state,
               float grad_scale, void* stream);
 
-/* Measurement aid: when `stream` reaches this point one thread stores the GPU's constant-rate 100 MHz timestamp counter
- * (wall_clock64) to *dst.  Unlike HIP events this can be timed INSIDE a replayed hipGraph: bench.py brackets the stages of
- * the captured training step with it (stems, transitions, fusion_a/b/c, stage2-4 with the modality stages beside them;
- * hrfuser_hrformer_based.py:535-607) for the per-stage roofline report. */
-int hrf_stamp(long long* dst, void* stream);
-/* Critical-lane probe (measurement aid, never on the product path): one idle workgroup that lasts `ticks` of the same clock.
- * Padding ONE lane of a multi-lane schedule with it and watching the step time tells whether that lane is on the critical
- * path (HRF_DEBUG_PAD in hrfuser_amd/backbone.py).                                                                       */
-int hrf_debug_spin(long ticks, void* stream);
+/* The digest (sha256, 64 hex characters) of the sources, headers, flags and target this library was built from
+ * (hrfuser_amd/build_ext.py compares it with the tree on every build(): a source change is never paired with an old binary). */
+const char* hrf_build_digest(void);
+
+/* Measurement and tuning entry points (GPU time stamps inside a captured graph, the critical-lane probe, kernel tuning knobs,
+ * the in-situ timing report of the grouped weight gradients) are NOT part of this interface: include/hrfuser_hip_debug.h. */
 
 /* hipMemsetAsync on `stream` (the per-step zeroing of the replicated accumulators). */
 int hrf_memset(void* ptr, int value, long bytes, void* stream);

@@ -19,7 +19,7 @@ def build(force=False, sanitize=False):
     h = hashlib.sha256()
     files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
     files += [os.path.join(HERE, 'emul_rt.h'), os.path.join(HERE, 'emul_rt.cpp'),
-              os.path.join(ROOT, 'include', 'hrfuser_hip.h')]
+              os.path.join(ROOT, 'include', 'hrfuser_hip.h'), os.path.join(ROOT, 'include', 'hrfuser_hip_debug.h')]
     for f in sorted(files):
         h.update(open(f, 'rb').read())
     h.update(b'asan' if sanitize else b'plain')

@@ -21,6 +21,17 @@ def test_header_symbols_exported():
     assert len(protos) >= 19
     for name in protos:
         assert hasattr(dll, name), f'{name} declared in include/hrfuser_hip.h but not exported'
+    assert hasattr(dll, 'hrf_build_digest')                     # (const char*: not a status-returning entry point)
+    debug = _lib.parse_header(_lib.DEBUG_HEADER)
+    assert set(debug) == {'hrf_debug_knob', 'hrf_wgrad_group_report', 'hrf_stamp', 'hrf_debug_spin'} and not set(debug) & set(protos)
+    for name in debug:
+        assert hasattr(dll, name), f'{name} declared in include/hrfuser_hip_debug.h but not exported'
+    # ... and nothing ELSE is exported: every dynamic hrf_* symbol of the library is declared in one of the two headers
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith('hrf_')}
+    allowed = set(protos) | set(debug) | {'hrf_build_digest', 'hrf_wgrad_stamps'}      # (-DHRF_WG_TIMING builds only)
+    assert exported <= allowed, sorted(exported - allowed)
 
 
 def test_library_contains_gfx950_code_object():

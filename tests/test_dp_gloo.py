@@ -22,8 +22,10 @@ def _short(cfg):
         cfg['extra'][k]['num_modules'] = 1
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, schedule):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HRF_EMUL_THREADS='2')
+    os.environ.pop('HRF_SYNC_P2P', None)                 # auto: peer-to-peer after the handshake, or the agreed fallback
+    os.environ['HRF_P2P_TIMEOUT_S'] = '120'
     for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
     torch.set_num_threads(2)
@@ -32,10 +34,22 @@ def _worker(rank, world, port, ret):
     from helpers import build_pair, enable_relu_probe, relu_masks, use_backend
     from hrfuser_amd.trainer import Trainer
     dev = use_backend('emul')
+    if schedule == 'fallback':
+        # the auto mode's fallback (more than 8 ranks, a peer on another node, no IPC): mapping a peer's inbox fails on THIS
+        # rank only - every rank must still end up on the collective schedule, with a warning, and Trainer.check() must work
+        from hrfuser_amd import _lib
+        L = _lib.lib()
+        real = L._fns['hrf_p2p_open']
+
+        def refuse(*a):
+            if rank == 1:
+                raise _lib.HRFuserHipError('hrf_p2p_open: refused by the test')
+            return real(*a)
+        L._fns['hrf_p2p_open'] = refuse
     net, orc, cfg = build_pair('t_nus', dev, edit=_short)           # SyncBN config
     net.train()
     enable_relu_probe(net)
-    B, (H, W) = 3, HW
+    B, (H, W) = 3, (HW if schedule == 'p2p' else (32, 32))
     x, mods = O.seeded_inputs(B, H, W, [3, 3], seed=1)
     sl = slice(0, 1) if rank == 0 else slice(1, 3)      # rank 0: one image, rank 1: two
     g = torch.Generator().manual_seed(5)
@@ -43,7 +57,24 @@ def _worker(rank, world, port, ret):
     cots = [torch.randn(s, generator=g) for s in shapes]
     tr = Trainer(net, lr=1e-3, group=dist.group.WORLD, world_size=world)
     assert len(tr.buckets(4_000_000)) == 4 and tr.buckets(10)[0] == (0, 10)
-    outs = tr.step(x[sl], [m[sl] for m in mods], [c[sl] * world for c in cots])
+    import warnings
+    with warnings.catch_warnings(record=True) as wlog:
+        warnings.simplefilter('always')
+        outs = tr.step(x[sl], [m[sl] for m in mods], [c[sl] * world for c in cots])
+    tr.check()                                             # (crashed on the fallback's (group, world, None, mode) entry)
+    fell_back = any('peer-to-peer exchange is not available' in str(w.message) for w in wlog)
+    if schedule == 'p2p':
+        # two emulator PROCESSES, inboxes in POSIX shared memory: the product's exchange protocol itself (push, flags, spin,
+        # rank-order sums, generation parity) across address spaces - not the fallback
+        assert not fell_back and tr.p2p_exchanges_per_step > 40 and 'peer-to-peer' in tr.sync_schedule, (tr.p2p_exchanges_per_step, tr.sync_schedule)
+    else:
+        assert fell_back and tr.p2p_exchanges_per_step == 0 and 'peer-to-peer' not in tr.sync_schedule
+        assert 20 < tr.collectives_per_step <= 150, tr.collectives_per_step   # packed exchanges of the lock-step schedule
+        assert bool(torch.isfinite(net._engine().flat_g).all())
+        ret[f'fallback{rank}'] = float(net._engine().flat_g.double().norm())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     eng = net._engine()
     N = lambda t: t.detach().float().cpu().numpy().copy()
     res = dict(out=[N(o.t) for o in outs], grad=N(eng.flat_g), param=N(eng.flat_p),
@@ -63,6 +94,7 @@ def _worker(rank, world, port, ret):
     ncots = [torch.randn(B, 8 >> i, 16 >> i, 32, generator=gm) for i in range(3)]
     ntr = Trainer(neck, lr=0.0, weight_decay=0.0, group=dist.group.WORLD, world_size=world)
     ntr.step(maps[0][sl], [maps[1][sl]], [c[sl] for c in ncots])
+    ntr.check()
     res['neck_grad'] = N(neck._engine().flat_g)
     if rank == 0:
         ys = norc(maps)
@@ -78,11 +110,18 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_syncbn_and_grad_exchange_equal_single_process():
+@pytest.mark.parametrize('schedule', ['p2p', 'fallback'])
+def test_two_rank_syncbn_and_grad_exchange_equal_single_process(schedule):
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + (0 if schedule == 'p2p' else 1)
+    mp.spawn(_worker, args=(2, port, ret, schedule), nprocs=2, join=True)
+    if schedule == 'fallback':
+        # the agreed fallback of the auto mode (one rank cannot map its peer's inbox): both ranks on the collective schedule,
+        # identical all-reduced gradient arenas, Trainer.check() usable.  (The schedule's parity against the oracle is the
+        # subject of tests/test_syncbn_gpu.py and of the peer-to-peer == collective comparisons of tests/test_p2p_exchange.py.)
+        assert ret['fallback0'] > 0 and ret['fallback0'] == ret['fallback1']
+        return
     res = ret['res']
     for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
         if p not in sys.path:
@@ -138,6 +177,7 @@ def test_two_rank_syncbn_and_grad_exchange_equal_single_process():
     assert ret['wd_mask_sum'] > 0
     # batching: 330 BatchNorms x 2 directions would be 660 exchanges one by one; the lock-step schedule packs the
     # independent ones (sensor streams, HRModule branches, exchange chains)
-    assert res['ncoll'] <= 150, res['ncoll']
+    # peer-to-peer schedule: only the gradient buckets are collectives
+    assert res['ncoll'] <= 8, res['ncoll']
     # neck: all-reduced arena = gradient of the whole-batch loss (no normalisation layers in HRFPN)
     assert rel(res['neck_grad'], ret['neck_ref']) < 1e-4

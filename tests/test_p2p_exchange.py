@@ -97,6 +97,12 @@ def test_p2p_protocol_in_halves_emul():
     _call(L, ctxs[0], stats[0], Cs, rows[0], offs, ids, junk, 3)
     e = int(errs[0])
     assert e != 0 and (e >> 32) - 1 == 1 and (e & 0xffffffff) - 1 in ids
+    assert bool(torch.isnan(junk).all())                # a lost exchange never yields statistics: NaN, all of it
+    # ... and every later exchange of the process is poisoned as well, without waiting (the host raises at its next step boundary)
+    L.hrf_p2p_tick(gens[0], 0)
+    junk2 = torch.zeros_like(junk)
+    _call(L, ctxs[0], stats[0], Cs, rows[0], offs, ids, junk2, 3)
+    assert bool(torch.isnan(junk2).all())
 
 
 def test_p2p_argument_checks_emul():
@@ -157,6 +163,7 @@ def test_p2p_timeout_sets_error_word_gpu():
     torch.cuda.synchronize()
     e = int(errs[0])
     assert (e >> 32) - 1 == 1 and (e & 0xffffffff) - 1 == 1
+    assert bool(torch.isnan(out).all())                 # never a sum over an inbox whose flag did not arrive
     assert float(torch.ones(4, device=dev).sum()) == 4.0
 
 
