@@ -1269,7 +1269,7 @@ class HipModule(nn.Module, EngineOwner):
             saved = eng.keep
             eng.keep = ent.keep                              # the capture's step buffers live as long as the entry
             try:
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                with R.gc_paused(), torch.cuda.graph(g, capture_error_mode='thread_local'):
                     ent.ctx, ent.outs, ent.srcs = self._execute(tuple(ent.ins), ent.ctx_record, ent.needs)
             finally:
                 eng.keep = saved
@@ -1305,7 +1305,7 @@ class HipModule(nn.Module, EngineOwner):
             eng.keep = ent.keep
             ent.ctx.gen = eng.gen
             try:
-                with torch.cuda.graph(g, pool=ent.fwd.pool(), capture_error_mode='thread_local'):
+                with R.gc_paused(), torch.cuda.graph(g, pool=ent.fwd.pool(), capture_error_mode='thread_local'):
                     R.use_keep_list(ent.keep)
                     for o, d in zip(ent.outs, ent.gouts):
                         o.grad = R.gpu_clone(d)

@@ -125,7 +125,7 @@ class ExtractTrainer:
             import time
             time.sleep(float(os.environ.get('HRF_CAPTURE_SETTLE', '1.0')))       # see Trainer.capture
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        with R.gc_paused(), torch.cuda.graph(g, capture_error_mode='thread_local'):
             self._graph_outs = self._step_impl(x, mods, cots)
         self.graph = g
         return g

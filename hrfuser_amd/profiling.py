@@ -9,6 +9,7 @@ import time
 import torch
 
 from . import _lib
+from .runtime import gc_paused as _gc_paused
 
 
 def _pick_nt(C):
@@ -185,7 +186,7 @@ def _graph_time(fn, reps=20, replays=5):
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _gc_paused(), torch.cuda.graph(g):
         for _ in range(reps):
             fn()
     g.replay()
@@ -573,7 +574,7 @@ def time_eval_forward(net, x, mods, iters=30, use_graph=True):
                     net(x, list(mods))
                 torch.cuda.current_stream().wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _gc_paused(), torch.cuda.graph(g):
                     net(x, list(mods))
                 run = g.replay
             except Exception:

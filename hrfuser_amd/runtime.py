@@ -382,6 +382,26 @@ class _LibProxy:
         return call
 
 
+class gc_paused:
+    """Pause Python's cyclic garbage collector for the duration of a hipGraph capture.  The collector may run at any allocation
+    (an Event, a list) and destroy whatever unreachable cycle it finds - e.g. the captured graphs of a module that went out of
+    scope a moment ago: hipGraphExecDestroy inside ANOTHER stream capture fails, the destructor throws, the process aborts
+    (seen as `Fatal Python error: Aborted ... Garbage-collecting` in a wait_stream of a capturing forward).  torch.cuda.graph
+    collects once BEFORE the capture starts; this keeps the collector out until it has ended."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        if self.was:
+            import gc
+            gc.enable()
+        return False
+
+
 class Ctx:
     """Per-forward execution context: library handle, current lane/stream, mode, strand tree with the reverse tapes."""
 
@@ -413,6 +433,11 @@ class Ctx:
         # lanes - every BatchNorm exchanges on its own lane, at once, with ONE launch
         self.p2p = owner._engine().p2p_context(self.group, self.world) if self.coll else None
         self.n_p2p = 0
+        # gradient exchange of the step (hrfuser_amd.trainer): (buckets [(a, b) slices of the flat gradient arena], fn(a, b) =
+        # all-reduce of one slice, rounds) - set by the trainer before run_backward, which then issues the weight-gradient leaves
+        # bucket by bucket and every bucket's all-reduce as soon as its slice of the arena is final
+        self.exchange = None
+        self.n_grad_collectives = 0
         self.pending = []               # forward BatchNorm exchanges parked by the strands (SyncBN)
         self.bpending = []              # backward ones: (BNState, lane)
         # lock-step strands need coroutines; HRF_LOCKSTEP=0 (or no greenlet) runs the bodies one after the other: no merged
@@ -834,17 +859,20 @@ class Ctx:
     def on(self, lane):
         return _LaneScope(self, lane)
 
-    def side_launch(self, fn, cost=1.0, key=None):
+    def side_launch(self, fn, cost=1.0, key=None, target=None):
         """Run `fn` (one off-critical-path launch) on a side lane that starts after the current lane's
-        work so far and is joined into the main lane at the end of the backward pass."""
+        work so far and is joined into the main lane at the end of the backward pass.  `target`: the parameter whose
+        gradient the launch writes STRAIGHT into the flat arena (None: through the replicated accumulators, or unknown) -
+        with a gradient exchange pending (Ctx.exchange) the leaves are issued bucket by bucket, see run_backward."""
         mode = os.environ.get('HRF_WGRAD', 'defer')
-        if not self.multi or mode == 'inline':
+        bucketed = self.exchange is not None and mode == 'defer'
+        if (not self.multi and not bucketed) or mode == 'inline':
             fn()
             return
-        if mode in ('defer', 'flush'):
+        if mode in ('defer', 'flush') or bucketed:
             # weight-gradient launches are leaves of the backward graph: collect them and issue them
             # as one wide, fully parallel phase after the (serial, latency-bound) data-gradient chain
-            self._deferred.append((float(cost), fn, key))
+            self._deferred.append((float(cost), fn, key, target))
             return
         pool = self.owner._side_pool()
         lane = pool[self._side_i % len(pool)]
@@ -935,36 +963,45 @@ class Ctx:
         if eng0.rpb_pending():
             # every attn_block_bwd has left its dS planes: ONE gather launch for all relative-position-bias tables, a leaf of the
             # weight-gradient phase (52 launches of its own for HRFuser-T before)
-            if self._deferred and self.multi:
-                self._deferred.append((eng0.fs_rpb_bytes, lambda: eng0.rpb_grad_now(self.L, self.stream)))
+            if self._deferred:
+                self._deferred.append((eng0.fs_rpb_bytes, lambda: eng0.rpb_grad_now(self.L, self.stream), None, None))
             else:
                 eng0.rpb_grad_now(self.L, self.stream)
-        if self._deferred and self.multi and eng0.fs_used and os.environ.get('HRF_FOLD_LEAF', '1') != '0':
+        if self._deferred and eng0.fs_used and os.environ.get('HRF_FOLD_LEAF', '1') != '0':
             # the per-window slots of the fused attention blocks are complete (every attn_block_bwd has run) and their targets
             # in the gradient arena are touched by no other leaf: the fold (370 MB for HRFuser-T) joins the weight-gradient
             # phase as one more leaf instead of running alone on the main lane behind it
-            self._deferred.append((4.0 * eng0.fs_bytes(), lambda: eng0.fold_slots_now(self.L, self.stream)))
+            self._deferred.append((4.0 * eng0.fs_bytes(), lambda: eng0.fold_slots_now(self.L, self.stream), None, None))
+        comm = None
         if self._deferred:
             items, self._deferred = self._deferred, []
             k = int(os.environ.get('HRF_WGRAD_LANES', '4'))
             group = os.environ.get('HRF_WGRAD_GROUP', '1') != '0'
             self.strand = self.root
-            lanes = self.fork(k)
-            parts = _balance(items, k) if os.environ.get('HRF_WGRAD_BALANCE', '1') != '0' else \
-                [[it[1] for it in items[j::k]] for j in range(k)]
-            for j in range(k):
-                with _LaneScope(self, lanes[j]):
-                    # the dense weight gradients of a lane are queued and issued as a few grouped launches
-                    # (up to 16 same-variant problems each, include/hrfuser_hip.h); everything else launches at once
-                    if group:
-                        self.L.hrf_wgrad_group_begin()
-                    try:
-                        for fn in parts[j]:
-                            fn()
-                    finally:
+            for r, (its, ready) in enumerate(self._exchange_rounds(items)):
+                lanes = self.fork(k)
+                parts = _balance(its, k) if os.environ.get('HRF_WGRAD_BALANCE', '1') != '0' else \
+                    [[it[1] for it in its[j::k]] for j in range(k)]
+                for j in range(k):
+                    with _LaneScope(self, lanes[j]):
+                        # the dense weight gradients of a lane are queued and issued as a few grouped launches
+                        # (up to 16 same-variant problems each, include/hrfuser_hip.h); everything else launches at once
                         if group:
-                            self.L.hrf_wgrad_group_end(self.stream)
-            self.join(lanes)
+                            self.L.hrf_wgrad_group_begin()
+                        try:
+                            for fn in parts[j]:
+                                fn()
+                        finally:
+                            if group:
+                                self.L.hrf_wgrad_group_end(self.stream)
+                self.join(lanes)
+                if self.exchange is not None:
+                    if r == 0:
+                        # every leaf that goes through the replicated accumulators or the per-window slots ran in round 0:
+                        # after these folds a slice of the arena is final as soon as its own dense leaves are done
+                        with _LaneScope(self, self.main):
+                            eng0.fold_grads(self.L, self.main.ptr)
+                    comm = self._exchange_issue(ready, comm)
             self.root.tape.clear()              # (fork / join recorded markers: the pass is over)
         if self.multi:
             for lane in self._side_used.values():
@@ -975,9 +1012,64 @@ class Ctx:
             st = self.owner.__dict__.get('_stage_stamps')
             if st is not None:
                 st.take(self, 'bwd', 'weight_gradients')      # end of the deferred weight-gradient phase + folds
+        if self.exchange is not None:
+            if self.n_grad_collectives == 0:                  # nothing was deferred (frozen weights, HRF_WGRAD=inline / flush)
+                comm = self._exchange_issue(list(self.exchange[0]), comm)
+            if comm is not None and comm.stream is not None:
+                self.main.stream.wait_stream(comm.stream)
+                self._free.append(comm)
         if self.multi:
             torch.cuda.set_stream(entry)
             entry.wait_stream(self.main.stream)
+
+    def _exchange_rounds(self, items):
+        """-> [(leaf items, arena slices that are final after them)]: without a gradient exchange one round with everything.
+        With one (Ctx.exchange = (buckets, fn, rounds)): the buckets are dealt to `rounds` consecutive groups; round 0 carries
+        every leaf without a known arena target (depthwise / LayerNorm / relative-position-bias gradients through the
+        replicated accumulators, the slot fold, the neck) plus the dense leaves of the first group, round r the dense leaves
+        whose parameter lies in group r.  The reference overlaps its bucketed all-reduce with the backward through DDP's hooks
+        (mmdet/apis/train.py:113-121, MMDistributedDataParallel); here the weight gradients are LEAVES deferred behind the
+        data-gradient chain, so the overlap is inside that phase: all-reduce of group r beside the leaves of group r + 1."""
+        if self.exchange is None:
+            return [(items, [])]
+        buckets, _, rounds = self.exchange
+        rounds = max(1, min(int(rounds), len(buckets)))
+        per = (len(buckets) + rounds - 1) // rounds
+        groups = [buckets[g * per:(g + 1) * per] for g in range(rounds)]
+        groups = [g for g in groups if g]
+        offs = self.owner._engine()._poffs
+        out = [([], list(g)) for g in groups]
+        for it in items:
+            tgt = it[3] if len(it) > 3 else None
+            o = offs.get(id(tgt)) if tgt is not None else None
+            r = 0
+            if o is not None:
+                for gi, g in enumerate(groups):
+                    if g[0][0] <= o < g[-1][1]:
+                        r = gi
+                        break
+            out[r][0].append(it)
+        return out
+
+    def _exchange_issue(self, ready, comm):
+        """All-reduce the arena slices `ready` on the communication lane (a direct child of the main lane, like every lane),
+        behind everything the main lane has joined so far."""
+        if not ready:
+            return comm
+        fn = self.exchange[1]
+        if self.multi:
+            if comm is None:
+                comm = self._free.pop() if self._free else self.owner._lane_pool(grow=True)
+            comm.stream.wait_stream(self.main.stream)
+            with _LaneScope(self, comm):
+                for a, b in ready:
+                    fn(a, b)
+                    self.n_grad_collectives += 1
+        else:
+            for a, b in ready:
+                fn(a, b)
+                self.n_grad_collectives += 1
+        return comm
 
 
 def _balance(items, k, chunk=None):
@@ -1282,7 +1374,7 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
         ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
             dy, ldD, doff, yraw, cA, cB, cC, xw, *sw, B, H, W, Cin, KH, stride, Cout,
             tf, sc, sh, rowstat, weight.grad, bgrad, ctx.stream), cost=cost,
-            key=('conv_w', Cin, Cout, KH, stride, tf, cA is not None))
+            key=('conv_w', Cin, Cout, KH, stride, tf, cA is not None), target=weight)
 
 
 # ----------------------------------------------------------------------------- GroupNorm (norm_cfg type 'GN')

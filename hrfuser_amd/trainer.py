@@ -80,6 +80,16 @@ class Trainer:
         step = (n + nb - 1) // nb
         return [(i, min(n, i + step)) for i in range(0, n, step)]
 
+    def overlap_rounds(self, n):
+        """Groups of buckets whose all-reduce overlaps the weight-gradient leaves of the next group.  HRF_GRAD_OVERLAP: a number,
+        or auto = one group per bucket from 64 MB of gradients (HRFuser-B: 243 MB, ~5 ms on xGMI beside a > 10 ms
+        weight-gradient phase), a single group below (HRFuser-T: 16 MB = 0.3 ms - every extra fork / join of the leaf lanes
+        costs more than it hides)."""
+        v = os.environ.get('HRF_GRAD_OVERLAP', 'auto').strip().lower()
+        if v not in ('', 'auto'):
+            return max(1, int(v))
+        return self.n_buckets if 4 * n >= (64 << 20) else 1
+
     def _step_impl(self, x, mods, cots, grads_only=False):
         net = self.net
         eng = net._engine()
@@ -88,14 +98,17 @@ class Trainer:
         ctx, outs, _ = net._execute((x,) + tuple(mods), True)
         for o, c in zip(outs, cots):
             o.grad = R.gpu_clone(c)         # synthetic loss  L = sum_i <out_i, cot_i>   
-        ctx.run_backward()
-        ncoll = ctx.n_collectives
-        self.p2p_exchanges_per_step = ctx.n_p2p
         if self.world > 1 or self.force:
             import torch.distributed as dist
-            for a, b in self.buckets(eng.flat_g.numel()):
-                dist.all_reduce(eng.flat_g[a:b], group=self.group)
-                ncoll += 1
+            # the gradient exchange is part of the backward pass: the weight-gradient leaves are issued bucket group by bucket
+            # group and a group's all-reduce runs on a communication lane beside the next group's leaves (runtime.Ctx.
+            # _exchange_rounds; the reference: DDP's bucketed overlap, mmdet/apis/train.py:113-121)
+            ctx.exchange = (self.buckets(eng.flat_g.numel()),
+                            lambda a, b: dist.all_reduce(eng.flat_g[a:b], group=self.group), self.overlap_rounds(eng.flat_g.numel()))
+        ctx.run_backward()
+        ncoll = ctx.n_collectives + ctx.n_grad_collectives
+        self.p2p_exchanges_per_step = ctx.n_p2p
+        self.grad_collectives_per_step = ctx.n_grad_collectives
         self.collectives_per_step = ncoll
         self.exchange_hist = dict(ctx.xhist)
         self.sync_schedule = ctx.schedule_desc()
@@ -151,7 +164,7 @@ class Trainer:
         # thread_local: the RCCL watchdog thread polls events of earlier (eager) collectives while we
         # capture; in the default "global" mode such a call from another thread invalidates the capture
         # ("capturing stream has unjoined work", seen in ~3 of 4 runs with collectives in the graph)
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        with R.gc_paused(), torch.cuda.graph(g, capture_error_mode='thread_local'):
             self._graph_outs = self._step_impl(x, mods, cots)
         self.graph = g
         px = self._exchange()

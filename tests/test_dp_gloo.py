@@ -26,6 +26,9 @@ def _worker(rank, world, port, ret, schedule):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HRF_EMUL_THREADS='2')
     os.environ.pop('HRF_SYNC_P2P', None)                 # auto: peer-to-peer after the handshake, or the agreed fallback
     os.environ['HRF_P2P_TIMEOUT_S'] = '120'
+    # the gradient exchange inside the weight-gradient phase: four bucket groups (auto would use one for 16 MB of gradients),
+    # leaves issued group by group, a group's all-reduce behind its own leaves and the folds - same gradients as one exchange
+    os.environ['HRF_GRAD_OVERLAP'] = '4' if schedule == 'p2p' else 'auto'
     for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
     torch.set_num_threads(2)
@@ -57,6 +60,7 @@ def _worker(rank, world, port, ret, schedule):
     cots = [torch.randn(s, generator=g) for s in shapes]
     tr = Trainer(net, lr=1e-3, group=dist.group.WORLD, world_size=world)
     assert len(tr.buckets(4_000_000)) == 4 and tr.buckets(10)[0] == (0, 10)
+    assert tr.overlap_rounds(4_000_000) == (4 if schedule == 'p2p' else 1) and Trainer(net, group=None).overlap_rounds(61_000_000) in (4, 1)
     import warnings
     with warnings.catch_warnings(record=True) as wlog:
         warnings.simplefilter('always')
@@ -67,6 +71,7 @@ def _worker(rank, world, port, ret, schedule):
         # two emulator PROCESSES, inboxes in POSIX shared memory: the product's exchange protocol itself (push, flags, spin,
         # rank-order sums, generation parity) across address spaces - not the fallback
         assert not fell_back and tr.p2p_exchanges_per_step > 40 and 'peer-to-peer' in tr.sync_schedule, (tr.p2p_exchanges_per_step, tr.sync_schedule)
+        assert tr.grad_collectives_per_step == len(tr.buckets(net._engine().flat_g.numel()))
     else:
         assert fell_back and tr.p2p_exchanges_per_step == 0 and 'peer-to-peer' not in tr.sync_schedule
         assert 20 < tr.collectives_per_step <= 150, tr.collectives_per_step   # packed exchanges of the lock-step schedule
