@@ -56,6 +56,7 @@ def struct_from_header(tag, path=HEADER):
 BnFin = struct_from_header('hrf_bn_fin')            # BatchNorm of a consumer's input finalised on load
 BnBFin = struct_from_header('hrf_bn_bfin')          # BatchNorm-backward coefficients derived on load
 AttnBlock = struct_from_header('hrf_attn_block')    # fused window-attention block (csrc/attn_block.hip)
+FfnEval = struct_from_header('hrf_ffn_eval')        # eval-mode CrossFFN in one launch (csrc/ffn_eval.hip)
 P2p = struct_from_header('hrf_p2p')                 # peer-to-peer SyncBN exchange context (csrc/p2p_exchange.hip)
 
 
@@ -63,7 +64,8 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_RAW_RETURN = ('hrf_conv3_wgrad_wide_scratch', 'hrf_wgrad_group_report', 'hrf_attn_block_supported', 'hrf_attn_block_bwd_supported', 'hrf_group_count')       # return a value, not a status
+_RAW_RETURN = ('hrf_conv3_wgrad_wide_scratch', 'hrf_wgrad_group_report', 'hrf_attn_block_supported', 'hrf_attn_block_bwd_supported', 'hrf_group_count',
+               'hrf_ffn_eval_supported')       # return a value, not a status
 _ERR = {1: 'HRF_ERR_ARG (bad argument)', 2: 'HRF_ERR_LAUNCH (kernel launch failed)'}
 
 

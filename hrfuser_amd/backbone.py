@@ -649,6 +649,15 @@ class HRFormerBlock(nn.Module):
             ticks = int(_debug_pad()[C] * 100)
             ctx.L.hrf_debug_spin(ticks, ctx.stream)
             ctx.push(lambda: ctx.L.hrf_debug_spin(ticks, ctx.stream))
+        if R.ffn_eval_ok(ctx, C, self.ffn):
+            # eval forward (frozen BatchNorms, no tape): the attention half, then the WHOLE CrossFFN half in one launch with the
+            # hidden tensor in LDS (csrc/ffn_eval.hip; hrformer.py:284-295) - 2 launches per block instead of 3 - 10
+            if R.attn_block_ok(ctx, C, msa.num_heads):
+                x1, _ = R.attn_block(ctx, id(self), msa.num_heads, x, x, self.norm1, self.norm1, (msa.qkv, 0), (msa.qkv, C),
+                                     (msa.qkv, 2 * C), msa.relative_position_bias_table, msa.out_proj, x)
+            else:
+                x1 = self.attn.run(ctx, R.force(ctx, x), self.norm1)
+            return R.ffn_eval(ctx, x1, self.norm2, self.ffn)
         if R.attn_block_ok(ctx, C, msa.num_heads) and self.ffn.layers[0].weight.shape[0] == 4 * C and not R.is_gn(self.ffn.layers[1]):
             # one launch: norm1 -> qkv -> window attention -> out_proj -> residual -> norm2 -> CrossFFN 1x1 expansion
             # (x may be the previous block's lazy tail: the launch forms it on load)
@@ -764,10 +773,13 @@ class HRFuserFusionBlock(nn.Module):
                     ctx.owner._engine().rng_site = (id(self), k)
                     mask = ctx.owner._engine().dropout_mask(tuple(x.t.shape), p) if p > 0 else None
                     drop = (mask, 1.0 / (1.0 - p) if p > 0 else 1.0, dps)
+                fe = R.ffn_eval_ok(ctx, C, self.ffn)
                 acc, h1 = R.attn_block(ctx, (id(self), k), heads, x, z, self.norm1[k], self.norm2[k], (a.q_proj, 0),
                                        (a.k_proj, 0), (a.v_proj, 0), a.relative_position_bias_table, a.out_proj, acc,
                                        res2=z, drop=drop,
-                                       ffn=(self.norm3, self.ffn.layers[0], self.ffn.layers[1]) if k == M - 1 else None)
+                                       ffn=(self.norm3, self.ffn.layers[0], self.ffn.layers[1]) if (k == M - 1 and not fe) else None)
+            if fe:                                  # eval: norm3 + the whole CrossFFN + residual in one launch
+                return R.ffn_eval(ctx, acc, self.norm3, self.ffn)
             tail = self.ffn.run_tail(ctx, h1)
             return R.materialize(ctx, tail, R.ACT_GELU, res=acc, act_first=True,
                                  rowscale=self._droppath_scale(ctx, B, dev))
@@ -776,6 +788,8 @@ class HRFuserFusionBlock(nn.Module):
             q_in = R.ln_input(ctx, x, self.norm1[k], cache)      # every modality queries the PRE-fusion camera
             kv_in = R.ln_input(ctx, z, self.norm2[k])
             acc = self.attn[k].run(ctx, q_in, kv_in, acc, z, self._droppath_scale(ctx, B, dev))
+        if R.ffn_eval_ok(ctx, C, self.ffn):
+            return R.ffn_eval(ctx, acc, self.norm3, self.ffn)
         tail = self.ffn.run(ctx, R.ln_input(ctx, acc, self.norm3))
         return R.materialize(ctx, tail, R.ACT_GELU, res=acc, act_first=True,
                              rowscale=self._droppath_scale(ctx, B, dev))

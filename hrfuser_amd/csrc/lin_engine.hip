@@ -405,7 +405,7 @@ inline void lin_fwd_plan(const LinFwdArgs& a, int& ntw, bool& sk) {
       case 2: HRF_LF_ONE(2, TF_) break;                  \
       case 3: HRF_LF_ONE(3, TF_) break;                  \
       case 5: HRF_LF_ONE(5, TF_) break;                  \
-      default: HRF_LF_ONE(9, TF_) break;                 \
+      default: HRF_LF_WIDE(9, TF_, SK_) break;           \
     }                                                    \
   } else                                                 \
   switch (ntw) {                                         \
@@ -454,15 +454,14 @@ int hrf_lin_fwd_launch(const LinFwdArgs& a, void* stream) {
       case 2: HRF_LB_ONE(2, BNB_) break;                 \
       case 3: HRF_LB_ONE(3, BNB_) break;                 \
       case 5: HRF_LB_ONE(5, BNB_) break;                 \
-      default: HRF_LB_ONE(9, BNB_) break;                \
+      default: HRF_LB_ONE(5, BNB_) break;                \
     }                                                    \
   } else                                                 \
   switch (ntw) {                                         \
     case 1: HRF_LB_LAUNCH(1, BNB_, LIN_SB, SK_); break;  \
     case 2: HRF_LB_LAUNCH(2, BNB_, LIN_SB, SK_); break;  \
     case 3: HRF_LB_LAUNCH(3, BNB_, LIN_SB, SK_); break;  \
-    case 5: HRF_LB_WIDE(5, BNB_, SK_) break;             \
-    default: HRF_LB_WIDE(9, BNB_, SK_) break;            \
+    default: HRF_LB_WIDE(5, BNB_, SK_) break;            \
   }
 #define HRF_LB_V4(BNB_) { if (sk) { HRF_LB_NT(BNB_, true) } else { HRF_LB_NT(BNB_, false) } }
 
@@ -475,7 +474,8 @@ int hrf_lin_bwd_data_launch(const LinBwdDataArgs& a, void* stream) {
   int ntw = pick_ntw(sk ? 4 * a.M : a.M, T);
   // the epilogue variants keep their raw-input tile and the activation temporaries next to the accumulators: 9 tiles per
   // wave do not fit the register file (HRFuser-B, 312 output channels: 150 us at 10 TFLOP/s); more channel groups instead
-  if (a.epi == 1 && ntw > LIN_BWD_EPI_MAX_NT) ntw = LIN_BWD_EPI_MAX_NT;
+  // (round 5: the cap holds for every variant - the 9-tile instantiations held 256 VGPRs + 71 ... 186 AGPRs, ONE wave per SIMD)
+  if (ntw > LIN_BWD_EPI_MAX_NT) ntw = LIN_BWD_EPI_MAX_NT;
   const dim3 grid(hrf_cdiv(a.M, sk ? 16 : 64), hrf_cdiv(T, ntw));
   if (a.cA != nullptr) { HRF_LB_V4(true) } else { HRF_LB_V4(false) }
   return hrf_check_launch();

@@ -995,6 +995,9 @@ class Ctx:
                             if group:
                                 self.L.hrf_wgrad_group_end(self.stream)
                 self.join(lanes)
+                xs = self.owner.__dict__.get('_exchange_stamps')      # measurement aid (tools/exchange_overlap.py)
+                if xs is not None:
+                    xs.take(self, 'leaves_done', f'group {r}', stream=self.main.ptr)
                 if self.exchange is not None:
                     if r == 0:
                         # every leaf that goes through the replicated accumulators or the per-window slots ran in round 0:
@@ -1061,9 +1064,14 @@ class Ctx:
             if comm is None:
                 comm = self._free.pop() if self._free else self.owner._lane_pool(grow=True)
             comm.stream.wait_stream(self.main.stream)
+            xs = self.owner.__dict__.get('_exchange_stamps')
             with _LaneScope(self, comm):
                 for a, b in ready:
+                    if xs is not None:
+                        xs.take(self, 'allreduce_begin', f'[{a}:{b})')
                     fn(a, b)
+                    if xs is not None:
+                        xs.take(self, 'allreduce_end', f'[{a}:{b})')
                     self.n_grad_collectives += 1
         else:
             for a, b in ready:
@@ -1589,6 +1597,47 @@ def window_attention(ctx, q, qoff, k, koff, v, voff, kpad, vpad, kbias, kboff, v
                               racc, cs, B, H, W, C, heads, s)
     ctx.push(bwd)
     return o
+
+
+# ----------------------------------------------------------------------------- eval-mode CrossFFN in one launch
+_FFN_EVAL = os.environ.get('HRF_FFN_EVAL', '1') != '0'
+# widest block that takes the one-launch route (the kernel is built for every width hrf_ffn_eval_supported names; measured on
+# MI355X it beats dw + fc3 + the fc1 head of the attention launch on the finest branch only, where a launch has 480+ tiles)
+_FFN_EVAL_MAXC = int(os.environ.get('HRF_FFN_EVAL_MAXC', '18'))
+
+
+def ffn_eval_ok(ctx, C, ffn):
+    """Can the CrossFFN of this block run as ONE launch (csrc/ffn_eval.hip)?  Only without a tape (an eval forward: nothing
+    will back-propagate through it), with every BatchNorm of the CrossFFN frozen (eval mode / norm_eval: running statistics
+    as a per-channel affine) and for the widths the kernel is built for.  `norm_eval=True` TRAINING keeps the per-op route."""
+    if not _FFN_EVAL or ctx.record or ctx.training or C > _FFN_EVAL_MAXC:
+        return False
+    l = ffn.layers
+    if any(is_gn(l[k]) or l[k].training or l[k].running_mean is None for k in (1, 4, 7)):
+        return False
+    return l[0].weight.shape[0] == 4 * C and l[3].bias is not None and l[0].bias is not None and l[6].bias is not None and \
+        bool(ctx.L.hrf_ffn_eval_supported(C, 4 * C))
+
+
+def ffn_eval(ctx, x, ln, ffn):
+    """x + GELU(BN3(fc3(GELU(BN2(dw(GELU(BN1(fc1(LN(x))))))))))  (hrformer.py:351,267-295,371-372 with frozen BatchNorms; DropPath
+    is the identity in eval): one launch, the 4C-wide hidden tensor stays on the chip."""
+    B, H, W, C = x.t.shape
+    l = ffn.layers
+    eng = ctx.owner._engine()
+    P = _lib._ptr
+    a = _lib.FfnEval()
+    a.B, a.H, a.W, a.C, a.hidden = B, H, W, C, 4 * C
+    a.x = P(x.t)
+    a.ln_g, a.ln_b, a.ln_eps = P(ln.weight), P(ln.bias), float(ln.eps)
+    (s1, t1, _, _), (s2, t2, _, _), (s3, t3, _, _) = (eng.bn_eval_affine(l[k]) for k in (1, 4, 7))
+    a.w1, a.b1, a.s1, a.t1 = P(l[0].weight), P(l[0].bias), P(s1), P(t1)
+    a.wd, a.bd, a.s2, a.t2 = P(l[3].weight), P(l[3].bias), P(s2), P(t2)
+    a.w3, a.b3, a.s3, a.t3 = P(l[6].weight), P(l[6].bias), P(s3), P(t3)
+    out = Act(_new((B, H, W, C), x.t.device))
+    a.out = P(out.t)
+    ctx.L.hrf_ffn_eval(a, ctx.stream)
+    return out
 
 
 # ----------------------------------------------------------------------------- fused window-attention block

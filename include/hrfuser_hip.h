@@ -203,6 +203,26 @@ int hrf_attn_block_bwd_supported(int C, int heads);
 int hrf_attn_block_fwd(const hrf_attn_block_t* p, void* stream);
 int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream);
 int hrf_rpb_grad(const float* ds_plane, int nwin, int heads, float* drpb, long copy_stride, void* stream);
+
+/* ---- eval-mode CrossFFN in one launch (csrc/ffn_eval.hip) ---------------------------------------------------------------
+ * out = x + GELU(BN3(fc3( GELU(BN2(dw3x3( GELU(BN1(fc1( LN(x) ))) ))) ))) with FROZEN BatchNorm statistics: the second half
+ * of an HRFormerBlock / HRFuserFusionBlock in eval mode - hrformer.py:351 (norm2), :267-295 (CrossFFN.forward), :371-372
+ * (residual; DropPath is the identity) resp. hrfuser_hrformer_based.py:291,315-316.  x, out: (B,H,W,C) NHWC fp32; w1 [hidden][C]
+ * + b1, wd [hidden][3][3] + bd, w3 [C][hidden] + b3 in their Conv2d layouts; (s_k, t_k) = the frozen-statistics affine of
+ * BatchNorm k (scale = gamma * rsqrt(running_var + eps), shift = beta - running_mean * scale).  hidden = 4 C;
+ * hrf_ffn_eval_supported: C in {18, 36, 72, 144} (HRFuser-T / STF, every branch) and {78, 156} (HRFuser-B's two finest
+ * branches); other widths keep the per-op kernels.  The 4C-wide hidden tensor never leaves the chip.                        */
+typedef struct hrf_ffn_eval {
+  int B, H, W, C, hidden;
+  const float* x;
+  const float* ln_g; const float* ln_b; float ln_eps;
+  const float* w1; const float* b1; const float* s1; const float* t1;
+  const float* wd; const float* bd; const float* s2; const float* t2;
+  const float* w3; const float* b3; const float* s3; const float* t3;
+  float* out;
+} hrf_ffn_eval_t;
+int hrf_ffn_eval_supported(int C, int hidden);
+int hrf_ffn_eval(const hrf_ffn_eval_t* p, void* stream);
 /* the same gather for EVERY fused layer of a step in one launch: seg = nseg rows of 5 longs on the device {offset (floats) of the
  * layer's ds_plane in `planes`, windows, heads, address of its drpb accumulator, copy_stride}; max_nwin / max_heads = the
  * largest of the rows (launch geometry).                                                                               */
