@@ -95,7 +95,29 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
   const int xbeg = S == 1 ? 0 : (rg & 1) * 8, xcnt = S == 1 ? 16 : 8;
   const int oy = oy0 + row;
   float s1 = 0.f, s2 = 0.f;
-  if (cv && oy < a.Ho) {
+  if (S == 1) {
+    // stride 1: the thread's three halo rows (18 columns) are read ONCE into registers - 54 LDS reads for 16 outputs instead of
+    // 144 - and the row is straight-line code (the column loop used to stop at the image edge with a `break`: rolled, one
+    // dependent LDS round trip per output); outputs beyond the edge are computed and not stored
+    float win[3][IW];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int x = 0; x < IW; ++x) win[dy][x] = sIn[((row + dy) * IW + x) * CB + c];
+    const bool rowv = cv && oy < a.Ho;
+    float* yrow = a.y + (((long)b * a.Ho + (rowv ? oy : 0)) * a.Wo) * a.C + cg;
+#pragma unroll
+    for (int q = 0; q < TW; ++q) {
+      float acc = bv;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) acc = fmaf(win[dy][q + dx], wr[dy * 3 + dx], acc);
+      const bool ok = rowv && ox0 + q < a.Wo;
+      if (ok) yrow[(long)(ox0 + q) * a.C] = acc;
+      s1 += ok ? acc : 0.f; s2 = ok ? fmaf(acc, acc, s2) : s2;
+    }
+  } else if (cv && oy < a.Ho) {
     for (int q = 0; q < xcnt; ++q) {
       const int oxl = xbeg + q, ox = ox0 + oxl;
       if (ox >= a.Wo) break;
@@ -211,6 +233,14 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs
   float wacc[WG ? 10 : 1];
 #pragma unroll
   for (int k = 0; k < (WG ? 10 : 1); ++k) wacc[k] = 0.f;
+  // stride 1: the thread's three staged rows (18 columns) are read ONCE into registers: 54 LDS reads for 16 outputs instead of 144
+  float win[S == 1 ? 3 : 1][S == 1 ? RW : 1];
+  if (S == 1) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int x = 0; x < RW; ++x) win[k][x] = sD[((r + k) * RW + x) * CB + c];
+  }
 #pragma unroll
   for (int q = 0; q < TW; ++q) {
     const int xi = x0 + q;
@@ -227,7 +257,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         if (S == 1) {
-          const float d = sD[((r + 2 - dy) * RW + (q + 2 - dx)) * CB + c];
+          const float d = win[2 - dy][q + 2 - dx];
           acc = fmaf(d, wr[dy * 3 + dx], acc);
           if (WG) {
             wacc[dy * 3 + dx] = fmaf(d, xv, wacc[dy * 3 + dx]);

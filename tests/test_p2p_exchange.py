@@ -174,7 +174,7 @@ for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 import torch.distributed as dist
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-mode = sys.argv[1]                                        # 'ab' | 'dead_peer'
+mode = sys.argv[1]                                        # 'ab' | 'dead_peer' | 'skew'
 dev = torch.device('cuda:0')                               # the ranks SHARE GPU 0 (RCCL refuses that; IPC inboxes do not)
 torch.cuda.set_device(dev)
 dist.init_process_group('gloo')
@@ -218,6 +218,21 @@ if mode == 'ab':
     assert err < 1e-6, err
     dist.barrier()
     print('P2P_AB_OK', rank)
+elif mode == 'skew':
+    # two-process race check: the lane timing of ONE rank is perturbed (idle launches in front of every 18 / 36-channel block,
+    # one weight-gradient lane instead of four) - the exchange launches of that rank reach their spin-waits late and in another
+    # interleaving across lanes.  Both ranks must still finish (no dead-lock: the enqueue order per lane is the program's, not
+    # the clock's) with the unperturbed gradients.
+    g_ref, tr0, _ = grads(True)
+    if rank == 1:
+        os.environ.update(HRF_DEBUG_PAD='18:40,36:40', HRF_WGRAD_LANES='1')
+    g_pad, tr1, _ = grads(True)
+    assert tr1.p2p_exchanges_per_step > 40
+    err = float((g_pad.double() - g_ref.double()).norm() / g_ref.double().norm())
+    print(json.dumps({'rank': rank, 'rel_l2_vs_unperturbed': err}))
+    assert err < 1e-3, err
+    dist.barrier()
+    print('P2P_SKEW_OK', rank)
 else:
     os.environ['HRF_P2P_TIMEOUT_S'] = '2'
     g, tr, net = grads(True)                                # builds the inboxes with both ranks present
@@ -270,6 +285,15 @@ def test_p2p_two_processes_share_one_gpu():
     for rc, o, e in outs:
         sys.stdout.write(o[-1500:])
         assert 'P2P_AB_OK' in o, (rc, o[-1500:], e[-3000:])
+
+
+@pytest.mark.gpu
+def test_p2p_two_processes_one_rank_perturbed_gpu():
+    """VERDICT r4 #7 (ii): lane-timing perturbation on ONE rank only - the other must still finish, gradients equal."""
+    outs = _run_two('skew', 29679, timeout=600)
+    for rc, o, e in outs:
+        sys.stdout.write(o[-600:])
+        assert 'P2P_SKEW_OK' in o, (rc, o[-1500:], e[-3000:])
 
 
 @pytest.mark.gpu

@@ -34,8 +34,9 @@ def mark_start(ctx):
 
 
 tr.step(x, mods, cots)
+tr.step(x, mods, cots)
 st.reset()
-tr.capture(x, mods, cots, warmup=1)
+tr.capture(x, mods, cots, warmup=0)            # (no eager step inside: every mark below belongs to the captured step)
 marks = list(st.marks)
 rows = []
 for _ in range(5):
@@ -57,4 +58,5 @@ print(f'first all-reduce starts {(last_leaf - first_ar) / 100.0:.1f} us BEFORE t
       else 'no overlap: the first all-reduce starts after the last leaf group')
 tr.check()
 torch.cuda.synchronize()
+sys.stdout.flush()
 os._exit(0)

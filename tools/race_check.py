@@ -108,9 +108,28 @@ def check_captured(tag, size=(2, 192, 320), replays=8):
     return worst
 
 
+def check_two_process_p2p():
+    """Two ranks sharing this GPU through the peer-to-peer SyncBN exchange, lane timing perturbed on ONE of them
+    (tests/test_p2p_exchange.py, mode 'skew'): -> worst rel-L2 against the unperturbed step."""
+    import re
+    import test_p2p_exchange as TP
+    outs = TP._run_two('skew', 29681, timeout=600)
+    worst = 0.0
+    for rc, o, e in outs:
+        m = re.findall(r'"rel_l2_vs_unperturbed": ([0-9.e+-]+)', o)
+        if 'P2P_SKEW_OK' not in o or not m:
+            print('two-process peer-to-peer arm FAILED', rc, o[-400:], e[-800:])
+            return 1.0
+        worst = max(worst, float(m[-1]))
+    print(f'two processes, peer-to-peer exchange, one rank perturbed: worst rel-L2 {worst:.2e}')
+    return worst
+
+
 if __name__ == '__main__':
     tags = sys.argv[1:] or ['t_nus_bn', 'b_nus_bn', 't_stf_bn', 'hrformer_t_bn', 'hrnet', 'stage_d']
     w = max(check(t) for t in tags)
     w = max([w] + [check_captured(t) for t in tags if t in ('t_nus_bn', 'b_nus_bn', 't_stf_bn')])
+    if not sys.argv[1:]:
+        w = max(w, check_two_process_p2p())
     print('RACE CHECK', 'OK' if w <= 1e-3 else 'FAILED', f'(worst {w:.2e})')
     sys.exit(0 if w <= 1e-3 else 1)
