@@ -703,11 +703,11 @@ struct AbBwdArgs {
 #define AB_MINW18 5
 #endif
 #ifndef AB_NWB18
-#define AB_NWB18 0          // role-B waves of the 18-channel kernel: 0 = four waves run both roles (see the kernel)
+#define AB_NWB18 4          // role-B waves of the 18-channel kernel (0: four waves run both roles; 4: eight waves at 80 registers)
 #endif
 
 template <int C, int HEADS, int NWB, bool FFN, bool CROSS, bool TAIL>
-__global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NWB == 2 ? AB_MINW18 : 2))) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs> grp) {
+__global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (C <= 18 ? (NWB == 4 ? 6 : 5) : 2))) void attn_block_bwd_kernel(HrfGroup<AbBwdArgs> grp) {
   const hrf_attn_block_t& a = grp.sel().a;
   const hrf_bn_bfin_t& bf = grp.sel().bf;
   constexpr int D = C / HEADS, PC = C + 1, CT = (C + 15) / 16, PW = (C + 3) & ~3;
@@ -715,6 +715,11 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
   constexpr int TILE = 64 * PC, N1 = 4 * C, PH = N1 + 1;
   constexpr bool W1A = N1 * PW <= 2 * TILE;   // w1 fits the (dy, dO) tiles, which are written only after its last use
   constexpr int NT = 64 * (4 + NWB);                                // threads of the workgroup
+  // GXP: role A parks its gradient row gx (8 registers that live from the prologue to the LayerNorm_1 epilogue) in memory
+  // behind dy / dO and fetches it back in ONE batch in front of the epilogue.  At 80 registers (three 8-wave workgroups per CU)
+  // the allocator spilled exactly these values and reloaded them one at a time, each a dependent L2 round trip: 54 us
+  // instead of ~30 for the 18-channel window
+  constexpr bool GXP = NWB != 0 && C <= 18;
   constexpr int NBW = NWB == 0 ? 4 : NWB, NB = 64 * NBW;            // waves / threads that carry role B (NWB = 0: all four, after A)
   constexpr bool ffn = FFN, cross = CROSS, tail = TAIL;
   HRF_DYN_SMEM(float, smem);
@@ -928,9 +933,36 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
   }
   __syncthreads();
 
+  // Every phase re-derives its lane coordinates from threadIdx.x behind an opaque copy (and the token's pixel from LDS): kept alive
+  // across the whole kernel they are ~12 registers per lane that the allocator, at 80 registers, spilled one by one and
+  // reloaded one by one - every reload a dependent L2 round trip on a path whose cost IS its dependent latency
+#define AB_LANE()                                                                                   \
+  int tid_ = threadIdx.x; HRF_KEEP(tid_);                                                           \
+  const int lane = tid_ & 63, i = lane & 15, q = lane >> 4, tok0 = 16 * ((tid_ >> 6) & 3), tok = tok0 + i; \
+  (void)lane; (void)i; (void)q; (void)tok0; (void)tok
+#define AB_PIX()                                                                                    \
+  const int pix = sPix[tok]; const long pc = pix >= 0 ? pix : 0; const bool tokv = pix >= 0;        \
+  (void)pc; (void)tokv
   AB_T(3);
+  // ================================================================================================================ roles
+  // The phases below are written once (lambdas) and stitched together three ways: NWB = 0 - four waves run A then B between
+  // the same barriers; NWB > 0 - ONE top-level scalar branch, role A's waves run only A phases and role B's only B phases, each
+  // arm with the same __syncthreads() sequence (a hardware barrier counts arrivals, not call sites).  Each role keeps its
+  // state in variables of its own: with the roles interleaved in one control flow (round-5 first form) every long-lived value
+  // of A - the gradient row gx, the 8 score / dP tiles across the statistics barrier - was live through B's code as well and
+  // the register allocation was the SUM of the two (60 - 95 spills at 80 registers; B alone fits in 75, A alone in 80 + its gx).
+  constexpr int NT1 = (N1 + 15) / 16;                               // 16-row tiles of d w1 [4C][C] = dy1^T LN_2(x')
+  constexpr int NTC = C / 16 + (C % 16 ? 1 : 0);                    // 16-row tiles of a [C][C] weight gradient
+  constexpr int VA = (CT + 1) / 2;
+  constexpr int lkv = CROSS ? 2 : 1;
+  const float* sXk = cross ? sXkv : sX;
+  hrf_f4 dnA[CT], sA[4], dpA[4];                                    // role A: d LN_2 output; score / dP tiles (query columns)
+  float DlA = 0.f;
+  hrf_f4 sB[4], dpB[4], o1B[DT], o2B[DT];                           // role B: score / dP tiles (key columns); dv / dk of a key tile
+
   // dy rows = gx * dropout mask * scales (the out_proj output enters the residual through Dropout / DropPath), dO = dy Wo
-  auto dy_and_dO = [&]() {
+  auto dy_and_dO = [&]() __attribute__((always_inline)) {
+    AB_LANE(); AB_PIX();
     const float rs = rs_out;
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
@@ -953,31 +985,43 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int k = 16 * t + 4 * q + r; if (k < C) sG[tok * PC + k] = acc[t][r]; }
   };
-  if (ffn) {
-    constexpr int NT1 = (N1 + 15) / 16;                             // 16-row tiles of d w1 [4C][C] = dy1^T LN_2(x')
-    auto w1tile = [&](int nt) {
-      hrf_f4 acc[CT];
+  auto w1tile = [&](int nt) __attribute__((always_inline)) {
+    AB_LANE();
+    hrf_f4 acc[CT];
 #pragma unroll
-      for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-      wave_tgemm<CT, true>(sH, PH, 16 * nt, N1, sO, PC, 0, C, sGam[0], sBet[0], sReal, lane, acc);
-      store_wtile<CT>(slot + a.off_w1, 16 * nt, N1, 0, C, lane, acc);
-    };
-    hrf_f4 dn[CT];
+    for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+    wave_tgemm<CT, true>(sH, PH, 16 * nt, N1, sO, PC, 0, C, sGam[0], sBet[0], sReal, lane, acc);
+    store_wtile<CT>(slot + a.off_w1, 16 * nt, N1, 0, C, lane, acc);
+  };
+  // ---- phase 3: CrossFFN head backward.  A: d LN_2 output = dy1 W1 | barrier (w1 may occupy the dy / dO tiles) | LayerNorm
+  // backward, gx += ., dy, dO.   B: the d w1 tiles (dy1^T LN_2(x')), d b1
+  auto A3a = [&]() __attribute__((always_inline)) {
+    AB_LANE();
+    if (ffn) {
 #pragma unroll
-    for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
-    if (roleA) wave_gemm_tl<N1, PW, CT>(sW1, C, sH + tok * PH, lane, dn);   // d LN_2 output = dy1 W1 (this wave's tokens)
-    if (roleB && wb < NT1) w1tile(wb);
-  __syncthreads();                                                // w1 (it may occupy the dy / dO tiles): last use by every wave
-    if (roleA) {
-      // LayerNorm backward, added to gx; then dy and dO
-      ln_bwd_rows<C, CT>(dn, sO, PC, tok, tokv, sRs2[tok], sGam[0], sPar[wave][0], lane);
+      for (int t = 0; t < CT; ++t) dnA[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
+      wave_gemm_tl<N1, PW, CT>(sW1, C, sH + tok * PH, lane, dnA);
+    }
+  };
+  auto B3a = [&]() __attribute__((always_inline)) { if (ffn && wb < NT1) w1tile(wb); };
+  auto A3b = [&]() __attribute__((always_inline)) {
+    AB_LANE(); AB_PIX();
+    if (ffn) {
+      ln_bwd_rows<C, CT>(dnA, sO, PC, tok, tokv, sRs2[tok], sGam[0], sPar[wave & 3][0], lane);
 #pragma unroll
       for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gx[t][r] += tokv ? dn[t][r] : 0.f;
-      dy_and_dO();
+        for (int r = 0; r < 4; ++r) gx[t][r] += tokv ? dnA[t][r] : 0.f;
     }
-    if (roleB) {
+    dy_and_dO();
+    if (GXP) {
+      float* park = a.gx_park + ((long)blockIdx.x * 64 + tok) * (CT * 16) + 4 * q;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) hrf_st4(park + 16 * t, gx[t]);
+    }
+  };
+  auto B3b = [&]() __attribute__((always_inline)) {
+    if (ffn) {
       for (int nt = wb + NBW; nt < NT1; nt += NBW) w1tile(nt);
       for (int n = lt; n < N1; n += NB) {                           // d b1 = column sums of dy1
         float sacc = 0.f;
@@ -985,260 +1029,240 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
         slot[a.off_b1 + n] = sacc;
       }
     }
-  } else if (roleA) {
-    dy_and_dO();
-  }
-  AB_T(4);
-  __syncthreads();                                                  // sH / xhat_2 are dead from here on (sH aliases sQ .. sDQ:
-                                                                    // what it leaves in their pad cells is finite, which is all they need)
-
-  AB_T(5);
-  // ---- recompute the projections: q / k / v with the LayerNorm affine applied on read (0 for tokens outside the image).
-  // NWB = 4: role A: q and the first channel tiles of v, role B: k and the remaining tiles of v (own token tile each);
-  // NWB = 2: role A: q and v, role B wave w: k of the token tiles w and w + 2
-  const float* sXk = cross ? sXkv : sX;
-  constexpr int lkv = CROSS ? 2 : 1;
-  {
-    constexpr int VA = (CT + 1) / 2;
+  };
+  // ---- phase 5: recompute the projections q / k / v with the LayerNorm affine applied on read (0 for tokens outside the
+  // image).  NWB = 4: A: q and the first channel tiles of v, B: k and the remaining tiles of v (own token tile each);
+  // NWB = 0: A: q and v, B: k;  NWB = 2: A: q and v, B wave w: k of the token tiles w and w + 2
+  auto proj = [&](const float* sW, const float* bias, const float* xh, int ln, float* dstT, float mul, int t_lo, int t_hi, int tk) __attribute__((always_inline)) {
+    AB_LANE();
     hrf_f4 acc[CT];
-    auto proj = [&](const float* sW, const float* bias, const float* xh, int ln, float* dstT, float mul, int t_lo, int t_hi, int tk) {
-      acc_bias_l<CT>(bias, 0, PW, lane, acc);
-      const bool real = sReal[tk] != 0.f;
-      constexpr int NS = (C + 15) / 16;
+    acc_bias_l<CT>(bias, 0, PW, lane, acc);
+    const bool real = sReal[tk] != 0.f;
+    constexpr int NS = (C + 15) / 16;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const int kbase = 16 * s + 4 * q;
-        const bool kin = kbase < PW;
-        float bv[4];
+    for (int s = 0; s < NS; ++s) {
+      const int kbase = 16 * s + 4 * q;
+      const bool kin = kbase < PW;
+      float bv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = kbase + r < C ? kbase + r : 0;
-          float aff = fmaf(xh[tk * PC + k], sGam[ln][k], sBet[ln][k]);
-          HRF_KEEP(aff);
-          bv[r] = (kbase + r < C && real) ? aff : 0.f;
-        }
-#pragma unroll
-        for (int t = 0; t < CT; ++t) {
-          if (t < t_lo || t >= t_hi) continue;                      // (uniform)
-          const int n = 16 * t + i;
-          const hrf_f4 w = hrf_ld4(sW + (n < C ? n : 0) * PW + (kin ? kbase : 0));
-          const bool ok = kin && n < C;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[t] = hrf_mfma16(ok ? w[r] : 0.f, bv[r], acc[t]);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int k = kbase + r < C ? kbase + r : 0;
+        float aff = fmaf(xh[tk * PC + k], sGam[ln][k], sBet[ln][k]);
+        HRF_KEEP(aff);
+        bv[r] = (kbase + r < C && real) ? aff : 0.f;
       }
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
-        if (t < t_lo || t >= t_hi) continue;
+        if (t < t_lo || t >= t_hi) continue;                        // (uniform)
+        const int n = 16 * t + i;
+        const hrf_f4 w = hrf_ld4(sW + (n < C ? n : 0) * PW + (kin ? kbase : 0));
+        const bool ok = kin && n < C;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) dstT[tk * PC + n] = acc[t][r] * mul; }
+        for (int r = 0; r < 4; ++r) acc[t] = hrf_mfma16(ok ? w[r] : 0.f, bv[r], acc[t]);
       }
-    };
-    if (roleA) {
-      proj(sWq, sB3[0], sX, 1, sQ, a.scale, 0, CT, tok);
-      proj(sWv, sB3[2], sXk, lkv, sV, 1.f, 0, NWB == 4 ? VA : CT, tok);
     }
-    if (NWB == 0) {
-      proj(sWk, sB3[1], sXk, lkv, sK, 1.f, 0, CT, tok);
-    } else if (!roleA && NWB == 4) {
-      proj(sWk, sB3[1], sXk, lkv, sK, 1.f, 0, CT, tok);
-      proj(sWv, sB3[2], sXk, lkv, sV, 1.f, VA, CT, tok);
-    } else if (!roleA) {
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      if (t < t_lo || t >= t_hi) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int n = 16 * t + 4 * q + r; if (n < C) dstT[tk * PC + n] = acc[t][r] * mul; }
+    }
+  };
+  auto A5 = [&]() __attribute__((always_inline)) {
+    AB_LANE();
+    proj(sWq, sB3[0], sX, 1, sQ, a.scale, 0, CT, tok);
+    proj(sWv, sB3[2], sXk, lkv, sV, 1.f, 0, NWB == 4 ? VA : CT, tok);
+  };
+  auto B5 = [&]() __attribute__((always_inline)) {
+    AB_LANE();
+    if (NWB == 2) {
 #pragma unroll 1
-      for (int tt = wb; tt < 4; tt += NWB) proj(sWk, sB3[1], sXk, lkv, sK, 1.f, 0, CT, 16 * tt + i);
+      for (int tt = wb; tt < 4; tt += 2) proj(sWk, sB3[1], sXk, lkv, sK, 1.f, 0, CT, 16 * tt + i);
+    } else {
+      proj(sWk, sB3[1], sXk, lkv, sK, 1.f, 0, CT, tok);
+      if (NWB == 4) proj(sWv, sB3[2], sXk, lkv, sV, 1.f, VA, CT, tok);
     }
-  }
-  __syncthreads();
-
-  AB_T(6);
-  // ---- attention backward per head (attention.hip's MFMA formulation on the packed tiles): role A = query columns, role B =
+  };
+  // ---- phase 6: attention backward per head (attention.hip's MFMA formulation on the packed tiles).  A = query columns, B =
   // key columns; the row statistics (max, 1 / sum, D = sum P dP) pass from A to B through LDS at the first barrier of a head.
-  // NWB = 4: a role-B wave owns one key tile and computes its raw scores / dP beside role A's softmax, before that barrier;
-  // NWB = 2: it owns two key tiles, one after the other behind the barrier (the finished dk / dv rows wait in registers).
-#pragma unroll 1
-  for (int h = 0; h < HEADS; ++h) {
+  // NWB = 4: a B wave owns one key tile and computes its raw scores / dP beside A's softmax, before that barrier; NWB = 0 / 2:
+  // behind it (NWB = 2: two key tiles per wave, the second one behind the second barrier - one head only).
+  auto A6a = [&](int h) __attribute__((always_inline)) {                                           // wave = queries tok0 .. tok0+15: scores, dP, statistics
+    AB_LANE();
     const float* bias = sT + h * 176;
-    float* dsp = a.ds_plane + ((long)blockIdx.x * HEADS + h) * (NTOK * NTOK);   // dS[key][query] of this (window, head)
-    hrf_f4 s[4], dp[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
-    float Dl = 0.f;
-    // key-column scores of key tile kt0: S[query 16t+4q+r][key kt0+i] and dP
-    auto key_scores = [&](int kt0) {
-      const float* krow = sK + (kt0 + i) * PC + h * D + q;
-      const float* vrow = sV + (kt0 + i) * PC + h * D + q;
+    for (int t = 0; t < 4; ++t) { sA[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dpA[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+    const float* qrow = sQ + (tok0 + i) * PC + h * D + q;
+    const float* grow = sG + (tok0 + i) * PC + h * D + q;
 #pragma unroll
-      for (int kk = 0; kk < KSD; ++kk) {
-        const bool kv = 4 * kk + q < D;
-        const float kvv = ldz(krow, 4 * kk, kv), vv = ldz(vrow, 4 * kk, kv);
+    for (int kk = 0; kk < KSD; ++kk) {
+      const bool kv = 4 * kk + q < D;
+      const float qv = ldz(qrow, 4 * kk, kv), gv = ldz(grow, 4 * kk, kv);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          s[t] = hrf_mfma16(sQ[(16 * t + i) * PC + h * D + 4 * kk + q], kvv, s[t]);
-          dp[t] = hrf_mfma16(sG[(16 * t + i) * PC + h * D + 4 * kk + q], vv, dp[t]);
-        }
+      for (int t = 0; t < 4; ++t) {
+        sA[t] = hrf_mfma16(sK[(16 * t + i) * PC + h * D + 4 * kk + q], qv, sA[t]);
+        dpA[t] = hrf_mfma16(sV[(16 * t + i) * PC + h * D + 4 * kk + q], gv, dpA[t]);
       }
-    };
-    if (roleA) {                                                    // wave = queries tok0 .. tok0+15
-      const float* qrow = sQ + (tok0 + i) * PC + h * D + q;
-      const float* grow = sG + (tok0 + i) * PC + h * D + q;
-#pragma unroll
-      for (int kk = 0; kk < KSD; ++kk) {
-        const bool kv = 4 * kk + q < D;
-        const float qv = ldz(qrow, 4 * kk, kv), gv = ldz(grow, 4 * kk, kv);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          s[t] = hrf_mfma16(sK[(16 * t + i) * PC + h * D + 4 * kk + q], qv, s[t]);
-          dp[t] = hrf_mfma16(sV[(16 * t + i) * PC + h * D + 4 * kk + q], gv, dp[t]);
-        }
-      }
-      const int qi = tok0 + i, qc = qi < NTOK ? qi : 0;
-      const int yi = qc / 7, xi = qc - 7 * yi;
-      float m = -3.0e38f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = 16 * t + 4 * q + r, jc = j < NTOK ? j : 0;
-          const int yj = jc / 7, xj = jc - 7 * yj;
-          float bj = bias[(yi - yj + 6) * 13 + (xi - xj + 6)];
-          HRF_KEEP(bj);
-          const float sv = j < NTOK ? s[t][r] + bj : -3.0e38f;
-          s[t][r] = sv;
-          m = fmaxf(m, sv);
-        }
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
-      float l = 0.f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s[t][r] = __expf(s[t][r] - m); l += s[t][r]; }
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
-      const float inv = 1.0f / l;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s[t][r] *= inv; Dl = fmaf(s[t][r], dp[t][r], Dl); }
-      Dl += __shfl_xor(Dl, 16);
-      Dl += __shfl_xor(Dl, 32);
-      if (q == 0) { sM[qi] = m; sIL[qi] = inv; sDl[qi] = Dl; }
-    } else if (NWB == 4) {
-      key_scores(tok0);
     }
-    (void)roleB;
-  __syncthreads();                                                // the row statistics of head h
+    const int qi = tok0 + i, qc = qi < NTOK ? qi : 0;
+    const int yi = qc / 7, xi = qc - 7 * yi;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * t + 4 * q + r, jc = j < NTOK ? j : 0;
+        const int yj = jc / 7, xj = jc - 7 * yj;
+        float bj = bias[(yi - yj + 6) * 13 + (xi - xj + 6)];
+        HRF_KEEP(bj);
+        const float sv = j < NTOK ? sA[t][r] + bj : -3.0e38f;
+        sA[t][r] = sv;
+        m = fmaxf(m, sv);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sA[t][r] = __expf(sA[t][r] - m); l += sA[t][r]; }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    float Dl = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sA[t][r] *= inv; Dl = fmaf(sA[t][r], dpA[t][r], Dl); }
+    Dl += __shfl_xor(Dl, 16);
+    Dl += __shfl_xor(Dl, 32);
+    DlA = Dl;
+    if (q == 0) { sM[qi] = m; sIL[qi] = inv; sDl[qi] = Dl; }
+  };
+  auto A6b = [&](int h) __attribute__((always_inline)) {                                           // O = P V again (for d wo), dS -> plane, dQ = dS K
+    AB_LANE();
+    float* dsp = a.ds_plane + ((long)blockIdx.x * HEADS + h) * (NTOK * NTOK);   // dS[key][query] of this (window, head)
+    const int qi = tok0 + i;
     hrf_f4 o1[DT], o2[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { o1[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; o2[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
-    // role B, one key tile: P and dS in key-column orientation from the row statistics, dV = P^T dO and dK = dS^T Q
-    auto key_tile = [&](int kt0, bool scores) {
-      if (scores) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
-        key_scores(kt0);
-      }
-      const int kj = kt0 + i, kc = kj < NTOK ? kj : 0;
-      const int yj = kc / 7, xj = kc - 7 * yj;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qi = 16 * t + 4 * q + r, qc = qi < NTOK ? qi : 0;
-          const int yi = qc / 7, xi = qc - 7 * yi;
-          const bool ok = kj < NTOK && qi < NTOK;
-          float bj = bias[(yi - yj + 6) * 13 + (xi - xj + 6)], mq = sM[qc], ilq = sIL[qc], dlq = sDl[qc];
-          HRF_KEEP(bj); HRF_KEEP(mq); HRF_KEEP(ilq); HRF_KEEP(dlq);
-          const float p = ok ? __expf(s[t][r] + bj - mq) * ilq : 0.f;
-          s[t][r] = p;
-          dp[t][r] = ok ? p * (dp[t][r] - dlq) : 0.f;
-        }
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) { o1[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; o2[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* gr = sG + (16 * t + 4 * q + r) * PC + h * D + i;
-          const float* qr = sQ + (16 * t + 4 * q + r) * PC + h * D + i;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            o1[dt] = hrf_mfma16(s[t][r], gr[16 * dt], o1[dt]);      // dV = P^T dO
-            o2[dt] = hrf_mfma16(dp[t][r], qr[16 * dt], o2[dt]);     // dK = dS^T Q
-          }
-        }
-    };
-    auto key_store = [&](int kt0) {
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ko = kt0 + 4 * q + r;
+        const float* vrow = sV + (16 * t + 4 * q + r) * PC + h * D + i;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o1[dt] = hrf_mfma16(sA[t][r], vrow[16 * dt], o1[dt]);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { const int d = 16 * dt + i; if (d < D) sO[(tok0 + 4 * q + r) * PC + h * D + d] = o1[dt][r]; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ds = sA[t][r] * (dpA[t][r] - DlA);
+        sA[t][r] = ds;
+        const int j = 16 * t + 4 * q + r;
+        if (j < NTOK && qi < NTOK) dsp[j * NTOK + qi] = ds;
+      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* krow = sK + (16 * t + 4 * q + r) * PC + h * D + i;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o2[dt] = hrf_mfma16(sA[t][r], krow[16 * dt], o2[dt]);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qo = tok0 + 4 * q + r;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { const int d = 16 * dt + i; if (d < D) sDQ[qo * PC + h * D + d] = qo < NTOK ? o2[dt][r] * a.scale : 0.f; }
+    }
+  };
+  // key-column scores of key tile kt0: S[query 16t+4q+r][key kt0+i] and dP
+  auto key_scores = [&](int h, int kt0) __attribute__((always_inline)) {
+    AB_LANE();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { sB[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dpB[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+    const float* krow = sK + (kt0 + i) * PC + h * D + q;
+    const float* vrow = sV + (kt0 + i) * PC + h * D + q;
+#pragma unroll
+    for (int kk = 0; kk < KSD; ++kk) {
+      const bool kv = 4 * kk + q < D;
+      const float kvv = ldz(krow, 4 * kk, kv), vv = ldz(vrow, 4 * kk, kv);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sB[t] = hrf_mfma16(sQ[(16 * t + i) * PC + h * D + 4 * kk + q], kvv, sB[t]);
+        dpB[t] = hrf_mfma16(sG[(16 * t + i) * PC + h * D + 4 * kk + q], vv, dpB[t]);
+      }
+    }
+  };
+  // one key tile: P and dS in key-column orientation from the row statistics, dV = P^T dO and dK = dS^T Q
+  auto key_tile = [&](int h, int kt0, bool scores) __attribute__((always_inline)) {
+    AB_LANE();
+    const float* bias = sT + h * 176;
+    if (scores) key_scores(h, kt0);
+    const int kj = kt0 + i, kc = kj < NTOK ? kj : 0;
+    const int yj = kc / 7, xj = kc - 7 * yj;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = 16 * t + 4 * q + r, qc = qi < NTOK ? qi : 0;
+        const int yi = qc / 7, xi = qc - 7 * yi;
+        const bool ok = kj < NTOK && qi < NTOK;
+        float bj = bias[(yi - yj + 6) * 13 + (xi - xj + 6)], mq = sM[qc], ilq = sIL[qc], dlq = sDl[qc];
+        HRF_KEEP(bj); HRF_KEEP(mq); HRF_KEEP(ilq); HRF_KEEP(dlq);
+        const float p = ok ? __expf(sB[t][r] + bj - mq) * ilq : 0.f;
+        sB[t][r] = p;
+        dpB[t][r] = ok ? p * (dpB[t][r] - dlq) : 0.f;
+      }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { o1B[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; o2B[dt] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* gr = sG + (16 * t + 4 * q + r) * PC + h * D + i;
+        const float* qr = sQ + (16 * t + 4 * q + r) * PC + h * D + i;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const int d = 16 * dt + i;
-          if (d < D) { sK[ko * PC + h * D + d] = o2[dt][r]; sV[ko * PC + h * D + d] = o1[dt][r]; }
+          o1B[dt] = hrf_mfma16(sB[t][r], gr[16 * dt], o1B[dt]);     // dV = P^T dO
+          o2B[dt] = hrf_mfma16(dpB[t][r], qr[16 * dt], o2B[dt]);    // dK = dS^T Q
         }
       }
-    };
-    if (roleA) {
-      const int qi = tok0 + i;
-      // attention output rows again (O = P V) for the out_proj weight gradient
+  };
+  auto key_store = [&](int h, int kt0) __attribute__((always_inline)) {
+    AB_LANE();
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 4; ++r) {
+      const int ko = kt0 + 4 * q + r;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* vrow = sV + (16 * t + 4 * q + r) * PC + h * D + i;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) o1[dt] = hrf_mfma16(s[t][r], vrow[16 * dt], o1[dt]);
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) { const int d = 16 * dt + i; if (d < D) sO[(tok0 + 4 * q + r) * PC + h * D + d] = o1[dt][r]; }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ds = s[t][r] * (dp[t][r] - Dl);
-          s[t][r] = ds;
-          const int j = 16 * t + 4 * q + r;
-          if (j < NTOK && qi < NTOK) dsp[j * NTOK + qi] = ds;
-        }
-      // dQ = dS K (contraction over keys)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* krow = sK + (16 * t + 4 * q + r) * PC + h * D + i;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) o2[dt] = hrf_mfma16(s[t][r], krow[16 * dt], o2[dt]);
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qo = tok0 + 4 * q + r;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) { const int d = 16 * dt + i; if (d < D) sDQ[qo * PC + h * D + d] = qo < NTOK ? o2[dt][r] * a.scale : 0.f; }
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + i;
+        if (d < D) { sK[ko * PC + h * D + d] = o2B[dt][r]; sV[ko * PC + h * D + d] = o1B[dt][r]; }
       }
     }
-    if (roleB) {
-      key_tile(NWB == 2 ? 16 * wb : tok0, NWB != 4);
+  };
+  static_assert(NWB != 2 || HEADS == 1, "two key tiles per role-B wave: one head (the statistics of the head must stay)");
+  const int ktB = NWB == 2 ? 16 * wb : 16 * (wave & 3);                        // (first) key tile of a role-B wave
+  auto B6a = [&](int h) __attribute__((always_inline)) { if (NWB == 4) key_scores(h, ktB); };
+  auto B6b = [&](int h) __attribute__((always_inline)) { key_tile(h, ktB, NWB != 4); };
+  auto B6c = [&](int h) __attribute__((always_inline)) {                                           // behind the barrier: every wave is done reading head h of sK / sV
+    key_store(h, ktB);
+    if (NWB == 2) {
+      // the second key tile of this wave: it reads its OWN rows of sK / sV (nobody writes those) and all rows of sQ / sG;
+      // role A waits at the barrier behind the head loop
+      key_tile(h, 16 * (wb + 2), true);
+      key_store(h, 16 * (wb + 2));
     }
-  __syncthreads();                                                // every wave is done reading head h of sK / sV
-    if (roleB) {
-      key_store(NWB == 2 ? 16 * wb : tok0);
-      if (NWB == 2) {
-        // the second key tile of this wave: it reads its OWN rows of sK / sV (nobody writes those) and all rows of sQ / sG;
-        // role A waits at the barrier behind the loop (one head only: the statistics of this head must stay)
-        static_assert(NWB != 2 || HEADS == 1, "two key tiles per role-B wave: one head");
-        key_tile(16 * (wb + 2), true);
-        key_store(16 * (wb + 2));
-      }
-    }
-  }
-  __syncthreads();                                                  // dk / dv rows of the last head
-
-  AB_T(7);
-  constexpr int NTC = C / 16 + (C % 16 ? 1 : 0);                    // 16-row tiles of a [C][C] weight gradient
-  auto wtile = [&](int which, int nt) {                             // weight-gradient tile: [16 out rows][all input channels]
+  };
+  // ---- phases 7 / 8.  Weight-gradient tile: [16 out rows][all input channels]
+  auto wtile = [&](int which, int nt) __attribute__((always_inline)) {
+    AB_LANE();
     hrf_f4 acc[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
@@ -1253,13 +1277,13 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
       store_wtile<CT>(slot + (which == 2 ? a.off_wk : a.off_wv), 16 * nt, C, 0, C, lane, acc);
     }
   };
-  if (roleA) {
+  auto A7 = [&]() __attribute__((always_inline)) {
     // ---- d LN outputs = dq Wq (+ dk Wk + dv Wv), LayerNorm backward, output gradients
     // (the row offset is formed again from the pixel index, behind an opaque copy: kept alive since the prologue it is a 64-bit
     // pair per lane that the register allocator spills in the variants that sit at their budget)
-    int pix7 = pix, lane7 = threadIdx.x & 63;
-    HRF_KEEP(pix7); HRF_KEEP(lane7);
-    const long pc7 = pix7 >= 0 ? pix7 : 0;
+    AB_LANE(); AB_PIX();
+    const int lane7 = lane;
+    const long pc7 = pc;
     hrf_f4 tr[CT];                                                  // raw rows of the preceding block's tail (u = sc*raw + sh)
     if (tail) {
 #pragma unroll
@@ -1268,6 +1292,10 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
         tr[t] = ld_sel(16 * (t + 1) <= C, a.tail_raw, pc7 * C + nb, tokv ? C - nb : 0);
       }
     }
+    hrf_f4 gx7[CT];                                                 // the gradient row again (GXP: parked by A3b)
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+      gx7[t] = GXP ? hrf_ld4(a.gx_park + ((long)blockIdx.x * 64 + tok) * (CT * 16) + 4 * q + 16 * t) : gx[t];
     hrf_f4 dn[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
@@ -1276,7 +1304,7 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
       wave_gemm_tl<C, PW, CT>(sWk, C, sK + tok * PC, lane7, dn);
       wave_gemm_tl<C, PW, CT>(sWv, C, sV + tok * PC, lane7, dn);
     }
-    ln_bwd_rows<C, CT>(dn, sX, PC, tok, tokv, sRsQ[tok], sGam[1], sPar[wave][1], lane7);
+    ln_bwd_rows<C, CT>(dn, sX, PC, tok, tokv, sRsQ[tok], sGam[1], sPar[wave & 3][1], lane7);
     if (a.dq != nullptr && tokv) {
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
@@ -1284,7 +1312,7 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (nb + r < C) {
-            float v = dn[t][r] + (a.dq_add_res ? gx[t][r] : 0.f);
+            float v = dn[t][r] + (a.dq_add_res ? gx7[t][r] : 0.f);
             dn[t][r] = v;                                           // dx of this launch alone (the tail below needs it)
             if (a.dq_acc) v += a.dq[pc7 * C + nb + r];
             a.dq[pc7 * C + nb + r] = v;
@@ -1307,7 +1335,7 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
           const float du = (tokv && nb + r < C) ? dn[t][r] * rs * gg : 0.f;
           if (tokv && nb + r < C) a.tail_du[pc7 * C + nb + r] = du;
           const float m1 = hrf_row16_sum(du), m2 = hrf_row16_sum(du * rw);
-          if (i == 0 && nb + r < C) { sTst[wave][nb + r] = m1; sTst[wave][C + nb + r] = m2; }
+          if (i == 0 && nb + r < C) { sTst[wave & 3][nb + r] = m1; sTst[wave & 3][C + nb + r] = m2; }
         }
       }
     }
@@ -1316,7 +1344,7 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
       for (int t = 0; t < CT; ++t) dn[t] = hrf_f4{0.f, 0.f, 0.f, 0.f};
       wave_gemm_tl<C, PW, CT>(sWk, C, sK + tok * PC, lane7, dn);
       wave_gemm_tl<C, PW, CT>(sWv, C, sV + tok * PC, lane7, dn);
-      ln_bwd_rows<C, CT>(dn, sXkv, PC, tok, tokv, sRsKV[tok], sGam[2], sPar[wave][2], lane7);
+      ln_bwd_rows<C, CT>(dn, sXkv, PC, tok, tokv, sRsKV[tok], sGam[2], sPar[wave & 3][2], lane7);
       if (a.dkv != nullptr && tokv) {
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -1324,7 +1352,7 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (nb + r < C) {
-              float v = dn[t][r] + (a.dkv_add_res ? gx[t][r] : 0.f);
+              float v = dn[t][r] + (a.dkv_add_res ? gx7[t][r] : 0.f);
               if (a.dkv_acc) v += a.dkv[pc7 * C + nb + r];
               a.dkv[pc7 * C + nb + r] = v;
             }
@@ -1339,7 +1367,7 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (nb + r < C) {
-            float v = gx[t][r];
+            float v = gx7[t][r];
             if (a.dres_acc) v += a.dres[pc7 * C + nb + r];
             a.dres[pc7 * C + nb + r] = v;
           }
@@ -1348,19 +1376,77 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (NW
     }
     AB_T(8);
     // the out_proj weight gradient (dy^T O) and the four bias gradients behind the data path: role B holds the q / k / v tiles
-    for (int nt = wave; nt < NTC; nt += 4) wtile(0, nt);
+    for (int nt = wave & 3; nt < NTC; nt += 4) wtile(0, nt);
     // bias gradients = column sums over the 49 tokens (tokens outside the image included: their k / v ARE the biases)
-    for (int e = tid; e < 4 * C; e += 256) {
+    for (int e = tid & 255; e < 4 * C; e += 256) {
       const int which = e / C, n = e - which * C;
       const float* T = which == 0 ? sDY : (which == 1 ? sDQ : (which == 2 ? sK : sV));
       float sacc = 0.f;
       for (int j = 0; j < NTOK; ++j) sacc += T[j * PC + n];
       slot[(which == 0 ? a.off_bo : (which == 1 ? a.off_bq : (which == 2 ? a.off_bk : a.off_bv))) + n] = sacc;
     }
-  }
-  if (roleB) {
-    // ---- weight gradients of the q / k / v projections: [out tile of 16][all input channels] per wave, round-robin
-    for (int wt = wb; wt < 3 * NTC; wt += NBW) wtile(1 + wt / NTC, wt % NTC);
+  };
+  // weight gradients of the q / k / v projections: [out tile of 16][all input channels] per wave, round-robin
+  auto B8 = [&]() __attribute__((always_inline)) { for (int wt = wb; wt < 3 * NTC; wt += NBW) wtile(1 + wt / NTC, wt % NTC); };
+
+  if (NWB == 0) {                                                   // four waves, both roles between the same barriers
+    A3a(); B3a();
+    __syncthreads();                                                // w1 (it may occupy the dy / dO tiles): last use by every wave
+    A3b(); B3b();
+    AB_T(4);
+    __syncthreads();                                                // sH / xhat_2 are dead from here on (sH aliases sQ .. sDQ)
+    AB_T(5);
+    A5(); B5();
+    __syncthreads();
+    AB_T(6);
+#pragma unroll 1
+    for (int h = 0; h < HEADS; ++h) {
+      A6a(h);
+      __syncthreads();                                              // the row statistics of head h
+      A6b(h); B6b(h);
+      __syncthreads();                                              // every wave is done reading head h of sK / sV
+      B6c(h);
+    }
+    __syncthreads();                                                // dk / dv rows of the last head
+    AB_T(7);
+    A7(); B8();
+  } else if (roleA) {
+    A3a();
+    __syncthreads();
+    A3b();
+    AB_T(4);
+    __syncthreads();
+    AB_T(5);
+    A5();
+    __syncthreads();
+    AB_T(6);
+#pragma unroll 1
+    for (int h = 0; h < HEADS; ++h) {
+      A6a(h);
+      __syncthreads();
+      A6b(h);
+      __syncthreads();
+    }
+    __syncthreads();
+    AB_T(7);
+    A7();
+  } else {
+    B3a();
+    __syncthreads();
+    B3b();
+    __syncthreads();
+    B5();
+    __syncthreads();
+#pragma unroll 1
+    for (int h = 0; h < HEADS; ++h) {
+      B6a(h);
+      __syncthreads();
+      B6b(h);
+      __syncthreads();
+      B6c(h);
+    }
+    __syncthreads();
+    B8();
   }
   __syncthreads();
   AB_T(9);
@@ -1496,6 +1582,7 @@ extern "C" int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream) {
   ab_geometry(a);
   const int nwin = a.B * a.nWh * a.nWw;
   if (nwin <= 0) return HRF_OK;
+  if (a.heads == 1 && AB_NWB18 != 0 && a.gx_park == nullptr) return HRF_ERR_ARG;   // 8-wave form: [windows][64][32] floats of scratch
   if (a.heads == 1) return launch_bwd<18, 1, AB_NWB18>(a, bf, nwin, stream);
   return launch_bwd<36, 2, 4>(a, bf, nwin, stream);
 }

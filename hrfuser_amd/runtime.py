@@ -1767,6 +1767,8 @@ def attn_block(ctx, key, heads, xq, xkv, lnq, lnkv, wq, wk, wv, rpb, out_proj, r
             g, acc = xq.grad_target()
             a.dq, a.dq_acc, a.dq_add_res = P(g), acc, 1
         a.pslot, a.slot_stride = eng.fs_buffer(key), offs['_n']
+        if C <= 18:            # the 8-wave form parks role A's gradient rows here (step-lifetime scratch, never read by anyone else)
+            a.gx_park = P(_new((nwin * 64 * 32,), dev))
         dsp = None if rpb_one else _new((nwin * heads * 49 * 49,), dev)
         a.ds_plane = eng.fs_plane(key) if rpb_one else P(dsp)
         for nm in ('w1', 'b1', 'g2', 'bt2', 'wo', 'bo', 'wq', 'bq', 'wk', 'bk', 'wv', 'bv', 'gq', 'btq', 'gkv', 'btkv', 'rpb'):

@@ -184,6 +184,7 @@ typedef struct hrf_attn_block {
   const float* gout; const float* du1; const float* cA1; const float* cB1; const float* cC1; const hrf_bn_bfin_t* bfin1;
   float* dres; int dres_acc; float* dq; int dq_acc; int dq_add_res; float* dkv; int dkv_acc; int dkv_add_res;
   float* pslot; long slot_stride; float* ds_plane;
+  float* gx_park;      /* [windows][64][ceil(C/16)*16] floats of step-lifetime scratch (18-channel backward, 8-wave form; else unused) */
   /* CrossFFN tail of the PRECEDING block formed on load (hrformer.py:371-372 x = x' + DropPath(GELU(BN3(fc3(.)))), self-
    * attention only, tail_raw != NULL): the block input rows are x = tail_res + tail_rowscale[b] * GELU(tail_scale *
    * tail_raw + tail_shift) (tail_fin: scale / shift derived on load from the producer's moments, as hrf_conv_fwd's fin).

@@ -152,6 +152,8 @@ def _run(C, heads, B, H, W, cross, with_ffn, backward, backend, tail=False):
     else:
         a.dq_add_res = 1
     a.pslot, a.slot_stride, a.ds_plane = P(pslot), slot, P(dsp)
+    park = torch.full((nwin * 64 * 32,), float('nan'), device=dev)       # scratch of the 8-wave 18-channel backward
+    a.gx_park = P(park)
     for n in ('w1', 'b1', 'g2', 'bt2', 'wo', 'bo', 'wq', 'bq', 'wk', 'bk', 'wv', 'bv', 'gq', 'btq', 'gkv', 'btkv', 'rpb'):
         setattr(a, 'off_' + n, offs.get(n, -1))
     L.hrf_attn_block_bwd(a, _lib.stream_ptr())
