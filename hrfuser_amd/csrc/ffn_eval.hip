@@ -273,7 +273,9 @@ int fe_launch(const hrf_ffn_eval_t& a, void* stream) {
 
 extern "C" int hrf_ffn_eval_supported(int C, int hidden) {
   if (hidden != 4 * C) return 0;
-  return (C == 18 || C == 36 || C == 72 || C == 144 || C == 78 || C == 156) ? 1 : 0;
+  // (the kernel body is generic in C / HC - 72 / 144 / 78 / 156 were built and measured: with 36 or 12 tiles per launch and 4 - 8
+  // serial hidden chunks per tile they lose to the per-op launches by 2 - 6x, DESIGN.md section 11 - only the widths that pay are instantiated)
+  return (C == 18 || C == 36) ? 1 : 0;
 }
 
 extern "C" int hrf_ffn_eval(const hrf_ffn_eval_t* p, void* stream) {
@@ -283,12 +285,6 @@ extern "C" int hrf_ffn_eval(const hrf_ffn_eval_t* p, void* stream) {
       a.s1 == nullptr || a.t1 == nullptr || a.wd == nullptr || a.bd == nullptr || a.s2 == nullptr || a.t2 == nullptr ||
       a.w3 == nullptr || a.b3 == nullptr || a.s3 == nullptr || a.t3 == nullptr) return HRF_ERR_ARG;
   if (a.B <= 0 || a.H <= 0 || a.W <= 0) return HRF_OK;
-  switch (a.C) {
-    case 18: return fe_launch<18, 72>(a, stream);
-    case 36: return fe_launch<36, 72>(a, stream);
-    case 72: return fe_launch<72, 72>(a, stream);
-    case 144: return fe_launch<144, 72>(a, stream);
-    case 78: return fe_launch<78, 78>(a, stream);
-    default: return fe_launch<156, 78>(a, stream);
-  }
+  if (a.C == 18) return fe_launch<18, 72>(a, stream);
+  return fe_launch<36, 72>(a, stream);
 }

@@ -211,8 +211,8 @@ int hrf_rpb_grad(const float* ds_plane, int nwin, int heads, float* drpb, long c
  * (residual; DropPath is the identity) resp. hrfuser_hrformer_based.py:291,315-316.  x, out: (B,H,W,C) NHWC fp32; w1 [hidden][C]
  * + b1, wd [hidden][3][3] + bd, w3 [C][hidden] + b3 in their Conv2d layouts; (s_k, t_k) = the frozen-statistics affine of
  * BatchNorm k (scale = gamma * rsqrt(running_var + eps), shift = beta - running_mean * scale).  hidden = 4 C;
- * hrf_ffn_eval_supported: C in {18, 36, 72, 144} (HRFuser-T / STF, every branch) and {78, 156} (HRFuser-B's two finest
- * branches); other widths keep the per-op kernels.  The 4C-wide hidden tensor never leaves the chip.                        */
+ * hrf_ffn_eval_supported: C in {18, 36} (the two finest branches of HRFuser-T / STF, where a launch has hundreds of tiles);
+ * other widths keep the per-op kernels.  The 4C-wide hidden tensor never leaves the chip.                                   */
 typedef struct hrf_ffn_eval {
   int B, H, W, C, hidden;
   const float* x;

@@ -25,4 +25,10 @@ cp gpurun_out/pmc_sq_$R/${R}_pmc_sq.json $O/ 2>/dev/null
 bash tools/prof_timeline.sh > /dev/null 2>&1
 cp gpurun_out/timeline/step_timeline.txt $O/${R}_step_timeline.txt; cp gpurun_out/timeline/step_timeline.json $O/${R}_step_timeline.json
 bash tools/stage_trace.sh final_$R/st t_nus_bn -- "fwd stage3" "bwd stage3" "fwd stage4" > /dev/null 2>&1; cp $O/st/stage_trace.txt $O/${R}_stage_trace.txt 2>/dev/null; rm -rf $O/st
+# gradient all-reduce inside the weight-gradient phase (HRFuser-B: four bucket groups; HRFuser-T forced to four)
+python tools/exchange_overlap.py b_nus_bn > $O/${R}_grad_exchange_overlap_b_nus.txt 2>> $O/bench.err
+python tools/exchange_overlap.py t_nus_bn 4 > $O/${R}_grad_exchange_overlap_t_nus_forced4.txt 2>> $O/bench.err
+# the full GPU suite with its slowest calls
+timeout 1400 python -m pytest tests -m gpu -x -q > $O/${R}_gpu_suite_durations.txt 2>&1; echo "gpu suite rc $?" >> $O/${R}_gpu_suite_durations.txt
 for f in $O/${R}_bench_*.json; do echo $f; tail -1 $f | cut -c1-260; done
+tail -3 $O/${R}_gpu_suite_durations.txt
