@@ -41,17 +41,12 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
   const int c0 = blockIdx.y * CB;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-  // BatchNorm of the input finalised on load: this block's CB channels only (hrf_bn_fin_t)
+  // the filter taps, the bias and the whole halo tile are requested FIRST; the BatchNorm of the input is finalised (this
+  // block's CB channels only, hrf_bn_fin_t) while they are in flight - in front of the loads it was a memory round trip +
+  // fp64 arithmetic + a barrier of its own: 1.4 of the kernel's 13.3 us at 2x96x160x72
   __shared__ float sFin[2 * CB];
   const float* scp = a.tf_scale;
   const float* shp = a.tf_shift;
-  if (a.fin.stats != nullptr) {
-    hrf_bn_fin_onload(a.fin, sFin, sFin + CB, tid, 256, blockIdx.x == 0, c0, CB);
-    __syncthreads();
-    scp = sFin - c0; shp = sFin + CB - c0;
-  }
-  // the filter taps and the bias join the first batch of global loads (they used to be a round trip of their own behind the
-  // staging barrier)
   float wr[9];
   {
     const int cgw = c0 + (tid & 31);
@@ -62,8 +57,6 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
   {
     const int c = tid & 31, cg = c0 + c;
     const bool cv = cg < a.C;
-    float sc = 1.f, sh = 0.f;
-    if (a.tf_mode != HRF_TF_NONE) { sc = scp[cv ? cg : c0]; sh = shp[cv ? cg : c0]; }
     // unconditional clamped loads (no load under a per-element branch), value selected afterwards
     constexpr int NIT = (IH * IW + 7) / 8;
     float raw[NIT];
@@ -75,6 +68,13 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
       const bool ok = cv && pix < IH * IW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
       raw[it] = a.x[ok ? (((long)b * a.H + gy) * a.W + gx) * a.C + cg : 0];
     }
+    if (a.fin.stats != nullptr) {
+      hrf_bn_fin_onload(a.fin, sFin, sFin + CB, tid, 256, blockIdx.x == 0, c0, CB);
+      __syncthreads();
+      scp = sFin - c0; shp = sFin + CB - c0;
+    }
+    float sc = 1.f, sh = 0.f;
+    if (a.tf_mode != HRF_TF_NONE) { sc = scp[cv ? cg : c0]; sh = shp[cv ? cg : c0]; }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int pix = it * 8 + (tid >> 5);
@@ -145,6 +145,28 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
   }
 }
 
+// Tail of the weight-gradient kernels: sAcc = [8 row groups][10][CB] partial sums (taps 0..8, bias 9) of this block's CB
+// channels.  dw is [C][9]: the block's slice is ONE contiguous run of 9 * CB floats, and walked in MEMORY order a wave's
+// atomic instruction touches 2 cache lines; walked tap-major (lanes = channels, 36 B apart) it touched 18, and the atomic
+// units work line by line: the tail was 9.4 of dw_bwd_data_kernel<1, true>'s 25.3 us at 2x96x160x72.
+__device__ __forceinline__ void dw_wgt_tail(const float* sAcc, float* dw, float* dbias, long cp, int c0, int C, int tid) {
+  const int nc = C - c0 < CB ? C - c0 : CB;
+  for (int i = tid; i < 9 * nc; i += 256) {
+    const int cl = i / 9, k = i - 9 * cl;
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) tot += sAcc[(g * 10 + k) * CB + cl];
+    hrf_atomic_add(&dw[cp + (long)c0 * 9 + i], tot);
+  }
+  const int cl = tid - (256 - CB);                        // the bias sums: the last CB threads (they sit out the second pass above)
+  if (dbias != nullptr && cl >= 0 && cl < nc) {
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) tot += sAcc[(g * 10 + 9) * CB + cl];
+    hrf_atomic_add(&dbias[cp + c0 + cl], tot);
+  }
+}
+
 // ------------------------------------------------------------------------------- backward data
 struct DwBwdDataArgs {
   const float* dy; const float* yraw; const float* cA; const float* cB; const float* cC;
@@ -175,18 +197,13 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs
   const int ry0 = S == 1 ? y0 - 1 : y0 / 2, rx0 = S == 1 ? x0 - 1 : x0 / 2;
   const int c = tid & 31, cg = c0 + c;
   const bool cv = cg < a.C;
-  // BatchNorm-backward coefficients derived on load: this block's CB channels only (hrf_bn_bfin_t)
+  // everything the kernel needs from memory is requested with the first batch of loads: the filter taps, the producer's
+  // affine, this thread's row of raw producer outputs / previous dx values and the staged dY region; the BatchNorm-backward
+  // coefficients (this block's CB channels only, hrf_bn_bfin_t) are derived while those are in flight
   __shared__ float sFin[3 * CB];
   const float* cAp = a.cA;
   const float* cBp = a.cB;
   const float* cCp = a.cC;
-  if (a.bfin.gstats != nullptr) {
-    hrf_bn_bfin_onload(a.bfin, sFin, sFin + CB, sFin + 2 * CB, tid, 256, blockIdx.x == 0, c0, CB);
-    __syncthreads();
-    cAp = sFin - c0; cBp = sFin + CB - c0; cCp = sFin + 2 * CB - c0;
-  }
-  // everything the epilogue needs from memory is requested with the first batch of loads: the filter taps, the producer's
-  // affine, and this thread's row of raw producer outputs / previous dx values (they were a round trip behind the barrier)
   const int r = tid >> 5;                                 // input row within tile (0..7)
   float wr[9];
 #pragma unroll
@@ -203,8 +220,6 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs
   }
   {
     const bool bnb = a.cA != nullptr;
-    float ca = 1.f, cb = 0.f, cc = 0.f;
-    if (bnb) { const int cs = cv ? cg : c0; ca = cAp[cs]; cb = cBp[cs]; cc = cCp[cs]; }
     constexpr int NIT = (RH * RW + 7) / 8;
     float rd[NIT], ry[NIT];
 #pragma unroll
@@ -217,6 +232,13 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs
       rd[it] = a.dy[idx];
       ry[it] = bnb ? a.yraw[idx] : 0.f;
     }
+    if (a.bfin.gstats != nullptr) {
+      hrf_bn_bfin_onload(a.bfin, sFin, sFin + CB, sFin + 2 * CB, tid, 256, blockIdx.x == 0, c0, CB);
+      __syncthreads();
+      cAp = sFin - c0; cBp = sFin + CB - c0; cCp = sFin + 2 * CB - c0;
+    }
+    float ca = 1.f, cb = 0.f, cc = 0.f;
+    if (bnb) { const int cs = cv ? cg : c0; ca = cAp[cs]; cb = cBp[cs]; cc = cCp[cs]; }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int pix = it * 8 + (tid >> 5);
@@ -296,17 +318,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs
 #pragma unroll
     for (int k = 0; k < 10; ++k) sAcc[(r * 10 + k) * CB + c] = wacc[k];
     __syncthreads();
-    const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride;
-    for (int i = tid; i < 10 * CB; i += 256) {
-      const int k = i / CB, cc2 = c0 + (i % CB);
-      float tot = 0.f;
-#pragma unroll
-      for (int g = 0; g < 8; ++g) tot += sAcc[g * 10 * CB + i];
-      if (cc2 < a.C) {
-        if (k < 9) hrf_atomic_add(&a.dw[cp + cc2 * 9 + k], tot);
-        else if (a.dbias) hrf_atomic_add(&a.dbias[cp + cc2], tot);
-      }
-    }
+    dw_wgt_tail(sAcc, a.dw, a.dbias, (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride, c0, a.C, tid);
   }
 }
 
@@ -395,17 +407,7 @@ __device__ __forceinline__ void dw_bwd_wgt_body(const DwBwdWgtArgs& a) {
 #pragma unroll
   for (int k = 0; k < 10; ++k) sAcc[(rg * 10 + k) * CB + c] = acc[k];
   __syncthreads();
-  const long cp = (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride;
-  for (int i = tid; i < 10 * CB; i += 256) {
-    const int k = i / CB, cc2 = c0 + (i % CB);
-    float tot = 0.f;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) tot += sAcc[g * 10 * CB + i];
-    if (cc2 < a.C) {
-      if (k < 9) hrf_atomic_add(&a.dw[cp + cc2 * 9 + k], tot);
-      else if (a.dbias) hrf_atomic_add(&a.dbias[cp + cc2], tot);
-    }
-  }
+  dw_wgt_tail(sAcc, a.dw, a.dbias, (long)(blockIdx.x % HRF_STAT_COPIES) * a.copy_stride, c0, a.C, tid);
 }
 
 template <int S>

@@ -11,7 +11,7 @@ for v in "$@"; do
 import json,re
 d=json.loads(open('$O/b_${v}.json').read().strip().splitlines()[-1])
 k=json.load(open('$O/k_${v}.json'))
-rows=[(s['shape'][:70],round(s['avg_launch_us'],1),s['launches_per_step']) for s in k['signatures'] if re.search(r'$PAT', s['shape']+' '+s['kernel'])][:8]
+rows=[(s['shape'][:70],round(s['avg_launch_us'],1),s['launches_per_step']) for s in k['signatures'] if re.search(r'$PAT', s['shape']+' '+s['kernel'])][:14]
 print('$v rep$rep', d['ms_per_step'], 'fwd', d.get('fwd_ms_per_img'), rows)
 PY
 done; done
