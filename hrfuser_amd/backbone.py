@@ -795,6 +795,7 @@ class HRFuserFusionBlock(nn.Module):
                              rowscale=self._droppath_scale(ctx, B, dev))
 
 
+_STAGE_ANCHOR = os.environ.get('HRF_STAGE_ANCHOR', '0') == '1'
 _CAM_LANES = int(os.environ.get('HRF_CAM_LANES', '0') or 0)      # 0: one stream per camera branch (A/B knob)
 _FORK_EXCHANGE = os.environ.get('HRF_FORK_EXCHANGE', '1') != '0'   # exchange chains on sibling lanes (0: serial)
 _BRANCH_ORDER = os.environ.get('HRF_BRANCH_ORDER', '')
@@ -1708,14 +1709,24 @@ class HRFuserHRFormerBased(HipModule):
         each of its modules forking branch lanes from main (flat, never nested)."""
         M = self.num_fused_modalities
         cap = max(1, 4 - len(xs)) if ctx.mod_lanes == 'auto' else int(ctx.mod_lanes or 0)
-        lanes = ctx.bundle_lanes(M, 'stages', cap=cap)
+        lanes = ctx.bundle_lanes(M, 'stages', cap=cap, anchor=_STAGE_ANCHOR)
         mods = [None] * M
         ys = [None]
 
+        def pad(us):
+            # critical-lane probe (HRF_DEBUG_PAD="-1:300" pads every modality stage, "-2:300" every camera stage by 300 us of
+            # idle time, forward and backward): a strand whose padding shows up in the step time is not hidden behind the other
+            if us:
+                ticks = int(us * 100)
+                ctx.L.hrf_debug_spin(ticks, ctx.stream)
+                ctx.push(lambda: ctx.L.hrf_debug_spin(ticks, ctx.stream))
+
         def mod_stage(k):
+            pad(_debug_pad().get(-1))
             mods[k] = self._run_stage(ctx, mod_stages[k], [m0[k]])[0]
 
         def camera():
+            pad(_debug_pad().get(-2))
             ctx.branch_lane_cap = _CAM_LANES          # streams for the camera stage's branches while M modality stages run beside it
             try:
                 ys[0] = self._run_stage(ctx, cam_stage, xs)
@@ -1725,7 +1736,7 @@ class HRFuserHRFormerBased(HipModule):
             ctx.parallel([ctx.cur] + list(lanes), [camera] + [lambda k=k: mod_stage(k) for k in range(M)])
         else:
             ctx.parallel(list(lanes) + [ctx.cur], [lambda k=k: mod_stage(k) for k in range(M)] + [camera])
-        ctx.join(lanes)
+        ctx.join(lanes, anchor=_STAGE_ANCHOR)
         return ys[0], mods
 
 

@@ -761,7 +761,7 @@ class Ctx:
             self.n_collectives += 1
 
     # ---- lanes ---------------------------------------------------------------------------------
-    def fork(self, n, keep_first=False, cap=0):
+    def fork(self, n, keep_first=False, cap=0, anchor=False):
         """n sibling lanes that start after everything enqueued so far on the current lane.  keep_first: the first
         sibling stays on the current lane (its launches can then merge with equal-shape strands bundled on that lane)."""
         # lanes are always direct children of the main lane: nested stream forks crash hipGraph
@@ -789,7 +789,7 @@ class Ctx:
         uniq = [self._free.pop() for _ in range(m)]
         for k in uniq:
             k.stream.wait_stream(self.cur.stream)
-        self._fork_anchor(self.cur)
+        self._fork_anchor(self.cur, force=anchor)
         self._lane_stamp('fork', self.cur, uniq)
         if self.record and uniq:
             self.strand.tape.append(('F', self.cur, uniq))
@@ -818,28 +818,29 @@ class Ctx:
                 st.take(self, what, (k, 'parent', tag), parent.ptr)
             st.take(self, what, (k, idx, tag), l.ptr)
 
-    def _fork_anchor(self, parent):
+    def _fork_anchor(self, parent, force=False):
         """EXPERIMENT (HRF_FORK_ANCHOR=1): one trivial kernel on the PARENT lane right after a fork.  The ROCm graph executor
         gives the first child of a node the node's own stream and resolves a cross-stream dependency through a marker at the
         TAIL of the source stream at enqueue time - so without it the first sibling's whole chain sits between the fork
         point and the markers the other siblings wait for (they started 100-200 us late in the rocprofv3 timeline)."""
-        if not _FORK_ANCHOR or not self.multi or parent.stream is None:
+        if not (_FORK_ANCHOR or force) or not self.multi or parent.stream is None:
             return
         buf = self.owner.__dict__.get('_fork_scratch')
         if buf is None:
             buf = self.owner.__dict__['_fork_scratch'] = torch.zeros(8, dtype=torch.int64, device=torch.device('cuda', torch.cuda.current_device()))
         self.lib.hrf_stamp(buf.data_ptr(), parent.ptr)
 
-    def bundle_lanes(self, n, what='stems', cap=0):
+    def bundle_lanes(self, n, what='stems', cap=0, anchor=False):
         """Lanes for n strands of EQUAL shape (camera stem + modality stems, the modality stages beside the camera stage):
         all on the current lane when launch merging is on - their equal calls become one multi-problem launch, in order on
         one queue, no cross-queue edges - otherwise a stream each."""
         if self.bundle and what in self.bundle_what:
             return [self.cur] * n
-        return self.fork(n, cap=cap)
+        return self.fork(n, cap=cap, anchor=anchor)
 
-    def join(self, kids):
-        """The current lane continues after all sibling lanes have finished."""
+    def join(self, kids, anchor=False):
+        """The current lane continues after all sibling lanes have finished.  `anchor`: the backward pass re-opens these lanes
+        with a parent-lane anchor (see _fork_anchor)."""
         kids = [k for k in dict.fromkeys(kids) if k is not self.cur]     # lanes may repeat (HRF_MAX_LANES, bundles)
         if not kids:
             return
@@ -853,7 +854,7 @@ class Ctx:
         for k in kids:
             self.cur.stream.wait_stream(k.stream)
         if self.record:
-            self.strand.tape.append(('J', self.cur, kids))
+            self.strand.tape.append(('J', self.cur, kids, anchor))
         self._free.extend(kids)
 
     def on(self, lane):
@@ -916,7 +917,7 @@ class Ctx:
                     if self.multi and k.stream is not None:
                         k.stream.wait_stream(e[1].stream)
                 if self.multi and e[2] and e[2][0].stream is not None:
-                    self._fork_anchor(e[1])
+                    self._fork_anchor(e[1], force=len(e) > 3 and e[3])
                     self._lane_stamp('fork', e[1], e[2])
             elif e[0] == 'F':                   # reverse of a fork = join
                 if self.multi and e[2] and e[2][0].stream is not None:
