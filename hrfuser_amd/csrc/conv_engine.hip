@@ -31,6 +31,8 @@
 #include "hrf_lin.h"
 #include "../../include/hrfuser_hip.h"
 
+#include "hrf_wgrad.h"
+
 namespace {
 
 constexpr int BM = 64;      // output rows (pixels) per block: one 16-row MFMA tile per wave
@@ -38,7 +40,7 @@ constexpr int BK = 64;      // K elements staged per step (16 MFMA k-substeps)
 constexpr int LDK = 65;     // LDS pitch of the [row][k] tiles: bank = (row + k) % 32
 constexpr float SENT = -1.0e30f;   // staged pre-activation of a zero-padded tap: relu/gelu(SENT) == 0
 
-static int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static int g_knob[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 __device__ __forceinline__ float act_at_read(int tf, float u) {
   return tf == HRF_TF_AFFINE_RELU ? fmaxf(u, 0.f) : (tf == HRF_TF_AFFINE_GELU ? hrf_gelu(u) : u);
@@ -542,28 +544,6 @@ __global__ __launch_bounds__(256) void conv_bwd_wgt_kernel(ConvBwdWgtArgs a) {
 // (LDS float atomics run at ~1 lane/clk: measured 45 us for a 64x64 tile) and the block issues ONE
 // coalesced fp32 atomic per output element; the split count is capped at 128 because same-address
 // global atomics serialise at ~25 ns each.
-struct WgradDenseArgs {
-  const float* dy; int ldD; int doff; const float* yraw;
-  const float* cA; const float* cB; const float* cC;
-  const float* x; int ldX;
-  const float* tf_scale; const float* tf_shift; const float* tf_rowstat;   // rowstat != null: LayerNorm
-  float* dw; float* dbias;
-  int Cout, Cin, Mpix, chunk;
-  int H, W, Ho, Wo, stride, gyc;   // TAP (3x3) only: input / output grids, stride, channel groups per tap
-  int gx, gy, sp;                  // logical grid (co groups, n groups, pixel splits), see the XCD mapping below
-};
-
-// Weight gradients are LEAVES of the backward graph: up to WGMAX independent problems of the same kernel variant are
-// issued as ONE launch (hrf_wgrad_group_begin/_end): a 13 MB problem alone cannot fill 256 CUs for longer than its own
-// ramp-up, 16 of them back to back do.  Block b of the launch belongs to problem p with bstart[p] <= b < bstart[p+1]
-// (every problem's block count is a multiple of 8, so the XCD-aware mapping below is unchanged).
-constexpr int WGMAX = 16;
-struct WgradGroup {
-  int nprob;
-  int bstart[WGMAX + 1];
-  WgradDenseArgs p[WGMAX];
-};
-
 constexpr int WUMAX = 8;   // k-steps (of 4 pixels) whose loads are issued before the first use
 constexpr int WNW = 8;     // waves per block (512 threads)
 
@@ -984,7 +964,7 @@ extern "C" int hrf_debug_knob(int key, int value) {
   if (key >= 28 && key < 32) return hrf_lin2_knob(key - 28, value);    // lin2_engine.hip: 28 = 1 force / 2 disable the LDS-tiled row GEMM
   if (key >= 16 && key < 20) return hrf_pw_knob(key - 16, value);      // pointwise.hip tuning aids
   if (key >= 24 && key < 28) return hrf_conv3w_knob(key - 24, value);  // conv3w_engine.hip tuning aids
-  if (key < 0 || key >= 8) return HRF_ERR_ARG;
+  if (key < 0 || key >= 12) return HRF_ERR_ARG;      // (8: the LDS-tiled weight gradient, 1 = off, 2 = every 1x1 problem)
   g_knob[key] = value;
   return HRF_OK;
 }
@@ -1040,6 +1020,17 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     d.tf_rowstat = tf_mode == HRF_TF_LN ? tf_rowstat : nullptr;
     d.dw = dw; d.dbias = dbias; d.Cout = Cout; d.Cin = Cin; d.Mpix = a.Mpix;
     d.H = H; d.W = W; d.Ho = a.Ho; d.Wo = a.Wo; d.stride = stride;
+    const int act = tf_mode == HRF_TF_AFFINE_RELU ? 1 : (tf_mode == HRF_TF_AFFINE_GELU ? 2 : 0);
+    if (dense1 && g_knob[1] == 0) {
+      // wide 1x1 problems: the LDS-tiled kernel (wgrad_tiled.hip)
+      int tkey = 0, tblocks = 0;
+      if (hrf_wgrad_tiled_plan(d, cA != nullptr, act, g_wg_collect, g_knob[8], tkey, tblocks)) {
+        if (g_wg_collect) { g_wg_pending.push_back(WgPending{tkey, tblocks, d}); return HRF_OK; }
+        WgradGroup one;
+        one.nprob = 1; one.bstart[0] = 0; one.bstart[1] = tblocks; one.p[0] = d;
+        return wgrad_dense_launch(tkey, one, tblocks, stream);
+      }
+    }
     // 16x16 tiles per wave in each dimension: the count in {2..5} with the least padding (+ one unit per
     // extra group, which re-reads the other operand); the 3x3 path keeps {2, 4} (N' = 9*Cin is large)
     auto pick_tiles = [](int C, bool wide) {
@@ -1080,7 +1071,6 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     sp = hrf_cdiv(a.Mpix, d.chunk);
     d.gx = hrf_cdiv(Cout, 16 * mt); d.gy = d.gyc; d.sp = sp;
     const int nblocks = d.gx * d.gy * hrf_cdiv(sp, 8) * 8;
-    const int act = tf_mode == HRF_TF_AFFINE_RELU ? 1 : (tf_mode == HRF_TF_AFFINE_GELU ? 2 : 0);
     const int key = ((((mt * 8 + (tapb ? 7 : nt)) * 2 + (cA != nullptr ? 1 : 0)) * 4 + act) * 2) + (tap3 ? 1 : 0);   // nt code 7 = tap-blocked (NT 9)
     if (g_wg_collect) {                                      // queued: launched by hrf_wgrad_group_end
       g_wg_pending.push_back(WgPending{key, nblocks, d});
@@ -1101,6 +1091,7 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
 
 // one launch of kernel variant `key` = (mt, nt, BatchNorm-backward, activation, 3x3) over a group of problems
 static int wgrad_dense_launch(int key, const WgradGroup& d, int total_blocks, void* stream) {
+    if (key >= 4096) return hrf_wgrad_tiled_launch(key, d, total_blocks, stream);   // wgrad_tiled.hip
     const bool tap3 = key & 1;
     const int act = (key >> 1) & 3;
     const bool bnb = (key >> 3) & 1;
@@ -1215,7 +1206,7 @@ extern "C" int hrf_wgrad_group_end(void* stream) {
       double best = -1;
       for (int k = 0; k < g.nprob; ++k) {
         const WgradDenseArgs& q = g.p[k];
-        const bool tap = key & 1, bnb = (key >> 3) & 1;
+        const bool tiled = key >= 4096, tap = !tiled && (key & 1), bnb = tiled ? (key >> 2) & 1 : (key >> 3) & 1;
         const double np = (tap ? 9.0 : 1.0) * q.Cin;
         const double inpix = tap ? (double)q.Mpix / ((double)q.Ho * q.Wo) * q.H * q.W : (double)q.Mpix;
         const double b = 4.0 * (inpix * q.Cin + (double)q.Mpix * q.Cout * (bnb ? 2 : 1) + (double)q.Cout * np);

@@ -663,10 +663,15 @@ def grouped_wgrad_report(trainer, x, mods, cots, steps=3):
     for r in range(n):
         key, launches, problems, us, nbytes, flops, cin, cout, h, w, stride, kh = [buf[12 * r + k] for k in range(12)]
         key = int(key)
-        tap, act, bnb, nt, mt = key & 1, (key >> 1) & 3, (key >> 3) & 1, (key >> 4) & 7, key >> 7
         tf = lambda b: 'true' if b else 'false'
-        tapm = 2 if (tap and nt == 7) else (1 if tap else 0)              # nt code 7 = tap-blocked (NT 9, TAPM 2)
-        rows.append({'kernel': f'wgrad_dense_kernel<{mt}, {9 if nt == 7 else nt}, {tf(bnb)}, {act}, {tapm}>',
+        if key >= 4096:                                                   # csrc/wgrad_tiled.hip: 4096 + (((mt * 2 + swap) * 2 + bnb) * 4 + act)
+            k = key - 4096
+            name = f'wgrad_tiled_kernel<{k >> 4}, {tf((k >> 3) & 1)}, {tf((k >> 2) & 1)}, {k & 3}>'
+        else:
+            tap, act, bnb, nt, mt = key & 1, (key >> 1) & 3, (key >> 3) & 1, (key >> 4) & 7, key >> 7
+            tapm = 2 if (tap and nt == 7) else (1 if tap else 0)          # nt code 7 = tap-blocked (NT 9, TAPM 2)
+            name = f'wgrad_dense_kernel<{mt}, {9 if nt == 7 else nt}, {tf(bnb)}, {act}, {tapm}>'
+        rows.append({'kernel': name,
                      'launches_per_step': round(launches / steps, 2), 'problems_per_launch': round(problems / launches, 2),
                      'avg_launch_us': round(us / launches, 2), 'time_per_step_ms': round(us / steps / 1e3, 4),
                      'bytes_per_launch': nbytes / launches, 'flops_per_launch': flops / launches,

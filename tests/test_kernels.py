@@ -702,6 +702,24 @@ def test_conv3w_gpu(case):
     run_conv3w(case, 'hip')
 
 
+# ------------------------------------------------------------------ LDS-tiled weight gradient
+# csrc/wgrad_tiled.hip serves wide 1x1 problems (>= 32 channels on both sides, >= 256 pixels, >= 60 % tile efficiency); the debug
+# knob 8 = 2 forces it on every stride-1 1x1 problem: ragged widths on either side (the 128-wide side is chosen per problem),
+# LayerNorm / BatchNorm + GELU / ReLU on load, BatchNorm-backward coefficients, fewer pixels than one chunk
+WT_CASES = LIN2_CASES + [(2, 16, 24, 64, 256, 1, 1, 2, True, True), (3, 40, 50, 16, 40, 1, 1, 1, False, True),
+                         (1, 6, 7, 330, 300, 1, 1, 4, True, False)]
+
+
+def run_wgrad_tiled(case, backend):
+    use_backend(backend)
+    L = _lib.lib()
+    L.hrf_debug_knob(8, 2)
+    try:
+        run_conv(case, backend)
+    finally:
+        L.hrf_debug_knob(8, 0)
+
+
 # ------------------------------------------------------------------ grouped weight-gradient launches
 def run_wgrad_group(backend):
     """hrf_wgrad_group_begin/_end: queued problems (several shapes / kernel variants, > 16 of one variant so that the
@@ -711,7 +729,8 @@ def run_wgrad_group(backend):
         L, s = _lib.lib(), _lib.stream_ptr()
         g = torch.Generator().manual_seed(3)
         probs = []
-        shapes = [(1, 6, 10, 18, 72, 1)] * 18 + [(1, 6, 10, 72, 18, 1)] * 3 + [(2, 5, 7, 64, 64, 3)] * 2 + [(1, 4, 9, 36, 36, 1)]
+        shapes = [(1, 6, 10, 18, 72, 1)] * 18 + [(1, 6, 10, 72, 18, 1)] * 3 + [(2, 5, 7, 64, 64, 3)] * 2 + [(1, 4, 9, 36, 36, 1)] + \
+            [(1, 16, 17, 64, 256, 1)] * 2 + [(1, 16, 18, 256, 64, 1)]      # (the last three: the LDS-tiled kernel)
         for (B, H, W, Cin, Cout, KH) in shapes:
             x = torch.randn(B, H, W, Cin, generator=g).to(dev)
             dy = torch.randn(B, H, W, Cout, generator=g).to(dev)
@@ -741,6 +760,18 @@ def run_wgrad_group(backend):
 
 def test_wgrad_group_emul():
     run_wgrad_group('emul')
+
+
+@pytest.mark.parametrize('case', WT_CASES, ids=str)
+def test_wgrad_tiled_emul(case):
+    run_wgrad_tiled(case, 'emul')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', WT_CASES + [(1, 70, 66, 64, 256, 1, 1, 2, True, True), (1, 66, 70, 256, 64, 1, 1, 1, True, False),
+                                             (2, 48, 80, 312, 78, 1, 1, 3, True, True), (2, 48, 80, 78, 312, 1, 1, 4, True, True)], ids=str)
+def test_wgrad_tiled_gpu(case):
+    run_wgrad_tiled(case, 'hip')
 
 
 @pytest.mark.gpu
