@@ -255,6 +255,9 @@ struct AbFwdArgs {
   hrf_bn_fin_t fin;     // BatchNorm of the preceding block's CrossFFN tail finalised on load (stats != null)
 };
 
+// K-steps of the token contractions whose four rows (tokens 16t + 4q + r, q = 0..3) all lie beyond the 49 tokens of a window:
+// t = 3, r = 1..3 (tokens 49 ... 63).  Their operands are exact zeros (P and dS of pad keys / queries): skipped, 13 of 16 steps remain
+#define AB_PADK(t, r) ((t) == 3 && (r) > 0)
 template <int C, int HEADS>
 __global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<AbFwdArgs> grp) {
   const hrf_attn_block_t& a = grp.sel().a;
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<AbFwdArgs>
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          if (AB_PADK(t, r)) continue;
           const float* vrow = sV + (16 * t + 4 * q + r) * PC + h * D + i;
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_mfma16(acc[t][r], vrow[16 * dt], o[dt]);
@@ -1150,6 +1154,7 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (C 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if (AB_PADK(t, r)) continue;
         const float* vrow = sV + (16 * t + 4 * q + r) * PC + h * D + i;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o1[dt] = hrf_mfma16(sA[t][r], vrow[16 * dt], o1[dt]);
@@ -1171,6 +1176,7 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (C 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if (AB_PADK(t, r)) continue;
         const float* krow = sK + (16 * t + 4 * q + r) * PC + h * D + i;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o2[dt] = hrf_mfma16(sA[t][r], krow[16 * dt], o2[dt]);
@@ -1226,6 +1232,7 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (C 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if (AB_PADK(t, r)) continue;
         const float* gr = sG + (16 * t + 4 * q + r) * PC + h * D + i;
         const float* qr = sQ + (16 * t + 4 * q + r) * PC + h * D + i;
 #pragma unroll

@@ -19,7 +19,7 @@ namespace {
 constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2, NPIX = IH * IW;   // 180 halo pixels
 constexpr int CS = 64;       // channel slab
 constexpr int CP = 66;       // halo pitch (floats per pixel): bank = (2*i + q) % 32
-constexpr int BP = 68;       // weight-tile pitch: bank = (4*j + q) % 32
+constexpr int BP = 66;       // weight-tile pitch: bank = (2*j + q) % 32 (ds_read_b32 is served in 32-lane halves: q in {0, 1} or {2, 3}; 68 was 2-way)
 constexpr int NWV = 8;        // waves per block: one output row (16-pixel MFMA row tile) each, 2 waves per SIMD
 constexpr int NHL = (NPIX + NWV - 1) / NWV;   // halo pixels per thread (NWV pixel groups x 64 channels)
 
