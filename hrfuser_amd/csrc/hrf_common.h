@@ -15,12 +15,13 @@ enum {
 };
 enum { HRF_ACT_NONE = 0, HRF_ACT_RELU = 1, HRF_ACT_GELU = 2 };
 
-// erf(x), branch-free, <= 2.5 ulp (max abs error 1.3e-7): |x| < 0.9: x*P7(x^2); else 1 - 2^Q9(|x|)
-// with Q9 a fit of log2(erfc) on [0.9, 4] (erf == 1 in fp32 beyond 3.92).  Coefficients fitted by
-// Chebyshev least squares (tools/fit_erf.py).  ~22 VALU ops + one v_exp_f32 and
-// NO divergent branch - the libm erff is a two-branch routine that both bloats the unrolled loaders
-// (GELU is evaluated on load at 189 sites per forward) and serialises the two paths per wave.
-// The resulting GELU is closer to the exact value (4.3e-7) than torch's own fp32 GELU (1.2e-6).
+// erf(z), branch-free: Abramowitz-Stegun 7.1.26, erf(|z|) = 1 - t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2) with
+// t = 1 / (1 + p |z|); in fp32 |error| <= 6.1e-7 absolute (GELU: 4.7e-7, its derivative 3.3e-7 - the accuracy of the previous
+// two-polynomial fit and closer to the exact value than torch's own fp32 GELU, 1.2e-6).  ~11 VALU operations + one reciprocal
+// and one exp2 (the two-polynomial form was ~22 + one exp2): GELU is evaluated ON LOAD at every consumer of a CrossFFN tensor
+// (~1.2 G evaluations per HRFuser-T step), so its length is step time; no libm erff either (a two-branch routine that bloats
+// the unrolled loaders and serialises both paths per wave).  E returns exp(-z^2): with z = x / sqrt(2) that is the Gaussian
+// of GELU's derivative, which therefore costs no second exponential.
 __device__ __forceinline__ float hrf_exp2(float x) {
 #ifdef HRF_EMUL
   return exp2f(x);
@@ -28,42 +29,37 @@ __device__ __forceinline__ float hrf_exp2(float x) {
   return __builtin_amdgcn_exp2f(x);
 #endif
 }
-__device__ __forceinline__ float hrf_erf(float x) {
-#ifdef HRF_LIBM_ERF
-  return erff(x);
+__device__ __forceinline__ float hrf_rcp(float x) {
+#ifdef HRF_EMUL
+  return 1.0f / x;
+#else
+  return __builtin_amdgcn_rcpf(x);
 #endif
-  const float ax = fabsf(x), t = ax * ax;
-  float ps = -1.0492395631445106e-05f;
-  ps = fmaf(ps, t, 0.00011508714669616893f);
-  ps = fmaf(ps, t, -0.0008512076456099749f);
-  ps = fmaf(ps, t, 0.005222628358751535f);
-  ps = fmaf(ps, t, -0.026865895837545395f);
-  ps = fmaf(ps, t, 0.11283788830041885f);
-  ps = fmaf(ps, t, -0.37612637877464294f);
-  ps = fmaf(ps, t, 1.128379225730896f);
-  ps *= ax;
-  const float ac = fminf(ax, 4.0f);
-  float q = -4.564023825537333e-08f;
-  q = fmaf(q, ac, 3.329453193146037e-06f);
-  q = fmaf(q, ac, -7.52767373342067e-05f);
-  q = fmaf(q, ac, 0.000906358181964606f);
-  q = fmaf(q, ac, -0.00701051764190197f);
-  q = fmaf(q, ac, 0.038408491760492325f);
-  q = fmaf(q, ac, -0.1591843068599701f);
-  q = fmaf(q, ac, -0.9112436771392822f);
-  q = fmaf(q, ac, -1.6307036876678467f);
-  q = fmaf(q, ac, 0.00048264043289236724f);
-  const float pl = 1.0f - hrf_exp2(q);
-  const float r = ax < 0.9f ? ps : pl;
-  return x < 0.f ? -r : r;
 }
+__device__ __forceinline__ float hrf_erf_e(float z, float& E) {
+#ifdef HRF_LIBM_ERF
+  E = expf(-z * z);
+  return erff(z);
+#endif
+  const float az = fabsf(z);
+  const float t = hrf_rcp(fmaf(0.3275911f, az, 1.0f));
+  E = hrf_exp2(-1.4426950408889634f * az * az);
+  float p = 1.061405429f;
+  p = fmaf(p, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = fmaf(-(p * t), E, 1.0f);
+  return copysignf(r, z);
+}
+__device__ __forceinline__ float hrf_erf(float x) { float E; return hrf_erf_e(x, E); }
 __device__ __forceinline__ float hrf_gelu(float x) {
   return 0.5f * x * (1.0f + hrf_erf(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float hrf_gelu_grad(float x) {
-  const float cdf = 0.5f * (1.0f + hrf_erf(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float E;
+  const float cdf = 0.5f * (1.0f + hrf_erf_e(x * 0.70710678118654752440f, E));
+  return cdf + x * (0.39894228040143267794f * E);
 }
 __device__ __forceinline__ float hrf_act(int act, float u) {
   return act == HRF_ACT_RELU ? fmaxf(u, 0.f) : (act == HRF_ACT_GELU ? hrf_gelu(u) : u);
@@ -74,10 +70,10 @@ __device__ __forceinline__ float hrf_act_grad(int act, float u) {
 // act(u) and act'(u) from one evaluation (the erf / exp of GELU are shared)
 __device__ __forceinline__ void hrf_act_both(int act, float u, float& val, float& grad) {
   if (act == HRF_ACT_GELU) {
-    const float cdf = 0.5f * (1.0f + hrf_erf(u * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+    float E;
+    const float cdf = 0.5f * (1.0f + hrf_erf_e(u * 0.70710678118654752440f, E));
     val = u * cdf;
-    grad = cdf + u * pdf;
+    grad = cdf + u * (0.39894228040143267794f * E);
   } else if (act == HRF_ACT_RELU) {
     val = fmaxf(u, 0.f);
     grad = u > 0.f ? 1.f : 0.f;
