@@ -675,8 +675,10 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(HrfGroup<ActBwdArgs> g
   double* st2 = pa_.st2;
   double* st3 = pa_.st3;
   const long rows = pa_.rows;
-  HRF_DYN_SMEM(float, sacc);                              // [4*C]: sum g, sum g*y1, sum g*y2, sum g*y3
-  for (int i = threadIdx.x; i < 4 * C; i += 256) sacc[i] = 0.f;
+  // [R + 1][4*C]: per row group (sum g, sum g*y1, sum g*y2, sum g*y3), then their totals.  (The row groups used to meet in ONE
+  // [4*C] array through LDS float atomics - R lanes on every address, 4 * VW atomics per thread: ~1.5 us at the end of every
+  // launch of a latency-bound chain; plain stores + one pass that adds the R rows)
+  HRF_DYN_SMEM(float, sacc);
   const int cw = C / VW, R = 256 / cw;
   const int r = threadIdx.x / cw, c = VW * (threadIdx.x - r * cw);
   const bool active = r < R;
@@ -717,17 +719,20 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(HrfGroup<ActBwdArgs> g
     }
     if (ok) hrf_stv<VW>(g + idx, v);
   }
-  __syncthreads();
   if (active) {
+    float* pr = sacc + (size_t)r * 4 * C + c;
 #pragma unroll
-    for (int e = 0; e < VW; ++e) {
-      hrf_atomic_add(&sacc[c + e], a0[e]);
-      if (st1) hrf_atomic_add(&sacc[C + c + e], a1[e]);
-      if (st2) hrf_atomic_add(&sacc[2 * C + c + e], a2[e]);
-      if (st3) hrf_atomic_add(&sacc[3 * C + c + e], a3[e]);
-    }
+    for (int e = 0; e < VW; ++e) { pr[e] = a0[e]; pr[C + e] = a1[e]; pr[2 * C + e] = a2[e]; pr[3 * C + e] = a3[e]; }
   }
   __syncthreads();
+  float* stot = sacc + (size_t)R * 4 * C;
+  for (int i = threadIdx.x; i < 4 * C; i += 256) {
+    float t = 0.f;
+    for (int rr = 0; rr < R; ++rr) t += sacc[(size_t)rr * 4 * C + i];
+    stot[i] = t;
+  }
+  __syncthreads();
+  sacc = stot;
   const size_t cp = (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
   for (int cc = threadIdx.x; cc < C; cc += 256) {
     const double s = (double)sacc[cc];
@@ -1297,8 +1302,9 @@ extern "C" int hrf_act_bwd(const float* dout, const float* out, const float* y1,
     int grid = hrf_cdiv(hrf_cdiv(rows, 256 / (C / vw)), passes);
     if (grid > 2048) grid = 2048;
     const ActBwdArgs a{dout, out, y1, sc, sh, rowscale, rows_per_sample, mode, g, y2, y3, st1, st2, st3, rows, C};
-    if (vw == 4) { HRF_LAUNCH_G(act_bwd_vec_kernel<4>, dim3(grid), dim3(256), (unsigned)(4 * C * sizeof(float)), stream, a); }
-    else { HRF_LAUNCH_G(act_bwd_vec_kernel<2>, dim3(grid), dim3(256), (unsigned)(4 * C * sizeof(float)), stream, a); }
+    const unsigned smem = (unsigned)((256 / (C / vw) + 1) * 4 * C * sizeof(float));     // [R + 1][4*C]: <= 17 KB
+    if (vw == 4) { HRF_LAUNCH_G(act_bwd_vec_kernel<4>, dim3(grid), dim3(256), smem, stream, a); }
+    else { HRF_LAUNCH_G(act_bwd_vec_kernel<2>, dim3(grid), dim3(256), smem, stream, a); }
     return hrf_check_launch();
   }
   const int R = C <= 256 ? 256 / C : 1;
