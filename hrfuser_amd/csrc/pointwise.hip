@@ -860,8 +860,7 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(HrfGroup<FuseArgs> grp) {
 // (sum du, sum du*ylow) moments of the BatchNorm in front of it; one thread = one (low-res pixel, channel) at a time
 __global__ __launch_bounds__(256) void nearest_up_bwd_kernel(const float* g, int ldG, int goff, int B, int H, int W, int C,
                                                              const float* ylow, int Hs, int Ws, float* du, double* stats) {
-  HRF_DYN_SMEM(float, sacc);                              // [2*C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) sacc[i] = 0.f;
+  HRF_DYN_SMEM(float, sacc);                              // [R][2*C]
   const int cw = C <= 256 ? C : 256, R = C <= 256 ? 256 / C : 1;
   const int r = threadIdx.x / cw, c0 = threadIdx.x - r * cw;
   const bool active = r < R;
@@ -888,17 +887,19 @@ __global__ __launch_bounds__(256) void nearest_up_bwd_kernel(const float* g, int
     }
   }
   if (stats == nullptr) return;
-  __syncthreads();
+  // the R row groups of the block meet through plain stores ([R][2*C]) + one pass (LDS float atomics with R lanes per address
+  // cost ~1.5 us at the end of every launch: act_bwd_vec_kernel)
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int c = c0 + 256 * j;
-    if (active && c < C) { hrf_atomic_add(&sacc[c], a1[j]); hrf_atomic_add(&sacc[C + c], a2[j]); }
+    if (active && c < C) { sacc[(size_t)r * 2 * C + c] = a1[j]; sacc[(size_t)r * 2 * C + C + c] = a2[j]; }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.f;
+    for (int rr = 0; rr < R; ++rr) t += sacc[(size_t)rr * 2 * C + i];
     const size_t cp = (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
-    hrf_atomic_add(&stats[cp + c], (double)sacc[c]);
-    hrf_atomic_add(&stats[cp + C + c], (double)sacc[C + c]);
+    hrf_atomic_add(&stats[cp + i], (double)t);
   }
 }
 
@@ -934,8 +935,7 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(HrfGroup<BilUpBwdA
   int Ws = pa_.Ws;
   float* du = pa_.du;
   double* stats = pa_.stats;
-  HRF_DYN_SMEM(float, sacc);                              // [2*C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) sacc[i] = 0.f;
+  HRF_DYN_SMEM(float, sacc);                              // [R][2*C]
   const int cw = C <= 256 ? C : 256, R = C <= 256 ? 256 / C : 1;
   const int r = threadIdx.x / cw, c0 = threadIdx.x - r * cw;
   const bool active = r < R;
@@ -1018,17 +1018,19 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(HrfGroup<BilUpBwdA
     }
   }
   if (stats == nullptr) return;
-  __syncthreads();
+  // the R row groups of the block meet through plain stores ([R][2*C]) + one pass (LDS float atomics with R lanes per address
+  // cost ~1.5 us at the end of every launch: act_bwd_vec_kernel)
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int c = c0 + 256 * j;
-    if (active && c < C) { hrf_atomic_add(&sacc[c], a1[j]); hrf_atomic_add(&sacc[C + c], a2[j]); }
+    if (active && c < C) { sacc[(size_t)r * 2 * C + c] = a1[j]; sacc[(size_t)r * 2 * C + C + c] = a2[j]; }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.f;
+    for (int rr = 0; rr < R; ++rr) t += sacc[(size_t)rr * 2 * C + i];
     const size_t cp = (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C;
-    hrf_atomic_add(&stats[cp + c], (double)sacc[c]);
-    hrf_atomic_add(&stats[cp + C + c], (double)sacc[C + c]);
+    hrf_atomic_add(&stats[cp + i], (double)t);
   }
 }
 
@@ -1351,7 +1353,7 @@ extern "C" int hrf_bilinear_up_bwd(const float* g, int ldG, int goff, int B, int
   const int R = C <= 256 ? 256 / C : 1;
   int grid = hrf_cdiv(npix, R);
   if (grid > 1024) grid = 1024;
-  HRF_LAUNCH_G(bilinear_up_bwd_kernel, dim3(grid), dim3(256), (unsigned)(2 * C * sizeof(float)), stream,
+  HRF_LAUNCH_G(bilinear_up_bwd_kernel, dim3(grid), dim3(256), (unsigned)((size_t)R * 2 * C * sizeof(float)), stream,
                (BilUpBwdArgs{g, ldG, goff, B, H, W, C, ylow, Hs, Ws, du, stats}));
   return hrf_check_launch();
 }
@@ -1364,7 +1366,7 @@ extern "C" int hrf_nearest_up_bwd(const float* g, int ldG, int goff, int B, int 
   const int R = C <= 256 ? 256 / C : 1;
   int grid = hrf_cdiv(npix, R);
   if (grid > 1024) grid = 1024;
-  HRF_LAUNCH(nearest_up_bwd_kernel, dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), stream, g, ldG, goff,
+  HRF_LAUNCH(nearest_up_bwd_kernel, dim3(grid), dim3(256), (size_t)R * 2 * C * sizeof(float), stream, g, ldG, goff,
              B, H, W, C, ylow, Hs, Ws, du, stats);
   return hrf_check_launch();
 }
