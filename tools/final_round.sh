@@ -28,6 +28,10 @@ bash tools/stage_trace.sh final_$R/st t_nus_bn -- "fwd stage3" "bwd stage3" "fwd
 # gradient all-reduce inside the weight-gradient phase (HRFuser-B: four bucket groups; HRFuser-T forced to four)
 python tools/exchange_overlap.py b_nus_bn > $O/${R}_grad_exchange_overlap_b_nus.txt 2>> $O/bench.err
 python tools/exchange_overlap.py t_nus_bn 4 > $O/${R}_grad_exchange_overlap_t_nus_forced4.txt 2>> $O/bench.err
+# weight gradients: per-variant table of the grouped launches, isolated pixel-major vs LDS-tiled kernel
+python tools/wgrad_groups.py t_nus_bn > $O/${R}_wgrad_groups_t_nus.txt 2>> $O/bench.err
+python tools/wgrad_groups.py b_nus_bn > $O/${R}_wgrad_groups_b_nus.txt 2>> $O/bench.err
+python tools/bench_wgrad_tiled.py > $O/${R}_wgrad_tiled_microbench.txt 2>> $O/bench.err
 # the full GPU suite with its slowest calls
 timeout 1400 python -m pytest tests -m gpu -x -q > $O/${R}_gpu_suite_durations.txt 2>&1; echo "gpu suite rc $?" >> $O/${R}_gpu_suite_durations.txt
 for f in $O/${R}_bench_*.json; do echo $f; tail -1 $f | cut -c1-260; done
