@@ -29,10 +29,12 @@
  *   - hrf_ln_bwd / hrf_dwconv_bwd_weight take `copy_stride`: element distance between the copies of
  *     their fp32 parameter-gradient accumulators (0 = one copy, plain accumulation into the grads);
  *     hrf_fold_copies adds the summed copies into the gradient arena.
- * 8 copies: every block of a CONSUMER launch re-reads all copies in its finalize-on-load prologue (below), and the request
- * count on those hot cache lines is what that prologue costs.  Measured A/B on one box (tools/ab_copies.sh, HRFuser-T
- * training step): 16 copies 17.20 ms, 8: 16.70, 4: 16.64 (producers 15 % slower), 2: 17.1, 1: 18.3. */
-#define HRF_STAT_COPIES 8
+ * 4 copies: every block of a CONSUMER launch re-reads all copies in its finalize-on-load prologue (below), and the request
+ * count on those hot cache lines is what that prologue costs (tools/bench_fin.py: +0.5 us per consumer launch at 4 copies, +1.0 at
+ * 8, +2.0 at 16, +4.5 ... 11 at 32).  Same-box A/B of the captured training steps (tools/ab_copies.sh, ab_copies_models.sh):
+ * round 2: 16 copies 17.20 ms, 8: 16.70, 4: 16.64, 2: 17.1, 1: 18.3; round 5 (kernels 30 % shorter, the prologue a larger share):
+ * HRFuser-T 32 copies 16.14 ms, 16: 12.58, 8: 11.61, 4: **11.47**, 2: 11.54; STF 8: 23.63, 4: 23.39; HRFuser-B 8: 42.98, 4: 42.98. */
+#define HRF_STAT_COPIES 4
 
 /* BatchNorm finalize ON LOAD (consumer side).  A train-mode BatchNorm needs its batch moments complete before anything
  * can be normalised, i.e. a grid-wide dependency between the producing convolution and its consumer; the kernel boundary
