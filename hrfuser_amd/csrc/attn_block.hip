@@ -172,11 +172,11 @@ __device__ __forceinline__ void stage_ln_rows(const hrf_attn_block_t& a, const f
   float s = 0.f;
   for (int c = part; c < C; c += 4) s += row[c];
   s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
-  const float mean = s / (float)C;
+  const float mean = s * (1.0f / (float)C);
   float q = 0.f;
   for (int c = part; c < C; c += 4) { const float d = row[c] - mean; q = fmaf(d, d, q); }
   q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
-  const float rstd = 1.0f / sqrtf(q / (float)C + a.ln_eps);
+  const float rstd = hrf_rsqrt_nr(q * (1.0f / (float)C) + a.ln_eps);
   const bool real = sPix[t] >= 0;                                   // (rows 49..63 and out-of-image tokens stay zero)
   float* wrow = sX + t * PC;
   for (int c = part; c < C; c += 4) { const float y = fmaf((row[c] - mean) * rstd, gam[c], bet[c]); wrow[c] = real ? y : 0.f; }
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<AbFwdArgs>
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_mfma16(acc[t][r], vrow[16 * dt], o[dt]);
         }
-      const float inv = 1.0f / l;
+      const float inv = hrf_rcp(l);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float invr = __shfl(inv, 4 * q + r);
@@ -455,14 +455,14 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(HrfGroup<AbFwdArgs>
 #pragma unroll
     for (int r = 0; r < 4; ++r) sm += (16 * t + 4 * q + r < C) ? xo[t][r] : 0.f;
   sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
-  const float mu = sm / (float)C;
+  const float mu = sm * (1.0f / (float)C);
   float sq = 0.f;
 #pragma unroll
   for (int t = 0; t < CT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const float dd = (16 * t + 4 * q + r < C) ? xo[t][r] - mu : 0.f; sq = fmaf(dd, dd, sq); }
   sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
-  const float rstd = 1.0f / sqrtf(sq / (float)C + a.out_eps);
+  const float rstd = hrf_rsqrt_nr(sq * (1.0f / (float)C) + a.out_eps);
   if (a.out_rowstat != nullptr && q == 0 && pix >= 0) { a.out_rowstat[2 * pc] = mu; a.out_rowstat[2 * pc + 1] = rstd; }
   if (a.w1 == nullptr) return;                                      // (uniform)
 
@@ -631,11 +631,11 @@ __device__ __forceinline__ void stage_xhat_rows(const hrf_attn_block_t& a, const
   float s = 0.f;
   for (int c = part; c < C; c += 4) s += row[c];
   s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
-  const float mean = s / (float)C;
+  const float mean = s * (1.0f / (float)C);
   float qq = 0.f;
   for (int c = part; c < C; c += 4) { const float d = row[c] - mean; qq = fmaf(d, d, qq); }
   qq += __shfl_xor(qq, 1); qq += __shfl_xor(qq, 2);
-  const float rstd = 1.0f / sqrtf(qq / (float)C + eps);
+  const float rstd = hrf_rsqrt_nr(qq * (1.0f / (float)C) + eps);
   const bool real = sPix[t] >= 0;
   for (int c = part; c < C; c += 4) { const float y = (row[c] - mean) * rstd; row[c] = real ? y : 0.f; }
   if (part == 0) sRs[t] = real ? rstd : 0.f;
@@ -666,7 +666,7 @@ __device__ __forceinline__ void ln_bwd_rows(hrf_f4* dn, const float* sXh, int pi
     }
   s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
   s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-  const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+  const float m1 = s1 * (1.0f / (float)C), m2 = s2 * (1.0f / (float)C);
 #pragma unroll
   for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -926,11 +926,11 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (C 
       float s = 0.f;
       for (int c = part; c < C; c += 4) s += row[c];
       s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
-      const float mean = s / (float)C;
+      const float mean = s * (1.0f / (float)C);
       float qq = 0.f;
       for (int c = part; c < C; c += 4) { const float d = row[c] - mean; qq = fmaf(d, d, qq); }
       qq += __shfl_xor(qq, 1); qq += __shfl_xor(qq, 2);
-      const float rstd = 1.0f / sqrtf(qq / (float)C + eps);
+      const float rstd = hrf_rsqrt_nr(qq * (1.0f / (float)C) + eps);
       for (int c = part; c < C; c += 4) { const float y = (row[c] - mean) * rstd; row[c] = real ? y : 0.f; }
       if (part == 0) (which == 0 ? sRs2 : (which == 1 ? sRsQ : sRsKV))[t] = real ? rstd : 0.f;
     }
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(64 * (4 + NWB), (NWB == 0 ? (C <= 18 ? 3 : 1) : (C 
       for (int r = 0; r < 4; ++r) { sA[t][r] = __expf(sA[t][r] - m); l += sA[t][r]; }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
-    const float inv = 1.0f / l;
+    const float inv = hrf_rcp(l);
     float Dl = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)

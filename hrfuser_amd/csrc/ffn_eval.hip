@@ -99,11 +99,11 @@ __global__ __launch_bounds__(256) void ffn_eval_kernel(hrf_ffn_eval_t a) {
     float s = 0.f;
     for (int c = part; c < C; c += 2) s += row[c];
     s += __shfl_xor(s, 1);
-    const float mean = s / (float)C;
+    const float mean = s * (1.0f / (float)C);
     float qq = 0.f;
     for (int c = part; c < C; c += 2) { const float d = row[c] - mean; qq = fmaf(d, d, qq); }
     qq += __shfl_xor(qq, 1);
-    const float rstd = 1.0f / sqrtf(qq / (float)C + a.ln_eps);
+    const float rstd = hrf_rsqrt_nr(qq * (1.0f / (float)C) + a.ln_eps);
     if (p < FE_NPH)
       for (int c = part; c < C; c += 2) row[c] = fmaf((row[c] - mean) * rstd, a.ln_g[c], a.ln_b[c]);
   }
