@@ -529,6 +529,14 @@ def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None, grouped=None)
     if fam == 'wgrad_dense_kernel' and grouped:
         row = roofline_grouped(grouped, peak_f, peak_b)
         row['resources'] = kernel_resources(row['kernel'].replace(', ', ', ')) or kernel_resources('wgrad_dense_kernel')
+        t1 = traffic.get('kernel:' + row['kernel'])
+        if t1 is not None:
+            # PMC bytes exist for ONE problem of this variant launched on its own (tools/pmc_kernels.py), not for the grouped
+            # launch the row prices: reported beside it, `traffic` itself stays null
+            row['traffic_one_problem'] = {
+                'bytes': t1['bytes_per_launch'],
+                'source': f'profiles/{tname}[{row["kernel"]}]: 2 x FETCH_SIZE + WRITE_SIZE of one launch of this variant on the 2 x 96 x 160 '
+                          'problem of its family (separate rocprofv3 --pmc passes)'}
     else:
         key = max((k for k in table if base(k) == fam), key=lambda k: table[k][1])
         row = _family_row(table, key, peak_f, peak_b, traffic, tname)
