@@ -56,6 +56,7 @@ struct ConvFwdArgs {
   int B, H, W, Cin, Ho, Wo, Cout, stride, pad;
   int sB, sY, sX, sC;
   int M, K;
+  int ksplit;                                  // > 1: slice blockIdx.y / column blocks takes 1 / ksplit of the K steps and ADDS its partial tile into a zeroed y (no moments)
 };
 
 // --------------------------------------------------------------------------------- forward
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(HrfGroup<ConvFwdArgs> grp
   __shared__ float sStat[4 * 2 * BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kl = tid & 63, r0 = tid >> 6;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int nyb = (a.Cout + BN - 1) / BN, ksl = (int)blockIdx.y / nyb;           // (split over K: blockIdx.y = slice * nyb + column block;
+  const int m0 = blockIdx.x * BM, n0 = ((int)blockIdx.y - ksl * nyb) * BN;        //  blockIdx.z is the problem index of HrfGroup)
   __shared__ float sFin[(TF >= HRF_TF_AFFINE && TF <= HRF_TF_AFFINE_GELU) ? 2 * HRF_FIN_MAXC : 4];
   const float* scp = a.tf_scale;
   const float* shp = a.tf_shift;
@@ -151,15 +153,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(HrfGroup<ConvFwdArgs> grp
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
 
-  load_tile(0);
-  for (int k0 = 0; k0 < a.K; k0 += BK) {
+  // split over K (a.ksplit > 1, slice ksl): the 2 304-deep stride-2 transition convolutions have 120 row blocks for 256 CUs and 36
+  // serial 64-deep steps each; four slices of 9 steps fill the chip and their partial tiles meet in y through atomics
+  const int nstep = (a.K + BK - 1) / BK, sper = (nstep + a.ksplit - 1) / a.ksplit;
+  const int klo = ksl * sper * BK, khi = min(a.K, klo + sper * BK);
+  load_tile(klo);
+  for (int k0 = klo; k0 < khi; k0 += BK) {
 #pragma unroll
     for (int p = 0; p < RP; ++p) As[(r0 + 4 * p) * LDK + kl] = areg[p];
 #pragma unroll
     for (int q = 0; q < RQ; ++q) Bs[(r0 + 4 * q) * LDK + kl] = breg[q];
     __syncthreads();
-    if (k0 + BK < a.K) load_tile(k0 + BK);
-    const int ksub = min(16, (a.K - k0 + 3) >> 2);
+    if (k0 + BK < khi) load_tile(k0 + BK);
+    const int ksub = min(16, (khi - k0 + 3) >> 2);
 #pragma unroll 4
     for (int kk = 0; kk < ksub; ++kk) {
       const int kc = kk * 4 + (lane >> 4);
@@ -176,7 +182,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(HrfGroup<ConvFwdArgs> grp
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + j * 16 + col;
     const bool nv = n < a.Cout;
-    const float bv = a.bias != nullptr ? a.bias[nv ? n : 0] : 0.f;
+    const bool first = ksl == 0;                        // (split over K: bias / residuals join the first slice)
+    const float bv = (a.bias != nullptr && first) ? a.bias[nv ? n : 0] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -184,10 +191,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(HrfGroup<ConvFwdArgs> grp
       const bool ok = nv && m < a.M;
       float v = acc[j][r] + bv;
       const int ro = ok ? m * a.ldR + n : 0;
-      if (a.res != nullptr) v += a.res[ro];
-      if (a.res2 != nullptr) v += a.res2[ro];
+      if (a.res != nullptr && first) v += a.res[ro];
+      if (a.res2 != nullptr && first) v += a.res2[ro];
       if (ok) {
-        a.y[m * a.ldY + a.yoff + n] = v;
+        if (a.ksplit > 1) hrf_atomic_add(&a.y[m * a.ldY + a.yoff + n], v);
+        else a.y[m * a.ldY + a.yoff + n] = v;
         s1 += v; s2 = fmaf(v, v, s2);
       }
     }
@@ -817,7 +825,7 @@ inline int pick_nt(int C) {
 }  // namespace
 
 #define HRF_CF_LAUNCH(NT_, KH_, TF_) \
-  HRF_LAUNCH_G((conv_fwd_kernel<NT_, KH_, TF_>), dim3(hrf_cdiv(a.M, BM), hrf_cdiv(Cout, NT_ * 16)), dim3(256), 0, stream, a)
+  HRF_LAUNCH_G((conv_fwd_kernel<NT_, KH_, TF_>), dim3(hrf_cdiv(a.M, BM), hrf_cdiv(Cout, NT_ * 16) * a.ksplit), dim3(256), 0, stream, a)
 #define HRF_CF_NT(KH_, TF_)                          \
   switch (nt) {                                      \
     case 2: HRF_CF_LAUNCH(2, KH_, TF_); break;       \
@@ -854,7 +862,7 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
   a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin;
   a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KH) / stride + 1;
   a.Cout = Cout; a.stride = stride; a.pad = pad; a.sB = sB; a.sY = sY; a.sX = sX; a.sC = sC;
-  a.M = B * a.Ho * a.Wo; a.K = KH * KH * Cin;
+  a.M = B * a.Ho * a.Wo; a.K = KH * KH * Cin; a.ksplit = 1;
   if (a.M <= 0) return HRF_OK;
   if (KH == 1 && stride == 1 && sC == 1 && sY == W * sX && sB == H * sY && g_knob[4] == 0) {
     // channel-contiguous rows: LDS-free row-GEMM kernel (lin_engine.hip)
@@ -881,10 +889,23 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
     return rc3;
   }
   const int nt = pick_nt(Cout);
+  // deep contraction, few row blocks (the 256 -> 36 stride-2 transition: K = 2 304, 120 blocks): split over K, the moments of the
+  // summed output by a pass of their own (hrf_debug_knob(9, 1): off)
+  const int nblk = hrf_cdiv(a.M, BM) * hrf_cdiv(Cout, nt * 16);
+  const bool ksp = KH == 3 && a.K >= 1024 && nblk <= 128 && ldY == Cout && yoff == 0 && g_knob[9] != 1;
+  if (ksp) {
+    a.ksplit = 4;                                            // (HRFuser-T: 120 row blocks, 115.6 -> 61.6 us with the two extra launches; STF's 234 blocks in two slices: 118 -> 111 us, not taken)
+    a.stats = nullptr;
+    if (hrf_memset(y, 0, (long)a.M * Cout * (long)sizeof(float), stream) != HRF_OK) return HRF_ERR_LAUNCH;
+  }
   if (KH == 1) {
     if (tf_mode == HRF_TF_LN) { HRF_CF_NT(1, HRF_TF_LN) } else { HRF_CF_TF(1) }
   } else {
     HRF_CF_TF(3)
+  }
+  if (ksp && stats != nullptr) {
+    if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH;
+    if (hrf_gn_moments(y, nullptr, 1, a.M, Cout, stats, stream) != HRF_OK) return HRF_ERR_LAUNCH;   // (sum, sum of squares) into copy 0
   }
   if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();

@@ -15,7 +15,7 @@ extern "C" {
  * 1 = its atomics replaced by plain stores (wrong results; 2 = the ci*9+tap variant instead of the tap-blocked one), 2 = the
  * generic weight-gradient kernel, 3 = split cap of the pixel-major kernel, 4 / 6 = the generic implicit-GEMM engine instead of
  * the row-GEMM / 3x3 halo engines, 5 = minimum width of the halo engine's data gradient, 7 = time the grouped weight-gradient
- * launches (hrf_wgrad_group_report), 8 = the LDS-tiled weight gradient (1 = off, 2 = for every stride-1 1x1 problem); 16..19 pointwise.hip, 24..27 conv3w_engine.hip, 28..31 lin2_engine.hip. */
+ * launches (hrf_wgrad_group_report), 8 = the LDS-tiled weight gradient (1 = off, 2 = for every stride-1 1x1 problem), 9 = 1: no split over K in the generic forward convolution; 16..19 pointwise.hip, 24..27 conv3w_engine.hip, 28..31 lin2_engine.hip. */
 int hrf_debug_knob(int key, int value);
 
 /* hrf_debug_knob(7, 1): HIP-event durations of the grouped weight-gradient launches of eager steps, aggregated per kernel

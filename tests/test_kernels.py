@@ -780,7 +780,7 @@ def test_wgrad_group_gpu():
 
 
 # ------------------------------------------------------------------ emulator (CPU suite)
-@pytest.mark.parametrize('case', CONV_CASES[:8] + CONV_CASES[-3:], ids=str)
+@pytest.mark.parametrize('case', CONV_CASES[:8] + CONV_CASES[12:13] + CONV_CASES[-3:], ids=str)      # ([12]: the split over K)
 def test_conv_emul(case):
     run_conv(case, 'emul')
 
