@@ -47,14 +47,14 @@ __device__ __forceinline__ int tok_pixel(const AttnArgs& a, int b, int wy, int w
   return -1;
 }
 
-constexpr int SP = 65;      // pitch of the [key j][query i] dS plane of the backward kernel
+constexpr int SP = 51;      // pitch of the [key j][query i < 49] dS plane of the backward kernel (odd)
 
 // Staging for the MFMA kernels: [64][P] tiles of Q (scaled), K, V (and dO), zero outside the 49 x D payload.  All global
 // loads of a thread are issued before the first LDS store (one round trip instead of one per loop iteration).
-template <int D, int P, bool BWD>
+template <int D, int P, bool BWD, int ROWS = 64>
 __device__ __forceinline__ void stage_tiles(const AttnArgs& a, int b, int wy, int wx, int h, float* sQ, float* sK, float* sV,
                                             float* sG) {
-  for (int e = threadIdx.x; e < 64 * P; e += 256) {
+  for (int e = threadIdx.x; e < ROWS * P; e += 256) {
     const int j = e / P, d = e - j * P;
     if (j >= NT || d >= D) { sQ[e] = 0.f; sK[e] = 0.f; sV[e] = 0.f; if (BWD) sG[e] = 0.f; }
   }
@@ -198,10 +198,14 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(HrfGroup<AttnArgs> grp) {
   const AttnArgs& a = grp.sel();
   constexpr int KS = (D + 3) / 4, DT = (D + 15) / 16, P = DT * 16 + 1;
-  __shared__ float sQ[64 * P];
-  __shared__ float sK[64 * P];
-  __shared__ float sV[64 * P];
-  __shared__ float sG[64 * P];                                      // dO rows
+  // 49-ROW tiles (round 5): the MFMA fragments of token tile 3 read rows 48 .. 63, of which only row 48 exists - those reads are
+  // clamped to row 48 (finite values; every product they enter is masked: P = dS = 0 for tokens >= 49).  At head_dim 39
+  // (HRFuser-B) the block's LDS drops 65 -> 50 KB: three blocks per CU, the 1 288 (window, head) blocks of the 96x160 map run in two
+  // rounds instead of three
+  __shared__ float sQ[NT * P];
+  __shared__ float sK[NT * P];
+  __shared__ float sV[NT * P];
+  __shared__ float sG[NT * P];                                      // dO rows
   __shared__ float sD[NT * SP];                                     // dS[key][query] plane (relative position bias)
   // dK / dV rows reuse the K / V tiles once the last MFMA has read them: 48 KB of LDS per block at D = 18, i.e. three
   // resident blocks per CU - the 644 windows of the 96x160 map then run in one round instead of two
@@ -214,7 +218,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(HrfGroup<AttnArgs> g
   const int i = lane & 15, q = lane >> 4;
   const int win = blockIdx.x;
   const int wx = win % a.nWw, wy = (win / a.nWw) % a.nWh, b = win / (a.nWw * a.nWh);
-  stage_tiles<D, P, true>(a, b, wy, wx, h, sQ, sK, sV, sG);
+  stage_tiles<D, P, true, NT>(a, b, wy, wx, h, sQ, sK, sV, sG);
+  const int wrow = min(16 * wave + i, NT - 1);                      // the wave's own token row, clamped (see above)
   for (int e = threadIdx.x; e < 169; e += 256) sT[e] = a.rpb[e * a.heads + h];
   if (threadIdx.x < 64) sPad[threadIdx.x] = (threadIdx.x < NT && tok_pixel(a, b, wy, wx, threadIdx.x) < 0) ? 1 : 0;
   __syncthreads();
@@ -224,15 +229,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(HrfGroup<AttnArgs> g
     hrf_f4 s[4], dp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
-    const float* qrow = sQ + (16 * wave + i) * P + q;
-    const float* grow = sG + (16 * wave + i) * P + q;
+    const float* qrow = sQ + wrow * P + q;
+    const float* grow = sG + wrow * P + q;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const float qv = qrow[4 * kk], gv = grow[4 * kk];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        s[t] = hrf_mfma16(sK[(16 * t + i) * P + 4 * kk + q], qv, s[t]);
-        dp[t] = hrf_mfma16(sV[(16 * t + i) * P + 4 * kk + q], gv, dp[t]);
+        const int tr = t == 3 ? NT - 1 : 16 * t + i;                   // (tile 3: rows 48 .. 63 -> 48)
+        s[t] = hrf_mfma16(sK[tr * P + 4 * kk + q], qv, s[t]);
+        dp[t] = hrf_mfma16(sV[tr * P + 4 * kk + q], gv, dp[t]);
       }
     }
     const int qi = 16 * wave + i, qc = qi < NT ? qi : 0;
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(HrfGroup<AttnArgs> g
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float* krow = sK + (16 * t + 4 * q + r) * P + i;
+        const float* krow = sK + (t == 3 ? NT - 1 : 16 * t + 4 * q + r) * P + i;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = hrf_mfma16(s[t][r], krow[16 * dt], o[dt]);
       }
@@ -304,15 +310,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(HrfGroup<AttnArgs> g
     hrf_f4 s[4], dp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { s[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; dp[t] = hrf_f4{0.f, 0.f, 0.f, 0.f}; }
-    const float* krow = sK + (16 * wave + i) * P + q;
-    const float* vrow = sV + (16 * wave + i) * P + q;
+    const float* krow = sK + wrow * P + q;
+    const float* vrow = sV + wrow * P + q;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const float kv = krow[4 * kk], vv = vrow[4 * kk];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        s[t] = hrf_mfma16(sQ[(16 * t + i) * P + 4 * kk + q], kv, s[t]);       // S[query 16t+4q+r][key 16w+i]
-        dp[t] = hrf_mfma16(sG[(16 * t + i) * P + 4 * kk + q], vv, dp[t]);
+        const int tr = t == 3 ? NT - 1 : 16 * t + i;
+        s[t] = hrf_mfma16(sQ[tr * P + 4 * kk + q], kv, s[t]);                  // S[query 16t+4q+r][key 16w+i]
+        dp[t] = hrf_mfma16(sG[tr * P + 4 * kk + q], vv, dp[t]);
       }
     }
     const int kj = 16 * wave + i, kc = kj < NT ? kj : 0;
@@ -336,8 +343,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(HrfGroup<AttnArgs> g
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float* gr = sG + (16 * t + 4 * q + r) * P + i;
-        const float* qr = sQ + (16 * t + 4 * q + r) * P + i;
+        const int tr = t == 3 ? NT - 1 : 16 * t + 4 * q + r;
+        const float* gr = sG + tr * P + i;
+        const float* qr = sQ + tr * P + i;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           ov[dt] = hrf_mfma16(s[t][r], gr[16 * dt], ov[dt]);

@@ -892,7 +892,8 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
   // deep contraction, few row blocks (the 256 -> 36 stride-2 transition: K = 2 304, 120 blocks): split over K, the moments of the
   // summed output by a pass of their own (hrf_debug_knob(9, 1): off)
   const int nblk = hrf_cdiv(a.M, BM) * hrf_cdiv(Cout, nt * 16);
-  const bool ksp = KH == 3 && a.K >= 1024 && nblk <= 128 && ldY == Cout && yoff == 0 && g_knob[9] != 1;
+  const bool ksp = KH == 3 && a.K >= 1024 && nblk <= 128 && ldY == Cout && yoff == 0 && g_knob[9] != 1 &&
+                   !hrf_grp_collecting();          // (a merged multi-problem launch is issued LATER, at hrf_group_end: the zeroing and the moments pass around it are not)
   if (ksp) {
     a.ksplit = 4;                                            // (HRFuser-T: 120 row blocks, 115.6 -> 61.6 us with the two extra launches; STF's 234 blocks in two slices: 118 -> 111 us, not taken)
     a.stats = nullptr;
