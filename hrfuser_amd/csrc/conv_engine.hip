@@ -56,7 +56,8 @@ struct ConvFwdArgs {
   int B, H, W, Cin, Ho, Wo, Cout, stride, pad;
   int sB, sY, sX, sC;
   int M, K;
-  int ksplit;                                  // > 1: slice blockIdx.y / column blocks takes 1 / ksplit of the K steps and ADDS its partial tile into a zeroed y (no moments)
+  int ksplit; float* part;                     // ksplit > 1: slice blockIdx.y / column blocks takes 1 / ksplit of the K steps; slice 0 stores its partial
+                                               // tile (+ bias / residuals) to y, slice k >= 1 to part[(k - 1) * M * Cout ...] (dense [M][Cout]); no moments
 };
 
 // --------------------------------------------------------------------------------- forward
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(HrfGroup<ConvFwdArgs> grp
   for (int j = 0; j < NT; ++j) acc[j] = hrf_f4{0.f, 0.f, 0.f, 0.f};
 
   // split over K (a.ksplit > 1, slice ksl): the 2 304-deep stride-2 transition convolutions have 120 row blocks for 256 CUs and 36
-  // serial 64-deep steps each; four slices of 9 steps fill the chip and their partial tiles meet in y through atomics
+  // serial 64-deep steps each; four slices of 9 steps fill the chip; their partial tiles are added in a FIXED order by
+  // splitk_reduce_kernel (no atomics: the forward stays bit-reproducible)
   const int nstep = (a.K + BK - 1) / BK, sper = (nstep + a.ksplit - 1) / a.ksplit;
   const int klo = ksl * sper * BK, khi = min(a.K, klo + sper * BK);
   load_tile(klo);
@@ -194,8 +196,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(HrfGroup<ConvFwdArgs> grp
       if (a.res != nullptr && first) v += a.res[ro];
       if (a.res2 != nullptr && first) v += a.res2[ro];
       if (ok) {
-        if (a.ksplit > 1) hrf_atomic_add(&a.y[m * a.ldY + a.yoff + n], v);
-        else a.y[m * a.ldY + a.yoff + n] = v;
+        if (first) a.y[m * a.ldY + a.yoff + n] = v;
+        else a.part[(size_t)(ksl - 1) * a.M * a.Cout + (size_t)m * a.Cout + n] = v;
         s1 += v; s2 = fmaf(v, v, s2);
       }
     }
@@ -812,6 +814,15 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
   }
 }
 
+// y[i] += part[0][i] + part[1][i] + ... in a fixed order (i over the dense [M][Cout] output of a split-over-K forward)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(float* y, const float* part, long n, int nparts) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = y[i];
+    for (int k = 0; k < nparts; ++k) v += part[(size_t)k * n + i];
+    y[i] = v;
+  }
+}
+
 inline int pick_nt(int C) {
   const int T = (C + 15) / 16;
   int best = 2, cost = 1 << 30;
@@ -840,12 +851,23 @@ inline int pick_nt(int C) {
     default: HRF_CF_NT(KH_, HRF_TF_AFFINE_GELU) break;            \
   }
 
-extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin,
-                            const float* w, const float* bias, int KH, int stride, int Cout,
-                            float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
-                            int tf_mode, const float* tf_scale, const float* tf_shift,
-                            const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat,
-                            float ln_eps, void* stream) {
+// the policy of the split over K (shared by hrf_conv_fwd_split_scratch and the launch): slices, or 1
+static int conv_fwd_ksplit(int B, int H, int W, int Cin, int KH, int stride, int Cout, int ldY, int yoff, bool dense_nhwc) {
+  if (KH != 3 || g_knob[9] == 1 || ldY != Cout || yoff != 0) return 1;
+  if (stride == 1 && Cin >= 32 && dense_nhwc && g_knob[6] == 0) return 1;          // (the 3x3 halo engine takes these)
+  const int pad = 1, Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KH) / stride + 1;
+  const long M = (long)B * Ho * Wo;
+  const int nt = pick_nt(Cout);
+  if (M <= 0 || KH * KH * Cin < 1024 || hrf_cdiv(M, BM) * hrf_cdiv(Cout, nt * 16) > 128) return 1;
+  return 4;
+}
+
+static int conv_fwd_impl(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin,
+                         const float* w, const float* bias, int KH, int stride, int Cout,
+                         float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
+                         int tf_mode, const float* tf_scale, const float* tf_shift,
+                         const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat,
+                         float ln_eps, float* scratch, void* stream) {
   HRF_GROUP_CALL();
   if ((KH != 1 && KH != 3) || (stride != 1 && stride != 2)) return HRF_ERR_ARG;
   if (tf_mode < 0 || tf_mode > 4) return HRF_ERR_ARG;
@@ -862,7 +884,7 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
   a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin;
   a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KH) / stride + 1;
   a.Cout = Cout; a.stride = stride; a.pad = pad; a.sB = sB; a.sY = sY; a.sX = sX; a.sC = sC;
-  a.M = B * a.Ho * a.Wo; a.K = KH * KH * Cin; a.ksplit = 1;
+  a.M = B * a.Ho * a.Wo; a.K = KH * KH * Cin; a.ksplit = 1; a.part = nullptr;
   if (a.M <= 0) return HRF_OK;
   if (KH == 1 && stride == 1 && sC == 1 && sY == W * sX && sB == H * sY && g_knob[4] == 0) {
     // channel-contiguous rows: LDS-free row-GEMM kernel (lin_engine.hip)
@@ -891,25 +913,57 @@ extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int 
   const int nt = pick_nt(Cout);
   // deep contraction, few row blocks (the 256 -> 36 stride-2 transition: K = 2 304, 120 blocks): split over K, the moments of the
   // summed output by a pass of their own (hrf_debug_knob(9, 1): off)
-  const int nblk = hrf_cdiv(a.M, BM) * hrf_cdiv(Cout, nt * 16);
-  const bool ksp = KH == 3 && a.K >= 1024 && nblk <= 128 && ldY == Cout && yoff == 0 && g_knob[9] != 1 &&
-                   !hrf_grp_collecting();          // (a merged multi-problem launch is issued LATER, at hrf_group_end: the zeroing and the moments pass around it are not)
-  if (ksp) {
-    a.ksplit = 4;                                            // (HRFuser-T: 120 row blocks, 115.6 -> 61.6 us with the two extra launches; STF's 234 blocks in two slices: 118 -> 111 us, not taken)
-    a.stats = nullptr;
-    if (hrf_memset(y, 0, (long)a.M * Cout * (long)sizeof(float), stream) != HRF_OK) return HRF_ERR_LAUNCH;
-  }
+  // (HRFuser-T: 120 row blocks, 115.6 -> ~60 us with the two extra launches; STF's 234 blocks in two slices: 118 -> 111 us, not taken.
+  // Not while a merged multi-problem launch is being collected: that launch is issued LATER, at hrf_group_end - the passes behind
+  // it here would run first)
+  const int ks = (scratch != nullptr && !hrf_grp_collecting())
+                     ? conv_fwd_ksplit(B, H, W, Cin, KH, stride, Cout, ldY, yoff, sC == 1 && sY == W * sX && sB == H * sY) : 1;
+  const bool ksp = ks > 1;
+  if (ksp) { a.ksplit = ks; a.part = scratch; a.stats = nullptr; }
   if (KH == 1) {
     if (tf_mode == HRF_TF_LN) { HRF_CF_NT(1, HRF_TF_LN) } else { HRF_CF_TF(1) }
   } else {
     HRF_CF_TF(3)
   }
-  if (ksp && stats != nullptr) {
+  if (ksp) {
     if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH;
-    if (hrf_gn_moments(y, nullptr, 1, a.M, Cout, stats, stream) != HRF_OK) return HRF_ERR_LAUNCH;   // (sum, sum of squares) into copy 0
+    const long n = (long)a.M * Cout;
+    HRF_LAUNCH(splitk_reduce_kernel, dim3((unsigned)std::min<long>(2048, (n + 255) / 256)), dim3(256), 0, stream, y, (const float*)scratch, n, ks - 1);
+    if (stats != nullptr) {
+      if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH;
+      if (hrf_gn_moments(y, nullptr, 1, a.M, Cout, stats, stream) != HRF_OK) return HRF_ERR_LAUNCH;   // (sum, sum of squares) into copy 0
+    }
   }
   if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();
+}
+
+extern "C" int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin,
+                            const float* w, const float* bias, int KH, int stride, int Cout,
+                            float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
+                            int tf_mode, const float* tf_scale, const float* tf_shift,
+                            const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat,
+                            float ln_eps, void* stream) {
+  return conv_fwd_impl(x, sB, sY, sX, sC, B, H, W, Cin, w, bias, KH, stride, Cout, y, ldY, yoff, res, res2, ldR, tf_mode, tf_scale,
+                       tf_shift, tf_rowstat, stats, tf_fin, ln_rowstat, ln_eps, nullptr, stream);
+}
+
+extern "C" long hrf_conv_fwd_split_scratch(int sB, int sY, int sX, int sC, int B, int H, int W, int Cin, int KH, int stride, int Cout,
+                                           int ldY, int yoff) {
+  const int ks = conv_fwd_ksplit(B, H, W, Cin, KH, stride, Cout, ldY, yoff, sC == 1 && sY == W * sX && sB == H * sY);
+  if (ks <= 1) return 0;
+  const int Ho = (H + 2 - KH) / stride + 1, Wo = (W + 2 - KH) / stride + 1;
+  return (long)(ks - 1) * B * Ho * Wo * Cout;
+}
+
+extern "C" int hrf_conv_fwd_split(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin,
+                                  const float* w, const float* bias, int KH, int stride, int Cout,
+                                  float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
+                                  int tf_mode, const float* tf_scale, const float* tf_shift,
+                                  const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat,
+                                  float ln_eps, float* scratch, void* stream) {
+  return conv_fwd_impl(x, sB, sY, sX, sC, B, H, W, Cin, w, bias, KH, stride, Cout, y, ldY, yoff, res, res2, ldR, tf_mode, tf_scale,
+                       tf_shift, tf_rowstat, stats, tf_fin, ln_rowstat, ln_eps, scratch, stream);
 }
 
 #define HRF_BD_LAUNCH(NT_, KH_, BNB_) \

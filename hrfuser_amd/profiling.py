@@ -30,7 +30,7 @@ def _out_hw(H, W, KH, s):
 def work_model(name, a):
     """-> (kernel key as rocprof names it, algorithmic FLOPs, compulsory HBM bytes) of one launch."""
     f4 = 4.0
-    if name == 'hrf_conv_fwd':
+    if name in ('hrf_conv_fwd', 'hrf_conv_fwd_split'):       # (_split: K slices + fixed-order reduce + moments, priced as ONE call)
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         M, K = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']
         by = f4 * (a['B'] * a['H'] * a['W'] * a['Cin'] + a['Cout'] * K + M * a['Cout'] * (1 + (a['res'] is not None) + (a['res2'] is not None)))

@@ -1470,8 +1470,14 @@ def conv_bn(ctx, src, conv, bn, mode):
     slot = ctx.owner._bn_slot(bn)
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None
-    L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
-                   tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, s)
+    # deep contraction, few row blocks (the 256 -> 36 stride-2 transition): split over K, partial tiles in step-lifetime scratch
+    nsc = L.hrf_conv_fwd_split_scratch(*strides, B, H, W, Cin, KH, stride, Cout, Cout, 0) if KH == 3 else 0
+    if nsc > 0:
+        L.hrf_conv_fwd_split(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
+                             tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, _new((nsc,), x.device), s)
+    else:
+        L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
+                       tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, s)
     st = bn_forward(ctx, bn, y, stats)
     out = Lazy(st, mode)
     if ctx.probe is not None and mode == TF_RELU:

@@ -87,6 +87,19 @@ int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int B, int H, i
                  float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
                  int tf_mode, const float* tf_scale, const float* tf_shift,
                  const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat, float ln_eps, void* stream);
+/* The same forward with a SPLIT OVER K for deep contractions that leave the chip empty (3x3, K = 9*Cin >= 1024, <= 128 row blocks:
+ * the 256 -> 36 stride-2 transition, hrnet.py:430-459): four K slices write partial tiles (slice 0 into y, the others into
+ * `scratch`), a second launch adds them in a fixed order (bit-reproducible), a third takes the moments.
+ * hrf_conv_fwd_split_scratch -> floats of scratch this problem wants (0: it would not be split - call hrf_conv_fwd);
+ * hrf_conv_fwd_split with scratch == NULL is hrf_conv_fwd. */
+long hrf_conv_fwd_split_scratch(int sB, int sY, int sX, int sC, int B, int H, int W, int Cin, int KH, int stride, int Cout,
+                                int ldY, int yoff);
+int hrf_conv_fwd_split(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin,
+                       const float* w, const float* bias, int KH, int stride, int Cout,
+                       float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
+                       int tf_mode, const float* tf_scale, const float* tf_shift,
+                       const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat, float ln_eps,
+                       float* scratch, void* stream);
 /* dX (or, epi=1, dU = dX*act'(scale*xraw+shift) plus (sum dU, sum dU*xraw) for the producer BN).
  * (cA,cB,cC) != NULL applies the BatchNorm backward on load: dy = cA*du + cB*yraw + cC; with `bfin` (nullable, Cout <=
  * HRF_FIN_MAXC) the coefficients are derived in the kernel prologue from bfin->gstats instead of being read (see

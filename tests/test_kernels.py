@@ -160,6 +160,21 @@ def run_conv(case, backend):
     assert r(yk, yref) < TOL
     s1, s2 = yref.reshape(-1, Cout).double().sum(0), (yref.reshape(-1, Cout).double() ** 2).sum(0)
     assert r(fold(stats)[:Cout], s1) < TOL and r(fold(stats)[Cout:], s2) < TOL
+    # the split over K (deep 3x3 contractions with few row blocks): same output, same moments, bit-reproducible
+    nsc = L.hrf_conv_fwd_split_scratch(*st, B, H, W, Cin, KH, stride, Cout, Cout, 0)
+    if nsc > 0:
+        assert KH == 3 and 9 * Cin >= 1024
+        outs = []
+        for _ in range(2):
+            yk3, st3 = torch.zeros(B, Ho, Wo, Cout, device=dev), zstat(Cout, dev)
+            L.hrf_conv_fwd_split(D(xr), *st, B, H, W, Cin, D(w), D(bias), KH, stride, Cout, yk3, Cout, 0, D(res), None, Cout,
+                                 tf, D(sc) if (tf and fin is None) else None, D(sh) if (tf and fin is None) else None, D(rowstat), st3,
+                                 fin, None, 0.0, torch.empty(nsc, device=dev), _lib.stream_ptr())
+            outs.append(yk3)
+            if fin is None:
+                assert r(yk3, yref) < TOL
+                assert r(fold(st3)[:Cout], s1) < TOL and r(fold(st3)[Cout:], s2) < TOL
+        assert torch.equal(outs[0], outs[1])
     # NCHW input through strides (stem path)
     if tf == 0:
         yk2 = torch.zeros_like(yk)
