@@ -25,6 +25,7 @@
 // Reference ops replaced: every nn.Conv2d(k=1|3, groups=1) + nn.Linear reached from
 // mmdet/models/backbones/{hrfuser_hrformer_based,hrformer,hrnet,resnet}.py.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 #include "hrf_common.h"
 #include "hrf_group.h"
@@ -814,12 +815,31 @@ __global__ __launch_bounds__(64 * WNW) void wgrad_dense_kernel(WgradGroup grp_ar
   }
 }
 
-// y[i] += part[0][i] + part[1][i] + ... in a fixed order (i over the dense [M][Cout] output of a split-over-K forward)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(float* y, const float* part, long n, int nparts) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    float v = y[i];
-    for (int k = 0; k < nparts; ++k) v += part[(size_t)k * n + i];
-    y[i] = v;
+// y[row][c] += part[0][row][c] + part[1][row][c] + ... in a fixed order (dense [M][C] output of a split-over-K forward), and the
+// BatchNorm moments (sum, sum of squares) of the result: a thread keeps ONE channel (C <= 256: 256 / C rows per pass), its
+// partial sums meet in LDS in a fixed order, one fp64 atomic per channel and block - like every other producer of moments (the
+// generic hrf_gn_moments sums through LDS float atomics: the eager and the captured step then differed by 1.5e-5 in the gradients)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(float* y, const float* part, int M, int C, int nparts, double* stats) {
+  HRF_DYN_SMEM(float, sacc);                               // [R][2*C]
+  const int R = 256 / C, r = threadIdx.x / C, c = threadIdx.x - r * C;
+  const size_t n = (size_t)M * C;
+  float s1 = 0.f, s2 = 0.f;
+  if (r < R) {
+    for (int row = blockIdx.x * R + r; row < M; row += gridDim.x * R) {
+      const size_t i = (size_t)row * C + c;
+      float v = y[i];
+      for (int k = 0; k < nparts; ++k) v += part[(size_t)k * n + i];
+      y[i] = v;
+      s1 += v; s2 = fmaf(v, v, s2);
+    }
+    sacc[(size_t)r * 2 * C + c] = s1; sacc[(size_t)r * 2 * C + C + c] = s2;
+  }
+  if (stats == nullptr) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    double t = 0.0;
+    for (int rr = 0; rr < R; ++rr) t += (double)sacc[(size_t)rr * 2 * C + i];
+    hrf_atomic_add(&stats[(size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * C + i], t);
   }
 }
 
@@ -853,7 +873,8 @@ inline int pick_nt(int C) {
 
 // the policy of the split over K (shared by hrf_conv_fwd_split_scratch and the launch): slices, or 1
 static int conv_fwd_ksplit(int B, int H, int W, int Cin, int KH, int stride, int Cout, int ldY, int yoff, bool dense_nhwc) {
-  if (KH != 3 || g_knob[9] == 1 || ldY != Cout || yoff != 0) return 1;
+  static const bool off = std::getenv("HRF_NO_KSPLIT") != nullptr;               // (A/B switch, like hrf_debug_knob(9, 1))
+  if (KH != 3 || g_knob[9] == 1 || off || ldY != Cout || yoff != 0 || Cout > 256) return 1;
   if (stride == 1 && Cin >= 32 && dense_nhwc && g_knob[6] == 0) return 1;          // (the 3x3 halo engine takes these)
   const int pad = 1, Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KH) / stride + 1;
   const long M = (long)B * Ho * Wo;
@@ -927,12 +948,9 @@ static int conv_fwd_impl(const float* x, int sB, int sY, int sX, int sC, int B, 
   }
   if (ksp) {
     if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH;
-    const long n = (long)a.M * Cout;
-    HRF_LAUNCH(splitk_reduce_kernel, dim3((unsigned)std::min<long>(2048, (n + 255) / 256)), dim3(256), 0, stream, y, (const float*)scratch, n, ks - 1);
-    if (stats != nullptr) {
-      if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH;
-      if (hrf_gn_moments(y, nullptr, 1, a.M, Cout, stats, stream) != HRF_OK) return HRF_ERR_LAUNCH;   // (sum, sum of squares) into copy 0
-    }
+    const int R = 256 / Cout;
+    HRF_LAUNCH(splitk_reduce_kernel, dim3((unsigned)std::min<long>(1024, hrf_cdiv(a.M, R))), dim3(256), (unsigned)((size_t)R * 2 * Cout * sizeof(float)),
+               stream, y, (const float*)scratch, a.M, Cout, ks - 1, stats);
   }
   if (ln_rowstat != nullptr) { if (hrf_check_launch() != HRF_OK) return HRF_ERR_LAUNCH; return hrf_ln_stats(y, a.M, Cout, ln_eps, ln_rowstat, stream); }
   return hrf_check_launch();

@@ -89,7 +89,7 @@ int hrf_conv_fwd(const float* x, int sB, int sY, int sX, int sC, int B, int H, i
                  const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat, float ln_eps, void* stream);
 /* The same forward with a SPLIT OVER K for deep contractions that leave the chip empty (3x3, K = 9*Cin >= 1024, <= 128 row blocks:
  * the 256 -> 36 stride-2 transition, hrnet.py:430-459): four K slices write partial tiles (slice 0 into y, the others into
- * `scratch`), a second launch adds them in a fixed order (bit-reproducible), a third takes the moments.
+ * `scratch`), a second launch adds them in a fixed order (bit-reproducible) and takes the moments.
  * hrf_conv_fwd_split_scratch -> floats of scratch this problem wants (0: it would not be split - call hrf_conv_fwd);
  * hrf_conv_fwd_split with scratch == NULL is hrf_conv_fwd. */
 long hrf_conv_fwd_split_scratch(int sB, int sY, int sX, int sC, int B, int H, int W, int Cin, int KH, int stride, int Cout,
