@@ -57,6 +57,7 @@ BnFin = struct_from_header('hrf_bn_fin')            # BatchNorm of a consumer's 
 BnBFin = struct_from_header('hrf_bn_bfin')          # BatchNorm-backward coefficients derived on load
 AttnBlock = struct_from_header('hrf_attn_block')    # fused window-attention block (csrc/attn_block.hip)
 FfnEval = struct_from_header('hrf_ffn_eval')        # eval-mode CrossFFN in one launch (csrc/ffn_eval.hip)
+Conv3xPackJob = struct_from_header('hrf_conv3x_pack_job')   # one weight tensor of hrf_conv3x_pack (csrc/conv3x_engine.hip)
 P2p = struct_from_header('hrf_p2p')                 # peer-to-peer SyncBN exchange context (csrc/p2p_exchange.hip)
 
 
@@ -64,7 +65,7 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_RAW_RETURN = ('hrf_conv3_wgrad_wide_scratch', 'hrf_conv_fwd_split_scratch', 'hrf_wgrad_group_report', 'hrf_attn_block_supported', 'hrf_attn_block_bwd_supported', 'hrf_group_count',
+_RAW_RETURN = ('hrf_conv3_wgrad_wide_scratch', 'hrf_conv3x_pack_size', 'hrf_conv3x_supported', 'hrf_conv_fwd_split_scratch', 'hrf_wgrad_group_report', 'hrf_attn_block_supported', 'hrf_attn_block_bwd_supported', 'hrf_group_count',
                'hrf_ffn_eval_supported')       # return a value, not a status
 _ERR = {1: 'HRF_ERR_ARG (bad argument)', 2: 'HRF_ERR_LAUNCH (kernel launch failed)'}
 
@@ -116,7 +117,7 @@ class Lib:
         self._fns = {}
         for name, args in self.protos.items():
             fn = getattr(self._dll, name)          # AttributeError if a declared symbol is missing
-            fn.restype = ctypes.c_long if name in ('hrf_conv3_wgrad_wide_scratch', 'hrf_conv_fwd_split_scratch', 'hrf_wgrad_group_report', 'hrf_group_count') else ctypes.c_int
+            fn.restype = ctypes.c_long if name in ('hrf_conv3_wgrad_wide_scratch', 'hrf_conv3x_pack_size', 'hrf_conv_fwd_split_scratch', 'hrf_wgrad_group_report', 'hrf_group_count') else ctypes.c_int
             fn.argtypes = [ct for ct, _ in args]
             self._fns[name] = self._wrap(name, fn, args)
 

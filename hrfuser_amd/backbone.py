@@ -188,6 +188,42 @@ class Engine:
                 self.nbt_flat[i] = m.num_batches_tracked.to(device)
                 m.num_batches_tracked = self.nbt_flat[i]          # 0-dim view: one add_ per step updates all
         self.device = device
+        self._build_packs()
+
+    # ---- tap-major weight packs of the front-end 3x3 convolutions (csrc/conv3x_engine.hip): one persistent buffer per
+    # convolution and direction, refreshed by ONE hrf_conv3x_pack launch at the start of every forward (the optimizer and
+    # captured replays write the weights through raw pointers: nothing derived from them is cached across steps)
+    def _build_packs(self):
+        L = self.root._lib_handle()
+        self.packs, jobs = {}, []
+        if os.environ.get('HRF_CONV3X', '1') == '0' or not hasattr(L, 'hrf_conv3x_pack'):
+            self._pack_jobs = None
+            return
+        for m in self.root.modules():
+            if not (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.groups == 1 and m.padding == (1, 1)):
+                continue
+            Cout, Cin = m.weight.shape[:2]
+            ent = [None, None]
+            for d in (0, 1):
+                if L.hrf_conv3x_supported(Cin, Cout, 3, m.stride[0], d):
+                    ent[d] = torch.zeros(L.hrf_conv3x_pack_size(Cout, Cin, d), device=self.device, dtype=torch.float32)
+                    jobs.append((m.weight, ent[d], Cout, Cin, d))
+            if ent[0] is not None or ent[1] is not None:
+                self.packs[id(m.weight)] = tuple(ent)
+        arr = (_lib.Conv3xPackJob * max(1, len(jobs)))()
+        for i, (w, wp, Cout, Cin, d) in enumerate(jobs):
+            arr[i] = _lib.Conv3xPackJob(w.data_ptr(), wp.data_ptr(), Cout, Cin, d)
+        self._pack_jobs = (arr, len(jobs)) if jobs else None
+
+    def pack_weights(self):
+        if self.__dict__.get('_pack_jobs') is not None:
+            arr, n = self._pack_jobs
+            self.root._lib_handle().hrf_conv3x_pack(arr, n, _lib.stream_ptr())
+
+    def packed(self, weight, direction):
+        """-> the tap-major pack of `weight` for hrf_conv_fwd_packed (0) / hrf_conv_bwd_data_packed (1), or None"""
+        ent = self.packs.get(id(weight))
+        return None if ent is None else ent[direction]
 
     # ---- peer-to-peer SyncBN exchange (hrfuser_amd/p2p.py; HRF_SYNC_P2P=1 on every rank)
     def p2p_context(self, group, world):
@@ -402,6 +438,7 @@ class Engine:
             self._rng_calls = {}
         if self.arena_d.numel():
             R.gpu_zero_(self.arena_d)
+        self.pack_weights()
         if training and self.root.sync_group is not None and (self.root.sync_world > 1 or R.force_collectives()):
             px = self.p2p_context(self.root.sync_group, self.root.sync_world)
             if px is not None:

@@ -1051,6 +1051,61 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
   return hrf_check_launch();
 }
 
+// ---- the packed-weight front-end engine (conv3x_engine.hip)
+extern "C" int hrf_conv3x_supported(int Cin, int Cout, int KH, int stride, int dir) {
+  if (KH != 3 || Cin <= 0 || Cout <= 0) return 0;
+  if (dir == 0) return stride == 1 && Cout > 32 ? 1 : 0;
+  if (stride == 2) return Cin > 32 && Cout <= 64 ? 1 : 0;       // (the parity-class walk keeps ONE halo slab: <= 64 channels of dY)
+  return stride == 1 && Cin > 32 ? 1 : 0;
+}
+
+extern "C" int hrf_conv_fwd_packed(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin,
+                                   const float* w, const float* bias, int KH, int stride, int Cout,
+                                   float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
+                                   int tf_mode, const float* tf_scale, const float* tf_shift,
+                                   const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat,
+                                   float ln_eps, const float* wp, void* stream) {
+  HRF_GROUP_CALL();
+  (void)w; (void)tf_rowstat;
+  if (wp == nullptr || !hrf_conv3x_supported(Cin, Cout, KH, stride, 0)) return HRF_ERR_ARG;
+  if (!(sC == 1 && sY == W * sX && sB == H * sY) || tf_mode < 0 || tf_mode > HRF_TF_AFFINE_GELU) return HRF_ERR_ARG;
+  if (ln_rowstat != nullptr && (ldY != Cout || yoff != 0)) return HRF_ERR_ARG;
+  if (tf_fin != nullptr && (tf_mode < HRF_TF_AFFINE || tf_fin->C != Cin || Cin > 256 || tf_fin->stats == nullptr)) return HRF_ERR_ARG;
+  C3xArgs c{};
+  c.in = x; c.ldIn = sX; c.t0 = tf_scale; c.t1 = tf_shift; c.tf_mode = tf_mode; c.wp = wp;
+  c.Np = (Cout + 63) & ~63; c.Kp = (Cin + 31) & ~31; c.bias = bias;
+  c.out = y; c.ldOut = ldY; c.ooff = yoff; c.res = res; c.res2 = res2; c.ldR = ldR; c.stats = stats;
+  c.B = B; c.H = H; c.W = W; c.Cin = Cin; c.Cout = Cout;
+  if (tf_fin != nullptr) c.fin = *tf_fin;
+  const int rc = hrf_conv3x_fwd_launch(c, stream);
+  if (rc == HRF_OK && ln_rowstat != nullptr) return hrf_ln_stats(y, (long)B * H * W, Cout, ln_eps, ln_rowstat, stream);
+  return rc;
+}
+
+extern "C" int hrf_conv_bwd_data_packed(const float* dy, int ldD, int doff, const float* yraw,
+                                        const float* cA, const float* cB, const float* cC, const hrf_bn_bfin_t* bfin,
+                                        const float* w, int KH, int stride, int Cout,
+                                        int B, int H, int W, int Cin,
+                                        float* dx, int sB, int sY, int sX, int sC, int accumulate,
+                                        int epi, const float* xraw, int ldXr, const float* tf_scale,
+                                        const float* tf_shift, int act, double* stats, const float* wp, void* stream) {
+  HRF_GROUP_CALL();
+  (void)w;
+  if (wp == nullptr || !hrf_conv3x_supported(Cin, Cout, KH, stride, 1)) return HRF_ERR_ARG;
+  if (!(sC == 1 && sY == W * sX && sB == H * sY)) return HRF_ERR_ARG;
+  if (bfin != nullptr && (cA == nullptr || bfin->C != Cout || Cout > 256 || bfin->gstats == nullptr)) return HRF_ERR_ARG;
+  C3xArgs c{};
+  c.in = dy + doff; c.ldIn = ldD; c.in2 = cA != nullptr ? yraw + doff : nullptr; c.t0 = cA; c.t1 = cB; c.t2 = cC;
+  c.wp = wp; c.Np = (Cin + 63) & ~63; c.Kp = (Cout + 31) & ~31;
+  c.out = dx; c.ldOut = sX; c.accumulate = accumulate; c.epi = epi; c.xraw = xraw; c.ldXr = ldXr;
+  c.esc = tf_scale; c.esh = tf_shift; c.act = act; c.stats = stats;
+  if (bfin != nullptr) c.bfin = *bfin;
+  c.B = B; c.H = H; c.W = W; c.Cin = Cout; c.Cout = Cin;
+  if (stride == 1) return hrf_conv3x_bwd_data_launch(c, stream);
+  c.Hs = (H + 2 - KH) / stride + 1; c.Ws = (W + 2 - KH) / stride + 1;
+  return hrf_conv3xs2_bwd_data_launch(c, stream);
+}
+
 extern "C" __attribute__((visibility("hidden"))) int hrf_pw_knob(int key, int value);
 extern "C" __attribute__((visibility("hidden"))) int hrf_conv3w_knob(int key, int value);
 extern "C" __attribute__((visibility("hidden"))) int hrf_lin2_knob(int key, int value);

@@ -58,3 +58,32 @@ struct Conv3Args {
 int hrf_conv3_fwd_launch(const Conv3Args& a, void* stream);
 int hrf_conv3_bwd_data_launch(const Conv3Args& a, void* stream);
 int hrf_conv3s2_bwd_data_launch(const Conv3Args& a, void* stream);   // stride-2 conv, parity-class blocks
+
+// ---- conv3x_engine.hip: the same contract on tap-major PACKED weights (hrf_conv3x_pack), v_mfma_f32_32x32x2, two 4-wave blocks
+// per CU; Cout > 32.
+// MODE 0: forward, stride 1 (in = x, transform on load, bias / residual epilogue, (sum, sum of squares) moments)
+// MODE 1: backward data of the stride-1 convolution (in = dY [+ BatchNorm backward on load], pack dir 1, tap 8 - t)
+// MODE 2: backward data of the stride-2 convolution: the block's tile is a tile of the SOURCE grid (dY), its outputs the four
+//         parity classes (Y % 2, X % 2) of the 2 TH x 32 pixel patch of dX above it
+struct C3xArgs {
+  const float* in; int ldIn;                 // fwd: x rows; bwd: dY rows (column offset already added)
+  const float* in2;                          // bwd + BatchNorm backward: raw conv output (same indexing) or null
+  const float* t0; const float* t1; const float* t2;   // fwd: tf_scale, tf_shift, - ; bwd: cA, cB, cC
+  int tf_mode;
+  const float* wp; int Np, Kp;               // [9][Np][Kp]
+  const float* bias;
+  float* out; int ldOut; int ooff;
+  const float* res; const float* res2; int ldR;
+  int accumulate, epi; const float* xraw; int ldXr; const float* esc; const float* esh; int act;
+  double* stats;
+  hrf_bn_fin_t fin;
+  hrf_bn_bfin_t bfin;
+  int B, H, W, Cin, Cout;                    // output grid; channels of `in` / of `out`
+  int Hs, Ws;                                // grid of `in` (MODE 2: the convolution's output grid; otherwise = H, W)
+  int tilesX, tilesY, ntiles, per_xcd;
+  int cols_per_block;                        // 64-channel output groups one block walks over its staged halo
+};
+
+int hrf_conv3x_fwd_launch(const C3xArgs& a, void* stream);
+int hrf_conv3x_bwd_data_launch(const C3xArgs& a, void* stream);
+int hrf_conv3xs2_bwd_data_launch(const C3xArgs& a, void* stream);     // stride-2 conv: one block walks the four parity classes

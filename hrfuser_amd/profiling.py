@@ -30,21 +30,28 @@ def _out_hw(H, W, KH, s):
 def work_model(name, a):
     """-> (kernel key as rocprof names it, algorithmic FLOPs, compulsory HBM bytes) of one launch."""
     f4 = 4.0
-    if name in ('hrf_conv_fwd', 'hrf_conv_fwd_split'):       # (_split: K slices + fixed-order reduce + moments, priced as ONE call)
+    if name in ('hrf_conv_fwd', 'hrf_conv_fwd_split', 'hrf_conv_fwd_packed'):       # (_split: K slices + fixed-order reduce + moments, priced as ONE call)
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         M, K = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']
         by = f4 * (a['B'] * a['H'] * a['W'] * a['Cin'] + a['Cout'] * K + M * a['Cout'] * (1 + (a['res'] is not None) + (a['res2'] is not None)))
+        if name == 'hrf_conv_fwd_packed':
+            return 'conv3x_kernel<0, 2>', 2.0 * M * a['Cout'] * K, by
         if a['KH'] == 1 and a['stride'] == 1 and a['sC'] == 1 and a['Cin'] >= 4 and a['Cout'] >= 4:
             return 'lin_fwd_kernel', 2.0 * M * a['Cout'] * K, by
         return f"conv_fwd_kernel<{_pick_nt(a['Cout'])},{a['KH']},{a['tf_mode']}>", 2.0 * M * a['Cout'] * K, by
-    if name == 'hrf_conv_bwd_data':
+    if name in ('hrf_conv_bwd_data', 'hrf_conv_bwd_data_packed'):
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         M, K = a['B'] * a['H'] * a['W'], a['KH'] ** 2 * a['Cout']
         by = f4 * (a['B'] * Ho * Wo * a['Cout'] * (2 if a['cA'] is not None else 1) + a['Cin'] * K
                    + M * a['Cin'] * (2 if a['epi'] else 1 + bool(a['accumulate'])))
+        # algorithmic FLOPs: every (output pixel of the convolution, tap) pair once - a stride-2 problem has a quarter of the
+        # pairs per INPUT pixel (rounds 1-5 priced 9 taps per input pixel there: 4x too many)
+        fl = 2.0 * a['B'] * Ho * Wo * a['Cin'] * K
+        if name == 'hrf_conv_bwd_data_packed':
+            return f"conv3x_kernel<{a['stride']}, 2>", fl, by
         if a['KH'] == 1 and a['stride'] == 1 and a['sC'] == 1 and a['Cin'] >= 4 and a['Cout'] >= 4:
-            return 'lin_bwd_data_kernel', 2.0 * M * a['Cin'] * K, by
-        return f"conv_bwd_data_kernel<{_pick_nt(a['Cin'])},{a['KH']},{int(a['cA'] is not None)}>", 2.0 * M * a['Cin'] * K, by
+            return 'lin_bwd_data_kernel', fl, by
+        return f"conv_bwd_data_kernel<{_pick_nt(a['Cin'])},{a['KH']},{int(a['cA'] is not None)}>", fl, by
     if name == 'hrf_conv_bwd_weight':
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         Mp, Np = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']

@@ -349,7 +349,8 @@ class Strand:
 # entry points whose launches may be merged with an equal launch of a sibling strand (csrc/hrf_group.h: the kernels take
 # their arguments as an array of up to HRF_GROUP_MAX problems, blockIdx.z selects the problem)
 _GROUPABLE = frozenset((
-    'hrf_conv_fwd', 'hrf_conv_bwd_data', 'hrf_dwconv_fwd', 'hrf_dwconv_bwd_data', 'hrf_dwconv_bwd_data_weight',
+    'hrf_conv_fwd', 'hrf_conv_bwd_data', 'hrf_conv_fwd_packed', 'hrf_conv_bwd_data_packed', 'hrf_dwconv_fwd', 'hrf_dwconv_bwd_data',
+    'hrf_dwconv_bwd_data_weight',
     'hrf_attn_block_fwd', 'hrf_attn_block_bwd', 'hrf_affine_act_res', 'hrf_act_bwd', 'hrf_scale_add', 'hrf_ln_stats',
     'hrf_ln_bwd', 'hrf_window_attn_fwd', 'hrf_window_attn_bwd', 'hrf_fuse_sum', 'hrf_bilinear_up_bwd'))
 _NO_PARK = frozenset(_lib._RAW_RETURN) | frozenset((
@@ -1327,12 +1328,31 @@ def _conv_out_hw(H, W, KH, stride):
     return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KH) // stride + 1
 
 
+def _packed(ctx, weight, direction, strides, B, H, W, Cin):
+    """The tap-major pack of a front-end 3x3 convolution (csrc/conv3x_engine.hip; Engine.packed) when the activation is
+    dense NHWC - None: the call goes through the OIHW entry point."""
+    eng = ctx.owner._engine()
+    wp = eng.packed(weight, direction) if hasattr(eng, 'packed') else None
+    if wp is None or tuple(strides) != (H * W * Cin, W * Cin, Cin, 1):
+        return None
+    return wp
+
+
 def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw, st=None):
     """Shared backward of every dense conv / linear: dX routed by the source kind, then dW (+db).
     `st`: BNState of the BatchNorm that follows the convolution (dy = st.du, BatchNorm backward applied on load)."""
     L, s = ctx.L, ctx.stream
     x, strides, (B, H, W, Cin), tf, sc, sh, rowstat = _src_desc(src)
     needs = _needs_grad(src)
+    # (stride 2: one block walks the four parity classes of a SOURCE tile - worth it from ~64 tiles: 2 x 16 x 24 source pixels
+    # measured 34 vs 26 us on the parity-class blocks of conv3_engine.hip)
+    wpb = _packed(ctx, weight, 1, strides, B, H, W, Cin) if (KH == 3 and (stride == 1 or B * H * W >= 16384)) else None
+
+    def bwd_data(*args):
+        if wpb is not None:
+            L.hrf_conv_bwd_data_packed(*args[:-1], wpb, args[-1])
+        else:
+            L.hrf_conv_bwd_data(*args)
     bfin = None
     cA = cB = cC = None
     if st is not None:
@@ -1343,12 +1363,12 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
     elif isinstance(src, Lazy):
         ps = src.st
         ps.du = _new_like(ps.raw)
-        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
+        bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
                             ps.du, *strides, 0, 1, ps.raw, Cin, ps.scale, ps.shift, _TF2ACT[src.mode],
                             ps.gstats, s)
     elif isinstance(src, LNIn):
         da = _new_like(src.act.t)
-        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
+        bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
                             da, *strides, 0, 0, None, 0, None, None, 0, None, s)
         g, acc = src.act.grad_target()
         eng = ctx.owner._engine()
@@ -1357,7 +1377,7 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
         L.hrf_ln_bwd(da, src.act.t, src.rowstat, src.ln.weight, B * H * W, Cin, g, acc, gacc, bacc, cs, s)
     elif isinstance(src, Act):
         g, acc = src.grad_target()
-        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
+        bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
                             g, *strides, acc, 0, None, 0, None, None, 0, None, s)
     else:                                   # RawInput (NCHW gradient written through strides)
         if src.grad is None:
@@ -1365,7 +1385,7 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
             acc = 0
         else:
             acc = 1
-        L.hrf_conv_bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
+        bwd_data(dy, ldD, doff, yraw, cA, cB, cC, bfin, weight, KH, stride, Cout, B, H, W, Cin,
                             src.grad, *strides, acc, 0, None, 0, None, None, 0, None, s)
     if weight.requires_grad:
         # weight gradients are leaves of the backward graph: issue them on a side lane so they overlap
@@ -1476,8 +1496,13 @@ def conv_bn(ctx, src, conv, bn, mode):
         L.hrf_conv_fwd_split(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
                              tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, _new((nsc,), x.device), s)
     else:
-        L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
-                       tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, s)
+        wp = _packed(ctx, w, 0, strides, B, H, W, Cin) if (KH == 3 and tf != TF_LN) else None
+        if wp is not None:
+            L.hrf_conv_fwd_packed(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
+                                  tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, wp, s)
+        else:
+            L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
+                           tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, s)
     st = bn_forward(ctx, bn, y, stats)
     out = Lazy(st, mode)
     if ctx.probe is not None and mode == TF_RELU:

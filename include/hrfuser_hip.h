@@ -119,6 +119,41 @@ int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const float* yraw,
                         int tf_mode, const float* tf_scale, const float* tf_shift,
                         const float* tf_rowstat, float* dw, float* dbias, void* stream);
 
+/* ---- the front-end 3x3 convolutions on tap-major PACKED weights (csrc/conv3x_engine.hip) ----------------------------------
+ * The stems' second convolution, the Bottleneck conv2 of layer1 and transition1 (hrnet.py:341-358,417-459;
+ * resnet.py:263-302; hrfuser_hrformer_based.py:380-396) are the FLOP carriers of the backbone.  Their kernels want the weights
+ * as wp[tap][n][k] (a K step = one contiguous run per output channel; backward-data = the same kernel on the transposed pack):
+ *   hrf_conv3x_pack_size  floats of one pack: 9 * Np * Kp, N rounded up to 64, K to 32 (zero rows / columns past the tensor);
+ *   hrf_conv3x_pack       ONE launch (per 16 jobs) packs any number of OIHW tensors w = [Cout][Cin][3][3]:
+ *                         dir 0 (forward operand, N = Cout, K = Cin):        wp[tap][n][k] = w[n][k][tap]
+ *                         dir 1 (backward-data operand, N = Cin, K = Cout):  wp[tap][n][k] = w[k][n][tap]
+ *                         `jobs` is a HOST array; the packs are caller-owned scratch, refreshed whenever w changes (once per step);
+ *   hrf_conv3x_supported  1 when hrf_conv_fwd_packed (dir 0) / hrf_conv_bwd_data_packed (dir 1) take the shape:
+ *                         KH = 3, NHWC rows; dir 0: stride 1, Cout > 32; dir 1: stride 1, Cin > 32, or stride 2, Cin > 32 and
+ *                         Cout <= 64; on-load BatchNorm <= 256 channels.
+ *   hrf_conv_fwd_packed / hrf_conv_bwd_data_packed: hrf_conv_fwd / hrf_conv_bwd_data (same arguments, same results) with
+ *                         `wp` = the pack of `w` in the matching direction; HRF_ERR_ARG for unsupported shapes. */
+typedef struct hrf_conv3x_pack_job {
+  const float* w; float* wp;
+  int Cout, Cin, dir;
+} hrf_conv3x_pack_job_t;
+long hrf_conv3x_pack_size(int Cout, int Cin, int dir);
+int hrf_conv3x_pack(const hrf_conv3x_pack_job_t* jobs, int n, void* stream);
+int hrf_conv3x_supported(int Cin, int Cout, int KH, int stride, int dir);
+int hrf_conv_fwd_packed(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin,
+                        const float* w, const float* bias, int KH, int stride, int Cout,
+                        float* y, int ldY, int yoff, const float* res, const float* res2, int ldR,
+                        int tf_mode, const float* tf_scale, const float* tf_shift,
+                        const float* tf_rowstat, double* stats, const hrf_bn_fin_t* tf_fin, float* ln_rowstat, float ln_eps,
+                        const float* wp, void* stream);
+int hrf_conv_bwd_data_packed(const float* dy, int ldD, int doff, const float* yraw,
+                             const float* cA, const float* cB, const float* cC, const hrf_bn_bfin_t* bfin,
+                             const float* w, int KH, int stride, int Cout,
+                             int B, int H, int W, int Cin,
+                             float* dx, int sB, int sY, int sX, int sC, int accumulate,
+                             int epi, const float* xraw, int ldXr, const float* tf_scale,
+                             const float* tf_shift, int act, double* stats, const float* wp, void* stream);
+
 /* ---- depthwise 3x3 convolution, pad 1, stride 1|2, NHWC (F.conv2d groups=C) -----------------
  * CrossFFN hrformer.py:271-277 (bias, stride 1, input = GELU(BN(h1)) applied on load) and the
  * fuse-down chains hrformer.py:532-541 (stride 2, no bias).  w is (C,1,3,3).                    */

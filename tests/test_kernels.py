@@ -124,10 +124,25 @@ CONV_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
 ]
 
 
-def run_conv(case, backend):
+def _pack3x(L, w, dev, direction):
+    """tap-major pack of an OIHW weight for csrc/conv3x_engine.hip (hrf_conv3x_pack: one job)"""
+    Cout, Cin = w.shape[:2]
+    wp = torch.full((L.hrf_conv3x_pack_size(Cout, Cin, direction),), float('nan'), device=dev)
+    jobs = (_lib.Conv3xPackJob * 1)()
+    jobs[0] = _lib.Conv3xPackJob(_lib._ptr(w), _lib._ptr(wp), Cout, Cin, direction)
+    L.hrf_conv3x_pack(jobs, 1, _lib.stream_ptr())
+    return wp
+
+
+def run_conv(case, backend, packed=False):
+    """packed: forward / backward-data through hrf_conv_fwd_packed / hrf_conv_bwd_data_packed (csrc/conv3x_engine.hip) where
+    hrf_conv3x_supported takes the shape - same arguments, same expected results"""
     dev = use_backend(backend)
     L = _lib.lib()
     B, H, W, Cin, Cout, KH, stride, tf, bnb, epi = case
+    conv_fwd, conv_bwd_data = L.hrf_conv_fwd, L.hrf_conv_bwd_data
+    if packed:
+        assert L.hrf_conv3x_supported(Cin, Cout, KH, stride, 0) or L.hrf_conv3x_supported(Cin, Cout, KH, stride, 1), case
     g = torch.Generator().manual_seed(sum(case[:7]))
     rn = lambda *s: torch.randn(*s, generator=g)
     xraw, w, bias = rn(B, Cin, H, W), rn(Cout, Cin, KH, KH) * 0.2, rn(Cout)
@@ -150,9 +165,15 @@ def run_conv(case, backend):
     yk = torch.zeros(B, Ho, Wo, Cout, device=dev)
     stats = zstat(Cout, dev)
     lnrs = torch.zeros(B * Ho * Wo, 2, device=dev)      # fused LayerNorm row statistics of the output
-    L.hrf_conv_fwd(D(xr), *st, B, H, W, Cin, D(w), D(bias), KH, stride, Cout, yk, Cout, 0, D(res), None, Cout,
-                   tf, D(sc) if (tf and fin is None) else None, D(sh) if (tf and fin is None) else None, D(rowstat), stats,
-                   fin, lnrs, 1e-6, _lib.stream_ptr())
+    if packed and L.hrf_conv3x_supported(Cin, Cout, KH, stride, 0):
+        wpf = _pack3x(L, D(w), dev, 0)
+        conv_fwd = lambda *a: L.hrf_conv_fwd_packed(*a[:-1], wpf, a[-1])
+    if packed and L.hrf_conv3x_supported(Cin, Cout, KH, stride, 1):
+        wpb = _pack3x(L, D(w), dev, 1)
+        conv_bwd_data = lambda *a: L.hrf_conv_bwd_data_packed(*a[:-1], wpb, a[-1])
+    conv_fwd(D(xr), *st, B, H, W, Cin, D(w), D(bias), KH, stride, Cout, yk, Cout, 0, D(res), None, Cout,
+             tf, D(sc) if (tf and fin is None) else None, D(sh) if (tf and fin is None) else None, D(rowstat), stats,
+             fin, lnrs, 1e-6, _lib.stream_ptr())
     if fin is not None:
         check_fin(ft)
     yr_ = yref.reshape(-1, Cout)
@@ -162,7 +183,7 @@ def run_conv(case, backend):
     assert r(fold(stats)[:Cout], s1) < TOL and r(fold(stats)[Cout:], s2) < TOL
     # the split over K (deep 3x3 contractions with few row blocks): same output, same moments, bit-reproducible
     nsc = L.hrf_conv_fwd_split_scratch(*st, B, H, W, Cin, KH, stride, Cout, Cout, 0)
-    if nsc > 0:
+    if nsc > 0 and not packed:
         assert KH == 3 and 9 * Cin >= 1024
         outs = []
         for _ in range(2):
@@ -176,7 +197,7 @@ def run_conv(case, backend):
                 assert r(fold(st3)[:Cout], s1) < TOL and r(fold(st3)[Cout:], s2) < TOL
         assert torch.equal(outs[0], outs[1])
     # NCHW input through strides (stem path)
-    if tf == 0:
+    if tf == 0 and not packed:
         yk2 = torch.zeros_like(yk)
         L.hrf_conv_fwd(D(xraw.contiguous()), Cin * H * W, W, 1, H * W, B, H, W, Cin, D(w), D(bias), KH, stride, Cout,
                        yk2, Cout, 0, None, None, 0, 0, None, None, None, None, None, None, 0.0, _lib.stream_ptr())
@@ -192,7 +213,7 @@ def run_conv(case, backend):
     dx = torch.zeros(B, H, W, Cin, device=dev)
     if epi:
         gst = zstat(Cin, dev)
-        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), *co, None, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 0, 1,
+        conv_bwd_data(D(du), Cout, 0, D(yraw), *co, None, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 0, 1,
                             D(xr), Cin, D(sc), D(sh), act, gst, _lib.stream_ptr())
         assert r(dx, gu) < TOL
         assert r(fold(gst)[:Cin], gu.reshape(-1, Cin).double().sum(0)) < TOL
@@ -200,7 +221,7 @@ def run_conv(case, backend):
     else:
         base = rn(B, H, W, Cin)
         dx.copy_(base)
-        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), *co, None, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 1, 0,
+        conv_bwd_data(D(du), Cout, 0, D(yraw), *co, None, D(w), KH, stride, Cout, B, H, W, Cin, dx, *st, 1, 0,
                             None, 0, None, None, 0, None, _lib.stream_ptr())
         assert r(dx, gu + base) < TOL
     if bnb:
@@ -209,10 +230,10 @@ def run_conv(case, backend):
         bfin, bt = make_bfin(L, Cout, 811.0, dev, g)
         dxa, dxb = torch.zeros(B, H, W, Cin, device=dev), torch.zeros(B, H, W, Cin, device=dev)
         tail = (1, D(xr), Cin, D(sc), D(sh), act, zstat(Cin, dev)) if epi else (0, None, 0, None, None, 0, None)
-        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), bt['ref_cA'], bt['ref_cB'], bt['ref_cC'], None, D(w), KH, stride, Cout,
+        conv_bwd_data(D(du), Cout, 0, D(yraw), bt['ref_cA'], bt['ref_cB'], bt['ref_cC'], None, D(w), KH, stride, Cout,
                             B, H, W, Cin, dxa, *st, 0, *tail, _lib.stream_ptr())
         tail = (1, D(xr), Cin, D(sc), D(sh), act, zstat(Cin, dev)) if epi else (0, None, 0, None, None, 0, None)
-        L.hrf_conv_bwd_data(D(du), Cout, 0, D(yraw), bt['cA'], bt['cB'], bt['cC'], bfin, D(w), KH, stride, Cout,
+        conv_bwd_data(D(du), Cout, 0, D(yraw), bt['cA'], bt['cB'], bt['cC'], bfin, D(w), KH, stride, Cout,
                             B, H, W, Cin, dxb, *st, 0, *tail, _lib.stream_ptr())
         check_bfin(bt)
         assert r(dxb, dxa) < 1e-6
@@ -819,6 +840,31 @@ def test_pointwise_emul():
 @pytest.mark.parametrize('case', CONV_CASES, ids=str)
 def test_conv_gpu(case):
     run_conv(case, 'hip')
+
+
+# the packed-weight front-end engine (csrc/conv3x_engine.hip): stems / Bottleneck conv2 (64 -> 64, stride 1 and the stride-2
+# backward by parity classes), the transitions' backward (18 / 36 -> 256 channels), ragged grids and channel counts
+C3X_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
+    (2, 10, 13, 64, 64, 3, 1, 2, True, True),
+    (1, 9, 35, 64, 64, 3, 2, 2, True, True),       # stride-2 backward only (forward stays on the generic engine)
+    (1, 7, 18, 96, 40, 3, 1, 1, True, False),      # two halo slabs (64 + 32), ragged output channels, accumulate epilogue
+    (1, 6, 5, 256, 18, 3, 1, 0, True, False),      # transition backward: 18 -> 256 channels (ragged K, four channel blocks)
+    (1, 9, 7, 72, 36, 3, 2, 3, True, True),        # GELU on load / GELU' epilogue, stride-2 backward 36 -> 72
+    (1, 7, 9, 40, 96, 3, 1, 2, True, True),        # backward with two halo slabs of dY (96 channels), ragged 40 outputs
+    (1, 18, 33, 64, 64, 3, 1, 0, False, False),
+]
+
+
+@pytest.mark.parametrize('case', C3X_CASES[:6], ids=str)
+def test_conv3x_emul(case):
+    run_conv(case, 'emul', packed=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', C3X_CASES + [(2, 50, 130, 64, 64, 3, 1, 2, True, True), (1, 33, 47, 256, 36, 3, 2, 0, True, False),
+                                              (2, 37, 70, 64, 64, 3, 2, 2, True, True)], ids=str)
+def test_conv3x_gpu(case):
+    run_conv(case, 'hip', packed=True)
 
 
 @pytest.mark.gpu
