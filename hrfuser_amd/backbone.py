@@ -243,7 +243,9 @@ class Engine:
             # word.  A context any capture has pinned is retired, never closed - a replay after set_sync_group or a change
             # of HRF_SYNC_P2P must not write into freed or unmapped (remote!) memory
             if cur[2].pins:
+                cur[2].retired = True                            # closed by the unpin of its last capture (P2PExchange.unpin)
                 self.__dict__.setdefault('_p2p_retired', []).append(cur[2])
+                self._p2p_retired[:] = [c for c in self._p2p_retired if c.base]      # (closed ones drop out)
             else:
                 cur[2].close()
         import torch.distributed as dist
@@ -1259,7 +1261,14 @@ class HipModule(nn.Module, EngineOwner):
 
     def reset_graphs(self):
         """Drop every captured instance (call after structural changes: freezing parameters, loading another device)."""
-        self.__dict__.pop('_hrf_graphs', None)
+        cache = self.__dict__.pop('_hrf_graphs', None) or {}
+        from . import p2p as _p2p
+        for k, ent in cache.items():
+            if k == '_setup':
+                continue
+            for r in getattr(ent, 'refs', None) or []:         # the entry's captures pinned their exchange context
+                if isinstance(r, _p2p.P2PExchange):
+                    r.unpin()
 
     def _graph_key(self, inputs, record):
         flags = tuple(m.training for m in self._engine()._bns) if self._engine()._bns else ()
@@ -1303,7 +1312,7 @@ class HipModule(nn.Module, EngineOwner):
         ent.refs.extend(eng.__dict__.get('_rng_pool', {}).values())
         px = eng.__dict__.get('_p2p')
         if px is not None and px[2] is not None and not any(r is px[2] for r in ent.refs):
-            px[2].pins += 1                                  # exchange launches of this capture point into the context's inboxes
+            px[2].pin()                                      # exchange launches of this capture point into the context's inboxes
             ent.refs.append(px[2])
 
     def _graph_forward(self, ent, inputs):
@@ -1317,6 +1326,9 @@ class HipModule(nn.Module, EngineOwner):
             d.copy_(t)
         if ent.fwd is None:
             torch.cuda.synchronize()
+            cur = eng.__dict__.get('_p2p')
+            if cur is not None and cur[2] is not None:
+                cur[2].verify_order()                        # the liveness assertion runs OUTSIDE the capture, before any replay
             g = torch.cuda.CUDAGraph()
             saved = eng.keep
             eng.keep = ent.keep                              # the capture's step buffers live as long as the entry

@@ -84,7 +84,12 @@ def parse_remarks(text):
             if key:
                 cur[key] = int(v)
     if rows:
-        names = subprocess.run(['c++filt'], input='\n'.join(r['mangled'] for r in rows), capture_output=True, text=True).stdout.split('\n')
+        try:                                       # (binutils may be absent: the table is a measurement aid - keep mangled names then)
+            names = subprocess.run(['c++filt'], input='\n'.join(r['mangled'] for r in rows), capture_output=True, text=True).stdout.split('\n')
+        except OSError:
+            names = []
+        if len(names) < len(rows):
+            names = [r['mangled'] for r in rows]
         for r, n in zip(rows, names):
             r['name'] = n.strip().replace('(anonymous namespace)::', '')
             r['name'] = r['name'][5:] if r['name'].startswith('void ') else r['name']
@@ -125,12 +130,25 @@ def build(force=False, verbose=True):
     table = {}
     for src, _ in procs:
         rp = os.path.join(CSRC, src.replace('.hip', '.o.remarks'))
-        for r in parse_remarks(open(rp).read()):
-            r['file'] = src
-            table[r.pop('name')] = r
-        os.remove(rp)
-    with open(RES, 'w') as fh:
-        json.dump({'digest': dg, 'arch': ARCH, 'flags': FLAGS, 'kernels': table}, fh, indent=0, sort_keys=True)
+        try:
+            text = open(rp).read()
+            # the compiler's stderr went into the remarks file: everything in it that is NOT a resource remark (warnings of a
+            # successful compile) is shown, as it would have been without the table
+            lines = text.splitlines()
+            other = [k for k, ln in enumerate(lines) if (' warning: ' in ln or ' error: ' in ln)]
+            if other and verbose:
+                sys.stderr.write('\n'.join('\n'.join(lines[k:k + 3]) for k in other[-20:]) + '\n')
+            for r in parse_remarks(text):
+                r['file'] = src
+                table[r.pop('name')] = r
+            os.remove(rp)
+        except Exception as e:                     # never fail a build over its resource table
+            sys.stderr.write(f'build_ext: resource remarks of {src} not parsed ({type(e).__name__}: {e})\n')
+    try:
+        with open(RES, 'w') as fh:
+            json.dump({'digest': dg, 'arch': ARCH, 'flags': FLAGS, 'kernels': table}, fh, indent=0, sort_keys=True)
+    except OSError as e:
+        sys.stderr.write(f'build_ext: {RES} not written ({e})\n')
     # Link against the HIP runtime by its unversioned soname: inside a PyTorch-ROCm process the
     # already-loaded libamdhip64.so (torch/lib) satisfies it, so the kernels share torch's
     # runtime, streams and allocations; standalone it resolves through the ROCm library path.

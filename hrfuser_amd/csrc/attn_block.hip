@@ -516,12 +516,8 @@ int launch_fwd(const hrf_attn_block_t& a0, const hrf_bn_fin_t& fin, int nwin, vo
   a.a = a0; a.fin = fin;
   constexpr size_t smem = ((size_t)(C <= 36 ? 8 * C * ((C + 3) & ~3) : 0) + 4 * 64 * (C + 1) + 32 + HEADS * 176) * sizeof(float);
 #ifndef HRF_EMUL
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_fwd_kernel<C, HEADS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return HRF_ERR_LAUNCH;
-    once = true;
-  }
+  static std::atomic<unsigned> lds_set{0u};
+  if (hrf_dyn_lds_once(lds_set, reinterpret_cast<const void*>(&attn_block_fwd_kernel<C, HEADS>), (int)smem) != HRF_OK) return HRF_ERR_LAUNCH;
 #endif
   return HRF_LAUNCH_G((attn_block_fwd_kernel<C, HEADS>), dim3(nwin), dim3(256), (unsigned)smem, stream, a);
 }
@@ -1479,12 +1475,8 @@ int launch_bwd_v(const hrf_attn_block_t& a, const hrf_bn_bfin_t& bf, int nwin, v
   constexpr int W1X = (4 * C * PW <= 2 * TILE) ? 0 : 4 * C * PW;     // w1 aliases the (dy, dO) tiles when it fits
   constexpr size_t smem = ((size_t)4 * C * PW + W1X + 8 * TILE + 32 + (CROSS ? TILE : 0)) * sizeof(float);
 #ifndef HRF_EMUL
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_bwd_kernel<C, HEADS, NWB, FFN, CROSS, TAIL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return HRF_ERR_LAUNCH;
-    once = true;
-  }
+  static std::atomic<unsigned> lds_set{0u};
+  if (hrf_dyn_lds_once(lds_set, reinterpret_cast<const void*>(&attn_block_bwd_kernel<C, HEADS, NWB, FFN, CROSS, TAIL>), (int)smem) != HRF_OK) return HRF_ERR_LAUNCH;
 #endif
   AbBwdArgs ab;
   ab.a = a; ab.bf = bf;

@@ -531,12 +531,8 @@ template <int WN>
 int launch_rg(const RgArgs& a, void* stream) {
   constexpr size_t smem = (size_t)2 * (GROWS + WN * 64) * GLP * sizeof(float);
 #ifndef HRF_EMUL
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess) return HRF_ERR_LAUNCH;
-    once = true;
-  }
+  static std::atomic<unsigned> lds_set{0u};
+  if (hrf_dyn_lds_once(lds_set, reinterpret_cast<const void*>(&rowgemm_kernel<WN>), (int)smem) != HRF_OK) return HRF_ERR_LAUNCH;
 #endif
   const dim3 grid(hrf_cdiv(a.M, GROWS), hrf_cdiv(a.N, WN * 64));
   HRF_LAUNCH((rowgemm_kernel<WN>), grid, dim3(NTHR), smem, stream, a);
@@ -574,12 +570,8 @@ template <int WN>
 int launch_w(C3wArgs a, void* stream) {
   constexpr size_t smem = (size_t)(NPIX * LP + 3 * WN * 64 * WP) * sizeof(float);
 #ifndef HRF_EMUL
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3w_kernel<WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess) return HRF_ERR_LAUNCH;
-    once = true;
-  }
+  static std::atomic<unsigned> lds_set{0u};
+  if (hrf_dyn_lds_once(lds_set, reinterpret_cast<const void*>(&conv3w_kernel<WN>), (int)smem) != HRF_OK) return HRF_ERR_LAUNCH;
 #endif
   const dim3 grid(a.tilesX * a.tilesY * a.B, hrf_cdiv(a.N, WN * 64));
   HRF_LAUNCH((conv3w_kernel<WN>), grid, dim3(NTHR), smem, stream, a);
@@ -643,12 +635,8 @@ extern "C" int hrf_conv3_wgrad_wide(const float* dy, int ldD, const float* x, in
   a.splits = wgrad3w_splits(B, H, W, Cin, Cout);
   constexpr size_t smem = (size_t)(2 * GPX * PY + 2 * GNP * PX) * sizeof(float);
 #ifndef HRF_EMUL
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess) return HRF_ERR_LAUNCH;
-    once = true;
-  }
+  static std::atomic<unsigned> lds_set{0u};
+  if (hrf_dyn_lds_once(lds_set, reinterpret_cast<const void*>(&wgrad3w_kernel), (int)smem) != HRF_OK) return HRF_ERR_LAUNCH;
 #endif
   HRF_LAUNCH(wgrad3w_kernel, dim3(a.splits, chan_blocks), dim3(NTHR), smem, stream, a);
   const int fgrid = hrf_cdiv(9L * Cout * Cin, 256);

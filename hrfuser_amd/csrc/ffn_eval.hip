@@ -257,12 +257,8 @@ int fe_launch(const hrf_ffn_eval_t& a, void* stream) {
   constexpr int HCP = (HC + 3) & ~3;
   constexpr size_t smem = ((size_t)FE_NPH * (C + 1) + (size_t)FE_NPH * (HCP + 4) + 12 * HCP + wl) * sizeof(float);
 #ifndef HRF_EMUL
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_eval_kernel<C, HC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess) return HRF_ERR_LAUNCH;
-    once = true;
-  }
+  static std::atomic<unsigned> lds_set{0u};
+  if (hrf_dyn_lds_once(lds_set, reinterpret_cast<const void*>(&ffn_eval_kernel<C, HC>), (int)smem) != HRF_OK) return HRF_ERR_LAUNCH;
 #endif
   const int tiles = a.B * ((a.H + FE_TH - 1) / FE_TH) * ((a.W + FE_TW - 1) / FE_TW);
   HRF_LAUNCH((ffn_eval_kernel<C, HC>), dim3(tiles), dim3(256), (unsigned)smem, stream, a);

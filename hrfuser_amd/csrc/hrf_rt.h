@@ -53,6 +53,19 @@ static inline int hrf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int hrf_check_launch() {
   return hipGetLastError() == hipSuccess ? HRF_OK : HRF_ERR_LAUNCH;
 }
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) of a kernel, once per DEVICE and safe under concurrent callers (forwards from two
+// Python threads, the autograd thread): `mask` = one bit per device ordinal; racing threads both set the attribute (idempotent)
+// before either publishes its bit.  (a plain `static bool once` was neither.)
+#include <atomic>
+static inline int hrf_dyn_lds_once(std::atomic<unsigned>& mask, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return HRF_ERR_LAUNCH;
+  const unsigned bit = 1u << (dev & 31);
+  if (mask.load(std::memory_order_acquire) & bit) return HRF_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return HRF_ERR_LAUNCH;
+  mask.fetch_or(bit, std::memory_order_release);
+  return HRF_OK;
+}
 #else
 static inline int hrf_check_launch() { return HRF_OK; }
 #endif

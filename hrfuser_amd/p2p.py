@@ -56,9 +56,13 @@ class P2PExchange:
         self.base, self.handle, self.opened, self.ctx = None, None, [], None
         self.peers = [None] * self.world
         self.exchanges = 0
-        # how long an exchange waits for a peer before the step is declared lost (NaN statistics + error word): NCCL's default
-        # watchdog time-out, 30 minutes - a rank that is merely slow (evaluation, a checkpoint, a data-loader stall) is waited for
-        self.timeout_s = float(os.environ.get('HRF_P2P_TIMEOUT_S', '1800')) if timeout_s is None else float(timeout_s)
+        # how long an exchange waits for a peer before the step is declared lost (NaN statistics + error word) - a rank that is
+        # merely slow (a checkpoint, a data-loader stall) is waited for
+        # (r6: 600 s - torch's NCCL watchdog default - instead of 1800: a dead peer holds the GPU in a spin-wait for that long, and
+        # Trainer.check() / .item() / synchronize() block the host behind it; long evaluation pauses between steps do NOT count -
+        # the wait only runs while a step's exchange kernel is resident.  bench.py sets 60 s for its first-contact runs.)
+        self.timeout_s = float(os.environ.get('HRF_P2P_TIMEOUT_S', '600')) if timeout_s is None else float(timeout_s)
+        self.retired = False           # replaced by a newer context (Engine.p2p_context) while captures still pinned it
         self._order = {}               # first step: {stream: [slot ids in enqueue order]} (verify_order), None once verified
         self.pins = 0                  # captured graphs that carry this context's pointers (Engine.p2p_context never closes those)
         self._poll = None              # (pinned host word, event) of the last non-blocking read of the error word
@@ -253,6 +257,17 @@ class P2PExchange:
                 f'(BatchNorm {slot // 2}, {"backward" if slot & 1 else "forward"}) of generation {int(self.gen.item())} within '
                 f'{self.timeout_s:g} s (HRF_P2P_TIMEOUT_S) - a peer died, runs a different model / schedule, or HRF_SYNC_P2P differs '
                 'between the ranks; the BatchNorm statistics of that step are NaN')
+
+    def pin(self):
+        """a captured graph carries this context's inbox / flag / counter pointers by value"""
+        self.pins += 1
+
+    def unpin(self):
+        """the capture that pinned the context was dropped; a RETIRED context (replaced in Engine.p2p_context) whose last pin goes
+        is closed - its IPC mappings and its inbox are released (pins only ever grew)"""
+        self.pins = max(0, self.pins - 1)
+        if self.pins == 0 and self.retired:
+            self.close()
 
     def close(self):
         for q in self.opened:

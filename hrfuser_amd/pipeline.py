@@ -26,8 +26,10 @@ class DeviceInputPipeline:
         ent = self._const.get((key, dev))
         if ent is None:
             c = self.sensors[key]
-            mean = np.asarray(c['mean'], dtype=np.float64).astype(np.float32)
-            stdinv = (1.0 / np.asarray(c['std'], dtype=np.float64)).astype(np.float32)     # mmcv.imnormalize_: 1 / float64(std)
+            # Normalize.__init__ stores float32 arrays (transforms.py:720-721); mmcv.imnormalize_ then forms float64(mean) and
+            # 1 / float64(std) FROM THOSE: the config value is rounded to float32 FIRST
+            mean = np.asarray(c['mean'], dtype=np.float32)
+            stdinv = (1.0 / np.asarray(c['std'], dtype=np.float32).astype(np.float64)).astype(np.float32)
             ent = self._const[(key, dev)] = (torch.from_numpy(mean).to(dev), torch.from_numpy(stdinv).to(dev))
         return ent
 

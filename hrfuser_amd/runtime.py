@@ -1002,6 +1002,13 @@ class Ctx:
                     xs.take(self, 'leaves_done', f'group {r}', stream=self.main.ptr)
                 if self.exchange is not None:
                     if r == 0:
+                        # HRF_WGRAD=flush left leaves on the side lanes (joined into main only behind this loop): the folds
+                        # and the bucket all-reduces below read the arena and the replicated accumulators those kernels are
+                        # still writing - join them FIRST (silently wrong gradients with world > 1 otherwise)
+                        if self.multi and self._side_used:
+                            for lane in self._side_used.values():
+                                self.main.stream.wait_stream(lane.stream)
+                            self._side_used = {}
                         # every leaf that goes through the replicated accumulators or the per-window slots ran in round 0:
                         # after these folds a slice of the arena is final as soon as its own dense leaves are done
                         with _LaneScope(self, self.main):

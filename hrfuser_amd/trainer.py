@@ -153,6 +153,14 @@ class Trainer:
                 self._step_impl(x, mods, cots)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        old = self.__dict__.pop('_graph_px', None)
+        if old is not None:
+            old.unpin()                  # the graph this capture replaces goes away with its pin
+        px = self._exchange()
+        if px is not None:
+            # the per-lane exchange-order digest of the first eager step is compared across ranks HERE, outside the capture: with
+            # warmup = 0 after one eager step the second forward would be the captured one and skip it
+            px.verify_order()
         if self.world > 1 or self.force:
             # The RCCL watchdog thread is still polling the end events of the warm-up collectives (one
             # sweep per 100 ms); an event query that lands on the communicator stream after it joined the
@@ -169,7 +177,7 @@ class Trainer:
         self.graph = g
         px = self._exchange()
         if px is not None:
-            px.pins += 1                 # the graph's exchange launches carry the context's inbox / flag / counter pointers
+            px.pin()                     # the graph's exchange launches carry the context's inbox / flag / counter pointers
             self._graph_px = px          # (Engine.p2p_context never closes a pinned context)
         return g
 

@@ -24,8 +24,9 @@ def imnormalize(img, mean, std, to_rgb):
     img = np.asarray(img).astype(np.float32)             # img.copy().astype(np.float32)
     if img.ndim == 2:
         img = img[..., None]
-    mean32 = np.asarray(mean, dtype=np.float64).reshape(1, -1).astype(np.float32)
-    stdinv32 = (1.0 / np.asarray(std, dtype=np.float64).reshape(1, -1)).astype(np.float32)
+    # transforms.py:720-721: Normalize keeps np.float32(mean) / np.float32(std); imnormalize_ widens THOSE to float64
+    mean32 = np.asarray(mean, dtype=np.float32).reshape(1, -1)
+    stdinv32 = (1.0 / np.asarray(std, dtype=np.float32).astype(np.float64).reshape(1, -1)).astype(np.float32)
     if to_rgb:
         img = img[..., ::-1]                             # cv2.cvtColor(img, cv2.COLOR_BGR2RGB)
     out = (img - mean32).astype(np.float32)              # cv2.subtract

@@ -118,3 +118,16 @@ def test_pretrained_and_init_cfg(tmp_path):
     c6['zero_init_residual'] = True
     z = build_backbone(c6)
     assert float(z.layer1[0].bn3.weight.min()) == 1.0          # norm3 NOT zeroed, as in the reference
+
+
+def test_packaged_configs_equal_golden():
+    """bench.py / smoke() take the resolved configs/hrfuser/*.py backbone dicts from the PACKAGE (hrfuser_amd/configs); they are
+    the dicts the reference-importing generator wrote into tests/golden/ (oracle/tools/make_golden.py)"""
+    import json
+    from hrfuser_amd.configs import backbone_cfg
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'backbone_cfgs.json')))
+    assert len(gold) >= 6
+    for tag, cfg in gold.items():
+        assert backbone_cfg(tag) == cfg, tag
+    with pytest.raises(KeyError):
+        backbone_cfg('no_such_config')

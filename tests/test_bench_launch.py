@@ -42,6 +42,70 @@ def test_too_few_gpus_fails_cleanly():
     assert p.stdout.strip() == ''
 
 
+STUB_WORKER = r'''
+import json, os, sys, time
+rank, att, mode = int(os.environ['RANK']), os.environ['HRF_BENCH_ATTEMPT'], os.environ['STUB_MODE']
+assert os.environ['HRF_BENCH_WORKER'] == '1' and os.environ['TORCHELASTIC_USE_AGENT_STORE'] == 'False'
+assert os.environ['HRF_BENCH_LAUNCHED_BY_BENCH'] == '1'          # the worker leaves the schedule A/B to its supervisor
+if att == 'auto':
+    assert os.environ.get('HRF_SYNC_P2P') != '0' and os.environ['HRF_P2P_TIMEOUT_S'] == '60'
+    if mode in ('hang', 'dead'):
+        time.sleep(600)                                          # a protocol hang: only the supervisor's limit ends it
+    if mode == 'fail':
+        sys.exit(7)                                              # the exchange's own 60 s limit fired: every rank exits non-zero
+else:
+    assert att == 'rccl_packed_fallback' and os.environ['HRF_SYNC_P2P'] == '0'
+    if mode == 'dead':
+        sys.exit(9)
+if rank == 0:
+    print('some other output')
+    print(json.dumps({'value': 1.0, 'n_gpus': 2, 'config': {'sync_schedule': att, 'port': os.environ['MASTER_PORT']}}))
+'''
+
+
+@pytest.mark.parametrize('mode', ['ok', 'hang', 'fail', 'dead'])
+def test_rank_supervisor_timeout_and_fresh_child_fallback(mode, tmp_path):
+    """VERDICT r5 #5: a rank process started by an external launcher is a supervisor that stays off the GPU; the real rank is a
+    child with a wall-clock limit, and a hang / failure on the default (peer-to-peer) SyncBN schedule ends in a FRESH child job
+    on the RCCL packed schedule - or, when that fails too, in a non-zero exit status and no result line, within the budget.
+    Two supervisors (RANK 0 / 1) run here against a stand-in worker (no GPU): the decisions are taken per rank from the own
+    child's exit status."""
+    import time
+    stub = tmp_path / 'stub_worker.py'
+    stub.write_text(STUB_WORKER)
+    procs = []
+    t0 = time.time()
+    for rank in (0, 1):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29720',
+                   HRF_BENCH_WORKER_CMD=f'{sys.executable} {stub}', STUB_MODE=mode, HRF_BENCH_ATTEMPT_TIMEOUT_S='6',
+                   HRF_BENCH_BUDGET_S='90')
+        for k in ('HRF_BENCH_WORKER', 'HRF_BENCH_LAUNCHED_BY_BENCH', 'HRF_SYNC_P2P', 'HRF_P2P_TIMEOUT_S'):
+            env.pop(k, None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                                       '--no-sync-ab'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=120) for p in procs]
+    wall = time.time() - t0
+    assert wall < 60, wall
+    if mode == 'dead':
+        assert all(p.returncode != 0 for p in procs)
+        assert not any(ln.startswith('{') for o, _ in outs for ln in o.splitlines())          # no result line: never a made-up one
+        assert 'attempt "auto" failed' in outs[0][1] and 'attempt "rccl_packed_fallback" failed' in outs[0][1]
+        return
+    assert [p.returncode for p in procs] == [0, 0], [o[1][-600:] for o in outs]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and outs[1][0].strip() == ''                                        # ONE line, from rank 0
+    line = json.loads(lines[0])
+    tried = line['config']['attempts']
+    if mode == 'ok':
+        assert [t['attempt'] for t in tried] == ['auto'] and line['config']['sync_schedule'] == 'auto'
+        assert line['config']['port'] == '29737'                                               # a rendezvous of the child's own
+    else:
+        assert [t['attempt'] for t in tried] == ['auto', 'rccl_packed_fallback'] and line['config']['sync_schedule'] == 'rccl_packed_fallback'
+        assert tried[0]['rc'] == (None if mode == 'hang' else 7) and tried[1]['rc'] == 0
+        assert line['config']['port'] == '29738'
+        assert 'attempt "auto" failed' in outs[0][1] and 'attempt "auto" failed' in outs[1][1]
+
+
 @pytest.mark.gpu
 def test_two_ranks_share_one_gpu_gloo():
     """N = 2 end to end on ONE GPU: self-launch, SyncBN (packed exchanges, lock-step strands), gradient all-reduce, JSON relay,

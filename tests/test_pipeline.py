@@ -33,6 +33,48 @@ def test_oracle_semantics():
     assert g.shape == (1, 4, 4)                                                    # 2-D image -> one channel
 
 
+def test_normalize_constants_are_float32_first():
+    """transforms.py:720-721 stores np.float32(mean) / np.float32(std); mmcv.imnormalize_ widens THOSE: the reciprocal is
+    1 / float64(float32(std)), not 1 / float64(std) - different for std = 1.7, equal for the nuScenes constants"""
+    cfg = dict(mean=[0.1], std=[1.7], to_rgb=False)
+    x = np.full((1, 1, 1), 3.0, dtype=np.float32)
+    out = P.imnormalize(x, cfg['mean'], cfg['std'], False)
+    want = (np.float32(3.0) - np.float32(0.1)) * np.float32(1.0 / np.float64(np.float32(1.7)))
+    assert out.dtype == np.float32 and out[0, 0, 0] == want
+    assert np.float32(1.0 / np.float64(np.float32(1.7))) != np.float32(1.0 / 1.7)
+    from hrfuser_amd import DeviceInputPipeline
+    mean, stdinv = DeviceInputPipeline({'p': cfg})._constants('p', torch.device('cpu'))
+    assert float(stdinv[0]) == float(np.float32(1.0 / np.float64(np.float32(1.7)))) and float(mean[0]) == float(np.float32(0.1))
+
+
+def _golden_cases():
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pipeline.npz')
+    if not os.path.exists(path):
+        pytest.skip('tests/golden/pipeline.npz absent: oracle/tools/make_golden_pipeline.py needs mmcv + cv2 (row f3 unpinned)')
+    z = np.load(path)
+    for i in range(int(z['n'])):
+        yield (z[f'c{i}/in'], dict(mean=z[f'c{i}/mean'].tolist(), std=z[f'c{i}/std'].tolist(), to_rgb=bool(z[f'c{i}/to_rgb'])),
+               bool(z[f'c{i}/flip']), z[f'c{i}/out'])
+
+
+def test_pipeline_golden_oracle():
+    """the numpy restatement against outputs of the REAL Normalize / imflip / impad_to_multiple (when the fixture exists)"""
+    for src, cfg, flip, want in _golden_cases():
+        got = P.run_sample({'s': src}, {'s': cfg}, flip=flip, drop={}, size_divisor=32)['s']
+        assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_pipeline_golden_gpu():
+    from hrfuser_amd import DeviceInputPipeline
+    dev = T.use_backend('hip')
+    for src, cfg, flip, want in _golden_cases():
+        pipe = DeviceInputPipeline({'s': cfg})
+        got = pipe({'s': torch.from_numpy(src[None]).to(dev)}, flip=torch.tensor([flip]).to(dev))['s']
+        assert np.array_equal(got[0].cpu().numpy(), want)
+
+
 def _batch(B, H0, W0, seed=0, u8=True):
     rng = np.random.default_rng(seed)
     cam = rng.integers(0, 256, (B, H0, W0, 3), dtype=np.uint8) if u8 else \

@@ -81,3 +81,14 @@ def test_syncbn_forced_rccl_eager_and_graph_gpu(tag):
     r = subprocess.run([sys.executable, '-c', WORKER % ROOT, tag, port], capture_output=True, text=True, timeout=1500)
     sys.stdout.write(r.stdout[-3000:])
     assert 'SYNCBN_GPU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_syncbn_forced_rccl_flush_mode_gpu():
+    """HRF_WGRAD=flush (weight-gradient leaves issued early on side lanes) with a gradient exchange: the folds and bucket
+    all-reduces of the exchange rounds must wait for the side lanes (they read the arena while flushed
+    leaves were still writing it) - same oracle gate, leaves flushed every 8."""
+    env = dict(os.environ, HRF_WGRAD='flush', HRF_WGRAD_FLUSH='8', HRF_GRAD_OVERLAP='4')
+    r = subprocess.run([sys.executable, '-c', WORKER % ROOT, 't_nus', '29647'], capture_output=True, text=True, timeout=1500, env=env)
+    sys.stdout.write(r.stdout[-3000:])
+    assert 'SYNCBN_GPU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
