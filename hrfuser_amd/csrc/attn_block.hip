@@ -67,6 +67,14 @@ __device__ __forceinline__ int ab_tok_pixel(const hrf_attn_block_t& a, int b, in
   return -1;
 }
 
+// A 16-deep contraction step issues four MFMAs, MFMA r taking k = 16 s + 4 q + r of lane group q.  With K = 18 (36 + 2 ...) the
+// last step's r >= K - 16 s touch nothing but the zero padding for EVERY q: skipped (2 of 8 MFMAs per tile at 18 channels).
+// Needs the step index at compile time: the loops that use it are fully unrolled or tested on the unrolled body.
+#ifndef AB_NO_SKIPK
+#define AB_SKIPK(kmin, K) ((kmin) >= (K))
+#else
+#define AB_SKIPK(kmin, K) false
+#endif
 // acc[t] (t < NT) += W[n0 + 16t + i][.] . rows[tok0 + j][.] over K: D[n][token], lane (j, q) ends up holding the four
 // output channels n0 + 16t + 4q + r of token tok0 + j.  W is [N][K] row-major in global memory, rows an LDS tile.
 template <int K, int NT>
@@ -89,9 +97,11 @@ __device__ __forceinline__ void wave_gemm(const float* W, int n0, int N, const f
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = ldz(brow, kbase + r, r < kval);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+      if (NS <= 2 && AB_SKIPK(16 * s + r, K)) continue;     // every k = 16s + 4q + r of this step lies beyond K: exact zeros (NS <= 2: s is a compile-time value)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = hrf_mfma16(wv[t][r], bv[r], acc[t]);
+    }
   }
 }
 
@@ -217,9 +227,11 @@ __device__ __forceinline__ void wave_gemm_l(const float* sW, int n0, int N, cons
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = ldz(brow, kbase + r, kbase + r < K);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+      if (AB_SKIPK(16 * s + r, K)) continue;
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = hrf_mfma16(wv[t][r], bv[r], acc[t]);
+    }
   }
 }
 
@@ -236,6 +248,7 @@ __device__ __forceinline__ void wave_gemm_tl(const float* sW, int K, const float
     const int nbase = 16 * s + 4 * q;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      if (NS <= 2 && AB_SKIPK(16 * s + r, N)) continue;     // contraction index 16s + 4q + r >= N for every q
       const bool nv = nbase + r < N;
       const float bv = ldz(brow, nbase + r, nv);
 #pragma unroll
@@ -547,9 +560,11 @@ __device__ __forceinline__ void wave_gemm_t(const float* W, int K, int k0, const
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+      if (NS <= 2 && AB_SKIPK(16 * s + r, N)) continue;
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = hrf_mfma16(wv[t][r], bv[r], acc[t]);
+    }
   }
 }
 

@@ -1094,6 +1094,27 @@ __global__ __launch_bounds__(256) void slice_cols_kernel(const float* src, int l
   }
 }
 
+// cols[(b, yo, xo)][ci * 9 + tap] = x(b, ci, yo * stride - 1 + tap / 3, xo * stride - 1 + tap % 3) (zero outside): the 3x3 / pad-1 patches
+// of a FEW-channel input as rows (the column order is the OIHW weight's memory order, so the 3x3 convolution is the row GEMM
+// cols . w.view(Cout, 9 Cin)^T and its weight gradient the 1x1 form dY^T . cols)
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* x, long sB, long sY, long sX, long sC, int B, int H, int W,
+                                                        int Cin, int stride, int Ho, int Wo, float* cols, int ld) {
+  const int K = Cin * 9;
+  const long total = (long)B * Ho * Wo * K;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / K;
+    const int k = (int)(i - row * K);
+    const int ci = k / 9, tap = k - 9 * ci;
+    const int xo = (int)(row % Wo);
+    const long r2 = row / Wo;
+    const int yo = (int)(r2 % Ho), b = (int)(r2 / Ho);
+    const int yi = yo * stride - 1 + tap / 3, xi = xo * stride - 1 + tap % 3;
+    const bool ok = (unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W;
+    const float v = x[ok ? b * sB + yi * sY + xi * sX + ci * sC : 0];
+    cols[row * ld + k] = ok ? v : 0.f;
+  }
+}
+
 // avg_pool2d(kernel = stride = k) on NHWC rows and its adjoint (hrfpn.py:90-91)
 __global__ __launch_bounds__(256) void avg_pool_kernel(const float* x, int B, int H, int W, int C, int k, float* out) {
   const int Ho = H / k, Wo = W / k;
@@ -1387,6 +1408,18 @@ extern "C" int hrf_pack_input(const void* in, int is_u8, int B, int H0, int W0, 
   if (total <= 0) return HRF_OK;
   HRF_LAUNCH(pack_input_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, in, is_u8, B, H0, W0, C, mean, stdinv, to_rgb,
              flip, drop, out, Hp, Wp);
+  return hrf_check_launch();
+}
+
+extern "C" int hrf_im2col3x3(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin, int stride,
+                             float* cols, int ld, void* stream) {
+  if (Cin < 1 || (stride != 1 && stride != 2) || ld < 9 * Cin) return HRF_ERR_ARG;
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  const long total = (long)B * Ho * Wo * Cin * 9;
+  if (total <= 0) return HRF_OK;
+  long g = (total + 255) / 256;
+  HRF_LAUNCH(im2col3x3_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, stream, x, (long)sB, (long)sY, (long)sX, (long)sC,
+             B, H, W, Cin, stride, Ho, Wo, cols, ld);
   return hrf_check_launch();
 }
 

@@ -277,11 +277,12 @@ def tail_onload():
 
 class RawInput:
     """A network input in its native NCHW layout (read through element strides by the stem conv)."""
-    __slots__ = ('t', 'grad', 'needs_grad', 'nhwc')
+    __slots__ = ('t', 'grad', 'needs_grad', 'nhwc', 'cols')
 
     def __init__(self, t, needs_grad, nhwc=None):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
         self.nhwc = nhwc             # optional channels-last copy made by the owner's pre_step()
+        self.cols = None             # (B, Ho, Wo, 9 C) 3x3 patches as rows, formed by the stem's first convolution (conv_bn)
 
     @property
     def shape(self):
@@ -1335,6 +1336,9 @@ def _conv_out_hw(H, W, KH, stride):
     return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KH) // stride + 1
 
 
+_IM2COL = os.environ.get('HRF_IM2COL', '1') != '0'      # A/B switch: the stem's first convolution through hrf_im2col3x3
+
+
 def _packed(ctx, weight, direction, strides, B, H, W, Cin):
     """The tap-major pack of a front-end 3x3 convolution (csrc/conv3x_engine.hip; Engine.packed) when the activation is
     dense NHWC - None: the call goes through the OIHW entry point."""
@@ -1399,6 +1403,18 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
         # the latency-bound data-gradient chain (operands are never mutated afterwards)
         bgrad = bias.grad if (bias is not None and bias.requires_grad) else None
         xw, sw = x, strides
+        if isinstance(src, RawInput) and KH == 3 and src.cols is not None:
+            # the forward formed the 3x3 patches as rows (hrf_im2col3x3): grad_weight = dY^T . cols, the 1x1 form on
+            # channel-contiguous rows - OIHW memory IS [Cout][9 Cin] (r6: 79 -> ~26 us per sensor stream)
+            Ho, Wo = _conv_out_hw(H, W, KH, stride)
+            K9 = 9 * Cin
+            cols = src.cols
+            cost = 4.0 * B * Ho * Wo * (K9 + Cout * (2 if cA is not None else 1))
+            ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
+                dy, ldD, doff, yraw, cA, cB, cC, cols, *_nhwc_strides(B, Ho, Wo, K9), B, Ho, Wo, K9, 1, 1, Cout,
+                TF_NONE, None, None, None, weight.grad, bgrad, ctx.stream), cost=cost,
+                key=('conv_w', K9, Cout, 1, 1, TF_NONE, cA is not None), target=weight)
+            return
         if isinstance(src, RawInput) and KH == 3:
             # NCHW network input: the pixel-major weight-gradient kernel wants channel-contiguous rows;
             # one 6 MB layout copy (torch, capturable) replaces the 207 us strided LDS kernel by ~40 us
@@ -1502,6 +1518,16 @@ def conv_bn(ctx, src, conv, bn, mode):
     if nsc > 0:
         L.hrf_conv_fwd_split(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
                              tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, _new((nsc,), x.device), s)
+    elif isinstance(src, RawInput) and KH == 3 and 9 * Cin <= 32 and _IM2COL:
+        # the stem's first convolution (3 -> 64, stride 2, NCHW network input): the 3x3 patches are formed ONCE as rows
+        # [B Ho Wo][9 Cin] (column order = OIHW memory order) and the convolution is a row GEMM on them; the weight gradient
+        # of the backward re-uses the same rows (27 strided gathers per output pixel in both kernels before)
+        K9 = 9 * Cin
+        cols = _new((B, Ho, Wo, K9), x.device)
+        L.hrf_im2col3x3(x, *strides, B, H, W, Cin, stride, cols, K9, s)
+        src.cols = cols
+        L.hrf_conv_fwd(cols, *_nhwc_strides(B, Ho, Wo, K9), B, Ho, Wo, K9, w, b, 1, 1, Cout, y, Cout, 0, None, None, 0,
+                       TF_NONE, None, None, None, stats, None, None, 0.0, s)
     else:
         wp = _packed(ctx, w, 0, strides, B, H, W, Cin) if (KH == 3 and tf != TF_LN) else None
         if wp is not None:

@@ -408,6 +408,14 @@ int hrf_nearest_up_bwd(const float* g, int ldG, int goff, int B, int H, int W, i
 int hrf_bilinear_up_into(const float* x, int Hs, int Ws, int C, float* out, int ldOut, int off, int B, int H, int W,
                          void* stream);
 int hrf_avg_pool(const float* x, int B, int H, int W, int C, int k, float* out, void* stream);
+/* The 3x3 / pad-1 patches of a FEW-channel input as rows (the stem's first convolution, 3 -> 64 stride 2 on the NCHW network input:
+ * hrnet.py:341-347, hrfuser_hrformer_based.py:380-386):  cols[(b, yo, xo)][ci * 9 + tap] = x(b, ci, yo * stride - 1 + tap / 3,
+ * xo * stride - 1 + tap % 3), zero outside the image; x through element strides (NCHW or channels-last), rows `ld` >= 9 Cin floats apart.
+ * The column order is the OIHW weight's memory order: F.conv2d(x, w, stride, 1) = cols . w.view(Cout, 9 Cin)^T (hrf_conv_fwd with KH = 1
+ * on the rows) and grad_weight = dY^T . cols (hrf_conv_bwd_weight with KH = 1) - both on the channel-contiguous row kernels
+ * instead of 27 strided gathers per output pixel, and the patches are formed once per step for both. */
+int hrf_im2col3x3(const float* x, int sB, int sY, int sX, int sC, int B, int H, int W, int Cin, int stride,
+                  float* cols, int ld, void* stream);
 int hrf_slice_cols(const float* src, int ld, int off, long rows, int C, float* dst, int accumulate, void* stream);
 int hrf_avg_pool_bwd(const float* g, int B, int H, int W, int C, int k, float* dx, int accumulate, void* stream);
 

@@ -121,6 +121,7 @@ CONV_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
     (2, 5, 6, 288, 72, 1, 1, 3, True, True),         # few rows, deep contraction (HRFuser-B's coarse branches in miniature)
     (1, 6, 7, 330, 300, 1, 1, 4, True, False),       # deep in both directions, ragged K and N
     (2, 6, 5, 144, 144, 1, 1, 4, True, False),       # 9 channel tiles in ONE wave (whole-row LayerNorm statistics) + split K
+    (1, 130, 128, 16, 24, 1, 1, 2, True, True),      # >= 16 384 rows with moments: 16-wave "fat" blocks of the row GEMMs, ragged last block
 ]
 
 
@@ -816,7 +817,7 @@ def test_wgrad_group_gpu():
 
 
 # ------------------------------------------------------------------ emulator (CPU suite)
-@pytest.mark.parametrize('case', CONV_CASES[:8] + CONV_CASES[12:13] + CONV_CASES[-3:], ids=str)      # ([12]: the split over K)
+@pytest.mark.parametrize('case', CONV_CASES[:8] + CONV_CASES[12:13] + CONV_CASES[-4:], ids=str)      # ([12]: the split over K)
 def test_conv_emul(case):
     run_conv(case, 'emul')
 
@@ -853,6 +854,48 @@ C3X_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
     (1, 7, 9, 40, 96, 3, 1, 2, True, True),        # backward with two halo slabs of dY (96 channels), ragged 40 outputs
     (1, 18, 33, 64, 64, 3, 1, 0, False, False),
 ]
+
+
+def run_im2col(backend):
+    """hrf_im2col3x3 (the stem's first convolution as a row GEMM): patches == F.unfold, NCHW and channels-last inputs, both strides;
+    conv = rows . w.view(Cout, 9 Cin)^T through hrf_conv_fwd(KH = 1), grad_weight through hrf_conv_bwd_weight(KH = 1)"""
+    dev = use_backend(backend)
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    for (B, C, H, W, stride, cl) in [(2, 3, 9, 14, 2, False), (1, 3, 8, 7, 1, True), (2, 1, 5, 6, 2, False)]:
+        x = torch.randn(B, C, H, W, generator=g)
+        xs = x.contiguous(memory_format=torch.channels_last) if cl else x
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        ref = F.unfold(x, 3, padding=1, stride=stride).transpose(1, 2).reshape(B, Ho, Wo, 9 * C)       # [.., ci * 9 + tap]
+        xd = xs.to(dev)
+        sB, sC, sY, sX = xd.stride()
+        cols = torch.full((B, Ho, Wo, 9 * C), float('nan'), device=dev)
+        L.hrf_im2col3x3(xd, sB, sY, sX, sC, B, H, W, C, stride, cols, 9 * C, _lib.stream_ptr())
+        assert torch.equal(cols.cpu(), ref)
+        Cout = 20
+        w = torch.randn(Cout, C, 3, 3, generator=g) * 0.3
+        y = torch.zeros(B, Ho, Wo, Cout, device=dev)
+        K9 = 9 * C
+        L.hrf_conv_fwd(cols, Ho * Wo * K9, Wo * K9, K9, 1, B, Ho, Wo, K9, w.to(dev), None, 1, 1, Cout, y, Cout, 0, None, None, 0, 0, None,
+                       None, None, None, None, None, 0.0, _lib.stream_ptr())
+        wq = w.clone().requires_grad_(True)
+        yr = F.conv2d(x, wq, None, stride, 1)
+        assert r(y, nhwc(yr.detach())) < TOL
+        du = torch.randn(B, Ho, Wo, Cout, generator=g)
+        yr.backward(du.permute(0, 3, 1, 2))
+        dw = torch.zeros(Cout, C, 3, 3, device=dev)
+        L.hrf_conv_bwd_weight(du.to(dev), Cout, 0, None, None, None, None, cols, Ho * Wo * K9, Wo * K9, K9, 1, B, Ho, Wo, K9, 1, 1, Cout, 0,
+                              None, None, None, dw, None, _lib.stream_ptr())
+        assert r(dw, wq.grad) < TOL
+
+
+def test_im2col_emul():
+    run_im2col('emul')
+
+
+@pytest.mark.gpu
+def test_im2col_gpu():
+    run_im2col('hip')
 
 
 @pytest.mark.parametrize('case', C3X_CASES[:6], ids=str)
