@@ -65,7 +65,7 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_RAW_RETURN = ('hrf_conv3_wgrad_wide_scratch', 'hrf_conv3x_pack_size', 'hrf_conv3x_supported', 'hrf_conv_fwd_split_scratch', 'hrf_wgrad_group_report', 'hrf_attn_block_supported', 'hrf_attn_block_bwd_supported', 'hrf_group_count',
+_RAW_RETURN = ('hrf_conv3_wgrad_wide_scratch', 'hrf_conv_bwd_weight_scratch', 'hrf_conv3x_pack_size', 'hrf_conv3x_supported', 'hrf_conv_fwd_split_scratch', 'hrf_wgrad_group_report', 'hrf_attn_block_supported', 'hrf_attn_block_bwd_supported', 'hrf_group_count',
                'hrf_ffn_eval_supported')       # return a value, not a status
 _ERR = {1: 'HRF_ERR_ARG (bad argument)', 2: 'HRF_ERR_LAUNCH (kernel launch failed)'}
 
@@ -117,7 +117,7 @@ class Lib:
         self._fns = {}
         for name, args in self.protos.items():
             fn = getattr(self._dll, name)          # AttributeError if a declared symbol is missing
-            fn.restype = ctypes.c_long if name in ('hrf_conv3_wgrad_wide_scratch', 'hrf_conv3x_pack_size', 'hrf_conv_fwd_split_scratch', 'hrf_wgrad_group_report', 'hrf_group_count') else ctypes.c_int
+            fn.restype = ctypes.c_long if name in ('hrf_conv3_wgrad_wide_scratch', 'hrf_conv_bwd_weight_scratch', 'hrf_conv3x_pack_size', 'hrf_conv_fwd_split_scratch', 'hrf_wgrad_group_report', 'hrf_group_count') else ctypes.c_int
             fn.argtypes = [ct for ct, _ in args]
             self._fns[name] = self._wrap(name, fn, args)
 

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, 'libhrfuser_hip.so')
 RES = os.path.join(HERE, 'kernel_resources.json')     # registers / scratch / LDS / waves per SIMD of every kernel of the build
-SOURCES = ['conv_engine.hip', 'wgrad_tiled.hip', 'lin_engine.hip', 'lin2_engine.hip', 'conv3_engine.hip', 'conv3x_engine.hip', 'conv3w_engine.hip', 'dwconv.hip', 'attention.hip', 'attn_block.hip', 'ffn_eval.hip', 'pointwise.hip', 'group.hip', 'p2p_exchange.hip']
+SOURCES = ['conv_engine.hip', 'wgrad_tiled.hip', 'lin_engine.hip', 'lin2_engine.hip', 'conv3_engine.hip', 'conv3x_engine.hip', 'wgrad3x_engine.hip', 'conv3w_engine.hip', 'dwconv.hip', 'attention.hip', 'attn_block.hip', 'ffn_eval.hip', 'pointwise.hip', 'group.hip', 'p2p_exchange.hip']
 HEADERS = ['hrf_rt.h', 'hrf_common.h', 'hrf_lin.h', 'hrf_group.h', 'hrf_wgrad.h', os.path.join(ROOT, 'include', 'hrfuser_hip.h'),
            os.path.join(ROOT, 'include', 'hrfuser_hip_debug.h')]
 ARCH = 'gfx950'

@@ -1109,7 +1109,9 @@ extern "C" int hrf_conv_bwd_data_packed(const float* dy, int ldD, int doff, cons
 extern "C" __attribute__((visibility("hidden"))) int hrf_pw_knob(int key, int value);
 extern "C" __attribute__((visibility("hidden"))) int hrf_conv3w_knob(int key, int value);
 extern "C" __attribute__((visibility("hidden"))) int hrf_lin2_knob(int key, int value);
+extern "C" __attribute__((visibility("hidden"))) int hrf_w3x_knob(int key, int value);
 extern "C" int hrf_debug_knob(int key, int value) {
+  if (key >= 32 && key < 36) return hrf_w3x_knob(key - 32, value);     // wgrad3x_engine.hip: 32 = blocks per problem, 33 = smallest problem (output pixels)
   if (key >= 28 && key < 32) return hrf_lin2_knob(key - 28, value);    // lin2_engine.hip: 28 = 1 force / 2 disable the LDS-tiled row GEMM
   if (key >= 16 && key < 20) return hrf_pw_knob(key - 16, value);      // pointwise.hip tuning aids
   if (key >= 24 && key < 28) return hrf_conv3w_knob(key - 24, value);  // conv3w_engine.hip tuning aids
@@ -1236,6 +1238,30 @@ extern "C" int hrf_conv_bwd_weight(const float* dy, int ldD, int doff, const flo
     if (cA != nullptr) { HRF_BW_TFA(false, true) } else { HRF_BW_TFA(false, false) }
   }
   return hrf_check_launch();
+}
+
+// ---- the LDS-staged 3x3 weight gradient (wgrad3x_engine.hip): per-split slabs in caller-owned scratch + a fold launch
+long hrf_wgrad3x_scratch(int B, int H, int W, int Cin, int KH, int stride, int Cout, int has_bias, int tf_mode, bool dense_nhwc);
+int hrf_wgrad3x_launch(const float* dy, int ldD, const float* yraw, const float* cA, const float* cB, const float* cC,
+                       const float* x, int ldX, int B, int H, int W, int Cin, int stride, int Cout,
+                       int tf_mode, const float* tf_scale, const float* tf_shift, float* dw, float* scratch, void* stream);
+
+extern "C" long hrf_conv_bwd_weight_scratch(int sB, int sY, int sX, int sC, int B, int H, int W, int Cin, int KH, int stride, int Cout,
+                                            int tf_mode, int has_bias) {
+  return hrf_wgrad3x_scratch(B, H, W, Cin, KH, stride, Cout, has_bias, tf_mode, sC == 1 && sY == W * sX && sB == H * sY);
+}
+
+extern "C" int hrf_conv_bwd_weight_s(const float* dy, int ldD, int doff, const float* yraw,
+                                     const float* cA, const float* cB, const float* cC,
+                                     const float* x, int sB, int sY, int sX, int sC,
+                                     int B, int H, int W, int Cin, int KH, int stride, int Cout,
+                                     int tf_mode, const float* tf_scale, const float* tf_shift,
+                                     const float* tf_rowstat, float* dw, float* dbias, float* scratch, void* stream) {
+  if (scratch == nullptr || hrf_conv_bwd_weight_scratch(sB, sY, sX, sC, B, H, W, Cin, KH, stride, Cout, tf_mode, dbias != nullptr) <= 0)
+    return hrf_conv_bwd_weight(dy, ldD, doff, yraw, cA, cB, cC, x, sB, sY, sX, sC, B, H, W, Cin, KH, stride, Cout, tf_mode, tf_scale,
+                               tf_shift, tf_rowstat, dw, dbias, stream);
+  return hrf_wgrad3x_launch(dy + doff, ldD, cA != nullptr ? yraw + doff : nullptr, cA, cB, cC, x, sX, B, H, W, Cin, stride, Cout, tf_mode,
+                            tf_scale, tf_shift, dw, scratch, stream);
 }
 
 // one launch of kernel variant `key` = (mt, nt, BatchNorm-backward, activation, 3x3) over a group of problems

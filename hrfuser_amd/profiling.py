@@ -52,6 +52,11 @@ def work_model(name, a):
         if a['KH'] == 1 and a['stride'] == 1 and a['sC'] == 1 and a['Cin'] >= 4 and a['Cout'] >= 4:
             return 'lin_bwd_data_kernel', fl, by
         return f"conv_bwd_data_kernel<{_pick_nt(a['Cin'])},{a['KH']},{int(a['cA'] is not None)}>", fl, by
+    if name == 'hrf_conv_bwd_weight_s':
+        Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
+        Mp, Np = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']
+        by = f4 * (Mp * a['Cout'] * (2 if a['cA'] is not None else 1) + a['B'] * a['H'] * a['W'] * a['Cin'] + a['Cout'] * Np)
+        return f"wgrad3x_kernel<{a['stride']}>", 2.0 * Mp * a['Cout'] * Np, by
     if name == 'hrf_conv_bwd_weight':
         Ho, Wo = _out_hw(a['H'], a['W'], a['KH'], a['stride'])
         Mp, Np = a['B'] * Ho * Wo, a['KH'] ** 2 * a['Cin']

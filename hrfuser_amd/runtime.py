@@ -1423,6 +1423,15 @@ def _conv_backward(ctx, src, weight, bias, KH, stride, Cout, dy, ldD, doff, yraw
         Ho, Wo = _conv_out_hw(H, W, KH, stride)
         # byte-equivalent cost for the lane balancer: operand traffic + flops at ~10 FLOP/B
         cost = 4.0 * B * (H * W * Cin + Ho * Wo * Cout * (2 if cA is not None else 1)) + 0.2 * B * Ho * Wo * Cout * Cin * KH * KH
+        # the large 3x3 problems (stems, transition1): LDS-staged kernel, per-split slabs in step-lifetime scratch + fold
+        nsc = L.hrf_conv_bwd_weight_scratch(*sw, B, H, W, Cin, KH, stride, Cout, tf, 1 if bgrad is not None else 0) if KH == 3 else 0
+        if nsc > 0:
+            scratch = _new((nsc,), weight.device)
+            ctx.side_launch(lambda: L.hrf_conv_bwd_weight_s(
+                dy, ldD, doff, yraw, cA, cB, cC, xw, *sw, B, H, W, Cin, KH, stride, Cout,
+                tf, sc, sh, rowstat, weight.grad, bgrad, scratch, ctx.stream), cost=cost,
+                key=('conv_w3x', Cin, Cout, KH, stride, tf, cA is not None), target=weight)
+            return
         ctx.side_launch(lambda: L.hrf_conv_bwd_weight(
             dy, ldD, doff, yraw, cA, cB, cC, xw, *sw, B, H, W, Cin, KH, stride, Cout,
             tf, sc, sh, rowstat, weight.grad, bgrad, ctx.stream), cost=cost,

@@ -154,6 +154,21 @@ int hrf_conv_bwd_data_packed(const float* dy, int ldD, int doff, const float* yr
                              int epi, const float* xraw, int ldXr, const float* tf_scale,
                              const float* tf_shift, int act, double* stats, const float* wp, void* stream);
 
+/* The weight gradient of the LARGE 3x3 problems (the stems' 64 -> 64 convolutions, transition1: >= 16 384 output pixels, >= 32 input
+ * channels, NHWC rows, no bias gradient) on the LDS-staged 32x32x2 kernel of csrc/wgrad3x_engine.hip: the pixel splits leave their
+ * sums as plain stores in caller-owned scratch, a second small launch of the same call folds them into dw (no atomics: bit-
+ * reproducible).  hrf_conv_bwd_weight_scratch -> floats of scratch the problem wants (0: it would not use any - call
+ * hrf_conv_bwd_weight); hrf_conv_bwd_weight_s = hrf_conv_bwd_weight with that scratch (contents irrelevant; NULL, or a problem
+ * that wants none: plain hrf_conv_bwd_weight).  Launches at once, also between hrf_wgrad_group_begin / _end. */
+long hrf_conv_bwd_weight_scratch(int sB, int sY, int sX, int sC, int B, int H, int W, int Cin, int KH, int stride, int Cout,
+                                 int tf_mode, int has_bias);
+int hrf_conv_bwd_weight_s(const float* dy, int ldD, int doff, const float* yraw,
+                          const float* cA, const float* cB, const float* cC,
+                          const float* x, int sB, int sY, int sX, int sC,
+                          int B, int H, int W, int Cin, int KH, int stride, int Cout,
+                          int tf_mode, const float* tf_scale, const float* tf_shift,
+                          const float* tf_rowstat, float* dw, float* dbias, float* scratch, void* stream);
+
 /* ---- depthwise 3x3 convolution, pad 1, stride 1|2, NHWC (F.conv2d groups=C) -----------------
  * CrossFFN hrformer.py:271-277 (bias, stride 1, input = GELU(BN(h1)) applied on load) and the
  * fuse-down chains hrformer.py:532-541 (stride 2, no bias).  w is (C,1,3,3).                    */

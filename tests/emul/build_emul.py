@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'hrfuser_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libhrfuser_emul.so')
-SOURCES = ['conv_engine.hip', 'wgrad_tiled.hip', 'lin_engine.hip', 'lin2_engine.hip', 'conv3_engine.hip', 'conv3x_engine.hip', 'conv3w_engine.hip', 'dwconv.hip', 'attention.hip', 'attn_block.hip', 'ffn_eval.hip', 'pointwise.hip', 'group.hip', 'p2p_exchange.hip']
+SOURCES = ['conv_engine.hip', 'wgrad_tiled.hip', 'lin_engine.hip', 'lin2_engine.hip', 'conv3_engine.hip', 'conv3x_engine.hip', 'wgrad3x_engine.hip', 'conv3w_engine.hip', 'dwconv.hip', 'attention.hip', 'attn_block.hip', 'ffn_eval.hip', 'pointwise.hip', 'group.hip', 'p2p_exchange.hip']
 
 
 def build(force=False, sanitize=False):

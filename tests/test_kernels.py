@@ -242,6 +242,24 @@ def run_conv(case, backend, packed=False):
     L.hrf_conv_bwd_weight(D(du), Cout, 0, D(yraw), *co, D(xr), *st, B, H, W, Cin, KH, stride, Cout, tf,
                           D(sc) if tf else None, D(sh) if tf else None, D(rowstat), dw, db, _lib.stream_ptr())
     assert r(dw, wq.grad) < TOL and r(db, bq.grad) < TOL
+    # the LDS-staged 3x3 weight gradient (csrc/wgrad3x_engine.hip: per-split slabs in scratch + fold, no atomics) where the shape
+    # qualifies - same gradient, and bit-reproducible
+    L.hrf_debug_knob(33, 64)                     # (product threshold: 16 384 output pixels)
+    try:
+        nsc = L.hrf_conv_bwd_weight_scratch(*st, B, H, W, Cin, KH, stride, Cout, tf, 0)
+        if nsc > 0:
+            assert KH == 3 and Cin >= 32
+            outs = []
+            for _ in range(2):
+                dw2 = torch.zeros_like(w, device=dev)
+                L.hrf_conv_bwd_weight_s(D(du), Cout, 0, D(yraw), *co, D(xr), *st, B, H, W, Cin, KH, stride, Cout, tf,
+                                        D(sc) if tf else None, D(sh) if tf else None, D(rowstat), dw2, None,
+                                        torch.full((nsc,), float('nan'), device=dev), _lib.stream_ptr())
+                outs.append(dw2)
+            assert r(outs[0], wq.grad) < TOL
+            assert torch.equal(outs[0], outs[1])
+    finally:
+        L.hrf_debug_knob(33, 0)
 
 
 # the LDS-tiled row GEMM (csrc/lin2_engine.hip) serves wide 1x1 problems (min(Cin, Cout) >= 64, >= 1024 rows); the debug knob 28
