@@ -570,7 +570,7 @@ constexpr int WNW = 8;     // waves per block (512 threads)
 // phase stamps of one workgroup (wave 0) for tools/time_wgrad_phases.py: compiled in only with -DHRF_WG_TIMING
 #if defined(HRF_WG_TIMING) && !defined(HRF_EMUL)
 __device__ long long g_wg_t[16];
-#define WG_T(k) do { if (blockIdx.x == 17 && threadIdx.x == 0) g_wg_t[k] = wall_clock64(); } while (0)
+#define WG_T(k) do { if (blockIdx.x == (gridDim.x > 17 ? 17u : 0u) && threadIdx.x == 0) g_wg_t[k] = wall_clock64(); } while (0)
 extern "C" int hrf_wgrad_stamps(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_t), sizeof(long long) * 16) == hipSuccess ? HRF_OK : HRF_ERR_LAUNCH;
 }

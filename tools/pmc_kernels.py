@@ -53,7 +53,28 @@ bst312 = torch.zeros(32 * 312, dtype=torch.float64, device=dev)
 bdy78, byr78, bw3, bdx312, bxr312 = R(B, H, W, 78), R(B, H, W, 78), R(78, 312, 1, 1) * 0.05, R(B, H, W, 312), R(B, H, W, 312)
 bc78, bs312 = [R(78) for _ in range(3)], R(312)
 bdw1, bdy312, byr312, bc312 = torch.zeros(312, 78, device=dev), R(B, H, W, 312), R(B, H, W, 312), [R(312) for _ in range(3)]
+# round 6: the packed-weight front-end engine (csrc/conv3x_engine.hip: forward, stride-1 and stride-2 data gradient) and the LDS-staged
+# 3x3 weight gradient (csrc/wgrad3x_engine.hip) on the same 64 -> 64 problem
+def _pack(wt, direction):
+    co_, ci_ = wt.shape[:2]
+    wp_ = torch.empty(L.hrf_conv3x_pack_size(co_, ci_, direction), device=dev)
+    jobs = (_lib.Conv3xPackJob * 1)()
+    jobs[0] = _lib.Conv3xPackJob(wt.data_ptr(), wp_.data_ptr(), co_, ci_, direction)
+    L.hrf_conv3x_pack(jobs, 1, sp())
+    return wp_
+
+
+wpf, wpb = _pack(w, 0), _pack(w, 1)
+H2, W2 = 2 * H, 2 * W
+dx2, x2 = R(B, H2, W2, Cin), R(B, H2, W2, Cin)
+nsc = L.hrf_conv_bwd_weight_scratch(H * W * Cin, W * Cin, Cin, 1, B, H, W, Cin, 3, 1, Cout, 2, 0)
+wscr = torch.empty(max(1, nsc), device=dev)
 for it in range(4):
+    L.hrf_conv_fwd_packed(x, H * W * Cin, W * Cin, Cin, 1, B, H, W, Cin, w, None, 3, 1, Cout, y, Cout, 0, None, None, 0, 2, sc, sh, None, st, None, None, 0.0, wpf, sp())
+    L.hrf_conv_bwd_data_packed(dy, Cout, 0, yr, cA, cB, cC, None, w, 3, 1, Cout, B, H, W, Cin, dx, H * W * Cin, W * Cin, Cin, 1, 0, 1, x, Cin, sc, sh, 1, st, wpb, sp())
+    L.hrf_conv_bwd_data_packed(dy, Cout, 0, yr, cA, cB, cC, None, w, 3, 2, Cout, B, H2, W2, Cin, dx2, H2 * W2 * Cin, W2 * Cin, Cin, 1, 0, 1, x2, Cin, sc, sh, 1, st, wpb, sp())
+    if nsc > 0:
+        L.hrf_conv_bwd_weight_s(dy, Cout, 0, yr, cA, cB, cC, x, H * W * Cin, W * Cin, Cin, 1, B, H, W, Cin, 3, 1, Cout, 2, sc, sh, None, dw, None, wscr, sp())
     L.hrf_conv_fwd(bx78, H * W * 78, W * 78, 78, 1, B, H, W, 78, bw1, None, 1, 1, 312, by312, 312, 0, None, None, 0, 4, bg78, bg78, brs, bst312, None, None, 0.0, sp())
     L.hrf_conv_bwd_data(bdy78, 78, 0, byr78, *bc78, None, bw3, 1, 1, 78, B, H, W, 312, bdx312, H * W * 312, W * 312, 312, 1, 0, 1, bxr312, 312, bs312, bs312, 2, bst312, sp())
     L.hrf_conv_bwd_weight(bdy312, 312, 0, byr312, *bc312, bx78, H * W * 78, W * 78, 78, 1, B, H, W, 78, 1, 1, 312, 4, bg78, bg78, brs, bdw1, None, sp())

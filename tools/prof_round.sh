@@ -50,7 +50,15 @@ SHAPES = {'wgrad_dense_kernel<2, 5, true, 2, 0>': ('conv_bwd_weight[B=2,H=96,W=1
           # HRFuser-B fc1 forward 78 -> 312 (x + rowstat + y), fc3 data gradient (dy, yraw, xraw, dx), fc1 weight gradient (dy, yraw, x)
           'lin2_fwd_kernel<Tile<2, 10, 2>, 4>': ('conv_fwd[B=2,H=96,W=160,Cin=78,Cout=312,KH=1,stride=1,tf_mode=4]', 30720 * (78 + 2 + 312) * 4),
           'lin2_bwd_data_kernel<Tile<2, 10, 2>, true>': ('conv_bwd_data[B=2,H=96,W=160,Cin=312,Cout=78,KH=1,stride=1,epi=1,accumulate=0,bnb=1]', 30720 * (78 + 78 + 312 + 312) * 4),
-          'wgrad_dense_kernel<5, 5, true, 0, 0>': ('conv_bwd_weight[B=2,H=96,W=160,Cin=78,Cout=312,KH=1,stride=1,tf_mode=4,bnb=1]', 30720 * (312 + 312 + 78 + 2) * 4)}
+          'wgrad_dense_kernel<5, 5, true, 0, 0>': ('conv_bwd_weight[B=2,H=96,W=160,Cin=78,Cout=312,KH=1,stride=1,tf_mode=4,bnb=1]', 30720 * (312 + 312 + 78 + 2) * 4),
+          # round 6: the fused attention block (algorithmic bytes of hrfuser_amd.profiling.work_model), the packed-weight 3x3 engine
+          # (x + y + weights; dy + yraw + xraw + dx + weights) and the LDS-staged 3x3 weight gradient (dy + yraw + x + dw)
+          'attn_block_bwd_kernel<18, 1, 4, true, false, false>': ('attn_block_bwd[B=2,H=96,W=160,C=18,heads=1,cross=0,w1=1]', 39414416),
+          'attn_block_fwd_kernel<18, 1>': ('attn_block_fwd[B=2,H=96,W=160,C=18,heads=1,cross=0,w1=1]', 13281408),
+          'conv3x_kernel<0, 2>': ('conv_fwd_packed[B=2,H=96,W=160,Cin=64,Cout=64,KH=3,stride=1,tf_mode=2]', (30720 * 128 + 36864) * 4),
+          'conv3x_kernel<1, 2>': ('conv_bwd_data_packed[B=2,H=96,W=160,Cin=64,Cout=64,KH=3,stride=1,epi=1,accumulate=0,bnb=1]', (30720 * 256 + 36864) * 4),
+          'conv3x_kernel<2, 2>': ('conv_bwd_data_packed[B=2,H=192,W=320,Cin=64,Cout=64,KH=3,stride=2,epi=1,accumulate=0,bnb=1]', (30720 * 128 + 122880 * 128 + 36864) * 4),
+          'wgrad3x_kernel<1, false>': ('conv_bwd_weight_s[B=2,H=96,W=160,Cin=64,Cout=64,KH=3,stride=1,tf_mode=2,bnb=1]', (30720 * 192 + 36864) * 4)}
 traffic = {'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over tools/pmc_kernels.py (each hot kernel '
                      'launched eagerly on its branch-0 shape, 2x96x160); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch',
            'kernels': {}, 'shapes': {}}

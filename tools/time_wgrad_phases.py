@@ -39,7 +39,21 @@ CASES = [('B fc1 dW 312x78  LN(x), BN-bwd(dy)     2x96x160', wgrad(2, 96, 160, 7
          ('B fc3 dW 312x1248 GELU(BN(x)), BN-bwd  2x24x40 ', wgrad(2, 24, 40, 1248, 312, 3, True)),
          ('B fc3 dW 624x2496 GELU(BN(x)), BN-bwd  2x12x20 ', wgrad(2, 12, 20, 2496, 624, 3, True)),
          ('T fc3 dW 18x72   GELU(BN(x)), BN-bwd   2x96x160', wgrad(2, 96, 160, 72, 18, 3, True)),
-         ('T fc3 dW 72x288  GELU(BN(x)), BN-bwd   2x24x40 ', wgrad(2, 24, 40, 288, 72, 3, True))]
+         ('T fc3 dW 72x288  GELU(BN(x)), BN-bwd   2x24x40 ', wgrad(2, 24, 40, 288, 72, 3, True)),
+         ('T q   dW 72x72   plain                 2x24x40 ', wgrad(2, 24, 40, 72, 72, 0, False)),
+         ('T fc1 dW 288x72  LN(x), BN-bwd         2x24x40 ', wgrad(2, 24, 40, 72, 288, 4, True)),
+         ('T fc3 dW 36x144  GELU(BN(x)), BN-bwd   2x48x80 ', wgrad(2, 48, 80, 144, 36, 3, True)),
+         ('T q   dW 144x144 plain                 2x12x20 ', wgrad(2, 12, 20, 144, 144, 0, False)),
+         ('T fuse dW 18x18  plain, BN-bwd         2x48x80 ', wgrad(2, 48, 80, 18, 18, 0, True))]
+if os.environ.get('HRF_WG_GROUPED'):
+    # as the step issues them: queued between hrf_wgrad_group_begin / _end (16 pixel splits at most instead of 128)
+    def grouped(fn):
+        def run():
+            L.hrf_wgrad_group_begin()
+            fn()
+            L.hrf_wgrad_group_end(sp())
+        return run
+    CASES = [(n + ' [grouped]', grouped(f)) for n, f in CASES]
 for name, fn in CASES:
     for _ in range(3):
         fn()
