@@ -6,6 +6,13 @@ R=${1:?round tag, e.g. r04}
 cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 O=gpurun_out/final_$R; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
+# round 6: the PMC passes run FIRST and their summaries go into profiles/ of this box's copy, so that the bench line's `traffic`,
+# `traffic_ratio`, per-stage MFMA-busy / bytes name files of THIS round (the same files are committed from gpurun_out/ afterwards)
+bash tools/prof_round.sh $R > $O/prof.log 2>&1
+cp gpurun_out/prof_$R/${R}_* gpurun_out/prof_$R/bench_under_rocprof.log $O/ 2>/dev/null
+cp gpurun_out/prof_$R/${R}_hbm_traffic.json profiles/ 2>/dev/null
+bash tools/prof_stages_pmc.sh $R > $O/prof_stages.log 2>&1
+cp gpurun_out/pmc_stages_$R/${R}_stage_hbm_traffic.json $O/ 2>/dev/null; cp gpurun_out/pmc_stages_$R/${R}_stage_hbm_traffic.json profiles/ 2>/dev/null
 python bench.py --dump-kernels $O/${R}_kernels_graph_timed.json > $O/${R}_bench_line.json 2> $O/bench.err
 python bench.py --model b_nus_bn --no-cpu-baseline --no-neck --no-eager --steps 20 --warmup 5 --dump-kernels $O/${R}_kernels_b_nus.json > $O/${R}_bench_b_nus.json 2>> $O/bench.err
 python bench.py --model t_stf_bn --no-cpu-baseline --no-neck --no-eager --steps 30 --warmup 5 --dump-kernels $O/${R}_kernels_t_stf.json > $O/${R}_bench_t_stf.json 2>> $O/bench.err
@@ -18,8 +25,6 @@ HRF_FORCE_COLLECTIVES=1 HRF_SYNC_P2P=1 python bench.py --model b_nus_bn --no-cpu
 python bench.py --gpus 2 --backend gloo --steps 3 --warmup 1 --height 128 --width 192 --no-roofline --sync-ab-timeout 600 > $O/${R}_bench_two_ranks_one_gpu.json 2>> $O/bench.err
 python bench.py --gpus 2 --steps 2 --warmup 1 > $O/${R}_bench_gpus2_on_one_gpu.txt 2>&1; echo "rc $?" >> $O/${R}_bench_gpus2_on_one_gpu.txt
 python tools/lane_stamps.py > $O/${R}_lane_stamps.txt 2>> $O/bench.err
-bash tools/prof_round.sh $R > $O/prof.log 2>&1
-cp gpurun_out/prof_$R/${R}_* gpurun_out/prof_$R/bench_under_rocprof.log $O/ 2>/dev/null
 bash tools/prof_pmc_sq.sh $R > $O/prof_sq.log 2>&1
 cp gpurun_out/pmc_sq_$R/${R}_pmc_sq.json $O/ 2>/dev/null
 bash tools/prof_timeline.sh > /dev/null 2>&1
@@ -32,6 +37,12 @@ python tools/exchange_overlap.py t_nus_bn 4 > $O/${R}_grad_exchange_overlap_t_nu
 python tools/wgrad_groups.py t_nus_bn > $O/${R}_wgrad_groups_t_nus.txt 2>> $O/bench.err
 python tools/wgrad_groups.py b_nus_bn > $O/${R}_wgrad_groups_b_nus.txt 2>> $O/bench.err
 python tools/bench_wgrad_tiled.py > $O/${R}_wgrad_tiled_microbench.txt 2>> $O/bench.err
+# round 6 microbenchmarks: front-end 3x3 engines old vs packed, 3x3 weight gradient pixel-major vs LDS-staged, row-GEMM decomposition
+# (what moments / transforms / epilogues cost), same-line atomics by copies and scope
+python tools/bench_conv3x.py $O/${R}_conv3x_microbench.json 2>> $O/bench.err | grep -v amdgpu > $O/${R}_conv3x_microbench.txt
+python tools/bench_wgrad3x.py 2>> $O/bench.err | grep -v amdgpu > $O/${R}_wgrad3x_microbench.txt
+python tools/bench_lin.py 2>> $O/bench.err | grep -v amdgpu > $O/${R}_stream_kernels_decomposition.txt
+./tools/microbench/atomics_scope > $O/${R}_atomics_scope.txt 2>> $O/bench.err
 # the full GPU suite with its slowest calls
 timeout 1400 python -m pytest tests -m gpu -x -q > $O/${R}_gpu_suite_durations.txt 2>&1; echo "gpu suite rc $?" >> $O/${R}_gpu_suite_durations.txt
 for f in $O/${R}_bench_*.json; do echo $f; tail -1 $f | cut -c1-260; done
