@@ -322,7 +322,7 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
     float bv = 0.f, esc = 1.f, esh = 0.f;
     if (MODE == 0) { if (a.bias != nullptr) bv = a.bias[chc]; }
     else if (a.epi == 1) { esc = a.esc[chc]; esh = a.esh[chc]; }
-    long prow[16]; bool ok[16]; float ev[16];
+    long prow[16]; bool ok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int yy = y0 + 2 * rp + (r >> 3), xx = x0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;
@@ -330,37 +330,45 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
       ok[r] = chv && y < a.H && x < a.W;
       prow[r] = (long)(b * a.H + y) * a.W + x;
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (MODE == 0) {
-        ev[r] = a.res != nullptr ? *(ok[r] ? a.res + prow[r] * a.ldR + ch : g_zero4x) : 0.f;
-        if (a.res2 != nullptr) ev[r] += *(ok[r] ? a.res2 + prow[r] * a.ldR + ch : g_zero4x);
-      } else if (a.epi == 1) {
-        ev[r] = *(ok[r] ? a.xraw + prow[r] * a.ldXr + ch : g_zero4x);
-      } else {
-        ev[r] = a.accumulate ? *(ok[r] ? a.out + prow[r] * a.ldOut + ch : g_zero4x) : 0.f;
-      }
-    }
-    if (MODE != 0 && a.epi == 1 && a.act == HRF_ACT_GELU) {
+    // (one uniform branch per epilogue KIND around whole loops - the same code with the kind tested per element inside one loop
+    // measured 10 us slower on the stride-2 backward, whose blocks run four epilogues)
+    if (MODE == 0) {
+      float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[r] * hrf_gelu_grad(fmaf(ev[r], esc, esh));
-        if (ok[r]) { a.out[prow[r] * a.ldOut + ch] = v; s1 += v; s2 = fmaf(v, ev[r], s2); }
+        rv[r] = a.res != nullptr ? *(ok[r] ? a.res + prow[r] * a.ldR + ch : g_zero4x) : 0.f;
+        if (a.res2 != nullptr) rv[r] += *(ok[r] ? a.res2 + prow[r] * a.ldR + ch : g_zero4x);
       }
-      return;
-    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (MODE == 0) {
-        const float v = acc[r] + bv + ev[r];
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[r] + bv + rv[r];
         if (ok[r]) { a.out[prow[r] * a.ldOut + a.ooff + ch] = v; s1 += v; s2 = fmaf(v, v, s2); }
-      } else if (a.epi == 1) {
-        const float u = fmaf(ev[r], esc, esh);
-        const float v = a.act == HRF_ACT_RELU ? (u > 0.f ? acc[r] : 0.f) : acc[r];
-        if (ok[r]) { a.out[prow[r] * a.ldOut + ch] = v; s1 += v; s2 = fmaf(v, ev[r], s2); }
-      } else if (ok[r]) {
-        a.out[prow[r] * a.ldOut + ch] = ev[r] + acc[r];
       }
+    } else if (a.epi == 1) {
+      float xr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xr[r] = *(ok[r] ? a.xraw + prow[r] * a.ldXr + ch : g_zero4x);
+      if (a.act == HRF_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[r] * hrf_gelu_grad(fmaf(xr[r], esc, esh));
+          if (ok[r]) { a.out[prow[r] * a.ldOut + ch] = v; s1 += v; s2 = fmaf(v, xr[r], s2); }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float u = fmaf(xr[r], esc, esh);
+          const float v = a.act == HRF_ACT_RELU ? (u > 0.f ? acc[r] : 0.f) : acc[r];
+          if (ok[r]) { a.out[prow[r] * a.ldOut + ch] = v; s1 += v; s2 = fmaf(v, xr[r], s2); }
+        }
+      }
+    } else {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pv[r] = a.accumulate ? *(ok[r] ? a.out + prow[r] * a.ldOut + ch : g_zero4x) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (ok[r]) a.out[prow[r] * a.ldOut + ch] = pv[r] + acc[r];
     }
   };
   // moments of a finished column group: lanes -> waves (LDS) -> one atomic per channel and block

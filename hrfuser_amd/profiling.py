@@ -501,6 +501,9 @@ def kernel_resources(key):
     from . import build_ext
     res = build_ext.resources()
     hits = {k: v for k, v in res.items() if k == key or k.startswith(key + '<') or k.replace(' ', '') == key.replace(' ', '')}
+    if not hits and key.endswith('>'):              # the work model names the fused kernels by their FIRST template arguments
+        pre = key[:-1].replace(' ', '')
+        hits = {k: v for k, v in res.items() if k.replace(' ', '').startswith(pre + ',') or k.replace(' ', '').startswith(pre + '>')}
     if not hits:
         return None
     tot = lambda v: v.get('vgpr', 0) + v.get('agpr', 0)
