@@ -93,10 +93,11 @@ __device__ __forceinline__ void xlds_st4(float* p, hrf_f4 v) { *reinterpret_cast
 // steps ahead) and by the consumer; every member is wave-uniform
 template <int MODE>
 struct XStep {
+  static constexpr int HSW = MODE == 3 ? 32 : 64;            // channels of a staged halo slab
   int col, hs, cls, ti, sub, nsub, cin, nhs, ncol;
-  __device__ __forceinline__ int nsub_of(int h) const { return (min(64, cin - 64 * h) + 31) >> 5; }
+  __device__ __forceinline__ int nsub_of(int h) const { return (min(HSW, cin - HSW * h) + 31) >> 5; }
   __device__ __forceinline__ void init(int Cin, int ncols) {
-    cin = Cin; nhs = (Cin + 63) >> 6; ncol = ncols; col = 0; hs = 0; cls = 0; ti = 0; sub = 0; nsub = nsub_of(0);
+    cin = Cin; nhs = (Cin + HSW - 1) / HSW; ncol = ncols; col = 0; hs = 0; cls = 0; ti = 0; sub = 0; nsub = nsub_of(0);
   }
   __device__ __forceinline__ bool done() const { return col >= ncol; }
   __device__ __forceinline__ int ntaps() const { return MODE == 2 ? (1 + (cls >> 1)) * (1 + (cls & 1)) : 9; }
@@ -111,6 +112,14 @@ struct XStep {
       const int iy = ti >= nsx ? 1 : 0, ix = ti - iy * nsx;
       wtap = (cpy ? 2 * iy : 1) * 3 + (cpx ? 2 * ix : 1);
       dy = cpy ? 1 - iy : 0; dx = cpx ? 1 - ix : 0;         // tap ky = 2 iy reads source row y' + 1 - iy
+    } else if (MODE == 3) {
+      // stride-2 forward: the staged patch lives in four PARITY PLANES (row / column parity of the source pixel 2 r + ky,
+      // 2 c + kx relative to the patch origin): plane (ky & 1, kx & 1) starts at row {0, 5, 10, 14}, tap (ky, kx) reads its
+      // pixel (r + (ky >> 1), c + (kx >> 1)) - `dy` carries the plane's first row, so the fragment address keeps one form
+      const int ky = ti >= 6 ? 2 : (ti >= 3 ? 1 : 0), kx = ti - 3 * ky;
+      const int pl = (ky & 1) * 2 + (kx & 1);
+      dy = (pl == 0 ? 0 : (pl == 1 ? 5 : (pl == 2 ? 10 : 14))) + (ky >> 1); dx = kx >> 1;
+      wtap = ti;
     } else {
       dy = ti >= 6 ? 2 : (ti >= 3 ? 1 : 0); dx = ti - 3 * dy;
       wtap = MODE == 1 ? 8 - ti : ti;
@@ -133,13 +142,20 @@ struct XStep {
 template <int MODE, int NCG>
 __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
   const C3xArgs& a = grp.sel();
+  constexpr bool FWD = MODE == 0 || MODE == 3;                 // forward contract (transform on load, bias / residual, moments of y)
   constexpr int RP = 4 / NCG, TH = 2 * RP;                       // row pairs (= waves per channel group), tile height
-  constexpr int SH = MODE == 2 ? TH + 1 : TH + 2, SW = MODE == 2 ? XW + 1 : XW + 2, ORG = MODE == 2 ? 0 : -1;
+  // staged source patch: rows x columns, origin relative to the tile origin; MODE 3: the 9 x 33 patch of the stride-2 forward
+  constexpr int SH = MODE == 2 ? TH + 1 : (MODE == 3 ? 2 * TH + 1 : TH + 2), SW = MODE == 2 ? XW + 1 : (MODE == 3 ? 2 * XW + 1 : XW + 2);
+  constexpr int ORG = MODE == 2 ? 0 : -1, SM = MODE == 3 ? 2 : 1;
+  constexpr int HSW = XStep<MODE>::HSW, C4N = HSW / 4;           // channels / float4 per staged pixel
+  constexpr int PPX = MODE == 3 ? 36 : XPP;                      // pixel pitch: 9 (17) granules - odd, so 16 pixels hit 16 bank groups
+  constexpr int RPX = MODE == 3 ? 640 : XRP;                     // row pitch = 0 mod 64 banks
+  constexpr int LROWS = MODE == 3 ? 18 : SH;                     // LDS rows (MODE 3: 5 + 5 + 4 + 4 rows of the four parity planes)
   constexpr int NPX = SH * SW;                                   // staged source pixels
   constexpr int NB = NCG * 32;                                   // output channels per block
   constexpr int WT = NB * 32;                                    // floats of a weight tile
-  constexpr int NHE = (NPX * 16 + XNT - 1) / XNT;                // halo float4 per thread
-  __shared__ __attribute__((aligned(16))) float sIn[SH * XRP];
+  constexpr int NHE = (NPX * C4N + XNT - 1) / XNT;               // halo float4 per thread
+  __shared__ __attribute__((aligned(16))) float sIn[LROWS * RPX];
   __shared__ __attribute__((aligned(16))) float sW[3 * WT];
   __shared__ __attribute__((aligned(16))) float sFin[3 * XFC];
   __shared__ float sStat[RP * 2 * NB];
@@ -159,30 +175,35 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
   const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
 
   // ---- staging maps (the thread's four channels are the same for every halo element it stages)
-  const int c4 = tid & 15;
+  const int c4 = tid & (C4N - 1);
   const float* hsrc[NHE]; int hdst[NHE]; bool hin[NHE];
 #pragma unroll
   for (int e = 0; e < NHE; ++e) {
     const int f = tid + e * XNT;
-    const int pix = min(f >> 4, NPX - 1);
+    const int pix = min(f / C4N, NPX - 1);
     const int py = pix / SW, px = pix - py * SW;
-    const int gy = y0 + ORG + py, gx = x0 + ORG + px;
-    hin[e] = f < NPX * 16 && (unsigned)gy < (unsigned)a.Hs && (unsigned)gx < (unsigned)a.Ws;
+    const int gy = y0 * SM + ORG + py, gx = x0 * SM + ORG + px;
+    hin[e] = f < NPX * C4N && (unsigned)gy < (unsigned)a.Hs && (unsigned)gx < (unsigned)a.Ws;
     hsrc[e] = a.in + ((long)(b * a.Hs + gy) * a.Ws + gx) * a.ldIn;
-    hdst[e] = f < NPX * 16 ? py * XRP + px * XPP + 4 * c4 : -1;
+    int lrow = py, lcol = px;
+    if (MODE == 3) {                                             // parity planes (see XStep::decode)
+      const int pl = (py & 1) * 2 + (px & 1);
+      lrow = (pl == 0 ? 0 : (pl == 1 ? 5 : (pl == 2 ? 10 : 14))) + (py >> 1); lcol = px >> 1;
+    }
+    hdst[e] = f < NPX * C4N ? lrow * RPX + lcol * PPX + 4 * c4 : -1;
   }
   hrf_f4 hv[NHE], hv2[NHE];
-  const bool two = MODE != 0 && a.in2 != nullptr;
+  const bool two = !FWD && a.in2 != nullptr;
   const long d2 = two ? a.in2 - a.in : 0;
   auto load_halo = [&](int hs) X_INLINE {
-    const int c = hs * 64 + 4 * c4;
+    const int c = hs * HSW + 4 * c4;
     if ((a.Cin & 3) == 0) {
       const bool cv = c < a.Cin;
 #pragma unroll
       for (int e = 0; e < NHE; ++e) {
         const float* p = (hin[e] && cv) ? hsrc[e] + c : g_zero4x;
         hv[e] = hrf_ld4(p);
-        if (MODE != 0) hv2[e] = hrf_ld4(two && hin[e] && cv ? p + d2 : g_zero4x);
+        if (!FWD) hv2[e] = hrf_ld4(two && hin[e] && cv ? p + d2 : g_zero4x);
       }
     } else {                                                     // ragged channel count (18, 36 + 2 ...): element loads
 #pragma unroll
@@ -192,7 +213,7 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
           const bool ok = hin[e] && c + r < a.Cin;
           const float* p = ok ? hsrc[e] + c + r : g_zero4x;
           hv[e][r] = *p;
-          if (MODE != 0) hv2[e][r] = *(two && ok ? p + d2 : g_zero4x);
+          if (!FWD) hv2[e][r] = *(two && ok ? p + d2 : g_zero4x);
         }
       }
     }
@@ -201,15 +222,15 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
   const float* t1p = sFin + XFC;
   const float* t2p = sFin + 2 * XFC;
   auto store_halo = [&](int hs) X_INLINE {
-    const int c = hs * 64 + 4 * c4;
+    const int c = hs * HSW + 4 * c4;
     float p0[4], p1[4], p2[4];
-    const bool tf = MODE == 0 ? a.tf_mode != HRF_TF_NONE : a.t0 != nullptr;
+    const bool tf = FWD ? a.tf_mode != HRF_TF_NONE : a.t0 != nullptr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int cc = min(c + r, a.Cin - 1);
-      p0[r] = tf ? t0p[cc] : 1.f; p1[r] = tf ? t1p[cc] : 0.f; p2[r] = (tf && MODE != 0) ? t2p[cc] : 0.f;
+      p0[r] = tf ? t0p[cc] : 1.f; p1[r] = tf ? t1p[cc] : 0.f; p2[r] = (tf && !FWD) ? t2p[cc] : 0.f;
     }
-    if (MODE == 0 && a.tf_mode == HRF_TF_AFFINE_GELU) {
+    if (FWD && a.tf_mode == HRF_TF_AFFINE_GELU) {
 #pragma unroll
       for (int e = 0; e < NHE; ++e) {
         hrf_f4 v = hv[e];
@@ -219,14 +240,14 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
       }
       return;
     }
-    const bool relu = MODE == 0 && a.tf_mode == HRF_TF_AFFINE_RELU;
+    const bool relu = FWD && a.tf_mode == HRF_TF_AFFINE_RELU;
 #pragma unroll
     for (int e = 0; e < NHE; ++e) {
       hrf_f4 v = hv[e];
       if (tf) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float u = MODE == 0 ? fmaf(v[r], p0[r], p1[r]) : fmaf(p0[r], v[r], fmaf(p1[r], hv2[e][r], p2[r]));
+          float u = FWD ? fmaf(v[r], p0[r], p1[r]) : fmaf(p0[r], v[r], fmaf(p1[r], hv2[e][r], p2[r]));
           if (relu) u = fmaxf(u, 0.f);
           v[r] = (hin[e] && c + r < a.Cin) ? u : 0.f;            // zero padding applies AFTER the transform
         }
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
   auto load_w = [&](const XStep<MODE>& s) X_INLINE {
     int wtap, dy, dx;
     s.decode(wtap, dy, dx);
-    const float* p = wrow + wtap * wtap_stride + (long)s.col * NB * a.Kp + s.hs * 64 + s.sub * 32;
+    const float* p = wrow + wtap * wtap_stride + (long)s.col * NB * a.Kp + s.hs * HSW + s.sub * 32;
 #pragma unroll
     for (int e = 0; e < NCG; ++e) wreg[e] = hrf_ld4(p + (long)e * 32 * a.Kp);
   };
@@ -259,7 +280,7 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
   ls = cs;
   load_halo(0);
   load_w(ls); ls.next();
-  if (MODE == 0) {
+  if (FWD) {
     if (a.fin.stats != nullptr) { if (X_VARIANT != 6) hrf_bn_fin_onload(a.fin, sFin, sFin + XFC, tid, XNT, writer); }
     else if (a.tf_mode != HRF_TF_NONE)
       for (int c = tid; c < a.Cin; c += XNT) { sFin[c] = a.t0[c]; sFin[XFC + c] = a.t1[c]; }
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
   float s1 = 0.f, s2 = 0.f;                                      // moments of channel n0 + 32 cg + j over this lane's pixels
 
   // fragment addressing: A = halo (pixel i = lane & 31 of the wave's 2 x 16 pixels, k half h), B = weight row j of group cg
-  const float* abase = sIn + (2 * rp + (j >> 4)) * XRP + (j & 15) * XPP + 4 * h;
+  const float* abase = sIn + (2 * rp + (j >> 4)) * RPX + (j & 15) * PPX + 4 * h;
   const float* bbase = sW + cg * 1024 + ((((j & 15) << 1) | (j >> 4)) << 5);
   int bsw[4];
 #pragma unroll
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
   auto read_frags = [&](const XStep<MODE>& s, int slot, int set) X_INLINE {
     int wtap, dy, dx;
     s.decode(wtap, dy, dx);
-    const float* ap = abase + dy * XRP + dx * XPP + s.sub * 32;
+    const float* ap = abase + dy * RPX + dx * PPX + s.sub * 32;
     const float* bp = bbase + slot * WT;
 #pragma unroll
     for (int g = 0; g < 4; ++g) { fa[set][g] = xlds_ld4(ap + 8 * g); fb[set][g] = xlds_ld4(bp + bsw[g]); }
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
     const int chc = chv ? ch : 0;
     const int cpy = cls >> 1, cpx = cls & 1;
     float bv = 0.f, esc = 1.f, esh = 0.f;
-    if (MODE == 0) { if (a.bias != nullptr) bv = a.bias[chc]; }
+    if (FWD) { if (a.bias != nullptr) bv = a.bias[chc]; }
     else if (a.epi == 1) { esc = a.esc[chc]; esh = a.esh[chc]; }
     long prow[16]; bool ok[16];
 #pragma unroll
@@ -332,7 +353,7 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
     }
     // (one uniform branch per epilogue KIND around whole loops - the same code with the kind tested per element inside one loop
     // measured 10 us slower on the stride-2 backward, whose blocks run four epilogues)
-    if (MODE == 0) {
+    if (FWD) {
       float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -417,7 +438,7 @@ __global__ __launch_bounds__(XNT, 2) void conv3x_kernel(HrfGroup<C3xArgs> grp) {
     slot = nslot;
     if (X_VARIANT != 5) __syncthreads();
   };
-  const bool want_stats = a.stats != nullptr && (MODE == 0 || a.epi == 1);      // (uniform)
+  const bool want_stats = a.stats != nullptr && (FWD || a.epi == 1);      // (uniform)
   for (; X_VARIANT != 2;) {
     read_frags(cs, slot, 0);
     X_WAIT_LDS();
@@ -474,14 +495,15 @@ __global__ __launch_bounds__(256) void conv3x_pack_kernel(PackJobs pj, int njobs
 template <int MODE>
 int conv3x_launch(C3xArgs a, void* stream) {
   if (a.B <= 0 || a.H <= 0 || a.W <= 0) return HRF_OK;
-  if (MODE != 2) { a.Hs = a.H; a.Ws = a.W; }
-  a.tilesX = hrf_cdiv(a.Ws, XW); a.tilesY = hrf_cdiv(a.Hs, 4);
+  if (MODE == 0 || MODE == 1) { a.Hs = a.H; a.Ws = a.W; }
+  // tiles: of the output grid, except MODE 2 (tiles of the SOURCE grid, four output parity classes each)
+  a.tilesX = hrf_cdiv(MODE == 2 ? a.Ws : a.W, XW); a.tilesY = hrf_cdiv(MODE == 2 ? a.Hs : a.H, 4);
   a.ntiles = a.tilesX * a.tilesY * a.B;
   a.per_xcd = hrf_cdiv(a.ntiles, 8);
   const int ncols = hrf_cdiv(a.Cout, 64);
   // one halo slab and enough tiles to fill the chip twice over: the block walks every column group over its staged halo
   // (2 x 16 x 24 pixels, 36 -> 256: 16 blocks x 4 groups 115 us, 64 blocks 20 us)
-  a.cols_per_block = (a.Cin <= 64 && a.ntiles >= 448) ? ncols : 1;
+  a.cols_per_block = (MODE != 3 && a.Cin <= 64 && a.ntiles >= 448) ? ncols : 1;
   const dim3 grid(a.per_xcd * 8, hrf_cdiv(ncols, a.cols_per_block));
   HRF_LAUNCH_G((conv3x_kernel<MODE, 2>), grid, dim3(XNT), 0, stream, a);
   return hrf_check_launch();
@@ -492,6 +514,7 @@ int conv3x_launch(C3xArgs a, void* stream) {
 int hrf_conv3x_fwd_launch(const C3xArgs& a, void* stream) { return conv3x_launch<0>(a, stream); }
 int hrf_conv3x_bwd_data_launch(const C3xArgs& a, void* stream) { return conv3x_launch<1>(a, stream); }
 int hrf_conv3xs2_bwd_data_launch(const C3xArgs& a, void* stream) { return conv3x_launch<2>(a, stream); }
+int hrf_conv3xs2_fwd_launch(const C3xArgs& a, void* stream) { return conv3x_launch<3>(a, stream); }
 
 extern "C" long hrf_conv3x_pack_size(int Cout, int Cin, int dir) {
   if (Cout <= 0 || Cin <= 0) return 0;

@@ -1054,7 +1054,7 @@ extern "C" int hrf_conv_bwd_data(const float* dy, int ldD, int doff, const float
 // ---- the packed-weight front-end engine (conv3x_engine.hip)
 extern "C" int hrf_conv3x_supported(int Cin, int Cout, int KH, int stride, int dir) {
   if (KH != 3 || Cin <= 0 || Cout <= 0) return 0;
-  if (dir == 0) return stride == 1 && Cout > 32 ? 1 : 0;
+  if (dir == 0) return (stride == 1 || stride == 2) && Cout > 32 ? 1 : 0;
   if (stride == 2) return Cin > 32 && Cout <= 64 ? 1 : 0;       // (the parity-class walk keeps ONE halo slab: <= 64 channels of dY)
   return stride == 1 && Cin > 32 ? 1 : 0;
 }
@@ -1077,8 +1077,14 @@ extern "C" int hrf_conv_fwd_packed(const float* x, int sB, int sY, int sX, int s
   c.out = y; c.ldOut = ldY; c.ooff = yoff; c.res = res; c.res2 = res2; c.ldR = ldR; c.stats = stats;
   c.B = B; c.H = H; c.W = W; c.Cin = Cin; c.Cout = Cout;
   if (tf_fin != nullptr) c.fin = *tf_fin;
-  const int rc = hrf_conv3x_fwd_launch(c, stream);
-  if (rc == HRF_OK && ln_rowstat != nullptr) return hrf_ln_stats(y, (long)B * H * W, Cout, ln_eps, ln_rowstat, stream);
+  int rc;
+  if (stride == 2) {                                             // the source grid is the input, tiles walk the output grid
+    c.Hs = H; c.Ws = W; c.H = (H + 2 - KH) / 2 + 1; c.W = (W + 2 - KH) / 2 + 1;
+    rc = hrf_conv3xs2_fwd_launch(c, stream);
+  } else {
+    rc = hrf_conv3x_fwd_launch(c, stream);
+  }
+  if (rc == HRF_OK && ln_rowstat != nullptr) return hrf_ln_stats(y, (long)B * c.H * c.W, Cout, ln_eps, ln_rowstat, stream);
   return rc;
 }
 

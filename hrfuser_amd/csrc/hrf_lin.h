@@ -86,4 +86,5 @@ struct C3xArgs {
 
 int hrf_conv3x_fwd_launch(const C3xArgs& a, void* stream);
 int hrf_conv3x_bwd_data_launch(const C3xArgs& a, void* stream);
+int hrf_conv3xs2_fwd_launch(const C3xArgs& a, void* stream);          // stride-2 forward: 9 x 33 source patch in four parity planes
 int hrf_conv3xs2_bwd_data_launch(const C3xArgs& a, void* stream);     // stride-2 conv: one block walks the four parity classes

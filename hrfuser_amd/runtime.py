@@ -1336,6 +1336,7 @@ def _conv_out_hw(H, W, KH, stride):
     return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KH) // stride + 1
 
 
+_S2F_MINPIX = int(os.environ.get('HRF_C3X_S2F_MINPIX', '4096'))   # A/B switch: stride-2 forward on the packed engine from this many output pixels
 _IM2COL = os.environ.get('HRF_IM2COL', '1') != '0'      # A/B switch: the stem's first convolution through hrf_im2col3x3
 
 
@@ -1523,7 +1524,12 @@ def conv_bn(ctx, src, conv, bn, mode):
     train = ctx.training and bn.training
     stats = slot['stats'] if train else None
     # deep contraction, few row blocks (the 256 -> 36 stride-2 transition): split over K, partial tiles in step-lifetime scratch
+    # packed-weight engine: stride 1, and stride 2 (parity-plane halo) from _S2F_MINPIX output pixels and 32 input channels up
+    # (the split-K engine keeps the deep, few-tile 256 -> 36 transition: 54.8 us against 76.8 us on 120 packed-engine blocks)
     nsc = L.hrf_conv_fwd_split_scratch(*strides, B, H, W, Cin, KH, stride, Cout, Cout, 0) if KH == 3 else 0
+    wp = None
+    if nsc == 0 and KH == 3 and tf != TF_LN and (stride == 1 or (B * Ho * Wo >= _S2F_MINPIX and Cin >= 32)):
+        wp = _packed(ctx, w, 0, strides, B, H, W, Cin)
     if nsc > 0:
         L.hrf_conv_fwd_split(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
                              tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, _new((nsc,), x.device), s)
@@ -1537,14 +1543,12 @@ def conv_bn(ctx, src, conv, bn, mode):
         src.cols = cols
         L.hrf_conv_fwd(cols, *_nhwc_strides(B, Ho, Wo, K9), B, Ho, Wo, K9, w, b, 1, 1, Cout, y, Cout, 0, None, None, 0,
                        TF_NONE, None, None, None, stats, None, None, 0.0, s)
+    elif wp is not None:
+        L.hrf_conv_fwd_packed(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
+                              tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, wp, s)
     else:
-        wp = _packed(ctx, w, 0, strides, B, H, W, Cin) if (KH == 3 and tf != TF_LN) else None
-        if wp is not None:
-            L.hrf_conv_fwd_packed(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
-                                  tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, wp, s)
-        else:
-            L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
-                           tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, s)
+        L.hrf_conv_fwd(x, *strides, B, H, W, Cin, w, b, KH, stride, Cout, y, Cout, 0, None, None, 0,
+                       tf, sc, sh, rowstat, stats, _src_fin(ctx, src), None, 0.0, s)
     st = bn_forward(ctx, bn, y, stats)
     out = Lazy(st, mode)
     if ctx.probe is not None and mode == TF_RELU:

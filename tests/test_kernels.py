@@ -865,12 +865,13 @@ def test_conv_gpu(case):
 # backward by parity classes), the transitions' backward (18 / 36 -> 256 channels), ragged grids and channel counts
 C3X_CASES = [  # B,H,W,Cin,Cout,KH,stride,tf,bnb,epi
     (2, 10, 13, 64, 64, 3, 1, 2, True, True),
-    (1, 9, 35, 64, 64, 3, 2, 2, True, True),       # stride-2 backward only (forward stays on the generic engine)
+    (1, 9, 35, 64, 64, 3, 2, 2, True, True),       # stride 2: forward over parity planes (two 32-channel slabs), backward over parity classes
     (1, 7, 18, 96, 40, 3, 1, 1, True, False),      # two halo slabs (64 + 32), ragged output channels, accumulate epilogue
     (1, 6, 5, 256, 18, 3, 1, 0, True, False),      # transition backward: 18 -> 256 channels (ragged K, four channel blocks)
     (1, 9, 7, 72, 36, 3, 2, 3, True, True),        # GELU on load / GELU' epilogue, stride-2 backward 36 -> 72
     (1, 7, 9, 40, 96, 3, 1, 2, True, True),        # backward with two halo slabs of dY (96 channels), ragged 40 outputs
     (1, 18, 33, 64, 64, 3, 1, 0, False, False),
+    (1, 11, 8, 80, 36, 3, 2, 1, True, False),      # stride-2 forward: three slabs (32 + 32 + 16), ragged 36 outputs, odd source rows
 ]
 
 
@@ -916,7 +917,7 @@ def test_im2col_gpu():
     run_im2col('hip')
 
 
-@pytest.mark.parametrize('case', C3X_CASES[:6], ids=str)
+@pytest.mark.parametrize('case', C3X_CASES[:6] + C3X_CASES[7:], ids=str)
 def test_conv3x_emul(case):
     run_conv(case, 'emul', packed=True)
 

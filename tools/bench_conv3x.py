@@ -59,22 +59,23 @@ def rel(a, b):
 rows = []
 
 
-def fwd_case(name, B, H, W, Cin, Cout, tf):
+def fwd_case(name, B, H, W, Cin, Cout, tf, stride=1):
     x, w = R(B, H, W, Cin), R(Cout, Cin, 3, 3) * 0.1
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     fin, ft = fin_of(Cin, B * H * W) if tf else (None, None)
     st = (H * W * Cin, W * Cin, Cin, 1)
-    y0, y1 = torch.empty(B, H, W, Cout, device=dev), torch.empty(B, H, W, Cout, device=dev)
+    y0, y1 = torch.empty(B, Ho, Wo, Cout, device=dev), torch.empty(B, Ho, Wo, Cout, device=dev)
     s0, s1 = (torch.zeros(KC * 2 * Cout, dtype=torch.float64, device=dev) for _ in range(2))
     wp = pack(w, 0)
-    old = lambda y=y0, s=s0: L.hrf_conv_fwd(x, *st, B, H, W, Cin, w, None, 3, 1, Cout, y, Cout, 0, None, None, 0, tf, None, None, None, s, fin,
+    old = lambda y=y0, s=s0: L.hrf_conv_fwd(x, *st, B, H, W, Cin, w, None, 3, stride, Cout, y, Cout, 0, None, None, 0, tf, None, None, None, s, fin,
                                             None, 0.0, sp())
-    new = lambda y=y1, s=s1: L.hrf_conv_fwd_packed(x, *st, B, H, W, Cin, w, None, 3, 1, Cout, y, Cout, 0, None, None, 0, tf, None, None, None,
+    new = lambda y=y1, s=s1: L.hrf_conv_fwd_packed(x, *st, B, H, W, Cin, w, None, 3, stride, Cout, y, Cout, 0, None, None, 0, tf, None, None, None,
                                                    s, fin, None, 0.0, wp, sp())
     old(); new()
     torch.cuda.synchronize()
     err = rel(y1, y0)
     serr = rel(s1.view(KC, -1).sum(0), s0.view(KC, -1).sum(0))
-    flops = 2.0 * 9 * Cin * Cout * B * H * W
+    flops = 2.0 * 9 * Cin * Cout * B * Ho * Wo
     rows.append(dict(name=name, old_us=_graph_time(old) * 1e6, new_us=_graph_time(new) * 1e6, gflop=flops / 1e9, err=err, stat_err=serr))
 
 
@@ -114,6 +115,9 @@ if os.environ.get('C3X_SMALL'):
 for nb in [int(v) for v in os.environ.get('C3X_B', '').split(',') if v]:
     fwd_case(f'fwd 64->64 s1 {nb}x96x160', nb, 96, 160, 64, 64, 2)
 fwd_case('fwd 64->64 s1 2x96x160 (Bottleneck conv2)', 2, 96, 160, 64, 64, 2)
+fwd_case('fwd 64->64 s2 2x192x320 (stem conv2)', 2, 192, 320, 64, 64, 2, 2)
+fwd_case('fwd 256->36 s2 2x96x160 (transition)', 2, 96, 160, 256, 36, 0, 2)
+fwd_case('fwd 18->36 s2 2x96x160 (fuse down)', 2, 96, 160, 18, 36, 2, 2)
 bwd_case('bwd 64->64 s1 2x96x160', 2, 96, 160, 64, 64, 1, True)
 bwd_case('bwd 64->64 s2 2x192x320 (stem conv2)', 2, 192, 320, 64, 64, 2, True)
 bwd_case('bwd 256->18 s1 2x96x160 (transition)', 2, 96, 160, 256, 18, 1, False)
