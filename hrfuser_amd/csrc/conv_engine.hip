@@ -347,34 +347,38 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(HrfGroup<ConvBwdData
     const int yi = rem / a.W, xi = rem - yi * a.W;
     orow[r] = b * a.sB + yi * a.sY + xi * a.sX;
   }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + j * 16 + col;
-    const bool nv = n < a.Cin;
-    float sc = 1.f, sh = 0.f;
-    if (a.epi == 1) { sc = a.tf_scale[nv ? n : 0]; sh = a.tf_shift[nv ? n : 0]; }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wave * 16 + (lane >> 4) * 4 + r;
-      const bool ok = nv && rowok[r];
-      const int o = ok ? orow[r] + n * a.sC : 0;
-      float v = acc[j][r];
-      if (a.epi == 1) {
-        const float xr = a.xraw[ok ? m * a.ldXr + n : 0];
-        v *= hrf_act_grad(a.act, fmaf(xr, sc, sh));
-        if (ok) { s1 += v; s2 = fmaf(v, xr, s2); a.dx[o] = v; }
-      } else {
-        const float prev = a.accumulate ? a.dx[o] : 0.f;
-        if (ok) a.dx[o] = prev + v;
+  // (one uniform branch per activation kind around the whole epilogue: hrf_with_act)
+  hrf_with_act(a.epi == 1 ? a.act : HRF_ACT_NONE, [&](auto kind) HRF_KIND_INLINE {
+    constexpr int ACT = decltype(kind)::value;
+  #pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 16 + col;
+      const bool nv = n < a.Cin;
+      float sc = 1.f, sh = 0.f;
+      if (a.epi == 1) { sc = a.tf_scale[nv ? n : 0]; sh = a.tf_shift[nv ? n : 0]; }
+      float s1 = 0.f, s2 = 0.f;
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wave * 16 + (lane >> 4) * 4 + r;
+        const bool ok = nv && rowok[r];
+        const int o = ok ? orow[r] + n * a.sC : 0;
+        float v = acc[j][r];
+        if (a.epi == 1) {
+          const float xr = a.xraw[ok ? m * a.ldXr + n : 0];
+          v *= hrf_act_grad(ACT, fmaf(xr, sc, sh));
+          if (ok) { s1 += v; s2 = fmaf(v, xr, s2); a.dx[o] = v; }
+        } else {
+          const float prev = a.accumulate ? a.dx[o] : 0.f;
+          if (ok) a.dx[o] = prev + v;
+        }
+      }
+      if (a.epi == 1 && a.stats != nullptr) {
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        if (lane < 16) { sStat[wave * 2 * BN + j * 16 + lane] = s1; sStat[wave * 2 * BN + BN + j * 16 + lane] = s2; }
       }
     }
-    if (a.epi == 1 && a.stats != nullptr) {
-      s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-      if (lane < 16) { sStat[wave * 2 * BN + j * 16 + lane] = s1; sStat[wave * 2 * BN + BN + j * 16 + lane] = s2; }
-    }
-  }
+  });
   if (a.epi == 1 && a.stats != nullptr) {
     __syncthreads();
     if (tid < 2 * BN) {
@@ -1116,7 +1120,9 @@ extern "C" __attribute__((visibility("hidden"))) int hrf_pw_knob(int key, int va
 extern "C" __attribute__((visibility("hidden"))) int hrf_conv3w_knob(int key, int value);
 extern "C" __attribute__((visibility("hidden"))) int hrf_lin2_knob(int key, int value);
 extern "C" __attribute__((visibility("hidden"))) int hrf_w3x_knob(int key, int value);
+extern "C" __attribute__((visibility("hidden"))) int hrf_dw_knob(int key, int value);
 extern "C" int hrf_debug_knob(int key, int value) {
+  if (key >= 40 && key < 44) return hrf_dw_knob(key - 40, value);      // dwconv.hip: 40 = float4-lane kernels (1 off, 2 / 3 tile height), 41 = grid threshold
   if (key >= 32 && key < 36) return hrf_w3x_knob(key - 32, value);     // wgrad3x_engine.hip: 32 = blocks per problem, 33 = smallest problem (output pixels)
   if (key >= 28 && key < 32) return hrf_lin2_knob(key - 28, value);    // lin2_engine.hip: 28 = 1 force / 2 disable the LDS-tiled row GEMM
   if (key >= 16 && key < 20) return hrf_pw_knob(key - 16, value);      // pointwise.hip tuning aids

@@ -7,6 +7,7 @@
 // bank conflicts.  The producer BatchNorm+GELU/ReLU is applied ONCE per element while staging the
 // halo tile ("transform on load"), never per tap.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 #include "hrf_common.h"
 #include "hrf_group.h"
@@ -26,6 +27,7 @@ struct DwFwdArgs {
   const float* x; const float* w; const float* bias; float* y; double* stats; hrf_bn_fin_t fin;
   int tf_mode; const float* tf_scale; const float* tf_shift;
   int B, H, W, C, Ho, Wo, tilesX, tilesY;
+  int nc4;                                               // dw4 kernels: float4 lanes (channels / 4) of a block's channel slab
 };
 
 template <int S>
@@ -75,16 +77,19 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
     }
     float sc = 1.f, sh = 0.f;
     if (a.tf_mode != HRF_TF_NONE) { sc = scp[cv ? cg : c0]; sh = shp[cv ? cg : c0]; }
+    hrf_with_tf(a.tf_mode, [&](auto kind) HRF_KIND_INLINE {
+      constexpr int MODE = decltype(kind)::value;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int pix = it * 8 + (tid >> 5);
-      const int iy = pix / IW, ix = pix - iy * IW;
-      const int gy = iy0 + iy, gx = ix0 + ix;
-      const bool ok = cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      float v = raw[it];
-      if (a.tf_mode != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
-      if (pix < IH * IW) sIn[pix * CB + c] = ok ? v : 0.f;
-    }
+      for (int it = 0; it < NIT; ++it) {
+        const int pix = it * 8 + (tid >> 5);
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool ok = cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        float v = raw[it];
+        if (MODE != HRF_TF_NONE) v = hrf_tf_affine(MODE, v, sc, sh);
+        if (pix < IH * IW) sIn[pix * CB + c] = ok ? v : 0.f;
+      }
+    });
   }
   __syncthreads();
   const int c = tid & 31, cg = c0 + c, rg = tid >> 5;
@@ -141,6 +146,135 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
       for (int g = 0; g < 8; ++g) tot += sStat[g * 2 * CB + tid];
       double* st = a.stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.C;
       hrf_atomic_add(&st[(tid < CB ? 0 : a.C) + c0 + (tid & (CB - 1))], (double)tot);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- float4-lane kernels (stride 1, C % 4 == 0)
+// The kernels above give a lane ONE channel: a wave's global access is 2 pixels x 128 B, 23 dword loads + 16 dword stores per
+// thread, 54 ds_read_b32 per 16 outputs, and at C = 72 the third 32-channel block runs 8 of its 32 lanes.  Here a lane owns
+// FOUR consecutive channels (one float4) of one tile column: thread = (c4 < nc4, column < 16), nc4 = the largest divisor of
+// C / 4 up to 18 (72 channels per slab: HRFuser-T's 72 / 144 / 288 / 576 have no ragged slab), so
+//   * a wave's global access is contiguous ((column, c4) -> 16 B each: 1 KB per instruction at nc4 = 16+), the halo is 12 (7)
+//     dwordx4 loads per thread, the outputs 8 (4) dwordx4 stores;
+//   * the staged tile is [halo pixel][nc4 float4]: the same (column, c4) -> 16 B map makes every ds_read_b128 / ds_write_b128
+//     of a wave one contiguous run (no bank conflict);
+//   * the thread walks DOWN its column: each halo row is read once (3 float4) and feeds the (up to) three output rows it
+//     touches - 3 (TH + 2) LDS reads for TH float4 outputs.
+constexpr int D4_MAXL = 18;                               // float4 lanes of a slab (72 channels)
+
+__host__ __device__ inline int dw4_lanes(int C) {
+  if (C & 3) return 0;
+  const int n = C >> 2;
+  for (int d = D4_MAXL; d >= 8; --d)
+    if (n % d == 0) return d;
+  return 0;
+}
+
+template <int TH>
+__global__ __launch_bounds__(16 * D4_MAXL) void dw4_fwd_kernel(HrfGroup<DwFwdArgs> grp) {
+  const DwFwdArgs& a = grp.sel();
+  constexpr int IH = TH + 2, IW = TW + 2, NPX = IH * IW, NIT = (NPX + 15) / 16;
+  __shared__ __attribute__((aligned(16))) float sIn[NPX * D4_MAXL * 4];
+  __shared__ __attribute__((aligned(16))) float sRed[16 * 2 * D4_MAXL * 4];
+  __shared__ __attribute__((aligned(16))) float sFin[2 * D4_MAXL * 4];
+  const int tid = threadIdx.x, nc4 = a.nc4, nt = 16 * nc4, CS = 4 * nc4;
+  const int col = tid / nc4, c4 = tid - col * nc4;
+  int t = blockIdx.x;
+  const int tx = t % a.tilesX; t /= a.tilesX;
+  const int ty = t % a.tilesY; const int b = t / a.tilesY;
+  const int c0 = blockIdx.y * CS, cg = c0 + 4 * c4;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  // every global operand is requested first (taps, bias, halo); the BatchNorm of the input is finalised while they fly
+  hrf_f4 wreg[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wreg[k] = hrf_ld4(a.w + (long)cg * 9 + 4 * k);
+  hrf_f4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bv = hrf_ld4(a.bias + cg);
+  hrf_f4 raw[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int p = col + 16 * it;                         // (the thread's float4 lane is the same for every element it stages)
+    const int iy = p / IW, ix = p - iy * IW;
+    const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+    const bool ok = p < NPX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    raw[it] = hrf_ld4(a.x + (ok ? (((long)b * a.H + gy) * a.W + gx) * a.C : 0) + cg);
+  }
+  hrf_f4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (a.fin.stats != nullptr) {
+    hrf_bn_fin_onload(a.fin, sFin, sFin + 4 * D4_MAXL, tid, nt, blockIdx.x == 0, c0, CS);
+    __syncthreads();
+    sc = *reinterpret_cast<const hrf_f4*>(sFin + 4 * c4); sh = *reinterpret_cast<const hrf_f4*>(sFin + 4 * D4_MAXL + 4 * c4);
+  } else if (a.tf_mode != HRF_TF_NONE) {
+    sc = hrf_ld4(a.tf_scale + cg); sh = hrf_ld4(a.tf_shift + cg);
+  }
+  // ONE uniform branch per transform kind around the whole staging loop: with the kind tested per element the loop body was
+  // 12 x 4 separately branched GELU chains (rcp -> 5 dependent FMAs -> exp2), none overlapping the next
+  auto stage = [&](auto kind) HRF_KIND_INLINE {
+    constexpr int MODE = decltype(kind)::value;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int p = col + 16 * it;
+      const int iy = p / IW, ix = p - iy * IW;
+      const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+      const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      hrf_f4 v = raw[it];
+      if (MODE != HRF_TF_NONE) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = hrf_tf_affine(MODE, v[m], sc[m], sh[m]);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) v[m] = ok ? v[m] : 0.f;  // zero padding of the TRANSFORMED tensor
+      if (p < NPX) *reinterpret_cast<hrf_f4*>(sIn + ((long)p * nc4 + c4) * 4) = v;
+    }
+  };
+  hrf_with_tf(a.tf_mode, stage);
+  __syncthreads();
+  hrf_f4 acc[TH];
+#pragma unroll
+  for (int o = 0; o < TH; ++o) acc[o] = bv;
+  // taps of channel cg + m: the 36 floats w[cg .. cg + 3][9] in memory order, element m * 9 + k
+#define DW4_W(m, k) wreg[((m) * 9 + (k)) >> 2][((m) * 9 + (k)) & 3]
+#pragma unroll
+  for (int h = 0; h < IH; ++h) {
+    const float* rp = sIn + ((long)(h * IW + col) * nc4 + c4) * 4;
+    hrf_f4 in[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) in[j] = *reinterpret_cast<const hrf_f4*>(rp + j * CS);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int o = h - ky;
+      if (o >= 0 && o < TH) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[o][m] = fmaf(in[kx][m], DW4_W(m, ky * 3 + kx), acc[o][m]);
+      }
+    }
+  }
+#undef DW4_W
+  hrf_f4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const int ox = ox0 + col;
+#pragma unroll
+  for (int o = 0; o < TH; ++o) {
+    const int oy = oy0 + o;
+    const bool ok = oy < a.Ho && ox < a.Wo;
+    if (ok) hrf_st4(a.y + (((long)b * a.Ho + oy) * a.Wo + ox) * a.C + cg, acc[o]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { s1[m] += ok ? acc[o][m] : 0.f; s2[m] = ok ? fmaf(acc[o][m], acc[o][m], s2[m]) : s2[m]; }
+  }
+  if (a.stats) {
+    // moments: the 16 columns of a channel meet in LDS, one atomic per channel and moment and block
+    *reinterpret_cast<hrf_f4*>(sRed + ((col * 2 + 0) * nc4 + c4) * 4) = s1;
+    *reinterpret_cast<hrf_f4*>(sRed + ((col * 2 + 1) * nc4 + c4) * 4) = s2;
+    __syncthreads();
+    if (tid < 2 * CS) {
+      const int which = tid / CS, ch = tid - which * CS;
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tot += sRed[(q * 2 + which) * CS + ch];
+      double* st = a.stats + (size_t)(blockIdx.x % HRF_STAT_COPIES) * 2 * a.C;
+      hrf_atomic_add(&st[(which ? a.C : 0) + c0 + ch], (double)tot);
     }
   }
 }
@@ -263,17 +397,27 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs
 #pragma unroll
       for (int x = 0; x < RW; ++x) win[k][x] = sD[((r + k) * RW + x) * CB + c];
   }
+  // act'(u) (WG: and x = act(u), from ONE evaluation) of the thread's 16 pixels, one uniform branch per kind around the loop
+  float xvq[WG ? TW : 1], gvq[TW];
+  if (a.epi == 1) {
+    hrf_with_act(a.act, [&](auto kind) HRF_KIND_INLINE {
+      constexpr int ACT = decltype(kind)::value;
+#pragma unroll
+      for (int q = 0; q < TW; ++q) {
+        const float u = fmaf(pre[q], sc, sh);
+        if (WG) hrf_act_both(ACT, u, xvq[q], gvq[q]);
+        else gvq[q] = hrf_act_grad(ACT, u);
+      }
+    });
+  }
 #pragma unroll
   for (int q = 0; q < TW; ++q) {
     const int xi = x0 + q;
     const bool ok = cv && yi < a.H && xi < a.W;
     float acc = 0.f;
-    // WG: x[p] = act(u) and act'(u) from ONE evaluation; every staged dy' element is read once for both products
-    float xv = 0.f, gv = 1.f;
-    if (WG) {
-      hrf_act_both(a.act, fmaf(pre[q], sc, sh), xv, gv);
-      xv = ok ? xv : 0.f;
-    }
+    // WG: every staged dy' element is read once for both products
+    float xv = 0.f;
+    if (WG) xv = ok ? xvq[q] : 0.f;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -294,7 +438,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(HrfGroup<DwBwdDataArgs
     const long o = (((long)b * a.H + yi) * a.W + xi) * a.C + cg;
     if (a.epi == 1) {
       const float xr = pre[q];
-      acc *= WG ? gv : hrf_act_grad(a.act, fmaf(xr, sc, sh));
+      acc *= gvq[q];
       if (ok) { s1 += acc; s2 = fmaf(acc, xr, s2); a.dx[o] = acc; }
     } else {
       if (ok) a.dx[o] = pre[q] + acc;
@@ -373,16 +517,19 @@ __device__ __forceinline__ void dw_bwd_wgt_body(const DwBwdWgtArgs& a) {
       const bool ok = cv && pix < IH * IW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
       raw[it] = a.x[ok ? (((long)b * a.H + gy) * a.W + gx) * a.C + cg : 0];
     }
+    hrf_with_tf(a.tf_mode, [&](auto kind) HRF_KIND_INLINE {
+      constexpr int MODE = decltype(kind)::value;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int pix = it * 8 + (tid >> 5);
-      const int iy = pix / IW, ix = pix - iy * IW;
-      const int gy = iy0 + iy, gx = ix0 + ix;
-      const bool ok = cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      float v = raw[it];
-      if (a.tf_mode != HRF_TF_NONE) v = hrf_tf_affine(a.tf_mode, v, sc, sh);
-      if (pix < IH * IW) sIn[pix * CB + c] = ok ? v : 0.f;
-    }
+      for (int it = 0; it < NIT; ++it) {
+        const int pix = it * 8 + (tid >> 5);
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool ok = cv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        float v = raw[it];
+        if (MODE != HRF_TF_NONE) v = hrf_tf_affine(MODE, v, sc, sh);
+        if (pix < IH * IW) sIn[pix * CB + c] = ok ? v : 0.f;
+      }
+    });
   }
   __syncthreads();
   float ca = 1.f, cb = 0.f, cc = 0.f;
@@ -458,6 +605,15 @@ int hrf_dw_wgt_flush(void* stream) {
   return rc;
 }
 
+// tuning aids (hrf_debug_knob 40 / 41): [0] float4-lane kernels: 0 auto, 1 off, 2 always 8-row tiles, 3 always 4-row tiles;
+// [1] smallest 8-row-tile grid that keeps 8-row tiles
+static int g_dw4[4] = {0, 200, 0, 0};
+extern "C" __attribute__((visibility("hidden"))) int hrf_dw_knob(int key, int value) {
+  if (key < 0 || key >= 4) return HRF_ERR_ARG;
+  g_dw4[key] = value;
+  return HRF_OK;
+}
+
 extern "C" int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias,
                               int stride, int tf_mode, const float* tf_scale, const float* tf_shift, float* y,
                               double* stats, const hrf_bn_fin_t* tf_fin, void* stream) {
@@ -473,6 +629,17 @@ extern "C" int hrf_dwconv_fwd(const float* x, int B, int H, int W, int C, const 
   const int th = stride == 1 ? 8 : 4;
   a.tilesX = hrf_cdiv(a.Wo, TW); a.tilesY = hrf_cdiv(a.Ho, th);
   if ((long)B * a.Ho * a.Wo <= 0) return HRF_OK;
+  a.nc4 = (stride == 1 && g_dw4[0] != 1) ? dw4_lanes(C) : 0;
+  if (a.nc4 > 0) {
+    // float4-lane kernel: 8-row tiles when they still give every CU ~two blocks, 4-row tiles otherwise
+    const int slabs = C / (4 * a.nc4);
+    const bool th8 = g_dw4[0] == 2 || (g_dw4[0] != 3 && (long)a.tilesX * a.tilesY * B * slabs >= g_dw4[1]);
+    if (!th8) a.tilesY = hrf_cdiv(a.Ho, 4);
+    dim3 grid4(a.tilesX * a.tilesY * B, slabs);
+    if (th8) { HRF_LAUNCH_G(dw4_fwd_kernel<8>, grid4, dim3(16 * a.nc4), 0, stream, a); }
+    else { HRF_LAUNCH_G(dw4_fwd_kernel<4>, grid4, dim3(16 * a.nc4), 0, stream, a); }
+    return hrf_check_launch();
+  }
   dim3 grid(a.tilesX * a.tilesY * B, hrf_cdiv(C, CB));
   if (stride == 1) { HRF_LAUNCH_G(dw_fwd_kernel<1>, grid, dim3(256), 0, stream, a); }
   else { HRF_LAUNCH_G(dw_fwd_kernel<2>, grid, dim3(256), 0, stream, a); }

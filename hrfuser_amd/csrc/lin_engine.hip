@@ -327,14 +327,21 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(HrfGroup<LinBwdDataAr
   }
 
   if (a.epi == 1) {
+    hrf_f4 esc[NT], esh[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int chb = n0w + 16 * t + 4 * q, nval = a.N - chb;
       const bool nfull = n0w + 16 * (t + 1) <= a.N;
-      const hrf_f4 sc = ld_sel(nfull, a.tf_scale, chb, nval), sh = ld_sel(nfull, a.tf_shift, chb, nval);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][r] *= hrf_act_grad(a.act, fmaf(xr[t][r], sc[r], sh[r]));
+      esc[t] = ld_sel(nfull, a.tf_scale, chb, nval); esh[t] = ld_sel(nfull, a.tf_shift, chb, nval);
     }
+    // one uniform branch per activation kind around the 4 NT elements (hrf_with_act: per element it was a branch each)
+    hrf_with_act(a.act, [&](auto kind) HRF_KIND_INLINE {
+      constexpr int ACT = decltype(kind)::value;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] *= hrf_act_grad(ACT, fmaf(xr[t][r], esc[t][r], esh[t][r]));
+    });
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {

@@ -304,7 +304,9 @@ def test_lin2_gpu(case, wn):
 
 DW_CASES = [(2, 9, 11, 72, 1, 3, True, True, True), (2, 17, 35, 40, 1, 0, False, False, False), (2, 19, 21, 18, 1, 3, False, True, True),
             (2, 10, 13, 18, 2, 0, False, True, False), (2, 11, 15, 36, 2, 2, False, True, True),
-            (1, 16, 32, 33, 2, 1, False, False, True)]
+            (1, 16, 32, 33, 2, 1, False, False, True),
+            (1, 13, 18, 144, 1, 3, True, True, True),      # float4-lane kernels: two 72-channel slabs, ragged tile rows / columns
+            (1, 9, 33, 52, 1, 2, False, True, True)]       # float4-lane kernels: one 13-lane slab (HRFuser-B widths are 13 x 4 x k)
 
 
 def run_dw(case, backend):
@@ -845,6 +847,18 @@ def test_dwconv_emul(case):
     run_dw(case, 'emul')
 
 
+@pytest.mark.parametrize('mode', [1, 2, 3])
+def test_dwconv_lane4_modes_emul(mode):
+    """hrf_debug_knob(40): the float4-lane depthwise kernels off (one-channel lanes) / 8-row tiles / 4-row tiles - same results"""
+    use_backend('emul')
+    L = _lib.lib()
+    L.hrf_debug_knob(40, mode)
+    try:
+        run_dw((2, 9, 11, 72, 1, 3, True, True, True), 'emul')
+    finally:
+        L.hrf_debug_knob(40, 0)
+
+
 @pytest.mark.parametrize('case', ATTN_CASES[:5], ids=str)
 def test_attention_emul(case):
     run_attn(case, 'emul')
@@ -933,6 +947,19 @@ def test_conv3x_gpu(case):
 @pytest.mark.parametrize('case', DW_CASES, ids=str)
 def test_dwconv_gpu(case):
     run_dw(case, 'hip')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', [1, 2, 3])
+def test_dwconv_lane4_modes_gpu(mode):
+    use_backend('hip')
+    L = _lib.lib()
+    L.hrf_debug_knob(40, mode)
+    try:
+        run_dw((2, 19, 37, 72, 1, 3, True, True, True), 'hip')
+        run_dw((1, 13, 18, 144, 1, 3, True, True, True), 'hip')
+    finally:
+        L.hrf_debug_knob(40, 0)
 
 
 @pytest.mark.gpu
