@@ -1,5 +1,7 @@
 """Where the time of the small row-GEMM launches goes: lin_fwd / lin_bwd_data at the CrossFFN fc3 shape (2x96x160, 72 <-> 18
-channels) with the transform, the moment emission and the epilogue switched off one at a time."""
+channels) with the transform, the moment emission and the epilogue switched off one at a time.
+python tools/bench_lin.py [out.json]"""
+import json
 import os
 import sys
 
@@ -34,12 +36,17 @@ def bwd(bnb, epi, stats):
                                        t72 if epi else None, 2 if epi else 0, stats if epi else None, sp())
 
 
+rows = {}
 for name, fn in [('lin_fwd 72->18 plain', fwd(0, None)), ('lin_fwd + moments', fwd(0, st18)), ('lin_fwd + affine', fwd(1, None)),
                  ('lin_fwd + affine+GELU', fwd(3, None)), ('lin_fwd + affine+GELU + moments', fwd(3, st18)),
                  ('lin_bwd 18->72 plain', bwd(False, False, None)), ('lin_bwd + BN-bwd on load', bwd(True, False, None)),
                  ('lin_bwd + BN-bwd + GELU\' epilogue', bwd(True, True, None)), ('lin_bwd + BN-bwd + epilogue + moments', bwd(True, True, st72))]:
-    print(f'{name:42s} {_graph_time(fn) * 1e6:6.2f} us', flush=True)
-a, b = R(B, H, W, 18), R(B, H, W, 18)
-print(f"{'scale_add 2x96x160x18 (3 tensors)':42s} {_graph_time(lambda: L.hrf_scale_add(a, None, 1.0, None, 1, b, None, a, B * H * W, 18, sp())) * 1e6:6.2f} us")
-a, b = R(B, H, W, 72), R(B, H, W, 72)
-print(f"{'scale_add 2x96x160x72 (3 tensors)':42s} {_graph_time(lambda: L.hrf_scale_add(a, None, 1.0, None, 1, b, None, a, B * H * W, 72, sp())) * 1e6:6.2f} us")
+    rows[name] = _graph_time(fn) * 1e6
+    print(f'{name:42s} {rows[name]:6.2f} us', flush=True)
+for C in (18, 72):                         # the floor of a launch in a graph: a trivial streaming kernel over the same rows
+    a, b = R(B, H, W, C), R(B, H, W, C)
+    name = f'scale_add 2x96x160x{C} (3 tensors)'
+    rows[name] = _graph_time(lambda: L.hrf_scale_add(a, None, 1.0, None, 1, b, None, a, B * H * W, C, sp())) * 1e6
+    print(f'{name:42s} {rows[name]:6.2f} us')
+if len(sys.argv) > 1:
+    json.dump(rows, open(sys.argv[1], 'w'), indent=1)

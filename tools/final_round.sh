@@ -41,8 +41,10 @@ python tools/bench_wgrad_tiled.py > $O/${R}_wgrad_tiled_microbench.txt 2>> $O/be
 # (what moments / transforms / epilogues cost), same-line atomics by copies and scope
 python tools/bench_conv3x.py $O/${R}_conv3x_microbench.json 2>> $O/bench.err | grep -v amdgpu > $O/${R}_conv3x_microbench.txt
 python tools/bench_wgrad3x.py 2>> $O/bench.err | grep -v amdgpu > $O/${R}_wgrad3x_microbench.txt
-python tools/bench_lin.py 2>> $O/bench.err | grep -v amdgpu > $O/${R}_stream_kernels_decomposition.txt
+python tools/bench_lin.py $O/${R}_lin_decomposition.json 2>> $O/bench.err | grep -v amdgpu > $O/${R}_stream_kernels_decomposition.txt
+python tools/bench_dw.py $O/${R}_dw_decomposition.json 2>> $O/bench.err | grep -v amdgpu >> $O/${R}_stream_kernels_decomposition.txt
 ./tools/microbench/atomics_scope > $O/${R}_atomics_scope.txt 2>> $O/bench.err
+python tools/stream_report.py $R $O > /dev/null 2>> $O/bench.err
 # the full GPU suite with its slowest calls
 timeout 1400 python -m pytest tests -m gpu -x -q > $O/${R}_gpu_suite_durations.txt 2>&1; echo "gpu suite rc $?" >> $O/${R}_gpu_suite_durations.txt
 for f in $O/${R}_bench_*.json; do echo $f; tail -1 $f | cut -c1-260; done

@@ -37,6 +37,7 @@ st = torch.zeros(32 * Cout, dtype=torch.float64, device=dev)
 wd, bd, y72 = R(72, 1, 3, 3), R(72), R(B, H, W, 72)
 st72 = torch.zeros(32 * 72, dtype=torch.float64, device=dev)
 w3, y18 = R(18, 72, 1, 1), R(B, H, W, 18)
+dx72, dwd = R(B, H, W, 72), torch.zeros(_lib.STAT_COPIES * 10 * 72, device=dev)
 st18 = torch.zeros(32 * 18, dtype=torch.float64, device=dev)
 # one HRFormerBlock at the branch-0 size: the fused attention block kernels (forward, backward) and the slot fold
 blk = BB.HRFormerBlock(18, 18, 1, norm_cfg=dict(type='BN', requires_grad=True, momentum=0.1), transformer_norm_cfg=dict(type='LN', eps=1e-6))
@@ -83,6 +84,10 @@ for it in range(4):
     L.hrf_conv_fwd(x, H * W * Cin, W * Cin, Cin, 1, B, H, W, Cin, w, None, 3, 1, Cout, y, Cout, 0, None, None, 0, 2, sc, sh, None, st, None, None, 0.0, sp())
     L.hrf_conv_bwd_data(dy, Cout, 0, yr, cA, cB, cC, None, w, 3, 1, Cout, B, H, W, Cin, dx, H * W * Cin, W * Cin, Cin, 1, 0, 1, x, Cin, sc, sh, 1, st, sp())
     L.hrf_dwconv_fwd(x72, B, H, W, 72, wd, bd, 1, 3, s72, s72, y72, st72, None, sp())
+    # round 6: the rest of the CrossFFN chain of the 18-channel branch (the "streaming" kernels) - the depthwise data +
+    # weight gradient (BatchNorm backward on load, GELU' epilogue, moments, dW / db) and the fc3 data gradient 18 -> 72
+    L.hrf_dwconv_bwd_data_weight(y72, x72, s72, s72, s72, None, wd, B, H, W, 72, dx72, x72, s72, s72, 2, st72, dwd, dwd[9 * 72:], 10 * 72, sp())
+    L.hrf_conv_bwd_data(dy18, 18, 0, yr18, *c18, None, w3, 1, 1, 18, B, H, W, 72, dx72, H * W * 72, W * 72, 72, 1, 0, 1, x72, 72, s72, s72, 2, st72, sp())
     L.hrf_conv_fwd(x72, H * W * 72, W * 72, 72, 1, B, H, W, 72, w3, None, 1, 1, 18, y18, 18, 0, None, None, 0, 3, s72, s72, None, st18, None, None, 0.0, sp())
     hn(xb)[0].backward(gb)
 torch.cuda.synchronize()

@@ -1,0 +1,102 @@
+"""profiles/rNN_stream_kernels.json: the CrossFFN kernels of the 18-channel branch at 2 x 96 x 160 - counters, static
+resources, fabric traffic and the timing decomposition (operand pieces switched off one at a time) in one place.
+
+    python tools/stream_report.py r06 gpurun_out/final_r06
+
+reads <dir>/r06_pmc_sq.json (tools/prof_pmc_sq.sh), r06_pmc_raw.json (tools/prof_round.sh: FETCH_SIZE / WRITE_SIZE in KB),
+r06_lin_decomposition.json (tools/bench_lin.py), r06_dw_decomposition.json (tools/bench_dw.py), r06_atomics_scope.txt
+(tools/microbench/atomics_scope) and hrfuser_amd/kernel_resources.json; writes <dir>/r06_stream_kernels.json."""
+import json
+import os
+import re
+import sys
+
+R, D = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 2 * 96 * 160
+
+
+def load(name):
+    p = os.path.join(D, f'{R}_{name}')
+    return json.load(open(p)) if os.path.exists(p) else {}
+
+
+sq, raw, lin, dw = load('pmc_sq.json'), load('pmc_raw.json'), load('lin_decomposition.json'), load('dw_decomposition.json')
+res = json.load(open(os.path.join(ROOT, 'hrfuser_amd', 'kernel_resources.json')))['kernels']
+dwrow = {r['name']: r for r in dw} if isinstance(dw, list) else {}
+
+
+def pick(table, prefix):
+    """entry of the first kernel whose name starts with `prefix` (template arguments vary with the build)"""
+    for k, v in table.items():
+        if k.startswith(prefix):
+            return k, v
+    return None, {}
+
+
+def dwt(what, tag):
+    r = dwrow.get(what)
+    return round(r[tag], 2) if r and tag in r else None
+
+
+KERNELS = [
+    dict(role='CrossFFN fc3 forward 72 -> 18 (BatchNorm finalised on load + GELU on load, moments of the output)', prefix='lin_fwd_kernel<2, 3',
+         algorithmic_bytes=P * (72 + 18) * 4, blocks=480, threads=256,
+         decomposition_us={k: round(v, 2) for k, v in lin.items() if k.startswith('lin_fwd')}),
+    dict(role="CrossFFN fc3 data gradient 18 -> 72 (BatchNorm backward on load, GELU' epilogue, moments of dx)", prefix='lin_bwd_data_kernel<5, true',
+         algorithmic_bytes=P * (18 + 18 + 72 + 72) * 4, blocks=480, threads=256,
+         decomposition_us={k: round(v, 2) for k, v in lin.items() if k.startswith('lin_bwd')}),
+    dict(role='CrossFFN depthwise 3x3 forward, 72 channels (finalize + GELU on load, moments)', prefix='dw4_fwd_kernel<8>',
+         algorithmic_bytes=P * 72 * 2 * 4, blocks=240, threads=288,
+         decomposition_us={k: dict(one_channel_lanes=dwt(f'dw_fwd 2x96x160x72 {k}', 'lane1'), float4_lanes_8_rows=dwt(f'dw_fwd 2x96x160x72 {k}', 'lane4 th8'),
+                                   float4_lanes_4_rows=dwt(f'dw_fwd 2x96x160x72 {k}', 'lane4 th4'))
+                           for k in ('plain', 'plain+moments', 'GELU+moments', 'fin+GELU', 'fin+GELU+moments')}),
+    dict(role="CrossFFN depthwise 3x3 data + weight gradient, 72 channels (BatchNorm backward on load, GELU' epilogue, moments, dW / db)",
+         prefix='dw_bwd_data_kernel<1, true>', algorithmic_bytes=P * 72 * 4 * 4, blocks=720, threads=256,
+         decomposition_us={'bfin+GELU\'+moments+dW': dwt("dw_bwd_data_weight 2x96x160x72 bfin+GELU'+moments", 'lane1'),
+                           'bfin+GELU\'+moments (no dW)': dwt("dw_bwd_data 2x96x160x72 bfin+GELU'+moments", 'lane1')}),
+]
+out = dict(shape='B=2, H=96, W=160 (30 720 rows), 18 <-> 72 channels', kernels=[])
+F, Wr = raw.get('FETCH_SIZE', {}), raw.get('WRITE_SIZE', {})
+for k in KERNELS:
+    name, c = pick(sq, k['prefix'])
+    rname, rs = pick(res, k['prefix'])
+    e = dict(kernel=name or k['prefix'], role=k['role'], algorithmic_bytes=k['algorithmic_bytes'], grid_blocks=k['blocks'], block_threads=k['threads'],
+             decomposition_us=k['decomposition_us'])
+    if rs:
+        wpb = (k['threads'] + 63) // 64
+        e['static'] = dict(vgpr=rs.get('vgpr'), lds_static=rs.get('lds_static'), waves_per_simd_by_registers=rs.get('waves_per_simd'),
+                           waves_in_grid=k['blocks'] * wpb, waves_per_cu_if_all_resident=round(k['blocks'] * wpb / 256.0, 2))
+    if c:
+        e['counters'] = {n: c[n] for n in ('SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY',
+                                             'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_INST_LEVEL_VMEM', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS',
+                                             'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE') if n in c}
+        e['derived'] = {n: c[n] for n in ('waves_per_cu_avg', 'wait_inst_frac', 'active_inst_frac', 'vmem_in_flight_per_cu', 'lds_conflict_frac') if n in c}
+        if c.get('GRBM_GUI_ACTIVE'):
+            e['derived']['launch_us_under_counters_at_2p4GHz'] = round(c['GRBM_GUI_ACTIVE'] / 8.0 / 2400.0, 2)
+    fn, f = pick(F, k['prefix'])
+    wn, w = pick(Wr, k['prefix'])
+    if f and w:   # KB; gfx950: FETCH_SIZE tallies 128-B requests at 64 B (profiles/README.md) -> 2 x FETCH + WRITE
+        e['traffic_bytes'] = round((2.0 * f['avg_per_launch'] + w['avg_per_launch']) * 1024)
+        e['traffic_ratio'] = round(e['traffic_bytes'] / k['algorithmic_bytes'], 3)
+    out['kernels'].append(e)
+out['launch_floor_us'] = {k: round(v, 2) for k, v in lin.items() if k.startswith('scale_add')}
+at = os.path.join(D, f'{R}_atomics_scope.txt')
+if os.path.exists(at):
+    rows = {}
+    for ln in open(at):
+        m = re.match(r'(\w+)\s+N=\s*(\d+) C=\s*(\d+):\s+([\d.]+) us', ln)
+        if m:
+            rows.setdefault(f'N={m.group(2)} blocks, C={m.group(3)}', {})[m.group(1)] = float(m.group(4))
+    out['moment_atomics_us_per_memset_plus_launch'] = rows
+out['reading'] = [
+    'a trivial streaming launch inside a graph costs launch_floor_us (2.7 us for 6.6 MB, 4.5 us for 26.5 MB): ~2.5 us of every kernel below is the launch itself',
+    'every workgroup of these launches is resident at once (waves_per_cu_if_all_resident <= 8): the launch lasts as long as ONE workgroup - '
+    'a dependent chain load -> (finalize, barrier) -> transform -> LDS -> multiply -> store -> atomics; wait_inst_frac is the share of wave-cycles '
+    'spent in that chain waiting, vmem_in_flight_per_cu how little memory parallelism it leaves',
+    'pieces of the chain, from the decomposition: moments +1.7 ... 3.4 us (same-line fp64 atomics serialise at ~24 ns per block and copy: '
+    'moment_atomics table; 480 blocks / 4 copies = 120 deep), GELU on load +0.9 ... 2.3 us (1.4 x halo recompute in the depthwise kernels), '
+    "finalize-on-load +0.5 ... 0.8 us, GELU' epilogue +2.8 us (was +3.6 us with a scalar branch per element)",
+]
+json.dump(out, open(os.path.join(D, f'{R}_stream_kernels.json'), 'w'), indent=1)
+print(json.dumps(out, indent=1)[:3000])
