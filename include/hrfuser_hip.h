@@ -34,7 +34,9 @@
  * 8, +2.0 at 16, +4.5 ... 11 at 32).  Same-box A/B of the captured training steps (tools/ab_copies.sh, ab_copies_models.sh):
  * round 2: 16 copies 17.20 ms, 8: 16.70, 4: 16.64, 2: 17.1, 1: 18.3; round 5 (kernels 30 % shorter, the prologue a larger share):
  * HRFuser-T 32 copies 16.14 ms, 16: 12.58, 8: 11.61, 4: **11.47**, 2: 11.54; STF 8: 23.63, 4: 23.39; HRFuser-B 8: 42.98, 4: 42.98. */
+#ifndef HRF_STAT_COPIES      /* (a build may override it: tools/ab_copies.sh) */
 #define HRF_STAT_COPIES 4
+#endif
 
 /* BatchNorm finalize ON LOAD (consumer side).  A train-mode BatchNorm needs its batch moments complete before anything
  * can be normalised, i.e. a grid-wide dependency between the producing convolution and its consumer; the kernel boundary
