@@ -605,9 +605,16 @@ int hrf_dw_wgt_flush(void* stream) {
   return rc;
 }
 
-// tuning aids (hrf_debug_knob 40 / 41): [0] float4-lane kernels: 0 auto, 1 off, 2 always 8-row tiles, 3 always 4-row tiles;
+// tuning aids (hrf_debug_knob 40 / 41): [0] float4-lane forward: 0 auto, 1 off (default), 2 always 8-row tiles, 3 always 4-row tiles;
 // [1] smallest 8-row-tile grid that keeps 8-row tiles
-static int g_dw4[4] = {0, 200, 0, 0};
+// The float4-lane forward is NOT the default (round 6, same-box A/B of two library builds, three interleaved pairs): isolated it is
+// 5 % (72 channels) ... 20 % (144 - 576) faster, in the captured step 10.71 -> 10.77 ms - its 288-thread blocks (61 KB of LDS, 169
+// registers) hold more of a CU than the 256-thread / 25 KB ones beside the kernels of the other lanes.  hrf_debug_knob(40, 0 / 2 / 3)
+// selects it (tests, tools/bench_dw.py); -DHRF_DW4_DEFAULT=0 builds a library that uses it.
+#ifndef HRF_DW4_DEFAULT
+#define HRF_DW4_DEFAULT 1
+#endif
+static int g_dw4[4] = {HRF_DW4_DEFAULT, 200, 0, 0};
 extern "C" __attribute__((visibility("hidden"))) int hrf_dw_knob(int key, int value) {
   if (key < 0 || key >= 4) return HRF_ERR_ARG;
   g_dw4[key] = value;

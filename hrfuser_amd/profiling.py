@@ -67,8 +67,7 @@ def work_model(name, a):
         Ho, Wo = _out_hw(a['H'], a['W'], 3, a['stride'])
         n_in, n_out = a['B'] * a['H'] * a['W'] * a['C'], a['B'] * Ho * Wo * a['C']
         if name == 'hrf_dwconv_fwd':
-            lane4 = a['stride'] == 1 and a['C'] % 4 == 0 and any((a['C'] // 4) % d == 0 for d in range(8, 19))   # csrc/dwconv.hip: dw4_lanes
-            return ('dw4_fwd_kernel' if lane4 else f"dw_fwd_kernel<{a['stride']}>"), 18.0 * n_out, f4 * (n_in + n_out)
+            return f"dw_fwd_kernel<{a['stride']}>", 18.0 * n_out, f4 * (n_in + n_out)
         return f"dw_bwd_wgt_kernel<{a['stride']}>", 20.0 * n_out, f4 * (n_in + n_out * (2 if a['cA'] is not None else 1))
     if name == 'hrf_dwconv_bwd_data':
         Ho, Wo = _out_hw(a['H'], a['W'], 3, a['stride'])

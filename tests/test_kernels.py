@@ -305,8 +305,8 @@ def test_lin2_gpu(case, wn):
 DW_CASES = [(2, 9, 11, 72, 1, 3, True, True, True), (2, 17, 35, 40, 1, 0, False, False, False), (2, 19, 21, 18, 1, 3, False, True, True),
             (2, 10, 13, 18, 2, 0, False, True, False), (2, 11, 15, 36, 2, 2, False, True, True),
             (1, 16, 32, 33, 2, 1, False, False, True),
-            (1, 13, 18, 144, 1, 3, True, True, True),      # float4-lane kernels: two 72-channel slabs, ragged tile rows / columns
-            (1, 9, 33, 52, 1, 2, False, True, True)]       # float4-lane kernels: one 13-lane slab (HRFuser-B widths are 13 x 4 x k)
+            (1, 13, 18, 144, 1, 3, True, True, True),      # five channel blocks (two 72-channel slabs of the float4-lane forward: test_dwconv_lane4_modes_*), ragged tile rows / columns
+            (1, 9, 33, 52, 1, 2, False, True, True)]       # 52 channels = one 13-lane slab of the float4-lane forward (HRFuser-B widths are 13 x 4 x k)
 
 
 def run_dw(case, backend):
@@ -847,16 +847,18 @@ def test_dwconv_emul(case):
     run_dw(case, 'emul')
 
 
-@pytest.mark.parametrize('mode', [1, 2, 3])
+@pytest.mark.parametrize('mode', [0, 2, 3])
 def test_dwconv_lane4_modes_emul(mode):
-    """hrf_debug_knob(40): the float4-lane depthwise kernels off (one-channel lanes) / 8-row tiles / 4-row tiles - same results"""
+    """hrf_debug_knob(40): the float4-lane depthwise forward (not the default: csrc/dwconv.hip) with automatic / 8-row / 4-row
+    tiles - same results as the one-channel-lane kernel the other tests run"""
     use_backend('emul')
     L = _lib.lib()
     L.hrf_debug_knob(40, mode)
     try:
         run_dw((2, 9, 11, 72, 1, 3, True, True, True), 'emul')
+        run_dw((1, 9, 33, 52, 1, 2, False, True, True), 'emul')          # one 13-lane slab, ReLU on load
     finally:
-        L.hrf_debug_knob(40, 0)
+        L.hrf_debug_knob(40, 1)
 
 
 @pytest.mark.parametrize('case', ATTN_CASES[:5], ids=str)
@@ -950,7 +952,7 @@ def test_dwconv_gpu(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', [1, 2, 3])
+@pytest.mark.parametrize('mode', [0, 2, 3])
 def test_dwconv_lane4_modes_gpu(mode):
     use_backend('hip')
     L = _lib.lib()
@@ -959,7 +961,7 @@ def test_dwconv_lane4_modes_gpu(mode):
         run_dw((2, 19, 37, 72, 1, 3, True, True, True), 'hip')
         run_dw((1, 13, 18, 144, 1, 3, True, True, True), 'hip')
     finally:
-        L.hrf_debug_knob(40, 0)
+        L.hrf_debug_knob(40, 1)
 
 
 @pytest.mark.gpu

@@ -72,7 +72,7 @@ def fwd_case(B, H, W, C):
         row['err'] = max(rel(ys[m][0], ys[1][0]) for m in (2, 3))
         row['stat_err'] = max(rel(ys[m][1], ys[1][1]) for m in (2, 3)) if want else 0.0
         rows.append(row)
-    L.hrf_debug_knob(40, 0)
+    L.hrf_debug_knob(40, 1)
 
 
 def bwd_case(B, H, W, C, wg=True):
@@ -100,7 +100,7 @@ def bwd_case(B, H, W, C, wg=True):
     row['stat_err'] = max(rel(outs[m][1], outs[1][1]) for m in (2, 3))
     row['dw_err'] = max(rel(outs[m][2], outs[1][2]) for m in (2, 3)) if wg else 0.0
     rows.append(row)
-    L.hrf_debug_knob(40, 0)
+    L.hrf_debug_knob(40, 1)
 
 
 for shape in [(2, 96, 160, 72), (2, 48, 80, 144), (2, 24, 40, 288), (2, 12, 20, 576)]:

@@ -46,8 +46,8 @@ KERNELS = [
     dict(role="CrossFFN fc3 data gradient 18 -> 72 (BatchNorm backward on load, GELU' epilogue, moments of dx)", prefix='lin_bwd_data_kernel<5, true',
          algorithmic_bytes=P * (18 + 18 + 72 + 72) * 4, blocks=480, threads=256,
          decomposition_us={k: round(v, 2) for k, v in lin.items() if k.startswith('lin_bwd')}),
-    dict(role='CrossFFN depthwise 3x3 forward, 72 channels (finalize + GELU on load, moments)', prefix='dw4_fwd_kernel<8>',
-         algorithmic_bytes=P * 72 * 2 * 4, blocks=240, threads=288,
+    dict(role='CrossFFN depthwise 3x3 forward, 72 channels (finalize + GELU on load, moments)', prefix='dw_fwd_kernel<1>',
+         algorithmic_bytes=P * 72 * 2 * 4, blocks=720, threads=256,
          decomposition_us={k: dict(one_channel_lanes=dwt(f'dw_fwd 2x96x160x72 {k}', 'lane1'), float4_lanes_8_rows=dwt(f'dw_fwd 2x96x160x72 {k}', 'lane4 th8'),
                                    float4_lanes_4_rows=dwt(f'dw_fwd 2x96x160x72 {k}', 'lane4 th4'))
                            for k in ('plain', 'plain+moments', 'GELU+moments', 'fin+GELU', 'fin+GELU+moments')}),
