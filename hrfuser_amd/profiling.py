@@ -151,8 +151,9 @@ class ProfLib:
                     v = getattr(p, f)
                     if f in ('B', 'H', 'W', 'C', 'heads', 'hidden'):
                         d[f] = v
-                d['cross'] = int(p.xq != p.xkv)
-                d['w1'] = int(bool(p.w1))
+                if hasattr(p, 'xq'):                       # (hrf_attn_block_t; hrf_ffn_eval_t has neither)
+                    d['cross'] = int(p.xq != p.xkv)
+                    d['w1'] = int(bool(p.w1))
             return d
 
         if name in _lib._RAW_RETURN or name in ('hrf_wgrad_group_begin', 'hrf_wgrad_group_end', 'hrf_debug_knob', 'hrf_group_begin',
