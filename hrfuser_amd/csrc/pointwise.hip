@@ -416,13 +416,20 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(HrfGroup<AffineActR
   hrf_bn_fin_t fin2 = pa_.fin2;
   // BatchNorm(s) of the inputs finalised on load (hrf_bn_fin_t)
   __shared__ float sFin[4 * HRF_FIN_MAXC];
-  if (fin1.stats != nullptr) { hrf_bn_fin_onload(fin1, sFin, sFin + HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0); sc1 = sFin; sh1 = sFin + HRF_FIN_MAXC; }
-  if (fin2.stats != nullptr) { hrf_bn_fin_onload(fin2, sFin + 2 * HRF_FIN_MAXC, sFin + 3 * HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0); sc2 = sFin + 2 * HRF_FIN_MAXC; sh2 = sFin + 3 * HRF_FIN_MAXC; }
-  if (fin1.stats != nullptr || fin2.stats != nullptr) __syncthreads();
+  // (round 6) the coefficients ALWAYS sit in LDS for C <= HRF_FIN_MAXC - finalised on load, or copied: a pointer that is LDS on one
+  // path and global on another is a GENERIC pointer, every sc[c] / sh[c] a flat_load (eval mode, explicit coefficients: 16 flat
+  // dword loads per 4 elements beside the three 16-byte streams - 43 us for the 256-channel residual merge that takes 19 us in
+  // training).  The loop bodies below are instantiated once per address space.
+  const bool lds_coef = C <= HRF_FIN_MAXC;
+  if (fin1.stats != nullptr) hrf_bn_fin_onload(fin1, sFin, sFin + HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0);
+  else if (lds_coef) for (int c = threadIdx.x; c < C; c += 256) { sFin[c] = sc1[c]; sFin[HRF_FIN_MAXC + c] = sh1[c]; }
+  if (fin2.stats != nullptr) hrf_bn_fin_onload(fin2, sFin + 2 * HRF_FIN_MAXC, sFin + 3 * HRF_FIN_MAXC, threadIdx.x, 256, blockIdx.x == 0);
+  else if (lds_coef && y2 != nullptr) for (int c = threadIdx.x; c < C; c += 256) { sFin[2 * HRF_FIN_MAXC + c] = sc2[c]; sFin[3 * HRF_FIN_MAXC + c] = sh2[c]; }
+  if (lds_coef) __syncthreads();
   // vector paths (C % 4 == 0: 16 bytes, C % 2 == 0: 8 bytes - the 18 / 78-channel rows): a thread owns VW consecutive channels of
   // a row; the channel group advances by a constant per iteration (no 64-bit modulo per element - the dword loop below spends
   // more instructions on `i % C` than on the arithmetic - and 1/VW of the memory instructions)
-  auto vbody = [&](auto vw) {
+  auto vbody = [&](auto vw, const float* sc1, const float* sh1, const float* sc2, const float* sh2) HRF_KIND_INLINE {
     constexpr int VW = decltype(vw)::value;
     const long nv = total / VW, stride = (long)gridDim.x * 256;
     const int CV = C / VW, dc = (int)(stride % CV);
@@ -454,8 +461,17 @@ __global__ __launch_bounds__(256) void affine_act_res_kernel(HrfGroup<AffineActR
       cv += dc; if (cv >= CV) cv -= CV;
     }
   };
-  if (pa_.vec4 == 4) { vbody(std::integral_constant<int, 4>{}); return; }
-  if (pa_.vec4 == 2) { vbody(std::integral_constant<int, 2>{}); return; }
+  if (pa_.vec4 == 4) {
+    if (lds_coef) vbody(std::integral_constant<int, 4>{}, sFin, sFin + HRF_FIN_MAXC, sFin + 2 * HRF_FIN_MAXC, sFin + 3 * HRF_FIN_MAXC);
+    else vbody(std::integral_constant<int, 4>{}, sc1, sh1, sc2, sh2);
+    return;
+  }
+  if (pa_.vec4 == 2) {
+    if (lds_coef) vbody(std::integral_constant<int, 2>{}, sFin, sFin + HRF_FIN_MAXC, sFin + 2 * HRF_FIN_MAXC, sFin + 3 * HRF_FIN_MAXC);
+    else vbody(std::integral_constant<int, 2>{}, sc1, sh1, sc2, sh2);
+    return;
+  }
+  if (lds_coef) { sc1 = sFin; sh1 = sFin + HRF_FIN_MAXC; sc2 = sFin + 2 * HRF_FIN_MAXC; sh2 = sFin + 3 * HRF_FIN_MAXC; }   // (odd C: the dword path keeps generic pointers)
   auto body = [&](auto i) {
     const int c = (int)(i % C);
     float v = fmaf(y1[i], sc1[c], sh1[c]);

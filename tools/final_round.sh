@@ -16,6 +16,8 @@ cp gpurun_out/pmc_stages_$R/${R}_stage_hbm_traffic.json $O/ 2>/dev/null; cp gpur
 python bench.py --dump-kernels $O/${R}_kernels_graph_timed.json > $O/${R}_bench_line.json 2> $O/bench.err
 python bench.py --model b_nus_bn --no-cpu-baseline --no-neck --no-eager --steps 20 --warmup 5 --dump-kernels $O/${R}_kernels_b_nus.json > $O/${R}_bench_b_nus.json 2>> $O/bench.err
 python bench.py --model t_stf_bn --no-cpu-baseline --no-neck --no-eager --steps 30 --warmup 5 --dump-kernels $O/${R}_kernels_t_stf.json > $O/${R}_bench_t_stf.json 2>> $O/bench.err
+# the reference's own per-GPU training batch for HRFuser-T (3 images: cascade_rcnn_hrfuser_t_1x_nus_r640_l_r_fusion.py:49)
+python bench.py --batch 3 --no-cpu-baseline --no-neck --no-eager --no-roofline > $O/${R}_bench_batch3.json 2>> $O/bench.err
 # the SyncBN configuration on ONE GPU (forced one-rank group): collective main-lane schedule, one communicator per lane, peer-to-peer exchange
 HRF_FORCE_COLLECTIVES=1 HRF_SYNC_P2P=0 python bench.py --no-cpu-baseline --no-neck --no-eager --no-roofline > $O/${R}_bench_forced_rccl.json 2>> $O/bench.err
 HRF_FORCE_COLLECTIVES=1 HRF_SYNC_P2P=0 HRF_SYNC_LANE_COMMS=1 python bench.py --no-cpu-baseline --no-neck --no-eager --no-roofline > $O/${R}_bench_forced_rccl_lane_comms.json 2>> $O/bench.err
@@ -45,6 +47,8 @@ python tools/bench_lin.py $O/${R}_lin_decomposition.json 2>> $O/bench.err | grep
 python tools/bench_dw.py $O/${R}_dw_decomposition.json 2>> $O/bench.err | grep -v amdgpu >> $O/${R}_stream_kernels_decomposition.txt
 ./tools/microbench/atomics_scope > $O/${R}_atomics_scope.txt 2>> $O/bench.err
 python tools/stream_report.py $R $O > /dev/null 2>> $O/bench.err
+python tools/eval_kernels.py t_nus_bn $O/${R}_eval_kernels.json 2>> $O/bench.err | grep -v amdgpu > $O/${R}_eval_kernels.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${R}_smoke.txt 2>&1
 # the full GPU suite with its slowest calls
 timeout 1400 python -m pytest tests -m gpu -x -q > $O/${R}_gpu_suite_durations.txt 2>&1; echo "gpu suite rc $?" >> $O/${R}_gpu_suite_durations.txt
 for f in $O/${R}_bench_*.json; do echo $f; tail -1 $f | cut -c1-260; done
