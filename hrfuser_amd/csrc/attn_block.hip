@@ -1514,6 +1514,9 @@ int launch_bwd(const hrf_attn_block_t& a, const hrf_bn_bfin_t& bf, int nwin, voi
 // Relative-position-bias gradient from the dS planes the backward kernel left in memory (a LEAF of the backward graph:
 // issued with the deferred weight gradients, off the dependency chain): drpb[(yi-yj+6)*13 + (xi-xj+6)][h] += dS[j][i].
 // grid = (window chunks, heads); the planes of a chunk pass through LDS, thread e < 169 owns bin e.
+#ifndef HRF_RPB_CHUNKS
+#define HRF_RPB_CHUNKS 128          // window chunks (= workgroups per layer and head) of the RPB gradient gather
+#endif
 __device__ __forceinline__ void rpb_grad_body(const float* ds, int nwin, int heads, float* drpb, long copy_stride) {
   __shared__ float sP[NTOK * NTOK];
   const int h = blockIdx.y, e = threadIdx.x;
@@ -1521,14 +1524,26 @@ __device__ __forceinline__ void rpb_grad_body(const float* ds, int nwin, int hea
   const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? 6 - dy : 6;
   const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? 6 - dx : 6;
   float acc = 0.f;
-  for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+  // a block walks several windows (round 6: one window per block was a bare load -> gather -> 169 atomics chain, 33 K blocks
+  // and 5.6 M atomics per step): the NEXT plane is in flight in registers while this one is gathered from LDS
+  constexpr int NP = (NTOK * NTOK + 255) / 256;
+  float pre[NP];
+  auto fetch = [&](int w) {
     const float* p = ds + ((long)w * heads + h) * (NTOK * NTOK);
-    for (int k = threadIdx.x; k < NTOK * NTOK; k += 256) sP[k] = p[k];
-  __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NP; ++u) { const int k = threadIdx.x + 256 * u; pre[u] = p[k < NTOK * NTOK ? k : 0]; }
+  };
+  int w = blockIdx.x;
+  if (w < nwin) fetch(w);
+  for (; w < nwin; w += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) { const int k = threadIdx.x + 256 * u; if (k < NTOK * NTOK) sP[k] = pre[u]; }
+    __syncthreads();
+    if (w + (int)gridDim.x < nwin) fetch(w + gridDim.x);
     if (e < 169)
       for (int yj = y0; yj <= y1; ++yj)
         for (int xj = x0; xj <= x1; ++xj) acc += sP[(yj * 7 + xj) * NTOK + (yj + dy) * 7 + xj + dx];
-  __syncthreads();
+    __syncthreads();
   }
   if (e < 169) hrf_atomic_add(&drpb[(long)(blockIdx.x % HRF_STAT_COPIES) * copy_stride + e * heads + h], acc);
 }
@@ -1603,7 +1618,7 @@ extern "C" int hrf_attn_block_bwd(const hrf_attn_block_t* p, void* stream) {
 
 extern "C" int hrf_rpb_grad(const float* ds_plane, int nwin, int heads, float* drpb, long copy_stride, void* stream) {
   if (nwin <= 0 || heads <= 0) return HRF_OK;
-  const int chunks = nwin < 1024 ? nwin : 1024;                    // one or two windows per workgroup: the kernel is latency-bound
+  const int chunks = nwin < HRF_RPB_CHUNKS ? nwin : HRF_RPB_CHUNKS;
   HRF_LAUNCH(rpb_grad_kernel, dim3(chunks, heads), dim3(256), 0, stream, ds_plane, nwin, heads, drpb, copy_stride);
   return hrf_check_launch();
 }
@@ -1611,7 +1626,7 @@ extern "C" int hrf_rpb_grad(const float* ds_plane, int nwin, int heads, float* d
 extern "C" int hrf_rpb_grad_all(const float* planes, const long* seg, int nseg, int max_nwin, int max_heads, void* stream) {
   if (nseg <= 0 || max_nwin <= 0 || max_heads <= 0) return HRF_OK;
   if (planes == nullptr || seg == nullptr || nseg > 65535 || max_heads > 65535) return HRF_ERR_ARG;
-  const int chunks = max_nwin < 1024 ? max_nwin : 1024;
+  const int chunks = max_nwin < HRF_RPB_CHUNKS ? max_nwin : HRF_RPB_CHUNKS;
   HRF_LAUNCH(rpb_grad_all_kernel, dim3(chunks, max_heads, nseg), dim3(256), 0, stream, planes, seg);
   return hrf_check_launch();
 }

@@ -347,3 +347,29 @@ def test_nearest_up_bwd_emul():
 @pytest.mark.parametrize('case', [(2, 3, 5, 2, 18), (1, 2, 3, 8, 36), (3, 5, 4, 4, 300)])
 def test_nearest_up_bwd_gpu(case):
     _nearest(*case, 'hip')
+
+
+def _rpb_many_windows(backend, nwin=300, heads=2):
+    """hrf_rpb_grad with more windows than window chunks (HRF_RPB_CHUNKS = 128): a block walks several planes, the next one in flight
+    in registers while this one is gathered (round 6) - against the definition drpb[(yi-yj+6)*13 + (xi-xj+6)][h] = sum dS[w][h][j][i]"""
+    dev = use_backend(backend)
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    ds = torch.randn(nwin, heads, 49, 49, generator=g)
+    idx = torch.arange(49)
+    yi, xi = idx // 7, idx % 7
+    bins = (yi[None, :] - yi[:, None] + 6) * 13 + (xi[None, :] - xi[:, None] + 6)            # [j][i]
+    want = torch.zeros(169, heads, dtype=torch.float64)
+    want.index_add_(0, bins.reshape(-1), ds.double().sum(0).permute(1, 2, 0).reshape(49 * 49, heads))
+    drpb = torch.zeros(KC * 169 * heads, device=dev)
+    L.hrf_rpb_grad(ds.to(dev), nwin, heads, drpb, 169 * heads, _lib.stream_ptr())
+    assert r(drpb.view(KC, 169, heads).sum(0), want) < 1e-5
+
+
+def test_rpb_grad_many_windows_emul():
+    _rpb_many_windows('emul')
+
+
+@pytest.mark.gpu
+def test_rpb_grad_many_windows_gpu():
+    _rpb_many_windows('hip', nwin=644)
