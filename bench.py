@@ -260,16 +260,28 @@ def run_child(cmd, env, timeout):
     import signal
     import subprocess
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True, start_new_session=True)
-    try:
-        out, _ = proc.communicate(timeout=timeout)
-        rc = proc.returncode
-    except subprocess.TimeoutExpired:
+
+    def kill_group():
         try:
             os.killpg(proc.pid, signal.SIGKILL)            # the process GROUP we started, nothing else
         except ProcessLookupError:
             pass
+
+    def on_signal(sig, _frame):                            # the launcher ends this supervisor (another rank failed, ^C): the worker
+        kill_group()                                       # sits in a session of its own and would otherwise keep its GPU
+        os._exit(128 + sig)
+
+    saved = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        kill_group()
         out, _ = proc.communicate()
         rc = None
+    finally:
+        for sg, h in saved.items():
+            signal.signal(sg, h)
     line, rest = None, []
     for ln in (out or '').splitlines():
         if ln.startswith('{') and ln.rstrip().endswith('}'):

@@ -133,3 +133,37 @@ def test_two_ranks_share_one_gpu_gloo():
     assert px['grad_rel_l2_vs_main_lane'] < 1e-6 and px['p2p_exchanges_per_step'] > 100 and px['ms_per_step'] > 0
     assert px['main_lane_ms_per_step'] > 0 and px['main_lane_collectives_per_step'] > 4
     print(json.dumps({k: line[k] for k in ('value', 'ms_per_step', 'sync_ab')}))
+
+
+def test_rank_supervisor_takes_its_worker_along_on_sigterm(tmp_path):
+    """A supervisor ended by its launcher (SIGTERM: another rank failed) kills the worker's process group: the worker runs in a
+    session of its own (so that a time-out can kill the whole group) and would otherwise keep its GPU after the job is gone."""
+    import signal
+    import time
+    stub = tmp_path / 'stub_worker.py'
+    pidfile = tmp_path / 'worker.pid'
+    stub.write_text(f"import os, time\nopen(r'{pidfile}', 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29760',
+               HRF_BENCH_WORKER_CMD=f'{sys.executable} {stub}', HRF_BENCH_ATTEMPT_TIMEOUT_S='120', HRF_BENCH_BUDGET_S='300')
+    for k in ('HRF_BENCH_WORKER', 'HRF_BENCH_LAUNCHED_BY_BENCH'):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-sync-ab'],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    t0 = time.time()
+    while not pidfile.exists() and time.time() - t0 < 60:
+        time.sleep(0.2)
+    assert pidfile.exists()
+    time.sleep(0.3)
+    wpid = int(pidfile.read_text())
+    p.send_signal(signal.SIGTERM)
+    p.communicate(timeout=30)
+    assert p.returncode == 128 + signal.SIGTERM
+    for _ in range(50):                                   # the worker is gone (reaped by init)
+        try:
+            os.kill(wpid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        os.kill(wpid, signal.SIGKILL)
+        raise AssertionError('worker survived its supervisor')
