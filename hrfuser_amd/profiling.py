@@ -615,6 +615,13 @@ def roofline_of_dominant(table, peak_f, peak_b, profiles_dir=None, grouped=None)
             row['timeline_dominant'] = {'family': top[0], 'in_step_ms': round(top[1].get('in_step_us', 0.0) / 1e3, 3),
                                         'source': f'profiles/{lname} (rocprofv3 --kernel-trace of one replayed step, committed; NOT this run)',
                                         'agrees': base(top[0]) == fam}
+            # the same family IN SITU (four lanes sharing the chip, under the tracer): launches are longer than alone - both
+            # fractions are stated so that the rocprofv3 summary and this line can be read against each other
+            mine = next((v for k, v in tl.items() if base(k) == fam), None)
+            if mine and mine.get('in_step_us') and row.get('launches_per_step') and row.get('avg_launch_us'):
+                us = mine['in_step_us'] / row['launches_per_step']
+                row['in_situ'] = {'avg_launch_us': round(us, 2), 'frac': round(row['frac'] * row['avg_launch_us'] / us, 4),
+                                  'source': f'profiles/{lname}: the family\'s kernel time inside one traced graph replay / its launches'}
     # the next families, for context
     others = sorted(table.items(), key=lambda kv: -kv[1][1])[:7]
     row['next_families'] = [{k2: _row(k, t, peak_f, peak_b)[k2] for k2 in ('kernel', 'bound', 'frac', 'launches_per_step', 'time_per_step_ms')}
